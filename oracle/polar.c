@@ -1,0 +1,255 @@
+/*
+ * oracle/polar.c -- TEST INFRASTRUCTURE (see modem_oracle.h header).
+ *
+ * Polar code pieces of the receive path.  polar_tables.hh is pure data and is
+ * NOT copied: the masks are regenerated with freezer.cc's recipe and pinned by
+ * the SHA-256 of the reference's own table (tests/test_oracle_polar.py).
+ * PolarSysEnc / PolarEncoder / PolarListDecoder live in the absent
+ * aicodix/code headers ("parity unpinned"): restated from the call sites
+ * decode.cc:200-203,245-261,530-541 and encode.cc:48,302.
+ */
+#include "modem_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- frozen-bit table: freezer.cc:14-32 ---------------------------------- */
+/* CODE::PolarCodeConst0<16> is absent; it is the BEC (Bhattacharyya)
+ * construction: z <- [p]; 16x { z[2i] = 2z-z^2 (degraded), z[2i+1] = z^2 }
+ * in long double, then the K most reliable (smallest z) are unfrozen.  This
+ * reproduces both reference tables with 0 mismatches. */
+typedef struct { long double z; int idx; } zi_t;
+static int zi_cmp(const void *a, const void *b)
+{
+	const zi_t *x = (const zi_t *)a, *y = (const zi_t *)b;
+	if (x->z < y->z) return -1;
+	if (x->z > y->z) return 1;
+	return x->idx - y->idx;   /* stable */
+}
+void orc_frozen_table(int table, uint32_t *frozen)
+{
+	const int M = 16, LEN = 1 << M;
+	int N = table ? 64512 : 64800;     /* freezer.cc:36-37 */
+	int K = 43040 + 32;
+	/* freezer.cc:17-24 */
+	long double erasure_probability = (long double)(N - K) / N;
+	double design_SNR = 10 * log10(-log((double)erasure_probability));
+	double better_SNR = design_SNR + 1.59175;
+	long double better_probability = expl(-(long double)pow(10.0, better_SNR / 10));
+	int Kp = K + LEN - N;              /* freezer.cc:25 */
+	long double *z = (long double *)malloc(sizeof(long double) * LEN * 2);
+	long double *a = z, *b = z + LEN;
+	a[0] = better_probability;
+	for (int m = 0, len = 1; m < M; ++m, len *= 2) {
+		for (int i = 0; i < len; ++i) {
+			b[2 * i] = 2 * a[i] - a[i] * a[i];
+			b[2 * i + 1] = a[i] * a[i];
+		}
+		long double *t = a; a = b; b = t;
+	}
+	zi_t *zi = (zi_t *)malloc(sizeof(zi_t) * LEN);
+	for (int i = 0; i < LEN; ++i) { zi[i].z = a[i]; zi[i].idx = i; }
+	qsort(zi, LEN, sizeof(zi_t), zi_cmp);
+	for (int i = 0; i < LEN / 32; ++i)
+		frozen[i] = 0xffffffffu;
+	for (int i = 0; i < Kp; ++i)
+		frozen[zi[i].idx / 32] &= ~(1u << (zi[i].idx % 32));
+	free(zi);
+	free(z);
+}
+const uint32_t *orc_frozen_get(int table)
+{
+	static uint32_t tabs[2][2048];
+	static int have[2];
+	table = !!table;
+	#pragma omp critical(orc_frozen)
+	{
+		if (!have[table]) {
+			orc_frozen_table(table, tabs[table]);
+			have[table] = 1;
+		}
+	}
+	return tabs[table];
+}
+
+static inline int is_frozen(const uint32_t *frozen, int i) { return (frozen[i / 32] >> (i % 32)) & 1; }
+
+/* ---- CODE::PolarEncoder: x = u F^{(x)n}, NRZ products, natural order ------ */
+/* decode.cc:256 call; frozen inputs = +1 */
+void orc_polar_enc(int8_t *code, const int8_t *mesg, const uint32_t *frozen, int level)
+{
+	int length = 1 << level;
+	for (int i = 0; i < length; ++i)
+		code[i] = is_frozen(frozen, i) ? 1 : *mesg++;
+	for (int h = 1; h < length; h *= 2)
+		for (int i = 0; i < length; i += 2 * h)
+			for (int j = i; j < i + h; ++j)
+				code[j] = (int8_t)(code[j] * code[j + h]);
+}
+/* ---- CODE::PolarSysEnc<int8_t> (encode.cc:302): systematic --------------- */
+/* encode -> force frozen positions to +1 -> encode again.  The decoder relies
+ * on code[unfrozen_i] == mesg[i] (decode.cc:547-553); the systematic codeword
+ * is unique, so any correct construction gives the same bits. */
+void orc_polar_sysenc(int8_t *code, const int8_t *mesg, const uint32_t *frozen, int level)
+{
+	int length = 1 << level;
+	orc_polar_enc(code, mesg, frozen, level);
+	for (int i = 0; i < length; ++i)
+		if (is_frozen(frozen, i))
+			code[i] = 1;
+	for (int h = 1; h < length; h *= 2)
+		for (int i = 0; i < length; i += 2 * h)
+			for (int j = i; j < i + h; ++j)
+				code[j] = (int8_t)(code[j] * code[j + h]);
+}
+
+/* ---- CODE::PolarListDecoder<SIMD<float,L>,16> (decode.cc:201,530) -------- */
+/*
+ * Successive-cancellation list decoding, min-sum, L lanes (L = SIMD width of
+ * the reference build, decode.cc:164-169: 8 with AVX2, else 4).
+ *   soft[(n+i)*L+k]  LLRs of the size-n node being decoded (reference layout
+ *                    soft[N+i] with one SIMD vector per entry)
+ *   hard[i*L+k]      partial sums, +1/-1
+ *   f(a,b) = sign(a)sign(b)min(|a|,|b|);  g(a,b,u) = u*a + b
+ *   left subtree = lower indices; each subtree returns the lane map it applied
+ *   frozen leaf: metric += |llr| when llr < 0, hard = +1, identity map
+ *   info leaf  : fork 2L candidates, keep the L smallest metrics.
+ * Tie rule (std::nth_element is implementation-defined there): candidates are
+ * ordered by (metric, candidate index 2k+u) and survivors are stored in that
+ * sorted order, so the result is deterministic.  Initial metrics: lane 0 = 0,
+ * others = 1000, so the list fills from one path.
+ */
+typedef struct {
+	int L, count;
+	float *soft;       /* 2N*L */
+	int8_t *hard;      /* N*L */
+	uint8_t *maps;     /* count*L */
+	int8_t *mesg;      /* count*L */
+	float metric[ORC_MAX_LIST];
+	const uint32_t *frozen;
+} scl_t;
+
+static inline float prod(float a, float b)
+{
+	float m = fminf(fabsf(a), fabsf(b));
+	return ((a < 0.f) != (b < 0.f)) ? -m : m;
+}
+
+static void scl_leaf(scl_t *s, int index, uint8_t *map)
+{
+	const int L = s->L;
+	float *sft = s->soft + 1 * L;
+	int8_t *hrd = s->hard + (size_t)index * L;
+	if (is_frozen(s->frozen, index)) {
+		for (int k = 0; k < L; ++k) {
+			if (sft[k] < 0.f)
+				s->metric[k] -= sft[k];
+			hrd[k] = 1;
+			map[k] = (uint8_t)k;
+		}
+		return;
+	}
+	float fork[2 * ORC_MAX_LIST];
+	int perm[2 * ORC_MAX_LIST];
+	for (int k = 0; k < L; ++k)
+		fork[2 * k] = fork[2 * k + 1] = s->metric[k];
+	for (int k = 0; k < L; ++k) {
+		if (sft[k] < 0.f)
+			fork[2 * k] -= sft[k];
+		else
+			fork[2 * k + 1] += sft[k];
+	}
+	/* rank by (value, index): insertion sort of 2L entries */
+	for (int c = 0; c < 2 * L; ++c) {
+		int j = c;
+		while (j > 0 && fork[perm[j - 1]] > fork[c]) {
+			perm[j] = perm[j - 1];
+			--j;
+		}
+		perm[j] = c;
+	}
+	for (int k = 0; k < L; ++k) {
+		s->metric[k] = fork[perm[k]];
+		map[k] = (uint8_t)(perm[k] >> 1);
+		hrd[k] = (int8_t)(1 - 2 * (perm[k] & 1));
+	}
+	memcpy(s->mesg + (size_t)s->count * L, hrd, (size_t)L);
+	memcpy(s->maps + (size_t)s->count * L, map, (size_t)L);
+	++s->count;
+}
+
+/* decode the size-n (n = 1<<m) node whose first leaf is 'index'; its input
+ * LLRs are soft[(n+i)*L+k]; returns accumulated lane map in 'map' */
+static void scl_node(scl_t *s, int m, int index, uint8_t *map)
+{
+	const int L = s->L;
+	if (m == 0) {
+		scl_leaf(s, index, map);
+		return;
+	}
+	const int n = 1 << m, h = n / 2;
+	float *soft = s->soft;
+	int8_t *hard = s->hard + (size_t)index * L;
+	uint8_t lmap[ORC_MAX_LIST], rmap[ORC_MAX_LIST];
+	for (int i = 0; i < h; ++i)
+		for (int k = 0; k < L; ++k)
+			soft[(h + i) * L + k] = prod(soft[(n + i) * L + k], soft[(n + h + i) * L + k]);
+	scl_node(s, m - 1, index, lmap);
+	for (int i = 0; i < h; ++i)
+		for (int k = 0; k < L; ++k)
+			soft[(h + i) * L + k] = (float)hard[i * L + k] * soft[(n + i) * L + lmap[k]]
+				+ soft[(n + h + i) * L + lmap[k]];
+	scl_node(s, m - 1, index + h, rmap);
+	for (int i = 0; i < h; ++i) {
+		int8_t t[ORC_MAX_LIST];
+		for (int k = 0; k < L; ++k)
+			t[k] = (int8_t)(hard[i * L + rmap[k]] * hard[(h + i) * L + k]);
+		memcpy(hard + i * L, t, (size_t)L);
+	}
+	for (int k = 0; k < L; ++k)
+		map[k] = lmap[rmap[k]];
+}
+
+int orc_polar_list_decode(float *metric_out, int8_t *mesg_out, const float *llr,
+	const uint32_t *frozen, int level, int L)
+{
+	const int N = 1 << level;
+	scl_t s;
+	s.L = L;
+	s.count = 0;
+	s.frozen = frozen;
+	s.soft = (float *)malloc(sizeof(float) * 2 * (size_t)N * L);
+	s.hard = (int8_t *)malloc((size_t)N * L);
+	s.maps = (uint8_t *)malloc((size_t)N * L);
+	s.mesg = mesg_out;
+	s.metric[0] = 0.f;
+	for (int k = 1; k < L; ++k)
+		s.metric[k] = 1000.f;
+	for (int i = 0; i < N; ++i)
+		for (int k = 0; k < L; ++k)
+			s.soft[(size_t)(N + i) * L + k] = llr[i];
+	uint8_t map[ORC_MAX_LIST];
+	scl_node(&s, level, 0, map);
+	/* back-trace: compose the lane maps from the last leaf to the first */
+	int count = s.count;
+	if (count > 0) {
+		uint8_t acc[ORC_MAX_LIST], nxt[ORC_MAX_LIST];
+		memcpy(acc, s.maps + (size_t)(count - 1) * L, (size_t)L);
+		for (int i = count - 2; i >= 0; --i) {
+			int8_t t[ORC_MAX_LIST];
+			for (int k = 0; k < L; ++k)
+				t[k] = mesg_out[(size_t)i * L + acc[k]];
+			memcpy(mesg_out + (size_t)i * L, t, (size_t)L);
+			for (int k = 0; k < L; ++k)
+				nxt[k] = s.maps[(size_t)i * L + acc[k]];
+			memcpy(acc, nxt, (size_t)L);
+		}
+	}
+	if (metric_out)
+		for (int k = 0; k < L; ++k)
+			metric_out[k] = s.metric[k];
+	free(s.soft);
+	free(s.hard);
+	free(s.maps);
+	return count;
+}

@@ -1,0 +1,207 @@
+"""Known-answer tests the build owns for the primitives the reference takes from absent headers
+(last column)."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as O
+
+
+def test_xorshift32_stream():
+    buf = np.zeros(8, np.uint8)
+    O.lib().orc_scramble(O.ptr(buf), 8)
+    y, exp = 2463534242, []
+    for _ in range(8):
+        y ^= (y << 13) & 0xffffffff; y ^= y >> 17; y ^= (y << 5) & 0xffffffff
+        exp.append(y & 255)
+    assert list(buf) == exp and exp[0] == (723471715 & 255)   # Marsaglia's first output
+
+
+def _mls(poly, n):
+    class M(C.Structure):
+        _fields_ = [("poly", C.c_int), ("test", C.c_int), ("reg", C.c_int)]
+    m = M()
+    O.lib().orc_mls_init(C.byref(m), poly)
+    return [O.lib().orc_mls_next(C.byref(m)) for _ in range(n)]
+
+
+def test_mls_period_and_balance():
+    for poly, per in ((0b10001001, 127), (0b100101011, 255), (0b100101010001, 2047)):
+        s = _mls(poly, 2 * per)
+        assert s[:per] == s[per:] and sum(s[:per]) == (per + 1) // 2
+        v = 1 - 2 * np.array(s[:per])
+        ac = np.array([np.dot(v, np.roll(v, d)) for d in range(1, min(per, 300))])
+        assert (ac == -1).all()                      # two-valued autocorrelation of an m-sequence
+
+
+def test_crc_bit_byte_equivalence_and_residue():
+    L = O.lib()
+    data = O.payload_for(3)
+    crc = L.orc_crc32_bytes(0xD419CC15, O.ptr(data), data.size)
+    ext = np.concatenate([data, np.frombuffer(int(crc).to_bytes(4, "little"), np.uint8)])
+    assert L.orc_crc32_bytes(0xD419CC15, O.ptr(ext), ext.size) == 0      # decode.cc:533-541 residue 0
+    md = (123456789 << 8) | 6
+    cs = L.orc_crc16_u64(0xA8F4, md << 9)
+    # appending the 16-bit CRC LSB-first gives residue 0 as well
+    assert L.orc_crc16_u64(0xA8F4, (md << 9)) == cs and 0 <= cs < 65536
+
+
+def test_base37():
+    L = O.lib()
+    L.orc_base37_encode.restype = C.c_longlong
+    assert L.orc_base37_encode(b"ZZZZZZZZZ") == 37 ** 9 - 1 == 129961739795077 - 1
+    buf = C.create_string_buffer(10)
+    L.orc_base37_decode.argtypes = [C.c_char_p, C.c_longlong, C.c_int]
+    L.orc_base37_decode(buf, L.orc_base37_encode(b"AB1CD"), 9)
+    assert buf.value == b"    AB1CD"
+
+
+def test_fft_against_double_dft():
+    rng = np.random.default_rng(0)
+    for n in (640, 1280, 5120):
+        x = (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex64)
+        for sign in (-1, 1):
+            out = np.zeros(n, np.complex64)
+            O.lib().orc_fft(O.ptr(out), O.ptr(x), n, sign)
+            ref = np.fft.fft(x.astype(np.complex128)) if sign < 0 else np.fft.ifft(x.astype(np.complex128)) * n
+            assert np.abs(out - ref).max() <= 1e-6 * np.abs(ref).max() * np.log2(n)
+
+
+def test_theil_sen_exact_line_with_outliers():
+    x = np.arange(-216, 216, dtype=np.float32)
+    y = (np.float32(0.002) * x + np.float32(0.1)).astype(np.float32)
+    y[::7] += 1.5
+    s, yi = C.c_float(), C.c_float()
+    O.lib().orc_theil_sen(O.ptr(x), O.ptr(y), 432, C.byref(s), C.byref(yi))
+    assert abs(s.value - 0.002) < 1e-6 and abs(yi.value - 0.1) < 1e-5
+    # definition check on a small case: nth_element at count/2 (upper median)
+    xs = np.array([0, 1, 2, 3], np.float32); ys = np.array([0, 1, 0, 5], np.float32)
+    O.lib().orc_theil_sen(O.ptr(xs), O.ptr(ys), 4, C.byref(s), C.byref(yi))
+    sl = sorted((ys[j] - ys[i]) / (xs[j] - xs[i]) for i in range(4) for j in range(i + 1, 4))
+    assert s.value == sl[len(sl) // 2]
+    ic = sorted(ys - np.float32(s.value) * xs)
+    assert yi.value == ic[2]
+
+
+def test_bch_generator_and_encoder():
+    L = O.lib()
+    g = np.zeros((71, 255), np.int8)
+    L.orc_bch_genmat(O.ptr(g))
+    assert (g[:, :71] == np.eye(71, dtype=np.int8)).all()
+    # every row is a codeword of the cyclic code: its cyclic shift stays in the row space
+    wts = g.sum(axis=1)
+    assert wts.min() >= 59          # designed distance of the (255,71) BCH code
+    data = np.zeros(9, np.uint8); par = np.ones(23, np.uint8)
+    L.orc_bch_encode(O.ptr(data), O.ptr(par))
+    assert not par.any()
+    # linearity: parity(a^b) = parity(a)^parity(b)
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, 9, dtype=np.uint8); a[8] &= 0xfe
+    b = rng.integers(0, 256, 9, dtype=np.uint8); b[8] &= 0xfe
+    pa, pb, pab = (np.zeros(23, np.uint8) for _ in range(3))
+    L.orc_bch_encode(O.ptr(a), O.ptr(pa)); L.orc_bch_encode(O.ptr(b), O.ptr(pb))
+    ab = a ^ b
+    L.orc_bch_encode(O.ptr(ab), O.ptr(pab))
+    assert (pab == pa ^ pb).all()
+
+
+def _codeword(rng):
+    L = O.lib()
+    data = rng.integers(0, 256, 9, dtype=np.uint8); data[8] &= 0xfe
+    par = np.zeros(23, np.uint8)
+    L.orc_bch_encode(O.ptr(data), O.ptr(par))
+    bits = np.concatenate([np.unpackbits(data)[:71], np.unpackbits(par)[:184]])
+    return bits
+
+
+def test_osd_clean_errors_and_ambiguity():
+    L = O.lib()
+    g = np.zeros((71, 255), np.int8)
+    L.orc_bch_genmat(O.ptr(g))
+    rng = np.random.default_rng(2)
+    cw = _codeword(rng)
+    soft = (127 * (1 - 2 * cw.astype(np.int32))).astype(np.int8)
+    hard = np.zeros(32, np.uint8)
+    assert L.orc_osd_decode(O.ptr(hard), O.ptr(soft), O.ptr(g)) == 1
+    assert (np.unpackbits(hard)[:255] == cw).all()
+    # 40 sign errors with low reliability, rest noisy: still decodes to cw
+    s2 = (60 * (1 - 2 * cw.astype(np.int32)) + rng.integers(-25, 25, 255)).astype(np.int32)
+    idx = rng.choice(255, 40, replace=False)
+    s2[idx] = -np.sign(s2[idx]) * rng.integers(1, 12, 40)
+    s2 = np.clip(s2, -128, 127).astype(np.int8)
+    assert L.orc_osd_decode(O.ptr(hard), O.ptr(s2), O.ptr(g)) == 1
+    assert (np.unpackbits(hard)[:255] == cw).all()
+    # all-zero reliabilities: every candidate has metric 0 -> not unique
+    z = np.zeros(255, np.int8)
+    assert L.orc_osd_decode(O.ptr(hard), O.ptr(z), O.ptr(g)) == 0
+
+
+def test_polar_systematic_property_and_involution():
+    L = O.lib()
+    fr = O.frozen(0)
+    bits = np.unpackbits(fr.astype("<u4").view(np.uint8), bitorder="little")
+    rng = np.random.default_rng(3)
+    mesg = (1 - 2 * rng.integers(0, 2, 43808)).astype(np.int8)
+    code = np.zeros(65536, np.int8)
+    L.orc_polar_sysenc(O.ptr(code), O.ptr(mesg), O.ptr(fr), 16)
+    assert (code[bits == 0] == mesg).all()                  # decode.cc:547-553 relies on this
+    # the codeword lies in the code: u = x F has +1 on every frozen position (F is an involution)
+    allun = np.zeros(2048, np.uint32)
+    u = np.zeros(65536, np.int8)
+    L.orc_polar_enc(O.ptr(u), O.ptr(code), O.ptr(allun), 16)
+    assert (u[bits == 1] == 1).all()
+
+
+def test_scl_small_codes_against_brute_force_ml():
+    """N=32 toy code: with L=8 the list decoder finds the ML codeword on noisy LLRs"""
+    L = O.lib()
+    N, m = 32, 5
+    # frozen: the 16 least reliable by index weight (RM-like rule) -> (32,16)
+    w = np.array([bin(i).count("1") for i in range(N)])
+    order = np.lexsort((np.arange(N), w))
+    frozen_idx = order[:16]
+    fr = np.zeros(1, np.uint32)
+    for i in frozen_idx:
+        fr[0] |= np.uint32(1 << int(i))
+    un = np.array([i for i in range(N) if not (int(fr[0]) >> i) & 1])
+    allun = np.zeros(1, np.uint32)
+    rng = np.random.default_rng(5)
+    # enumerate all 2^16 codewords
+    msgs = ((np.arange(1 << 16)[:, None] >> np.arange(16)) & 1).astype(np.int8)
+    U = np.zeros((1 << 16, N), np.int8); U[:, un] = msgs
+    X = U.copy()
+    h = 1
+    while h < N:
+        X = X.reshape(-1, N // (2 * h), 2, h)
+        X[:, :, 0, :] ^= X[:, :, 1, :]
+        X = X.reshape(-1, N); h *= 2
+    Xn = 1 - 2 * X.astype(np.int32)
+    ok = 0
+    for trial in range(40):
+        tx = Xn[rng.integers(0, 1 << 16)]
+        llr = (4.0 * tx + rng.normal(0, 2.2, N)).astype(np.float32)
+        corr = Xn @ llr.astype(np.float64)
+        ml = int(np.argmax(corr))
+        mesg = np.zeros((16, 8), np.int8); metric = np.zeros(8, np.float32)
+        cnt = L.orc_polar_list_decode(O.ptr(metric), O.ptr(mesg), O.ptr(llr), O.ptr(fr), m, 8)
+        assert cnt == 16
+        lanes = [tuple((mesg[:, k] < 0).astype(int)) for k in range(8)]
+        assert (np.diff(metric) >= 0).all()           # survivors stored sorted by metric
+        ok += tuple(msgs[ml]) in lanes
+    assert ok >= 38
+
+
+def test_hilbert_is_analytic():
+    """mono front end: a real tone becomes a one-sided spectrum (image rejected)"""
+    n = 8000
+    t = np.arange(n)
+    x = np.round(8000 * np.cos(2 * np.pi * 1000 * t / 8000)).astype(np.int16)
+    z = np.zeros((n, 2), np.float32)
+    O.lib().orc_front_end(O.ptr(x), O.FMT_S16, 1, n, O.ptr(z))
+    zc = z[2000:, 0] + 1j * z[2000:, 1]
+    S = np.abs(np.fft.fft(zc * np.hanning(zc.size)))
+    k = int(1000 * zc.size / 8000)
+    assert S[k - 2:k + 3].max() > 300 * S[-k - 2:-k + 3].max()
+    re, im = C.c_float(), (C.c_float * 5)()
+    O.lib().orc_hilbert_coeffs(C.byref(re), im)
+    assert re.value == 1.0 and abs(im[0] - 2 / np.pi * 0.98) < 0.02 and all(im[i] > im[i + 1] > 0 for i in range(4))
