@@ -1,0 +1,171 @@
+/*
+ * ofdmrx.h -- C ABI of the MI355X-native OFDM receive path (libofdmrx.so).
+ *
+ * Drop-in boundary.  The reference has no plugin / FFI layer;
+ * its only seams are
+ *   (1) the process boundary   decode OUTPUT INPUT [SKIP]       decode.cc:559-563
+ *   (2) the in-process seam    Decoder<value,cmplx,rate>(uint8_t *out,
+ *           DSP::ReadPCM<value> *pcm, int skip_count)            decode.cc:375
+ *       which pulls samples with pcm->read()/channels()/rate()   decode.cc:297-298,590
+ *       and leaves 5380 payload bytes in `out`, which main() descrambles
+ *       and writes                                               decode.cc:608-617
+ * This library replaces seam (2) for batches of independent frames: the caller
+ * (the `decode` CLI, a batch driver, or a binding) reads the WAV body into
+ * memory and hands over raw PCM; the library returns payload bytes plus a
+ * per-frame result struct carrying every diagnostic the reference prints to
+ * stderr (decode.cc:400-401,438,446,502-503,517-519,555) and every failure
+ * cause (decode.cc:393,419,430,435,440,543).
+ *
+ * Conventions: plain C, no exceptions across the ABI.  Return value 0 = ok,
+ * negative = API / HIP error (ofdmrx_strerror).  A frame that fails to decode
+ * is DATA (result.status), never an API error.  All buffers are caller-owned.
+ * A handle is not thread-safe: one handle per (host thread, GPU).
+ */
+#ifndef OFDMRX_H
+#define OFDMRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFDMRX_ABI_VERSION 1
+
+#define OFDMRX_PAYLOAD_BYTES 5380     /* decode.cc:587  data_len = 43040/8 */
+#define OFDMRX_CODE_LEN 65536         /* decode.cc:309  code_order 16 */
+#define OFDMRX_FRAME_SAMPLES 95200    /* one-frame file written by encode @ 8 kHz */
+#define OFDMRX_MAX_LIST 8
+
+/* sample formats of the PCM body (what DSP::ReadWAV accepts, decode.cc:576) */
+enum { OFDMRX_FMT_S16 = 0, OFDMRX_FMT_U8 = 1, OFDMRX_FMT_F32 = 2 };
+
+/* per-frame status: one value per exit of Decoder::Decoder */
+enum {
+	OFDMRX_OK = 0,
+	OFDMRX_NO_SYNC = 1,        /* decode.cc:393-394  stream ended while searching */
+	OFDMRX_OSD_ERROR = 2,      /* decode.cc:418-421 */
+	OFDMRX_HEADER_CRC = 3,     /* decode.cc:429-432 */
+	OFDMRX_BAD_MODE = 4,       /* decode.cc:434-437 (this build decodes mode 6 payloads) */
+	OFDMRX_BAD_CALLSIGN = 5,   /* decode.cc:439-442 */
+	OFDMRX_PAYLOAD_CRC = 6     /* decode.cc:542-545 */
+};
+
+/* API error codes */
+enum {
+	OFDMRX_E_ARG = -1, OFDMRX_E_NOMEM = -2, OFDMRX_E_HIP = -3, OFDMRX_E_NODEV = -4, OFDMRX_E_UNSUPPORTED = -5
+};
+
+typedef struct ofdmrx_handle ofdmrx_handle;
+
+typedef struct {
+	int32_t abi_version;       /* OFDMRX_ABI_VERSION */
+	int32_t sample_rate;       /* 8000 (decode.cc:590-593); other rates: OFDMRX_E_UNSUPPORTED */
+	int32_t list_size;         /* SCL list = SIMD width of the reference build (decode.cc:164-169): 8 */
+	int32_t device;            /* HIP device ordinal */
+	int32_t chunk_frames;      /* frames resident per pass (0 = default) */
+	int32_t max_samples;       /* max samples per frame (0 = OFDMRX_FRAME_SAMPLES) */
+	int32_t descramble;        /* 1 = XOR payload with Xorshift32 like main(), decode.cc:613-615 */
+	int32_t flags;             /* bit 0: keep the pre-rotation constellation (OFDMRX_TAP_CONS_RAW) */
+	void *stream;              /* hipStream_t to run on, NULL = library-owned stream */
+} ofdmrx_config;
+
+/* mirrors the reference's stderr diagnostics */
+typedef struct {
+	int32_t status;            /* OFDMRX_OK ... */
+	int32_t symbol_pos;        /* decode.cc:400 "symbol pos" (window coordinate) */
+	int64_t sc_start;          /* stream index of the Schmidl-Cox symbol body, -1 if none */
+	float cfo_rad;             /* decode.cc:399,401 coarse cfo, rad/sample */
+	float cfo_fine;            /* decode.cc:501,503 finer cfo */
+	float sfo_slope;           /* decode.cc:498 average Theil-Sen slope */
+	int32_t oper_mode;         /* decode.cc:438 */
+	uint64_t call_sign;        /* decode.cc:439-446, base-37 integer */
+	int32_t best_lane;         /* decode.cc:532-541, -1 if no lane passed CRC-32 */
+	int32_t bit_flips;         /* decode.cc:555 */
+	float esn0_db_last;        /* decode.cc:517-519, cumulative Es/N0 after the last row */
+	int32_t n_sync_rejects;    /* falling edges rejected at decode.cc:140-145 */
+} ofdmrx_frame_result;
+
+/* hipEvent timings of the last decode call, milliseconds, summed over chunks */
+enum {
+	OFDMRX_T_FRONT = 0, OFDMRX_T_SYNC, OFDMRX_T_HEADER, OFDMRX_T_DEMOD, OFDMRX_T_THEILSEN,
+	OFDMRX_T_LLR, OFDMRX_T_POLAR, OFDMRX_T_FINISH, OFDMRX_T_TOTAL, OFDMRX_T_COUNT
+};
+typedef struct {
+	float ms[OFDMRX_T_COUNT];
+	int32_t launches[OFDMRX_T_COUNT];   /* kernel launches per stage */
+} ofdmrx_timing;
+
+int ofdmrx_abi_version(void);
+const char *ofdmrx_strerror(int err);
+
+/* replaces `new Decoder<value,cmplx,8000>` (decode.cc:592): allocates device
+ * state, tables (frozen mask, twiddles, MLS kernels, BCH generator) once */
+int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out);
+void ofdmrx_destroy(ofdmrx_handle *h);
+
+/*
+ * Decode n_frames independent frames.  Frame f occupies
+ * samples + f*frame_stride_bytes, samples_per_frame sample frames of
+ * `channels` interleaved values (1 = real, 2 = analytic I/Q; decode.cc:578,298).
+ * skip_counts[f] (nullable) is decode.cc's SKIP argument (decode.cc:583-585,448).
+ * payload_out: n_frames*5380 bytes, zeroed for failed frames (the reference
+ * leaves them uninitialised, decode.cc:588).
+ * HOST pointers; blocks until done.
+ */
+int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int sample_format, int channels,
+	size_t samples_per_frame, size_t frame_stride_bytes, size_t n_frames,
+	const int32_t *skip_counts, uint8_t *payload_out, ofdmrx_frame_result *results);
+
+/* same with DEVICE pointers (inputs already resident in HBM); asynchronous on
+ * the handle's stream.  d_payload_out / d_results are device buffers. */
+int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int sample_format, int channels,
+	size_t samples_per_frame, size_t frame_stride_bytes, size_t n_frames,
+	const int32_t *d_skip_counts, uint8_t *d_payload_out, ofdmrx_frame_result *d_results);
+
+int ofdmrx_synchronize(ofdmrx_handle *h);
+int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t);
+int ofdmrx_chunk_frames(ofdmrx_handle *h);
+
+/* ---- stage taps for parity tests (host destination buffers) --------------
+ * Valid for frames of the LAST chunk processed (frame index relative to that
+ * chunk's first frame). */
+enum {
+	OFDMRX_TAP_HDR_SOFT = 1,   /* int8  [255]      decode.cc:413-416 */
+	OFDMRX_TAP_CONS_RAW = 2,   /* cf32  [21600]    decode.cc:464-477 */
+	OFDMRX_TAP_CONS_ROT = 3,   /* cf32  [21600]    decode.cc:481-495 */
+	OFDMRX_TAP_SLOPE = 4,      /* f32   [50] */
+	OFDMRX_TAP_YINT = 5,       /* f32   [50] */
+	OFDMRX_TAP_PRECISION = 6,  /* f32   [50]       decode.cc:517 */
+	OFDMRX_TAP_LLR = 7,        /* f32   [65536]    decode.cc:529 */
+	OFDMRX_TAP_METRIC = 8,     /* f32   [8] */
+	OFDMRX_TAP_LANE_MESG = 9,  /* u8    [8][5476]  systematic message bits per lane, LE packed */
+	OFDMRX_TAP_ANALYTIC = 10   /* cf32  [samples]  after D1 (mono only) */
+};
+int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *dst, size_t dst_bytes);
+
+/* ---- single-stage entry points for parity tests (HOST pointers) ---------- */
+/* D9+D10: CODE::PolarListDecoder + systematic() (decode.cc:530-531) */
+int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n,
+	uint8_t *lane_mesg /*n*8*5476*/, float *metric /*n*8*/);
+/* DSP::TheilSenEstimator::compute on rows of y[cols], x = i - cols/2 (decode.cc:488) */
+int ofdmrx_debug_theil_sen(ofdmrx_handle *h, const float *y, size_t rows, int cols,
+	float *slope, float *yint);
+/* CODE::OrderedStatisticsDecoder<255,71,4> (decode.cc:417): soft n*255 -> hard n*32 (BE bits), unique n */
+int ofdmrx_debug_osd(ofdmrx_handle *h, const int8_t *soft, size_t n, uint8_t *hard, int32_t *unique);
+/* DSP::FastFourierTransform<1280|640,cmplx,-1|+1> (decode.cc:191,43-44): n transforms */
+int ofdmrx_debug_fft(ofdmrx_handle *h, const float *in, size_t n, int len, int sign, float *out);
+
+/* ---- build-owned channel model on device (aicodix/disorders is absent) ----
+ * out frame f = base frame (f % n_base) + complex AWGN of power 10^(noise_db/10)
+ * (re/im split equally), counter-based RNG keyed by (seed, first_frame+f).
+ * 2-channel int16 in and out, DEVICE pointers, samples_per_frame each. */
+int ofdmrx_util_awgn_tile(ofdmrx_handle *h, const int16_t *d_base, size_t n_base,
+	int16_t *d_out, size_t n_out, size_t samples_per_frame, float noise_db,
+	uint64_t seed, uint64_t first_frame);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

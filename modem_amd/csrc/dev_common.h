@@ -1,0 +1,235 @@
+// dev_common.h -- shared device helpers for the gfx950 OFDM receive kernels.
+// Wave = 64 lanes everywhere (CDNA4); no warp-size abstraction on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rx {
+
+constexpr int SYMBOL_LEN = 1280;    // decode.cc:171
+constexpr int GUARD_LEN = 160;      // decode.cc:173
+constexpr int SYM_STRIDE = 1440;    // symbol_len + guard_len
+constexpr int HALF_LEN = 640;       // correlator symbol_len, decode.cc:196
+constexpr int BUFFER_LEN = 8640;    // decode.cc:188
+constexpr int SEARCH_POS = 2880;    // decode.cc:189
+constexpr int MATCH_LEN = 161;      // decode.cc:41
+constexpr int MATCH_DEL = 80;       // decode.cc:42
+constexpr int CONS_COLS = 432;      // decode.cc:306 (mode 6)
+constexpr int CONS_ROWS = 50;       // decode.cc:453
+constexpr int CONS_CNT = 21600;     // decode.cc:372
+constexpr int CONS_BITS = 64800;    // decode.cc:310
+constexpr int MESG_BITS = 43808;    // decode.cc:311
+constexpr int DATA_BITS = 43040;    // decode.cc:174
+constexpr int CRC_BITS = 43072;     // decode.cc:175
+constexpr int CODE_LEN = 65536;
+constexpr int PAYLOAD_BYTES = 5380;
+constexpr int MESG_BYTES = 5476;    // 43808 / 8
+constexpr int LIST = 8;             // decode.cc:164-169 (AVX2 build)
+constexpr int MLS1_LEN = 255;       // decode.cc:185
+constexpr int BCH_N = 255, BCH_K = 71;
+
+constexpr float TWO_PI_F = 6.28318530717958647692f;
+constexpr float PI_F = 3.14159265358979323846f;
+
+struct cf { float re, im; };
+
+__device__ __forceinline__ cf mk(float re, float im) { cf r; r.re = re; r.im = im; return r; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return mk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return mk(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__device__ __forceinline__ cf cconj(cf a) { return mk(a.re, -a.im); }
+__device__ __forceinline__ float cnorm(cf a) { return a.re * a.re + a.im * a.im; }
+__device__ __forceinline__ cf cmul_negj(cf a) { return mk(a.im, -a.re); }   // a * (-j)
+
+// DSP::Complex operator/ = a*conj(b)/norm(b); decode.cc:62-70 / 227-235
+__device__ __forceinline__ cf demod_or_erase(cf curr, cf prev)
+{
+	float d = cnorm(prev);
+	if (!(d > 0.f))
+		return mk(0.f, 0.f);
+	cf n = cmul(curr, cconj(prev));
+	cf c = mk(n.re / d, n.im / d);
+	if (!(cnorm(c) <= 4.f))
+		return mk(0.f, 0.f);
+	return c;
+}
+
+// unit phasor e^{j*omega*k}; phase in double like the oracle's closed form of DSP::Phasor
+__device__ __forceinline__ cf phasor(float omega, long k)
+{
+	double a = (double)omega * (double)k;
+	const double inv2pi = 0.15915494309189533577, twopi = 6.28318530717958647692;
+	a -= twopi * rint(a * inv2pi);
+	float s, c;
+	sincosf((float)a, &s, &c);
+	return mk(c, s);
+}
+
+// ---- raw PCM access: what DSP::ReadWAV + next_sample() deliver for 2-channel input
+struct SampleSrc {
+	const void *base;      // first sample of this frame
+	int fmt;               // OFDMRX_FMT_*
+	int channels;
+	long n;                // samples in the frame
+	const cf *analytic;    // mono: output of the front-end kernel (D1), else nullptr
+	__device__ __forceinline__ float scalar(long idx) const
+	{
+		if (fmt == 0) return (float)((const int16_t *)base)[idx] / 32767.f;
+		if (fmt == 1) return (float)((int)((const uint8_t *)base)[idx] - 128) / 127.f;
+		return ((const float *)base)[idx];
+	}
+	__device__ __forceinline__ cf at(long i) const
+	{
+		if (i < 0 || i >= n)
+			return mk(0.f, 0.f);
+		if (analytic)
+			return analytic[i];
+		if (fmt == 0) {
+			short2 v = ((const short2 *)base)[i];
+			return mk((float)v.x / 32767.f, (float)v.y / 32767.f);
+		}
+		return mk(scalar(2 * i), scalar(2 * i + 1));
+	}
+};
+
+// ---- Stockham radix stages in LDS, NT threads cooperate on one N-point transform.
+// Forward transform e^{-j 2 pi k n / N}; tw = table of 1280 roots e^{-j 2 pi m / 1280}.
+// P = product of the radices of the previous stages.  Caller syncs before the first stage.
+template <int R> struct Bfly;
+template <> struct Bfly<2> {
+	static __device__ __forceinline__ void run(cf *v) { cf a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b); }
+};
+template <> struct Bfly<4> {
+	static __device__ __forceinline__ void run(cf *v)
+	{
+		cf s0 = cadd(v[0], v[2]), s1 = csub(v[0], v[2]);
+		cf s2 = cadd(v[1], v[3]), s3 = cmul_negj(csub(v[1], v[3]));
+		v[0] = cadd(s0, s2); v[1] = cadd(s1, s3); v[2] = csub(s0, s2); v[3] = csub(s1, s3);
+	}
+};
+template <> struct Bfly<5> {
+	static __device__ __forceinline__ void run(cf *v)
+	{
+		const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+		const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+		cf a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]);
+		cf b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+		cf m1 = mk(v[0].re + c1 * a1.re + c2 * a2.re, v[0].im + c1 * a1.im + c2 * a2.im);
+		cf m2 = mk(v[0].re + c2 * a1.re + c1 * a2.re, v[0].im + c2 * a1.im + c1 * a2.im);
+		cf n1 = mk(s1 * b1.re + s2 * b2.re, s1 * b1.im + s2 * b2.im);
+		cf n2 = mk(s2 * b1.re - s1 * b2.re, s2 * b1.im - s1 * b2.im);
+		cf y0 = cadd(v[0], cadd(a1, a2));
+		cf jn1 = cmul_negj(n1), jn2 = cmul_negj(n2);   // -j*n
+		v[0] = y0;
+		v[1] = cadd(m1, jn1); v[4] = csub(m1, jn1);
+		v[2] = cadd(m2, jn2); v[3] = csub(m2, jn2);
+	}
+};
+
+template <int N, int R, int P, int NT>
+__device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
+{
+	constexpr int T = N / R;
+	constexpr int NB = (T + NT - 1) / NT;
+	constexpr int TWS = 1280 / (P * R);
+	cf v[NB][R];
+	#pragma unroll
+	for (int q = 0; q < NB; ++q) {
+		int b = tid + q * NT;
+		if (b < T) {
+			int k = b % P;
+			#pragma unroll
+			for (int t = 0; t < R; ++t) {
+				cf x = buf[b + t * T];
+				if (t && P > 1)
+					x = cmul(x, tw[(t * k) * TWS]);
+				v[q][t] = x;
+			}
+			Bfly<R>::run(v[q]);
+		}
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int q = 0; q < NB; ++q) {
+		int b = tid + q * NT;
+		if (b < T) {
+			int k = b % P;
+			int j = (b - k) * R + k;
+			#pragma unroll
+			for (int t = 0; t < R; ++t)
+				buf[j + t * P] = v[q][t];
+		}
+	}
+	__syncthreads();
+}
+
+// forward 1280 = 5*4*4*4*4, in place in LDS, natural order in and out
+template <int NT>
+__device__ __forceinline__ void fft1280(cf *buf, const cf *tw, int tid)
+{
+	fft_stage<1280, 5, 1, NT>(buf, tw, tid);
+	fft_stage<1280, 4, 5, NT>(buf, tw, tid);
+	fft_stage<1280, 4, 20, NT>(buf, tw, tid);
+	fft_stage<1280, 4, 80, NT>(buf, tw, tid);
+	fft_stage<1280, 4, 320, NT>(buf, tw, tid);
+}
+// forward 640 = 5*4*4*4*2
+template <int NT>
+__device__ __forceinline__ void fft640(cf *buf, const cf *tw, int tid)
+{
+	fft_stage<640, 5, 1, NT>(buf, tw, tid);
+	fft_stage<640, 4, 5, NT>(buf, tw, tid);
+	fft_stage<640, 4, 20, NT>(buf, tw, tid);
+	fft_stage<640, 4, 80, NT>(buf, tw, tid);
+	fft_stage<640, 2, 320, NT>(buf, tw, tid);
+}
+
+// ---- wave helpers ----------------------------------------------------------
+__device__ __forceinline__ double shfl_d(double v, int src)
+{
+	int lo = __double2loint(v), hi = __double2hiint(v);
+	lo = __shfl(lo, src);
+	hi = __shfl(hi, src);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_up_d(double v, int d)
+{
+	int lo = __double2loint(v), hi = __double2hiint(v);
+	lo = __shfl_up(lo, d);
+	hi = __shfl_up(hi, d);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_d(double v, int m)
+{
+	int lo = __double2loint(v), hi = __double2hiint(v);
+	lo = __shfl_xor(lo, m);
+	hi = __shfl_xor(hi, m);
+	return __hiloint2double(hi, lo);
+}
+// inclusive scan of one double per lane across the wave
+__device__ __forceinline__ double wave_scan_incl(double v, int lane)
+{
+	#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		double o = shfl_up_d(v, d);
+		if (lane >= d)
+			v += o;
+	}
+	return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+	#pragma unroll
+	for (int m = 32; m; m >>= 1)
+		v += shfl_xor_d(v, m);
+	return v;
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+	#pragma unroll
+	for (int m = 32; m; m >>= 1)
+		v = min(v, __shfl_xor(v, m));
+	return v;
+}
+
+}  // namespace rx

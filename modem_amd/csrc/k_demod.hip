@@ -1,0 +1,327 @@
+// k_demod.hip -- D4 (51 x FFT1280 + time-differential demod), D5 (Theil-Sen phase-slope
+// correction), D6/D7 (cumulative SNR estimate + 8PSK soft demap), D8 (lengthen) for gfx950.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace rx {
+
+// ---- psk.hh:90-140 PhaseShiftKeying<8, cmplx, float> ---------------------------------
+__device__ __forceinline__ cf psk8_hard_map(cf c)   // map(hard(c)): psk.hh:118-123,132-139
+{
+	const float cos_pi_8 = 0.92387953251128675613f, sin_pi_8 = 0.38268343236508977173f;
+	float b1 = c.re < 0.f ? -1.f : 1.f;
+	float b2 = c.im < 0.f ? -1.f : 1.f;
+	bool swap = fabsf(c.re) < fabsf(c.im);
+	float real = swap ? sin_pi_8 : cos_pi_8, imag = swap ? cos_pi_8 : sin_pi_8;
+	return mk(real * b1, imag * b2);
+}
+
+// ---------------------------------------------------------------- D4
+struct DemodShared {
+	cf fft[4][SYMBOL_LEN];
+	cf carr[8][CONS_COLS];
+};
+
+// decode.cc:453-477.  One workgroup (4 waves) per frame; wave w transforms symbol 4g+w of
+// group g in its own LDS buffer (radix 5,4,4,4,4 Stockham stages); the 432 payload carriers
+// of each symbol are parked in an 8-slot LDS ring so that cons = X_j / X_{j-1} needs no
+// second pass over HBM.  Samples are read once, straight from the raw PCM (int16 pairs).
+__global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
+	const SyncState *__restrict__ st_all, cf *__restrict__ cons_all)
+{
+	const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const SyncState st = st_all[f];
+	if (!st.okay)
+		return;
+	__shared__ DemodShared sh;
+	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, fb.samples_per_frame,
+		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
+	cf *cons = cons_all + (size_t)f * CONS_CNT;
+	const long body0 = st.sc_start + 2 * SYM_STRIDE;          // pilot body, decode.cc:456-459
+	const float omega = -st.cfo_rad;                          // decode.cc:403
+	const int code_off = -CONS_COLS / 2;                      // decode.cc:454
+	for (int g = 0; g < 13; ++g) {
+		const int s = 4 * g + wave;                           // 0 = pilot, 1..50 = data rows
+		const bool valid = s <= CONS_ROWS;
+		cf *buf = sh.fft[wave];
+		#pragma unroll 4
+		for (int q = 0; q < SYMBOL_LEN / 64; ++q) {
+			int i = lane + 64 * q;
+			cf v = mk(0.f, 0.f);
+			if (valid)   // osc() call count: 1280 (header) + s*1440 + i, decode.cc:459-470
+				v = cmul(src.at(body0 + (long)s * SYM_STRIDE + i), phasor(omega, 1280L + (long)s * SYM_STRIDE + i));
+			buf[i] = v;
+		}
+		__syncthreads();
+		fft1280<64>(buf, tb.tw1280, lane);
+		if (valid)
+			for (int i = lane; i < CONS_COLS; i += 64)
+				sh.carr[s & 7][i] = buf[(i + code_off + SYMBOL_LEN) % SYMBOL_LEN];
+		__syncthreads();
+		if (valid && s >= 1)
+			for (int i = lane; i < CONS_COLS; i += 64)      // decode.cc:474-475
+				cons[(s - 1) * CONS_COLS + i] = demod_or_erase(sh.carr[s & 7][i], sh.carr[(s - 1) & 7][i]);
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------- D5 Theil-Sen
+// DSP::TheilSenEstimator<value,512>::compute (decode.cc:488): median (rank count/2) of all
+// pairwise slopes, then median of the intercepts.  Exact selection by a 3-pass radix select
+// (11+11+10 bits of the order-preserving key) with the slopes recomputed on the fly from the
+// 432 phases held in LDS; fp32 division is correctly rounded so slopes are bit-identical to
+// the CPU's.
+struct TsShared {
+	float y[512];
+	float ic[512];
+	int hist[2048];
+	int part[256];
+	unsigned prefix;
+	int rank;
+};
+
+__device__ __forceinline__ unsigned fkey(float v)
+{
+	unsigned b = __float_as_uint(v);
+	return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k)
+{
+	unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+	return __uint_as_float(b);
+}
+
+template <typename F>
+__device__ __forceinline__ void for_each_pair(int n, int tid, F fn)
+{
+	// fold distance q with n-q so every fold has n items (i, d): all i<j pairs exactly once
+	const int folds = (n - 1) / 2;
+	for (int q = 1; q <= folds; ++q)
+		for (int e = tid; e < n; e += 256) {
+			int i, d;
+			if (e < n - q) { i = e; d = q; }
+			else { i = e - (n - q); d = n - q; }
+			fn(i, d);
+		}
+	if ((n & 1) == 0) {
+		int d = n / 2;
+		for (int e = tid; e < n - d; e += 256)
+			fn(e, d);
+	}
+}
+
+__device__ void radix_pass(TsShared &s, int n, int tid, int shift, int bits, unsigned mask_hi)
+{
+	for (int i = tid; i < 2048; i += 256)
+		s.hist[i] = 0;
+	__syncthreads();
+	const unsigned prefix = s.prefix, bmask = (1u << bits) - 1;
+	for_each_pair(n, tid, [&](int i, int d) {
+		float sl = (s.y[i + d] - s.y[i]) / (float)d;
+		unsigned k = fkey(sl);
+		if ((k & mask_hi) == prefix)
+			atomicAdd(&s.hist[(k >> shift) & bmask], 1);
+	});
+	__syncthreads();
+	const int nb = 1 << bits, per = nb / 256;
+	int acc = 0;
+	for (int q = 0; q < per; ++q)
+		acc += s.hist[tid * per + q];
+	s.part[tid] = acc;
+	__syncthreads();
+	if (tid == 0) {
+		int r = s.rank, t = 0;
+		while (t < 255 && r >= s.part[t]) { r -= s.part[t]; ++t; }
+		int b = t * per;
+		while (b < nb - 1 && r >= s.hist[b]) { r -= s.hist[b]; ++b; }
+		s.rank = r;
+		s.prefix = prefix | ((unsigned)b << shift);
+	}
+	__syncthreads();
+}
+
+// y[0..n) in s.y ; x[i] = i - n/2.  Returns slope and yint in all threads.
+__device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float &yint)
+{
+	const int count = n * (n - 1) / 2;
+	if (tid == 0) { s.prefix = 0; s.rank = count / 2; }
+	__syncthreads();
+	radix_pass(s, n, tid, 21, 11, 0u);
+	radix_pass(s, n, tid, 10, 11, 0xffe00000u);
+	radix_pass(s, n, tid, 0, 10, 0xfffffc00u);
+	slope = fkey_inv(s.prefix);
+	const int xoff = n / 2;
+	for (int i = tid; i < n; i += 256)
+		s.ic[i] = __fsub_rn(s.y[i], __fmul_rn(slope, (float)(i - xoff)));   // no FMA contraction: bit-exact vs CPU
+	__syncthreads();
+	// value at sorted position n/2 of the intercepts: rank counting
+	for (int i = tid; i < n; i += 256) {
+		float v = s.ic[i];
+		int less = 0, eq = 0;
+		for (int j = 0; j < n; ++j) {
+			float o = s.ic[j];
+			less += o < v;
+			eq += o == v;
+		}
+		if (less <= n / 2 && n / 2 < less + eq)
+			s.y[511] = v;   // every qualifying thread writes the same value
+	}
+	__syncthreads();
+	yint = s.y[511];
+	__syncthreads();
+}
+
+// decode.cc:479-504: one workgroup per (frame, row)
+__global__ __launch_bounds__(256) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
+	float *__restrict__ slope_all, float *__restrict__ yint_all)
+{
+	const int f = blockIdx.x / CONS_ROWS, j = blockIdx.x % CONS_ROWS, tid = threadIdx.x;
+	if (!st_all[f].okay)
+		return;
+	__shared__ TsShared s;
+	cf *row = cons_all + (size_t)f * CONS_CNT + (size_t)j * CONS_COLS;
+	for (int i = tid; i < CONS_COLS; i += 256) {              // decode.cc:482-487
+		cf c = row[i];
+		cf d = cmul(c, cconj(psk8_hard_map(c)));
+		s.y[i] = atan2f(d.im, d.re);
+	}
+	__syncthreads();
+	float slope, yint;
+	theil_sen_block(s, CONS_COLS, tid, slope, yint);
+	for (int i = tid; i < CONS_COLS; i += 256) {              // decode.cc:493-494
+		float a = -(yint + slope * (float)(i - CONS_COLS / 2));
+		float sn, cs;
+		sincosf(a, &sn, &cs);
+		row[i] = cmul(row[i], mk(cs, sn));
+	}
+	if (tid == 0) {
+		slope_all[(size_t)f * CONS_ROWS + j] = slope;
+		yint_all[(size_t)f * CONS_ROWS + j] = yint;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_theil_sen_raw(int cols, const float *__restrict__ y, float *__restrict__ slope_all,
+	float *__restrict__ yint_all)
+{
+	const int r = blockIdx.x, tid = threadIdx.x;
+	__shared__ TsShared s;
+	for (int i = tid; i < cols; i += 256)
+		s.y[i] = y[(size_t)r * cols + i];
+	__syncthreads();
+	float slope, yint;
+	theil_sen_block(s, cols, tid, slope, yint);
+	if (tid == 0) { slope_all[r] = slope; yint_all[r] = yint; }
+}
+
+// ---------------------------------------------------------------- D6 + D7 + D8
+// decode.cc:505-529.  sp/np accumulate ACROSS rows (decode.cc:507 is outside the row loop):
+// per row the 432 terms are reduced in double and folded into the running fp32 sums once,
+// then the row's soft bits are emitted with that row's cumulative precision.
+__global__ __launch_bounds__(256) void k_llr(const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
+	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
+	float *__restrict__ llr_all, Result *__restrict__ res_all)
+{
+	const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const SyncState st = st_all[f];
+	if (!st.okay)
+		return;
+	__shared__ double red[2][4];
+	const cf *cons = cons_all + (size_t)f * CONS_CNT;
+	float *llr = llr_all + (size_t)f * CODE_LEN;
+	const float DIST = 2.f * 0.38268343236508977173f;         // psk.hh:106
+	const float rcp_sqrt_2 = 0.70710678118654752440f;         // psk.hh:104
+	float sp = 0.f, np = 0.f, precision = 0.f;
+	for (int j = 0; j < CONS_ROWS; ++j) {
+		double dsp = 0.0, dnp = 0.0;
+		cf c[2];
+		#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			int i = tid + 256 * q;
+			c[q] = mk(0.f, 0.f);
+			if (i < CONS_COLS) {
+				c[q] = cons[j * CONS_COLS + i];
+				cf h = psk8_hard_map(c[q]);                   // decode.cc:509-511
+				double er = (double)c[q].re - h.re, ei = (double)c[q].im - h.im;
+				dsp += (double)h.re * h.re + (double)h.im * h.im;
+				dnp += er * er + ei * ei;
+			}
+		}
+		dsp = wave_sum_d(dsp);
+		dnp = wave_sum_d(dnp);
+		if (lane == 0) { red[0][wave] = dsp; red[1][wave] = dnp; }
+		__syncthreads();
+		dsp = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+		dnp = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+		__syncthreads();
+		sp = (float)((double)sp + dsp);
+		np = (float)((double)np + dnp);
+		precision = sp / np;                                  // decode.cc:516
+		if (tid == 0)
+			precision_all[(size_t)f * CONS_ROWS + j] = precision;
+		#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			int i = tid + 256 * q;
+			if (i < CONS_COLS) {                              // psk.hh:125-130, decode.cc:520-521
+				float *b = llr + 3 * (j * CONS_COLS + i);
+				float sc = DIST * precision;
+				b[1] = c[q].re * sc;
+				b[2] = c[q].im * sc;
+				b[0] = (rcp_sqrt_2 * (fabsf(c[q].re) - fabsf(c[q].im))) * sc;
+			}
+		}
+	}
+	// lengthen(): the shortened positions are the index tail [64800,65536), +9000
+	for (int i = CONS_BITS + tid; i < CODE_LEN; i += 256)
+		llr[i] = 9000.f;                                      // decode.cc:252
+	if (tid == 0) {
+		float sum_slope = 0.f, sum_yint = 0.f;
+		for (int j = 0; j < CONS_ROWS; ++j) {                 // decode.cc:491-492
+			sum_slope += slope_all[(size_t)f * CONS_ROWS + j];
+			sum_yint += yint_all[(size_t)f * CONS_ROWS + j];
+		}
+		Result &r = res_all[f];
+		r.sfo_slope = sum_slope / (float)CONS_ROWS;
+		r.cfo_fine = st.cfo_rad + (sum_yint / (float)CONS_ROWS) / (float)SYM_STRIDE;   // decode.cc:501
+		r.esn0_db_last = 10.f * log10f(precision);            // decode.cc:518
+	}
+}
+
+// ---------------------------------------------------------------- debug FFT entry
+__global__ __launch_bounds__(256) void k_fft_debug(int len, int sign, const cf *__restrict__ in, cf *__restrict__ out, const cf *__restrict__ tw)
+{
+	const int f = blockIdx.x, tid = threadIdx.x;
+	__shared__ cf buf[SYMBOL_LEN];
+	for (int i = tid; i < len; i += 256) {
+		cf v = in[(size_t)f * len + i];
+		buf[i] = sign > 0 ? cconj(v) : v;
+	}
+	__syncthreads();
+	if (len == SYMBOL_LEN) fft1280<256>(buf, tw, tid);
+	else fft640<256>(buf, tw, tid);
+	for (int i = tid; i < len; i += 256)
+		out[(size_t)f * len + i] = sign > 0 ? cconj(buf[i]) : buf[i];
+}
+
+void launch_demod(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons)
+{
+	hipLaunchKernelGGL(k_demod, dim3(n), dim3(256), 0, s, fb, z, tb, st, cons);
+}
+void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, float *slope, float *yint)
+{
+	hipLaunchKernelGGL(k_theil_sen, dim3(n * CONS_ROWS), dim3(256), 0, s, st, cons, slope, yint);
+}
+void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint)
+{
+	hipLaunchKernelGGL(k_theil_sen_raw, dim3(rows), dim3(256), 0, s, cols, y, slope, yint);
+}
+void launch_llr(hipStream_t s, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
+	float *precision, float *llr, Result *res)
+{
+	hipLaunchKernelGGL(k_llr, dim3(n), dim3(256), 0, s, st, cons, slope, yint, precision, llr, res);
+}
+void launch_fft_debug(hipStream_t s, int n, int len, int sign, const cf *in, cf *out, Tables tb)
+{
+	hipLaunchKernelGGL(k_fft_debug, dim3(n), dim3(256), 0, s, len, sign, in, out, tb.tw1280);
+}
+
+}  // namespace rx

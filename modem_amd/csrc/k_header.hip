@@ -1,0 +1,357 @@
+// k_header.hip -- D3h: header symbol (decode.cc:403-447) for gfx950.
+//   derotate 1280 samples at sc_start+1440, FFT1280, MLS1 descramble, differential
+//   BPSK across 255 bins -> int8 soft values -> OrderedStatisticsDecoder<255,71,4>
+//   -> 55-bit metadata + CRC-16 -> oper_mode / call sign checks.
+// One 256-thread workgroup per frame.  The OSD keeps the permuted generator matrix
+// bit-packed in LDS (71 rows x 8 words), reduces it with Gauss-Jordan (pivot search and
+// column swaps exactly as the row-echelon + back-substitution of the restated osd.hh:
+// the reduced form is unique for a given column order), then the 1 031 347 flip
+// patterns of weight <= 4 are spread over the threads as (a,b) work items pulled from an
+// LDS counter; candidate metrics come from a byte-sliced LDS lookup table.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace rx {
+
+constexpr int NPAIRS = BCH_K * (BCH_K - 1) / 2;   // 2485
+
+struct OsdShared {
+	uint32_t G[BCH_K][8];
+	short T[32][256];          // T[g][byte] = sum of x over set bits of byte g
+	short x[256];
+	short perm[256];
+	unsigned char rel[256];
+	signed char soft[256];
+	uint32_t cw[8];
+	int pivot_row, pivot_col;
+	int next_item;
+	int red_best[256], red_next[256], red_id[256];
+	int X;
+};
+
+__device__ __forceinline__ int lut_sum(const OsdShared &s, const uint32_t *e)
+{
+	int acc = 0;
+	#pragma unroll
+	for (int w = 0; w < 8; ++w) {
+		uint32_t v = e[w];
+		acc += s.T[4 * w + 0][v & 255];
+		acc += s.T[4 * w + 1][(v >> 8) & 255];
+		acc += s.T[4 * w + 2][(v >> 16) & 255];
+		acc += s.T[4 * w + 3][v >> 24];
+	}
+	return acc;
+}
+
+struct Track {
+	int best, next, id;
+	__device__ __forceinline__ void update(int met, int cand)
+	{
+		if (met > best) { next = best; best = met; id = cand; }
+		else if (met > next) { next = met; }
+	}
+};
+
+// soft[255] in s.soft must be valid; returns unique flag, writes hard bits (BE) to hard_out[32] (thread 0)
+__device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bits, const uint8_t *__restrict__ pairs,
+	uint8_t *hard_out /* LDS or global, 32 B */, int tid)
+{
+	// reliabilities, stable descending sort by rank counting
+	if (tid < 256)
+		s.rel[tid] = tid < BCH_N ? (unsigned char)abs(max((int)s.soft[tid], -127)) : 0;
+	__syncthreads();
+	if (tid < BCH_N) {
+		int r = 0, me = s.rel[tid];
+		for (int j = 0; j < BCH_N; ++j) {
+			int o = s.rel[j];
+			r += (o > me) || (o == me && j < tid);
+		}
+		s.perm[r] = (short)tid;
+	}
+	if (tid == 255)
+		s.perm[255] = 255;
+	__syncthreads();
+	// permuted generator: G[j] bit i = genmat[j][perm[i]]
+	for (int it = tid; it < BCH_K * 8; it += 256) {
+		int j = it >> 3, w = it & 7;
+		uint32_t v = 0;
+		for (int b = 0; b < 32; ++b) {
+			int i = 32 * w + b;
+			if (i < BCH_N) {
+				int c = s.perm[i];
+				v |= ((genmat_bits[j * 8 + (c >> 5)] >> (c & 31)) & 1u) << b;
+			}
+		}
+		s.G[j][w] = v;
+	}
+	__syncthreads();
+	// Gauss-Jordan with the pivoting rule of row_echelon()
+	for (int k = 0; k < BCH_K; ++k) {
+		if (tid == 0) {
+			int pr = -1, pc = k;
+			for (int j = k; j < BCH_K; ++j)
+				if ((s.G[j][k >> 5] >> (k & 31)) & 1) { pr = j; break; }
+			for (int c = k + 1; pr < 0 && c < BCH_N; ++c)
+				for (int h = k; h < BCH_K; ++h)
+					if ((s.G[h][c >> 5] >> (c & 31)) & 1) { pr = h; pc = c; break; }
+			s.pivot_row = pr;
+			s.pivot_col = pc;
+		}
+		__syncthreads();
+		const int pr = s.pivot_row, pc = s.pivot_col;
+		if (pc != k) {   // column swap k <-> pc in every row, and in perm
+			if (tid < BCH_K) {
+				uint32_t bk = (s.G[tid][k >> 5] >> (k & 31)) & 1, bc = (s.G[tid][pc >> 5] >> (pc & 31)) & 1;
+				if (bk != bc) {
+					s.G[tid][k >> 5] ^= 1u << (k & 31);
+					s.G[tid][pc >> 5] ^= 1u << (pc & 31);
+				}
+			}
+			if (tid == 255) { short t = s.perm[k]; s.perm[k] = s.perm[pc]; s.perm[pc] = t; }
+			__syncthreads();
+		}
+		if (pr != k && tid < 8) {   // row swap
+			uint32_t t = s.G[k][tid]; s.G[k][tid] = s.G[pr][tid]; s.G[pr][tid] = t;
+		}
+		__syncthreads();
+		{   // clear column k in every other row: read phase, barrier, write phase
+			uint32_t pv[3];
+			bool hit[3];
+			#pragma unroll
+			for (int q = 0; q < 3; ++q) {
+				int it = tid + 256 * q;
+				hit[q] = false;
+				pv[q] = 0;
+				if (it < BCH_K * 8) {
+					int j = it >> 3, w = it & 7;
+					hit[q] = j != k && ((s.G[j][k >> 5] >> (k & 31)) & 1);
+					pv[q] = s.G[k][w];
+				}
+			}
+			__syncthreads();
+			#pragma unroll
+			for (int q = 0; q < 3; ++q) {
+				int it = tid + 256 * q;
+				if (it < BCH_K * 8 && hit[q])
+					s.G[it >> 3][it & 7] ^= pv[q];
+			}
+		}
+		__syncthreads();
+	}
+	// permuted soft values and the byte-sliced table
+	if (tid < 256)
+		s.x[tid] = tid < BCH_N ? (short)max((int)s.soft[s.perm[tid]], -127) : 0;
+	__syncthreads();
+	for (int it = tid; it < 32 * 256; it += 256) {
+		int g = it >> 8, b = it & 255, acc = 0;
+		for (int q = 0; q < 8; ++q)
+			if ((b >> q) & 1)
+				acc += s.x[8 * g + q];
+		s.T[g][b] = (short)acc;
+	}
+	if (tid < 8) {   // order-0 codeword: hard decisions on the 71 most reliable positions
+		uint32_t v = 0;
+		for (int i = 0; i < BCH_K; ++i)
+			if (s.x[i] < 0)
+				v ^= s.G[i][tid];
+		s.cw[tid] = v;
+	}
+	if (tid == 0) {
+		int X = 0;
+		for (int i = 0; i < BCH_N; ++i)
+			X += s.x[i];
+		s.X = X;
+		s.next_item = 0;
+	}
+	__syncthreads();
+	const int X = s.X;
+	uint32_t base[8];
+	#pragma unroll
+	for (int w = 0; w < 8; ++w)
+		base[w] = s.cw[w];
+	Track tr;
+	tr.best = X - 2 * lut_sum(s, base);   // candidate id 0 = no flips
+	tr.next = -1;
+	tr.id = 0;
+	if (tid != 0) { tr.best = -0x7fffffff; tr.next = -0x7fffffff; }
+	// ids: singles 1+a ; pairs/triples/quads packed as (a+1) | (b+1)<<7 | (c+1)<<14 | (d+1)<<21
+	if (tid < BCH_K) {
+		uint32_t e[8];
+		#pragma unroll
+		for (int w = 0; w < 8; ++w)
+			e[w] = base[w] ^ s.G[tid][w];
+		tr.update(X - 2 * lut_sum(s, e), tid + 1);
+	}
+	for (;;) {
+		int item = atomicAdd(&s.next_item, 1);
+		if (item >= NPAIRS)
+			break;
+		const int a = pairs[2 * item], b = pairs[2 * item + 1];
+		uint32_t eab[8], eabc[8], e[8];
+		#pragma unroll
+		for (int w = 0; w < 8; ++w)
+			eab[w] = base[w] ^ s.G[a][w] ^ s.G[b][w];
+		const int idab = (a + 1) | ((b + 1) << 7);
+		tr.update(X - 2 * lut_sum(s, eab), idab);
+		for (int c = b + 1; c < BCH_K; ++c) {
+			#pragma unroll
+			for (int w = 0; w < 8; ++w)
+				eabc[w] = eab[w] ^ s.G[c][w];
+			const int idabc = idab | ((c + 1) << 14);
+			tr.update(X - 2 * lut_sum(s, eabc), idabc);
+			for (int d = c + 1; d < BCH_K; ++d) {
+				#pragma unroll
+				for (int w = 0; w < 8; ++w)
+					e[w] = eabc[w] ^ s.G[d][w];
+				tr.update(X - 2 * lut_sum(s, e), idabc | ((d + 1) << 21));
+			}
+		}
+	}
+	s.red_best[tid] = tr.best;
+	s.red_next[tid] = tr.next;
+	s.red_id[tid] = tr.id;
+	__syncthreads();
+	if (tid == 0) {
+		int gb = -0x7fffffff, gi = 0, cnt = 0, gn = -1;
+		for (int t = 0; t < 256; ++t)
+			if (s.red_best[t] > gb) { gb = s.red_best[t]; gi = s.red_id[t]; }
+		for (int t = 0; t < 256; ++t) {
+			if (s.red_best[t] == gb) ++cnt;
+			else if (s.red_best[t] > gn) gn = s.red_best[t];
+			if (s.red_next[t] > gn) gn = s.red_next[t];
+		}
+		if (cnt > 1) gn = gb;
+		uint32_t best[8];
+		for (int w = 0; w < 8; ++w) best[w] = s.cw[w];
+		for (int q = 0; q < 4; ++q) {
+			int r = (gi >> (7 * q)) & 127;
+			if (r)
+				for (int w = 0; w < 8; ++w) best[w] ^= s.G[r - 1][w];
+		}
+		for (int i = 0; i < 32; ++i) hard_out[i] = 0;
+		for (int i = 0; i < BCH_N; ++i) {
+			int p = s.perm[i];
+			if ((best[i >> 5] >> (i & 31)) & 1)
+				hard_out[p >> 3] |= (uint8_t)(0x80 >> (p & 7));
+		}
+		s.pivot_row = (gb != gn);
+	}
+	__syncthreads();
+	return s.pivot_row != 0;
+}
+
+__device__ __forceinline__ int be_bit(const uint8_t *b, int i) { return (b[i >> 3] >> (7 - (i & 7))) & 1; }
+
+// CRC<uint16_t>(0xA8F4)(uint64_t): reflected, low byte first (decode.cc:428-429)
+__device__ __forceinline__ unsigned crc16_u64(unsigned long long data)
+{
+	unsigned crc = 0;
+	for (int i = 0; i < 64; ++i) {
+		unsigned tmp = crc ^ (unsigned)((data >> i) & 1);
+		crc = (crc >> 1) ^ ((tmp & 1) * 0xA8F4u);
+	}
+	return crc & 0xffffu;
+}
+
+__global__ __launch_bounds__(256) void k_header(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
+	SyncState *__restrict__ st_all, int8_t *__restrict__ hdr_soft)
+{
+	const int f = blockIdx.x, tid = threadIdx.x;
+	__shared__ OsdShared s;
+	__shared__ cf buf[SYMBOL_LEN];
+	__shared__ uint8_t hard[32];
+	SyncState st = st_all[f];
+	if (!st.active)
+		return;
+	if (!st.found) {
+		if (tid == 0) {
+			st.status = st.status ? st.status : 1;   // NO_SYNC (decode.cc:393-394)
+			st.okay = 0;
+			st.active = 0;
+			st_all[f] = st;
+		}
+		return;
+	}
+	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, fb.samples_per_frame,
+		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
+	const long body = st.sc_start + SYM_STRIDE;               // decode.cc:405
+	for (int i = tid; i < SYMBOL_LEN; i += 256)
+		buf[i] = cmul(src.at(body + i), phasor(-st.cfo_rad, i));
+	__syncthreads();
+	fft1280<256>(buf, tb.tw1280, tid);
+	if (tid < MLS1_LEN) {                                     // decode.cc:407-416
+		const int mls1_off = -MLS1_LEN / 2;
+		int b1 = (tid + mls1_off + SYMBOL_LEN) % SYMBOL_LEN, b0 = (tid - 1 + mls1_off + SYMBOL_LEN) % SYMBOL_LEN;
+		cf cur = buf[b1], prv = buf[b0];
+		float s1 = tb.mls1_nrz[tid], s0 = tid ? tb.mls1_nrz[tid - 1] : 1.f;
+		cur = mk(cur.re * s1, cur.im * s1);
+		prv = mk(prv.re * s0, prv.im * s0);
+		float v = nearbyintf(127.f * demod_or_erase(cur, prv).re);
+		v = fminf(fmaxf(v, -128.f), 127.f);
+		s.soft[tid] = (signed char)v;
+		hdr_soft[(size_t)f * 256 + tid] = (int8_t)v;
+	}
+	if (tid == 255)
+		s.soft[255] = 0;
+	__syncthreads();
+	bool unique = osd_decode(s, tb.genmat_bits, tb.osd_pairs, hard, tid);
+	if (tid == 0) {
+		int status = 0;
+		unsigned long long md = 0;
+		if (!unique) {
+			status = 2;                                       // decode.cc:418-421
+		} else {
+			for (int i = 0; i < 55; ++i)
+				md |= (unsigned long long)be_bit(hard, i) << i;
+			unsigned cs = 0;
+			for (int i = 0; i < 16; ++i)
+				cs |= (unsigned)be_bit(hard, i + 55) << i;
+			if (crc16_u64(md << 9) != cs) {
+				status = 3;                                   // decode.cc:429-432
+			} else {
+				st.oper_mode = (int)(md & 255);
+				st.call_sign = md >> 8;
+				if (st.oper_mode < 6 || st.oper_mode > 13)
+					status = 4;                               // decode.cc:434-437
+				else if ((md >> 8) == 0 || (md >> 8) >= 129961739795077ULL)
+					status = 5;                               // decode.cc:439-442
+				else if (st.oper_mode != 6)
+					status = 4;                               // payload path of this build: mode 6 only
+			}
+		}
+		st.status = status;
+		st.okay = status == 0;
+		st.hdr_rounds += 1;
+		if (st.skip_left > 0) { st.skip_left -= 1; st.active = 1; }   // decode.cc:448
+		else st.active = 0;
+		st_all[f] = st;
+	}
+}
+
+// parity-test entry: OSD alone on caller-provided soft values
+__global__ __launch_bounds__(256) void k_osd_only(Tables tb, const int8_t *__restrict__ soft, uint8_t *__restrict__ hard_out,
+	int32_t *__restrict__ unique_out)
+{
+	const int f = blockIdx.x, tid = threadIdx.x;
+	__shared__ OsdShared s;
+	__shared__ uint8_t hard[32];
+	if (tid < 256)
+		s.soft[tid] = tid < BCH_N ? soft[(size_t)f * BCH_N + tid] : 0;
+	__syncthreads();
+	bool u = osd_decode(s, tb.genmat_bits, tb.osd_pairs, hard, tid);
+	if (tid < 32)
+		hard_out[(size_t)f * 32 + tid] = hard[tid];
+	if (tid == 0)
+		unique_out[f] = u ? 1 : 0;
+}
+
+void launch_header(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft)
+{
+	hipLaunchKernelGGL(k_header, dim3(n), dim3(256), 0, s, fb, z, tb, st, hdr_soft);
+}
+void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique)
+{
+	hipLaunchKernelGGL(k_osd_only, dim3(n), dim3(256), 0, s, tb, soft, hard, unique);
+}
+
+}  // namespace rx

@@ -1,0 +1,428 @@
+// k_polar.hip -- D9 (polar successive-cancellation list decoder, N = 65536, L = 8) and
+// D10 (systematic message, CRC-32 lane selection, bit packing) for gfx950.
+//
+// CODE::PolarListDecoder<SIMD<float,8>,16> (decode.cc:201,530): min-sum SCL.
+// One wavefront decodes one codeword.  Lane l = (j << 3) | k : k = list path (the
+// reference's SIMD lane), j = one of 8 butterflies processed per wave instruction.
+//   f(a,b)   = sign(a) sign(b) min(|a|,|b|)              left child LLRs
+//   g(a,b,u) = u ? b - a : a + b                          right child LLRs
+// Tree levels 4..15 live in HBM/L2 as soft[level m][i][k] (fp32, 2 MiB per codeword, the
+// reference's own soft[N+i] layout); level 16 is the shared channel LLR vector; levels
+// 3..0 (8-leaf sub-trees) never leave registers: butterflies are cross-lane shuffles.
+// Lane permutations after a fork are applied lazily exactly like the reference's vshuf at
+// the g step and at the partial-sum combine: per level the composition of all leaf maps
+// since that level's node started is kept as 3-bit fields packed in two registers per
+// lane (W0: levels 0..9, W1: levels 10..16), so one fork costs two cross-lane gathers.
+// Partial sums are bits: hard[i] is one byte per code position, bit k = path k; bytes are
+// assembled with __ballot.  The root's hard[] is the re-encoded codeword x = u F, and the
+// systematic message of decode.cc:254-261 is x at the unfrozen positions - no separate
+// re-encode, no message back-trace.
+// Selection rule at an information leaf: the 2L candidates are ranked by (metric,
+// candidate index 2k+u); survivors are stored in rank order (same rule as the CPU oracle).
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace rx {
+
+__device__ __forceinline__ float f_minsum(float a, float b)
+{
+	float m = fminf(fabsf(a), fabsf(b));
+	return ((a < 0.f) != (b < 0.f)) ? -m : m;
+}
+__device__ __forceinline__ float g_add(float a, float b, int u) { return u ? b - a : a + b; }
+
+constexpr uint32_t ID0 = 0x09249249u;   // 10 fields of 3 bits, each = 1
+constexpr uint32_t ID1 = 0x00049249u;   //  7 fields
+
+struct Maps {
+	uint32_t w0, w1;
+	__device__ __forceinline__ int get(int m) const { return m < 10 ? (w0 >> (3 * m)) & 7 : (w1 >> (3 * (m - 10))) & 7; }
+	// a node of every level <= c starts at this leaf: those fields become the identity
+	__device__ __forceinline__ void reset_upto(int c, int k)
+	{
+		int n0 = (c < 9 ? c : 9) + 1;
+		uint32_t m0 = (1u << (3 * n0)) - 1;
+		w0 = (w0 & ~m0) | ((ID0 * (uint32_t)k) & m0);
+		if (c >= 10) {
+			uint32_t m1 = (1u << (3 * (c - 9))) - 1;
+			w1 = (w1 & ~m1) | ((ID1 * (uint32_t)k) & m1);
+		}
+	}
+};
+
+constexpr int UB = 8;   // iterations batched per pass so that 2*UB loads are in flight per lane
+
+// level m+1 -> level m (left child), both in memory; m >= 4
+__device__ __forceinline__ void pass_f_mem(const float *__restrict__ src, float *__restrict__ dst, int m, int lane)
+{
+	const int half = 1 << m, iters = half >> 3;
+	for (int it0 = 0; it0 < iters; it0 += UB) {
+		float a[UB], b[UB];
+		#pragma unroll
+		for (int u = 0; u < UB; ++u)
+			if (it0 + u < iters) {
+				int idx = (it0 + u) * 64 + lane;
+				a[u] = src[idx];
+				b[u] = src[idx + half * 8];
+			}
+		#pragma unroll
+		for (int u = 0; u < UB; ++u)
+			if (it0 + u < iters)
+				dst[(it0 + u) * 64 + lane] = f_minsum(a[u], b[u]);
+	}
+}
+// level 16 (shared channel LLRs) -> level 15, left child
+__device__ __forceinline__ void pass_f_top(const float *__restrict__ llr, float *__restrict__ dst, int lane)
+{
+	const int half = 1 << 15, iters = half >> 3, j = lane >> 3;
+	for (int it0 = 0; it0 < iters; it0 += UB) {
+		float a[UB], b[UB];
+		#pragma unroll
+		for (int u = 0; u < UB; ++u) {
+			int i = (it0 + u) * 8 + j;
+			a[u] = llr[i];
+			b[u] = llr[i + half];
+		}
+		#pragma unroll
+		for (int u = 0; u < UB; ++u)
+			dst[(it0 + u) * 64 + lane] = f_minsum(a[u], b[u]);
+	}
+}
+// right child of the level-(m+1) node: level m from level m+1 with partial sums hard[o..o+2^m)
+// and lane map lk (per lane: source path of path k).  m >= 4, level m+1 <= 15.
+__device__ __forceinline__ void pass_g_mem(const float *__restrict__ src, float *__restrict__ dst,
+	const uint8_t *__restrict__ hard_o, int m, int lane, int lk)
+{
+	const int half = 1 << m, iters = half >> 3, j = lane >> 3, k = lane & 7;
+	const int gl = (j << 3) | lk;
+	for (int it0 = 0; it0 < iters; it0 += UB) {
+		float a[UB], b[UB];
+		int h[UB];
+		#pragma unroll
+		for (int u = 0; u < UB; ++u)
+			if (it0 + u < iters) {
+				int base = (it0 + u) * 64;
+				a[u] = src[base + gl];
+				b[u] = src[base + gl + half * 8];
+				h[u] = hard_o[(it0 + u) * 8 + j];
+			}
+		#pragma unroll
+		for (int u = 0; u < UB; ++u)
+			if (it0 + u < iters)
+				dst[(it0 + u) * 64 + lane] = g_add(a[u], b[u], (h[u] >> k) & 1);
+	}
+}
+__device__ __forceinline__ void pass_g_top(const float *__restrict__ llr, float *__restrict__ dst,
+	const uint8_t *__restrict__ hard_o, int lane)
+{
+	const int half = 1 << 15, iters = half >> 3, j = lane >> 3, k = lane & 7;
+	for (int it0 = 0; it0 < iters; it0 += UB) {
+		float a[UB], b[UB];
+		int h[UB];
+		#pragma unroll
+		for (int u = 0; u < UB; ++u) {
+			int i = (it0 + u) * 8 + j;
+			a[u] = llr[i];
+			b[u] = llr[i + half];
+			h[u] = hard_o[i];
+		}
+		#pragma unroll
+		for (int u = 0; u < UB; ++u)
+			dst[(it0 + u) * 64 + lane] = g_add(a[u], b[u], (h[u] >> k) & 1);
+	}
+}
+
+__global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all, float *__restrict__ soft_all,
+	uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen, float *__restrict__ metric_all)
+{
+	const int cw = blockIdx.x, lane = threadIdx.x, j = lane >> 3, k = lane & 7;
+	const float *llr = llr_all + (size_t)cw * CODE_LEN;
+	float *soft = soft_all + (size_t)cw * (8 * CODE_LEN);     // level m at soft + 8*2^m
+	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;
+	#define LV(m) (soft + (8 << (m)))
+	float M = k ? 1000.f : 0.f;                               // lane 0 carries the only real path
+	Maps A;
+	A.w0 = ID0 * (uint32_t)k;
+	A.w1 = ID1 * (uint32_t)k;
+	float r3 = 0.f, r2, r1, r0;
+	int hb = 0;
+
+	for (int t8 = 0; t8 < CODE_LEN / 8; ++t8) {
+		const int t = t8 * 8;
+		// ---------------- LLRs of this 8-leaf sub-tree into r3
+		if (t == 0) {
+			pass_f_top(llr, LV(15), lane);
+			__syncthreads();
+			for (int m = 14; m >= 4; --m) {
+				pass_f_mem(LV(m + 1), LV(m), m, lane);
+				__syncthreads();
+			}
+			r3 = f_minsum(LV(4)[lane], LV(4)[lane + 64]);
+		} else {
+			const int z = __builtin_ctz(t);                   // right child of the level-(z+1) node starts here
+			const int lk = A.get(z + 1);
+			const uint8_t *ho = hard + (t - (1 << z));
+			if (z == 3) {
+				const int gl = (j << 3) | lk;
+				float a = LV(4)[gl], b = LV(4)[gl + 64];
+				r3 = g_add(a, b, (ho[j] >> k) & 1);
+			} else {
+				if (z == 15) pass_g_top(llr, LV(15), ho, lane);
+				else pass_g_mem(LV(z + 1), LV(z), ho, z, lane, lk);
+				__syncthreads();
+				for (int m = z - 1; m >= 4; --m) {
+					pass_f_mem(LV(m + 1), LV(m), m, lane);
+					__syncthreads();
+				}
+				r3 = f_minsum(LV(4)[lane], LV(4)[lane + 64]);
+			}
+		}
+		const uint32_t fz = (frozen[t >> 5] >> (t & 31)) & 0xffu;
+		hb = 0;
+		// ---------------- the 8 leaves, all in registers
+		#pragma unroll
+		for (int p = 0; p < 8; ++p) {
+			const int tt = t + p;
+			A.reset_upto(tt ? __builtin_ctz(tt) : 16, k);
+			// LLRs down to the leaf
+			if (p == 0) {
+				r2 = f_minsum(r3, __shfl_xor(r3, 32));
+				r1 = f_minsum(r2, __shfl_xor(r2, 16));
+				r0 = f_minsum(r1, __shfl_xor(r1, 8));
+			} else {
+				const int zz = __builtin_ctz(p);              // 0,1,2 : g at level zz+1
+				const int mg = zz + 1;
+				const int hbit = 1 << zz;                     // half size of the level-mg node
+				const int q = p - hbit;                       // first leaf of the left child
+				const int lk = A.get(mg);
+				const float rsrc = mg == 3 ? r3 : (mg == 2 ? r2 : r1);
+				const float own = __shfl(rsrc, (j << 3) | lk);
+				const float oth = __shfl(rsrc, ((j ^ hbit) << 3) | lk);
+				const bool hi = (j >> zz) & 1;
+				const float a = hi ? oth : own, b = hi ? own : oth;
+				const int ub = __shfl(hb, ((q + (j & (hbit - 1))) << 3) | k);
+				const float v = g_add(a, b, ub);
+				if (mg == 3) { r2 = v; r1 = f_minsum(r2, __shfl_xor(r2, 16)); r0 = f_minsum(r1, __shfl_xor(r1, 8)); }
+				else if (mg == 2) { r1 = v; r0 = f_minsum(r1, __shfl_xor(r1, 8)); }
+				else { r0 = v; }
+			}
+			// leaf decision
+			int ubit = 0;
+			if ((fz >> p) & 1) {
+				if (r0 < 0.f)
+					M -= r0;
+			} else {
+				float v0 = M, v1 = M;
+				if (r0 < 0.f) v0 = M - r0; else v1 = M + r0;
+				const int umine = j & 1;
+				const float val = umine ? v1 : v0;
+				const int cidx = 2 * k + umine;
+				int rank = 0;
+				#pragma unroll
+				for (int kk = 0; kk < 8; ++kk) {
+					const float o0 = __shfl(v0, kk), o1 = __shfl(v1, kk);
+					rank += (2 * kk < cidx) ? (o0 <= val) : (o0 < val);
+					rank += (2 * kk + 1 < cidx) ? (o1 <= val) : (o1 < val);
+				}
+				const int dst = lane < 16 ? rank : lane;      // lanes 0..15 hold the 16 candidates
+				const int rc = __builtin_amdgcn_ds_permute(dst << 2, cidx);
+				const int rv = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(val));
+				const int mine = __shfl(rc, k);               // lane r (< 8) received the rank-r candidate
+				M = __int_as_float(__shfl(rv, k));
+				const int parent = mine >> 1;
+				ubit = mine & 1;
+				A.w0 = __shfl((int)A.w0, (j << 3) | parent);
+				A.w1 = __shfl((int)A.w1, (j << 3) | parent);
+			}
+			if (j == p)
+				hb = ubit;
+			// partial-sum combines that complete at this leaf (levels 1..3)
+			#pragma unroll
+			for (int m = 1; m <= 3; ++m) {
+				if (((p + 1) & ((1 << m) - 1)) == 0) {
+					const int hh = 1 << (m - 1), q = p + 1 - (1 << m);
+					const int rm = A.get(m - 1);
+					const int lft = __shfl(hb, (j << 3) | rm);
+					const int rgt = __shfl(hb, (((j + hh) & 7) << 3) | k);
+					if (j >= q && j < q + hh)
+						hb = lft ^ rgt;
+				}
+			}
+		}
+		// ---------------- partial sums of the sub-tree to memory, then the combines above
+		{
+			const unsigned long long bal = __ballot(hb != 0);
+			if (lane == 0)
+				*(unsigned long long *)(hard + t) = bal;
+		}
+		for (int m = 4; m <= 16 && ((t + 8) & ((1 << m) - 1)) == 0; ++m) {
+			__syncthreads();
+			const int hh = 1 << (m - 1), o = t + 8 - (1 << m);
+			const int rm = A.get(m - 1);
+			for (int it0 = 0; it0 < hh / 8; it0 += UB) {
+				int xl[UB], xr[UB];
+				#pragma unroll
+				for (int u = 0; u < UB; ++u)
+					if (it0 + u < hh / 8) {
+						xl[u] = hard[o + (it0 + u) * 8 + j];
+						xr[u] = hard[o + hh + (it0 + u) * 8 + j];
+					}
+				#pragma unroll
+				for (int u = 0; u < UB; ++u)
+					if (it0 + u < hh / 8) {
+						const int bit = ((xl[u] >> rm) ^ (xr[u] >> k)) & 1;
+						const unsigned long long bal = __ballot(bit != 0);
+						if (lane == 0)
+							*(unsigned long long *)(hard + o + (it0 + u) * 8) = bal;
+					}
+			}
+		}
+		__syncthreads();
+	}
+	if (j == 0)
+		metric_all[(size_t)cw * LIST + k] = M;
+	#undef LV
+}
+
+// ---------------------------------------------------------------- D10
+// decode.cc:254-261 (systematic message = codeword at the unfrozen positions),
+// decode.cc:532-541 (first lane whose CRC-32 over 43072 bits is 0), decode.cc:546-555
+// (LE bit packing + flip count), decode.cc:613-615 (descramble).
+__global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
+	const uint8_t *__restrict__ hard_all, Tables tb, int descramble, uint8_t *__restrict__ lane_mesg_all,
+	uint8_t *__restrict__ payload_all, Result *__restrict__ res_all)
+{
+	const int f = blockIdx.x, tid = threadIdx.x;
+	const SyncState st = st_all[f];
+	uint8_t *payload = payload_all + (size_t)f * PAYLOAD_BYTES;
+	__shared__ uint8_t mesg[LIST][MESG_BYTES];
+	__shared__ uint32_t crcs[LIST];
+	__shared__ int flips_red[4];
+	Result r = res_all[f];
+	r.status = st.status;
+	r.symbol_pos = st.symbol_pos;
+	r.sc_start = st.sc_start;
+	r.cfo_rad = st.cfo_rad;
+	r.oper_mode = st.oper_mode;
+	r.call_sign = st.call_sign;
+	r.n_sync_rejects = st.rejects;
+	r.best_lane = -1;
+	r.bit_flips = 0;
+	if (!st.okay) {
+		r.cfo_fine = st.cfo_rad;
+		r.sfo_slope = 0.f;
+		r.esn0_db_last = 0.f;
+		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
+			payload[i] = 0;
+		if (tid == 0)
+			res_all[f] = r;
+		return;
+	}
+	const uint8_t *hard = hard_all + (size_t)f * CODE_LEN;
+	const float *llr = llr_all + (size_t)f * CODE_LEN;
+	// transpose: 8 code positions (one byte each, bit k = path k) -> one message byte per path
+	for (int bi = tid; bi < MESG_BYTES; bi += 256) {
+		uint32_t o[LIST] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		#pragma unroll
+		for (int b = 0; b < 8; ++b) {
+			uint32_t x = hard[tb.info_pos[8 * bi + b]];
+			#pragma unroll
+			for (int k = 0; k < LIST; ++k)
+				o[k] |= ((x >> k) & 1u) << b;
+		}
+		#pragma unroll
+		for (int k = 0; k < LIST; ++k)
+			mesg[k][bi] = (uint8_t)o[k];
+	}
+	__syncthreads();
+	if (lane_mesg_all)
+		for (int i = tid; i < LIST * MESG_BYTES; i += 256)
+			lane_mesg_all[(size_t)f * LIST * MESG_BYTES + i] = mesg[i / MESG_BYTES][i % MESG_BYTES];
+	if (tid < LIST) {
+		uint32_t crc = 0;
+		for (int i = 0; i < CRC_BITS / 8; ++i)
+			crc = (crc >> 8) ^ tb.crc32_tab[(crc ^ mesg[tid][i]) & 255];
+		crcs[tid] = crc;
+	}
+	__syncthreads();
+	int best = -1;
+	for (int k = LIST - 1; k >= 0; --k)
+		if (crcs[k] == 0)
+			best = k;
+	r.best_lane = best;
+	if (best < 0) {
+		r.status = 6;                                         // decode.cc:542-545
+		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
+			payload[i] = 0;
+		if (tid == 0)
+			res_all[f] = r;
+		return;
+	}
+	int flips = 0;
+	for (int i = tid; i < DATA_BITS; i += 256) {              // decode.cc:546-554
+		int received = llr[tb.info_pos[i]] < 0.f;
+		int decoded = (mesg[best][i >> 3] >> (i & 7)) & 1;
+		flips += received != decoded;
+	}
+	#pragma unroll
+	for (int m = 32; m; m >>= 1)
+		flips += __shfl_xor(flips, m);
+	if ((tid & 63) == 0)
+		flips_red[tid >> 6] = flips;
+	for (int i = tid; i < PAYLOAD_BYTES; i += 256)
+		payload[i] = mesg[best][i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);
+	__syncthreads();
+	if (tid == 0) {
+		r.bit_flips = flips_red[0] + flips_red[1] + flips_red[2] + flips_red[3];
+		res_all[f] = r;
+	}
+}
+
+// ---------------------------------------------------------------- channel model utility
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+	x += 0x9e3779b97f4a7c15ull;
+	x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+	x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+	return x ^ (x >> 31);
+}
+// out frame f = base[f % n_base] + complex AWGN(sigma per component); counter-based RNG
+__global__ __launch_bounds__(256) void k_awgn_tile(const short2 *__restrict__ base, size_t n_base, short2 *__restrict__ out,
+	size_t spf, float sigma, unsigned long long seed, unsigned long long first_frame)
+{
+	const size_t f = blockIdx.x;
+	const unsigned long long key = splitmix64(seed ^ splitmix64(first_frame + f + 0x1234567ull));
+	const short2 *src = base + (f % n_base) * spf;
+	short2 *dst = out + f * spf;
+	for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < spf; i += (size_t)gridDim.y * 256) {
+		unsigned long long r = splitmix64(key + i);
+		float u1 = ((float)(unsigned)(r >> 40) + 0.5f) * (1.f / 16777216.f);
+		float u2 = ((float)(unsigned)((r >> 8) & 0xffffff) + 0.5f) * (1.f / 16777216.f);
+		float mag = sigma * sqrtf(-2.f * logf(u1));
+		float sn, cs;
+		sincosf(TWO_PI_F * u2, &sn, &cs);
+		short2 v = src[i];
+		float re = (float)v.x / 32767.f + mag * cs, im = (float)v.y / 32767.f + mag * sn;
+		re = fminf(fmaxf(re, -1.f), 1.f);
+		im = fminf(fmaxf(im, -1.f), 1.f);
+		dst[i] = make_short2((short)nearbyintf(32767.f * re), (short)nearbyintf(32767.f * im));
+	}
+}
+
+void launch_polar(hipStream_t s, int n, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric)
+{
+	hipLaunchKernelGGL(k_polar, dim3(n), dim3(64), 0, s, llr, soft, hard, tb.frozen, metric);
+}
+void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
+	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res)
+{
+	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, lane_mesg, payload, res);
+}
+void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t *out, size_t n_out,
+	size_t spf, float sigma, uint64_t seed, uint64_t first_frame)
+{
+	hipLaunchKernelGGL(k_awgn_tile, dim3((unsigned)n_out, 64), dim3(256), 0, s, (const short2 *)base, n_base, (short2 *)out,
+		spf, sigma, (unsigned long long)seed, (unsigned long long)first_frame);
+}
+
+}  // namespace rx

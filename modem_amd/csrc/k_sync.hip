@@ -1,0 +1,372 @@
+// k_sync.hip -- D1 (front end) and D2/D3 (Schmidl-Cox search) for gfx950.
+//
+// D1  Decoder::next_sample (decode.cc:294-301): BlockDC + Hilbert<cmplx,21> for
+//     mono input.  The 1st-order DC blocker is a linear recurrence: every thread
+//     runs it over a contiguous chunk from a zero state, the 256 chunk carries
+//     are composed serially, then the chunks are corrected by a^k * carry.
+// D2  SchmidlCox::operator() per-sample part (decode.cc:84-108): the three
+//     SMA4 sliding sums are running sums of (in - out) differences, prefix-summed
+//     in double precision per 1024-sample tile (one wave per frame, 16 samples
+//     per lane).  Trigger logic (Schmitt + falling edge + arg-max with the
+//     saturating age counter) is evaluated on the tile with wave reductions.
+// D3  trigger part (decode.cc:110-151): derotate 640, FFT640, differential
+//     demod across bins, FFT640, x conj(FFT(mls0))/640, IFFT640, peak search.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace rx {
+
+// ---------------------------------------------------------------- D1 front end
+__global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, float *__restrict__ dc_all, cf *__restrict__ z_all)
+{
+	const int f = blockIdx.x, tid = threadIdx.x;
+	const long n = fb.samples_per_frame;
+	const char *base = (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes;
+	SampleSrc src{ base, fb.fmt, 1, n, nullptr };
+	float *dc = dc_all + (size_t)f * fb.samples_per_frame;
+	cf *z = z_all + (size_t)f * fb.samples_per_frame;
+	__shared__ float carry_end[256], carry_pow[256], carry_in[256];
+	const long chunk = (n + 255) / 256;
+	const long s0 = min((long)tid * chunk, n), s1 = min(s0 + chunk, n);
+	const float a = co.dc_a, b = co.dc_b;
+	float x1 = s0 > 0 ? src.scalar(s0 - 1) : 0.f, y1 = 0.f, pw = 1.f;
+	for (long i = s0; i < s1; ++i) {
+		float x0 = src.scalar(i);
+		float y0 = b * (x0 - x1) + a * y1;
+		x1 = x0;
+		y1 = y0;
+		dc[i] = y0;
+		pw *= a;
+	}
+	carry_end[tid] = y1;
+	carry_pow[tid] = pw;
+	__syncthreads();
+	if (tid == 0) {
+		float y = 0.f;
+		for (int t = 0; t < 256; ++t) {
+			carry_in[t] = y;
+			y = carry_end[t] + carry_pow[t] * y;
+		}
+	}
+	__syncthreads();
+	{
+		float cin = carry_in[tid], p = a;
+		for (long i = s0; i < s1; ++i) {
+			dc[i] += p * cin;
+			p *= a;
+		}
+	}
+	__syncthreads();
+	// Hilbert<cmplx,21>: centre tap 10 back, odd taps +-1,3,5,7,9 around it
+	for (long i = tid; i < n; i += 256) {
+		long c = i - 10;
+		auto D = [&](long k) { return k >= 0 ? dc[k] : 0.f; };
+		float re = co.reco * D(c);
+		float im = co.imco[0] * (D(c - 1) - D(c + 1));
+		#pragma unroll
+		for (int k = 1; k < 5; ++k)
+			im += co.imco[k] * (D(c - (2 * k + 1)) - D(c + (2 * k + 1)));
+		z[i] = mk(re, im);
+	}
+}
+
+// ---------------------------------------------------------------- D2 + D3 sync
+constexpr int TILE = 1024, PER = 16, MRING = 2048;
+
+struct SyncShared {
+	double m[MRING];
+	float timing[TILE];
+	cf buf[HALF_LEN];
+	cf xr[HALF_LEN];
+};
+
+__device__ __forceinline__ int first_index(const float *timing, int T0, int lane, int lo_t, int hi_t, bool greater, float thr)
+{
+	int best = 0x7fffffff;
+	#pragma unroll
+	for (int e = 0; e < PER; ++e) {
+		int t = T0 + lane * PER + e;
+		float v = timing[lane * PER + e];
+		bool c = greater ? (v > thr) : (v < thr);
+		if (t >= lo_t && t < hi_t && c && best == 0x7fffffff)
+			best = t;
+	}
+	return wave_min_i(best);
+}
+
+// P at time t by direct summation (decode.cc:86), double accumulate
+__device__ __forceinline__ void direct_P(const SampleSrc &src, long t, int lane, double &re, double &im)
+{
+	double sr = 0.0, si = 0.0;
+	long a0 = t - (BUFFER_LEN - 1 - (SEARCH_POS + HALF_LEN));   // newest u
+	for (int q = 0; q < HALF_LEN / 64; ++q) {
+		long u = a0 - (q * 64 + lane);
+		cf x = src.at(u), y = src.at(u + HALF_LEN);
+		sr += (double)x.re * y.re + (double)x.im * y.im;
+		si += (double)x.im * y.re - (double)x.re * y.im;
+	}
+	re = wave_sum_d(sr);
+	im = wave_sum_d(si);
+}
+__device__ __forceinline__ double direct_R(const SampleSrc &src, long t, int lane)
+{
+	double s = 0.0;
+	long a0 = t - (BUFFER_LEN - 1 - (SEARCH_POS + 2 * HALF_LEN));
+	for (int q = 0; q < 2 * HALF_LEN / 64; ++q) {
+		cf x = src.at(a0 - (q * 64 + lane));
+		s += (double)x.re * x.re + (double)x.im * x.im;
+	}
+	return wave_sum_d(s);
+}
+
+// decode.cc:110-151 ; returns accept, fills symbol_pos (window coord) and cfo_rad
+__device__ bool sc_process(SyncShared &sh, const SampleSrc &src, const cf *tw, const cf *kern,
+	long t, int index_max, float phase_max, int lane, int &symbol_pos_out, float &cfo_out)
+{
+	const float frac_cfo = phase_max / (float)HALF_LEN;       // decode.cc:110
+	int symbol_pos = SEARCH_POS - index_max;                   // decode.cc:114
+	const long base = t - (BUFFER_LEN - 1);
+	__syncthreads();
+	for (int i = lane; i < HALF_LEN; i += 64)                  // decode.cc:117-118
+		sh.buf[i] = cmul(src.at(base + i + symbol_pos + HALF_LEN), phasor(frac_cfo, i));
+	__syncthreads();
+	fft640<64>(sh.buf, tw, lane);
+	for (int i = lane; i < HALF_LEN; i += 64)                  // decode.cc:120-121
+		sh.xr[i] = demod_or_erase(sh.buf[i], sh.buf[(i + HALF_LEN - 1) % HALF_LEN]);
+	__syncthreads();
+	for (int i = lane; i < HALF_LEN; i += 64)
+		sh.buf[i] = sh.xr[i];
+	__syncthreads();
+	fft640<64>(sh.buf, tw, lane);
+	// x kern, then backward transform as conj(FFT(conj(.)))
+	for (int i = lane; i < HALF_LEN; i += 64)
+		sh.buf[i] = cconj(cmul(sh.buf[i], kern[i]));
+	__syncthreads();
+	fft640<64>(sh.buf, tw, lane);
+	// decode.cc:127-139: peak = max, shift = first index of it, next = runner-up
+	float pk = -1.f;
+	int sh_i = 0x7fffffff;
+	for (int i = lane; i < HALF_LEN; i += 64) {
+		float p = cnorm(sh.buf[i]);
+		if (p > pk) { pk = p; sh_i = i; }
+	}
+	#pragma unroll
+	for (int m = 32; m; m >>= 1) {
+		float op = __shfl_xor(pk, m);
+		int oi = __shfl_xor(sh_i, m);
+		if (op > pk || (op == pk && oi < sh_i)) { pk = op; sh_i = oi; }
+	}
+	float nx = 0.f;
+	for (int i = lane; i < HALF_LEN; i += 64) {
+		float p = cnorm(sh.buf[i]);
+		if (i != sh_i && p > nx) nx = p;
+	}
+	#pragma unroll
+	for (int m = 32; m; m >>= 1)
+		nx = fmaxf(nx, __shfl_xor(nx, m));
+	const float peak = fmaxf(pk, 0.f);
+	const int shift = peak > 0.f ? sh_i : 0;
+	if (peak <= nx * 4.f)                                      // decode.cc:140-141
+		return false;
+	cf v = cconj(sh.buf[shift]);
+	int pos_err = (int)nearbyintf(atan2f(v.im, v.re) * (float)HALF_LEN / TWO_PI_F);
+	if (abs(pos_err) > GUARD_LEN / 2)                          // decode.cc:144-145
+		return false;
+	symbol_pos -= pos_err;
+	float cfo_rad = (float)shift * (TWO_PI_F / (float)HALF_LEN) - frac_cfo;   // decode.cc:148
+	if (cfo_rad >= PI_F)
+		cfo_rad -= TWO_PI_F;
+	symbol_pos_out = symbol_pos;
+	cfo_out = cfo_rad;
+	return true;
+}
+
+__global__ __launch_bounds__(64) void k_sync(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
+	const cf *__restrict__ kern, SyncState *__restrict__ st_all)
+{
+	const int f = blockIdx.x, lane = threadIdx.x;
+	SyncState st = st_all[f];
+	if (!st.active)
+		return;
+	const long n = fb.samples_per_frame;
+	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, n,
+		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
+	__shared__ SyncShared sh;
+	for (int i = lane; i < MRING; i += 64)
+		sh.m[i] = 0.0;
+	const float thr_lo = (float)(0.17 * MATCH_LEN), thr_hi = (float)(0.19 * MATCH_LEN);   // decode.cc:76
+	const float min_R = 0.0001f * HALF_LEN;                                                // decode.cc:88
+	const long t_start = st.t_next;
+	long T0 = t_start - (MATCH_LEN - 1);
+	if (T0 < 0) T0 = 0;
+	// running window sums at time T0-1
+	double Wr = 0.0, Wi = 0.0, Wp = 0.0, Wm = 0.0;
+	if (T0 > 0) {
+		direct_P(src, T0 - 1, lane, Wr, Wi);
+		Wp = direct_R(src, T0 - 1, lane);
+	}
+	bool collecting = false, found = false;
+	float tmax = 0.f;
+	long nmax = 0;
+	int rejects = st.rejects;
+	__syncthreads();
+	for (; T0 < n && !found; T0 += TILE) {
+		// ---- phase 1: P, R, m for the 16 times of this lane
+		double dr[PER], di[PER], dp[PER];
+		{
+			const long tb = T0 + lane * PER;
+			#pragma unroll
+			for (int e = 0; e < PER; ++e) {
+				long a = tb + e - (BUFFER_LEN - 1 - (SEARCH_POS + HALF_LEN));
+				cf zA = src.at(a - HALF_LEN), zB = src.at(a), zC = src.at(a + HALF_LEN);
+				double inr = (double)zB.re * zC.re + (double)zB.im * zC.im;
+				double ini = (double)zB.im * zC.re - (double)zB.re * zC.im;
+				double outr = (double)zA.re * zB.re + (double)zA.im * zB.im;
+				double outi = (double)zA.im * zB.re - (double)zA.re * zB.im;
+				double pin = (double)zC.re * zC.re + (double)zC.im * zC.im;
+				double pout = (double)zA.re * zA.re + (double)zA.im * zA.im;
+				double pr = inr - outr, pi = ini - outi, pp = pin - pout;
+				dr[e] = (e ? dr[e - 1] : 0.0) + pr;
+				di[e] = (e ? di[e - 1] : 0.0) + pi;
+				dp[e] = (e ? dp[e - 1] : 0.0) + pp;
+			}
+		}
+		double or_ = wave_scan_incl(dr[PER - 1], lane) - dr[PER - 1] + Wr;
+		double oi_ = wave_scan_incl(di[PER - 1], lane) - di[PER - 1] + Wi;
+		double op_ = wave_scan_incl(dp[PER - 1], lane) - dp[PER - 1] + Wp;
+		#pragma unroll
+		for (int e = 0; e < PER; ++e) {
+			float Pre = (float)(or_ + dr[e]), Pim = (float)(oi_ + di[e]);
+			float R = 0.5f * (float)(op_ + dp[e]);
+			R = fmaxf(R, min_R);
+			double m = ((double)Pre * Pre + (double)Pim * Pim) / ((double)R * R);   // decode.cc:90
+			sh.m[(T0 + lane * PER + e) & (MRING - 1)] = m;
+		}
+		Wr = shfl_d(or_ + dr[PER - 1], 63);
+		Wi = shfl_d(oi_ + di[PER - 1], 63);
+		Wp = shfl_d(op_ + dp[PER - 1], 63);
+		__syncthreads();
+		// ---- phase 2: timing = sliding sum of m over 161 (decode.cc:90)
+		double dm[PER];
+		#pragma unroll
+		for (int e = 0; e < PER; ++e) {
+			long t = T0 + lane * PER + e;
+			double in = sh.m[t & (MRING - 1)];
+			double out = (t - MATCH_LEN >= 0) ? sh.m[(t - MATCH_LEN) & (MRING - 1)] : 0.0;
+			dm[e] = (e ? dm[e - 1] : 0.0) + (in - out);
+		}
+		double om = wave_scan_incl(dm[PER - 1], lane) - dm[PER - 1] + Wm;
+		#pragma unroll
+		for (int e = 0; e < PER; ++e)
+			sh.timing[lane * PER + e] = (float)(om + dm[e]);
+		Wm = shfl_d(om + dm[PER - 1], 63);
+		__syncthreads();
+		// ---- trigger logic on the tile (decode.cc:93-108)
+		long cur = T0 > t_start ? T0 : t_start;
+		long tile_end = T0 + TILE < n ? T0 + TILE : n;
+		while (cur < tile_end && !found) {
+			if (!collecting) {
+				int fr = first_index(sh.timing, (int)T0, lane, (int)cur, (int)tile_end, true, thr_hi);
+				if (fr == 0x7fffffff)
+					break;
+				collecting = true;
+				cur = fr;
+			}
+			int g = first_index(sh.timing, (int)T0, lane, (int)cur, (int)tile_end, false, thr_lo);
+			long stop = g == 0x7fffffff ? tile_end : (long)g + 1;
+			// first arg-max over [cur, stop)
+			float bv = -1.f;
+			int bi = 0x7fffffff;
+			#pragma unroll
+			for (int e = 0; e < PER; ++e) {
+				int t = (int)T0 + lane * PER + e;
+				float v = sh.timing[lane * PER + e];
+				if (t >= cur && t < stop && v > bv) { bv = v; bi = t; }
+			}
+			#pragma unroll
+			for (int mm = 32; mm; mm >>= 1) {
+				float ov = __shfl_xor(bv, mm);
+				int oi = __shfl_xor(bi, mm);
+				if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+			}
+			if (tmax < bv) { tmax = bv; nmax = bi; }           // decode.cc:99-102
+			if (g == 0x7fffffff) {
+				cur = tile_end;
+				break;
+			}
+			collecting = false;
+			long age = MATCH_DEL + ((long)g - nmax);           // decode.cc:103-105
+			int index_max = (int)(age < HALF_LEN + GUARD_LEN + MATCH_DEL ? age : HALF_LEN + GUARD_LEN + MATCH_DEL);
+			float phase_max = 0.f;
+			{
+				long tp = nmax - MATCH_DEL;                    // decode.cc:91 delay(arg(P))
+				if (tp >= 0) {
+					double pr, pi;
+					direct_P(src, tp, lane, pr, pi);
+					phase_max = atan2f((float)pi, (float)pr);
+				}
+			}
+			tmax = 0.f;                                        // decode.cc:115-116
+			int sp;
+			float cfo;
+			if (sc_process(sh, src, tw, kern, g, index_max, phase_max, lane, sp, cfo)) {
+				found = true;
+				st.symbol_pos = sp;
+				st.cfo_rad = cfo;
+				st.sc_start = (long)g - (BUFFER_LEN - 1) + sp;
+				st.t_next = (long)g + 1;
+			} else {
+				++rejects;
+			}
+			cur = (long)g + 1;
+		}
+		__syncthreads();
+	}
+	st.rejects = rejects;
+	st.found = found ? 1 : 0;
+	if (!found)
+		st.t_next = n;
+	if (lane == 0)
+		st_all[f] = st;
+}
+
+}  // namespace rx
+
+namespace rx {
+
+__global__ void k_init_sync(int n, SyncState *st, const int32_t *skip)
+{
+	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= n)
+		return;
+	SyncState s;
+	s.t_next = 0;
+	s.sc_start = -1;
+	s.active = 1;
+	s.found = 0;
+	s.symbol_pos = 0;
+	s.cfo_rad = 0.f;
+	s.rejects = 0;
+	s.skip_left = skip ? skip[f] : 0;
+	s.status = 1;   // OFDMRX_NO_SYNC until a preamble is accepted
+	s.oper_mode = 0;
+	s.call_sign = 0;
+	s.hdr_rounds = 0;
+	s.okay = 0;
+	st[f] = s;
+}
+
+void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts)
+{
+	hipLaunchKernelGGL(k_init_sync, dim3((n + 255) / 256), dim3(256), 0, s, n, st, skip_counts);
+}
+void launch_front_end(hipStream_t s, int n, FrameBatch fb, FrontCoef co, float *dc, cf *z)
+{
+	hipLaunchKernelGGL(k_front_end, dim3(n), dim3(256), 0, s, fb, co, dc, z);
+}
+void launch_sync(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st)
+{
+	hipLaunchKernelGGL(k_sync, dim3(n), dim3(64), 0, s, fb, z, tb.tw1280, tb.sc_kern, st);
+}
+
+}  // namespace rx

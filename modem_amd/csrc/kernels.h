@@ -1,0 +1,81 @@
+// kernels.h -- structs shared by the host API (ofdmrx_api.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev_common.h"
+
+namespace rx {
+
+// one decode call's view of the raw PCM batch (what DSP::ReadPCM delivers, decode.cc:297-298)
+struct FrameBatch {
+	const void *samples;           // device pointer, frame 0
+	size_t frame_stride_bytes;
+	long samples_per_frame;
+	int fmt;                       // OFDMRX_FMT_*
+	int channels;                  // 1 or 2
+};
+
+struct FrontCoef {                 // BlockDC::samples(2880) + Hilbert<cmplx,21> (decode.cc:386,193)
+	float dc_a, dc_b;
+	float reco, imco[5];
+};
+
+struct SyncState {                 // per frame, across sync rounds (decode.cc:390-448 loop)
+	long t_next;                   // next sample time to examine
+	long sc_start;                 // stream index of the S&C body
+	int active;                    // still searching in this round
+	int found;
+	int symbol_pos;                // window coordinate, decode.cc:400
+	float cfo_rad;
+	int rejects;
+	int skip_left;                 // decode.cc:448 while (skip_count--)
+	int status;                    // OFDMRX_* so far
+	int oper_mode;
+	unsigned long long call_sign;
+	int hdr_rounds;                // header attempts so far
+	int okay;
+};
+
+struct Tables {                    // device-resident constants, built once per handle
+	const cf *tw1280;              // e^{-j 2 pi m / 1280}
+	const cf *sc_kern;             // conj(FFT640(mls0))/640, decode.cc:80-82
+	const float *mls1_nrz;         // +-1 descrambler, decode.cc:407-409
+	const uint32_t *frozen;        // 2048 words, bit set = frozen (polar_tables.hh data, regenerated)
+	const uint16_t *info_pos;      // ascending unfrozen positions [43808]
+	const uint32_t *genmat_bits;   // BCH(255,71) systematic generator, [71][8] words, bit i of row j
+	const uint8_t *osd_pairs;      // [2485][2] (a,b) enumeration order
+	const uint32_t *crc32_tab;     // 256-entry byte table of CRC<uint32_t>(0xD419CC15)
+	const uint8_t *scramble;       // 5380 bytes of the Xorshift32 stream (decode.cc:613-615)
+};
+
+struct Result {                    // device mirror of ofdmrx_frame_result (same layout)
+	int32_t status;
+	int32_t symbol_pos;
+	int64_t sc_start;
+	float cfo_rad, cfo_fine, sfo_slope;
+	int32_t oper_mode;
+	uint64_t call_sign;
+	int32_t best_lane, bit_flips;
+	float esn0_db_last;
+	int32_t n_sync_rejects;
+};
+
+// ---- launch wrappers (defined next to their kernels) ------------------------
+void launch_front_end(hipStream_t s, int n, FrameBatch fb, FrontCoef co, float *dc, cf *z);
+void launch_sync(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st);
+void launch_header(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft);
+void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique);
+void launch_demod(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons);
+void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, float *slope, float *yint);
+void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
+void launch_llr(hipStream_t s, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
+	float *precision, float *llr, Result *res);
+void launch_polar(hipStream_t s, int n, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric);
+void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
+	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res);
+void launch_fft_debug(hipStream_t s, int n, int len, int sign, const cf *in, cf *out, Tables tb);
+void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t *out, size_t n_out,
+	size_t spf, float sigma, uint64_t seed, uint64_t first_frame);
+void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts);
+
+}  // namespace rx

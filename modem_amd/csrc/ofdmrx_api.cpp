@@ -1,0 +1,541 @@
+// ofdmrx_api.cpp -- host side of libofdmrx.so: the C ABI of include/ofdmrx.h.
+// Replaces the in-process seam Decoder<value,cmplx,rate>(out, pcm, skip) (decode.cc:375)
+// for batches of independent frames.  One handle = one GPU + one stream; frames are
+// processed in resident chunks (device state for chunk_frames frames is allocated once and
+// reused).  There is NO CPU fallback: every stage is a HIP kernel, errors are returned.
+#include "../../include/ofdmrx.h"
+#include "kernels.h"
+#include "tables.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace rx;
+
+static_assert(sizeof(Result) == sizeof(ofdmrx_frame_result), "Result must mirror ofdmrx_frame_result");
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t bytes = 0;
+	int ensure(size_t need)
+	{
+		if (need <= bytes)
+			return 0;
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		bytes = 0;
+		hipError_t e = hipMalloc(&p, need);
+		if (e != hipSuccess) {
+			g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+			return OFDMRX_E_NOMEM;
+		}
+		bytes = need;
+		return 0;
+	}
+	void release()
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		bytes = 0;
+	}
+	template <typename T> T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct ofdmrx_handle {
+	ofdmrx_config cfg;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	int chunk = 0;
+	long max_samples = 0;
+	HostTables host;
+	Tables dev{};
+	std::vector<void *> table_allocs;
+	// per-chunk device state
+	int cap = 0;              // frames the buffers below are sized for
+	long cap_samples = 0;     // samples per frame the mono buffers are sized for
+	DevBuf st, hdr_soft, cons, slope, yint, precision, llr, soft, hard, metric, lane_mesg, res, payload;
+	DevBuf dc, z;             // mono front end only
+	DevBuf cons_raw;          // only with cfg.flags & 1 (keep the pre-rotation constellation for taps)
+	long last_spf = 0;
+	DevBuf in_stage, skip_stage;
+	int last_n = 0;           // frames in the last chunk (for taps)
+	bool last_mono = false;
+	// timing
+	std::vector<hipEvent_t> ev_pool;
+	size_t ev_used = 0;
+	struct Span { int stage; size_t a, b; };
+	std::vector<Span> spans;
+	ofdmrx_timing timing{};
+};
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+	g_last_error = std::string(#call) + ": " + hipGetErrorString(e_); return OFDMRX_E_HIP; } } while (0)
+
+template <typename T>
+static int upload(ofdmrx_handle *h, const std::vector<T> &v, const T **out)
+{
+	void *p = nullptr;
+	HIP_OK(hipMalloc(&p, v.size() * sizeof(T)));
+	HIP_OK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+	h->table_allocs.push_back(p);
+	*out = (const T *)p;
+	return 0;
+}
+
+extern "C" int ofdmrx_abi_version(void) { return OFDMRX_ABI_VERSION; }
+
+extern "C" const char *ofdmrx_strerror(int err)
+{
+	switch (err) {
+	case 0: return "ok";
+	case OFDMRX_E_ARG: return "invalid argument";
+	case OFDMRX_E_NOMEM: return g_last_error.empty() ? "out of device memory" : g_last_error.c_str();
+	case OFDMRX_E_HIP: return g_last_error.empty() ? "HIP error" : g_last_error.c_str();
+	case OFDMRX_E_NODEV: return "no usable HIP device (the receive path has no CPU fallback)";
+	case OFDMRX_E_UNSUPPORTED: return "unsupported configuration (8 kHz, list size 8 only)";
+	default: return "unknown error";
+	}
+}
+
+extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
+{
+	if (!cfg || !out || cfg->abi_version != OFDMRX_ABI_VERSION)
+		return OFDMRX_E_ARG;
+	if (cfg->sample_rate != 8000 || (cfg->list_size != 0 && cfg->list_size != 8))
+		return OFDMRX_E_UNSUPPORTED;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+		return OFDMRX_E_NODEV;
+	HIP_OK(hipSetDevice(cfg->device));
+	ofdmrx_handle *h = new (std::nothrow) ofdmrx_handle;
+	if (!h)
+		return OFDMRX_E_NOMEM;
+	h->cfg = *cfg;
+	h->chunk = cfg->chunk_frames > 0 ? cfg->chunk_frames : 8192;
+	h->max_samples = cfg->max_samples > 0 ? cfg->max_samples : OFDMRX_FRAME_SAMPLES;
+	if (cfg->stream) {
+		h->stream = (hipStream_t)cfg->stream;
+	} else {
+		hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+			delete h;
+			return OFDMRX_E_HIP;
+		}
+		h->own_stream = true;
+	}
+	build_tables(h->host);
+	int r = 0;
+	r = r ? r : upload(h, h->host.tw1280, &h->dev.tw1280);
+	r = r ? r : upload(h, h->host.sc_kern, &h->dev.sc_kern);
+	r = r ? r : upload(h, h->host.mls1_nrz, &h->dev.mls1_nrz);
+	r = r ? r : upload(h, h->host.frozen, &h->dev.frozen);
+	r = r ? r : upload(h, h->host.info_pos, &h->dev.info_pos);
+	r = r ? r : upload(h, h->host.genmat_bits, &h->dev.genmat_bits);
+	r = r ? r : upload(h, h->host.osd_pairs, &h->dev.osd_pairs);
+	r = r ? r : upload(h, h->host.crc32_tab, &h->dev.crc32_tab);
+	r = r ? r : upload(h, h->host.scramble, &h->dev.scramble);
+	if (r) {
+		ofdmrx_destroy(h);
+		return r;
+	}
+	*out = h;
+	return 0;
+}
+
+extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
+{
+	if (!h)
+		return;
+	(void)hipSetDevice(h->cfg.device);
+	if (h->stream)
+		(void)hipStreamSynchronize(h->stream);
+	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->skip_stage })
+		b->release();
+	for (void *p : h->table_allocs)
+		(void)hipFree(p);
+	for (hipEvent_t e : h->ev_pool)
+		(void)hipEventDestroy(e);
+	if (h->own_stream && h->stream)
+		(void)hipStreamDestroy(h->stream);
+	delete h;
+}
+
+extern "C" int ofdmrx_chunk_frames(ofdmrx_handle *h) { return h ? h->chunk : OFDMRX_E_ARG; }
+
+static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
+{
+	int r = 0;
+	if (n > h->cap) {
+		const size_t N = (size_t)n;
+		r = r ? r : h->st.ensure(N * sizeof(SyncState));
+		r = r ? r : h->hdr_soft.ensure(N * 256);
+		r = r ? r : h->cons.ensure(N * CONS_CNT * sizeof(cf));
+		r = r ? r : h->slope.ensure(N * CONS_ROWS * sizeof(float));
+		r = r ? r : h->yint.ensure(N * CONS_ROWS * sizeof(float));
+		r = r ? r : h->precision.ensure(N * CONS_ROWS * sizeof(float));
+		r = r ? r : h->llr.ensure(N * CODE_LEN * sizeof(float));
+		r = r ? r : h->soft.ensure(N * 8 * CODE_LEN * sizeof(float));
+		r = r ? r : h->hard.ensure(N * CODE_LEN);
+		r = r ? r : h->metric.ensure(N * LIST * sizeof(float));
+		r = r ? r : h->lane_mesg.ensure(N * LIST * MESG_BYTES);
+		r = r ? r : h->res.ensure(N * sizeof(Result));
+		r = r ? r : h->payload.ensure(N * PAYLOAD_BYTES);
+		if (h->cfg.flags & 1)
+			r = r ? r : h->cons_raw.ensure(N * CONS_CNT * sizeof(cf));
+		if (r)
+			return r;
+		h->cap = n;
+	}
+	if (mono) {
+		size_t need = (size_t)std::max(n, h->cap) * (size_t)samples;
+		r = r ? r : h->dc.ensure(need * sizeof(float));
+		r = r ? r : h->z.ensure(need * sizeof(cf));
+	}
+	return r;
+}
+
+static size_t mark(ofdmrx_handle *h)
+{
+	if (h->ev_used == h->ev_pool.size()) {
+		hipEvent_t e;
+		if (hipEventCreate(&e) != hipSuccess)
+			return (size_t)-1;
+		h->ev_pool.push_back(e);
+	}
+	size_t i = h->ev_used++;
+	(void)hipEventRecord(h->ev_pool[i], h->stream);
+	return i;
+}
+
+// one resident chunk: every stage of SURVEY 8(a) D1..D10 as kernels on the handle's stream
+static int run_chunk(ofdmrx_handle *h, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
+	uint8_t *d_payload, Result *d_res, bool want_lane_mesg)
+{
+	const bool mono = fb.channels == 1;
+	int r = ensure_capacity(h, n, mono, fb.samples_per_frame);
+	if (r)
+		return r;
+	hipStream_t s = h->stream;
+	SyncState *st = h->st.as<SyncState>();
+	const cf *z = mono ? h->z.as<cf>() : nullptr;
+	size_t e0 = mark(h);
+	if (mono)
+		launch_front_end(s, n, fb, h->host.front, h->dc.as<float>(), h->z.as<cf>());
+	size_t e1 = mark(h);
+	launch_init_sync(s, n, st, d_skip);
+	size_t e2 = e1, e3 = e1;
+	for (int round = 0; round <= max_skip; ++round) {      // decode.cc:390-448 do { } while (skip_count--)
+		size_t a = mark(h);
+		launch_sync(s, n, fb, z, h->dev, st);
+		size_t b = mark(h);
+		launch_header(s, n, fb, z, h->dev, st, h->hdr_soft.as<int8_t>());
+		size_t c = mark(h);
+		h->spans.push_back({ OFDMRX_T_SYNC, a, b });
+		h->spans.push_back({ OFDMRX_T_HEADER, b, c });
+		e2 = b;
+		e3 = c;
+	}
+	(void)e2;
+	launch_demod(s, n, fb, z, h->dev, st, h->cons.as<cf>());
+	if (h->cfg.flags & 1)
+		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_CNT * sizeof(cf), hipMemcpyDeviceToDevice, s));
+	size_t e4 = mark(h);
+	launch_theil_sen(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>());
+	size_t e5 = mark(h);
+	launch_llr(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
+		h->llr.as<float>(), d_res);
+	size_t e6 = mark(h);
+	launch_polar(s, n, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	size_t e7 = mark(h);
+	launch_finish(s, n, st, h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
+		want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res);
+	size_t e8 = mark(h);
+	h->spans.push_back({ OFDMRX_T_FRONT, e0, e1 });
+	h->spans.push_back({ OFDMRX_T_DEMOD, e3, e4 });
+	h->spans.push_back({ OFDMRX_T_THEILSEN, e4, e5 });
+	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
+	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
+	h->spans.push_back({ OFDMRX_T_FINISH, e7, e8 });
+	h->spans.push_back({ OFDMRX_T_TOTAL, e0, e8 });
+	HIP_OK(hipGetLastError());
+	h->last_n = n;
+	h->last_mono = mono;
+	h->last_spf = fb.samples_per_frame;
+	return 0;
+}
+
+static int check_args(ofdmrx_handle *h, const void *samples, int fmt, int channels, size_t spf, size_t stride,
+	size_t n, const void *payload, const void *results)
+{
+	if (!h || !samples || !payload || !results || n == 0)
+		return OFDMRX_E_ARG;
+	if (fmt < OFDMRX_FMT_S16 || fmt > OFDMRX_FMT_F32 || channels < 1 || channels > 2)   // decode.cc:578
+		return OFDMRX_E_ARG;
+	size_t bps = fmt == OFDMRX_FMT_S16 ? 2 : fmt == OFDMRX_FMT_U8 ? 1 : 4;
+	if (spf == 0 || spf > (size_t)0x7fffffff / 2 || stride < spf * bps * (size_t)channels)
+		return OFDMRX_E_ARG;
+	if (fmt == OFDMRX_FMT_S16 && channels == 2 && (stride & 3))
+		return OFDMRX_E_ARG;
+	return 0;
+}
+
+extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int fmt, int channels,
+	size_t spf, size_t stride, size_t n_frames, const int32_t *d_skip, uint8_t *d_payload, ofdmrx_frame_result *d_results)
+{
+	int r = check_args(h, d_samples, fmt, channels, spf, stride, n_frames, d_payload, d_results);
+	if (r)
+		return r;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	int max_skip = 0;
+	if (d_skip) {
+		std::vector<int32_t> hs(n_frames);
+		HIP_OK(hipMemcpy(hs.data(), d_skip, n_frames * sizeof(int32_t), hipMemcpyDeviceToHost));
+		for (int32_t v : hs)
+			max_skip = std::max(max_skip, (int)v);
+		max_skip = std::min(max_skip, 64);
+	}
+	h->ev_used = 0;
+	h->spans.clear();
+	for (size_t f0 = 0; f0 < n_frames; f0 += (size_t)h->chunk) {
+		int n = (int)std::min((size_t)h->chunk, n_frames - f0);
+		FrameBatch fb{ (const char *)d_samples + f0 * stride, stride, (long)spf, fmt, channels };
+		r = run_chunk(h, fb, n, d_skip ? d_skip + f0 : nullptr, max_skip, d_payload + f0 * PAYLOAD_BYTES,
+			(Result *)d_results + f0, true);
+		if (r)
+			return r;
+	}
+	return 0;
+}
+
+extern "C" int ofdmrx_synchronize(ofdmrx_handle *h)
+{
+	if (!h)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipStreamSynchronize(h->stream));
+	return 0;
+}
+
+extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fmt, int channels,
+	size_t spf, size_t stride, size_t n_frames, const int32_t *skip, uint8_t *payload_out, ofdmrx_frame_result *results)
+{
+	int r = check_args(h, samples, fmt, channels, spf, stride, n_frames, payload_out, results);
+	if (r)
+		return r;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	int max_skip = 0;
+	if (skip)
+		for (size_t i = 0; i < n_frames; ++i)
+			max_skip = std::max(max_skip, (int)skip[i]);
+	max_skip = std::min(max_skip, 64);
+	h->ev_used = 0;
+	h->spans.clear();
+	for (size_t f0 = 0; f0 < n_frames; f0 += (size_t)h->chunk) {
+		int n = (int)std::min((size_t)h->chunk, n_frames - f0);
+		r = h->in_stage.ensure((size_t)n * stride);
+		if (r)
+			return r;
+		r = ensure_capacity(h, n, channels == 1, (long)spf);
+		if (r)
+			return r;
+		HIP_OK(hipMemcpyAsync(h->in_stage.p, (const char *)samples + f0 * stride, (size_t)n * stride,
+			hipMemcpyHostToDevice, h->stream));
+		int32_t *d_skip = nullptr;
+		if (skip) {
+			r = h->skip_stage.ensure((size_t)n * sizeof(int32_t));
+			if (r)
+				return r;
+			d_skip = h->skip_stage.as<int32_t>();
+			HIP_OK(hipMemcpyAsync(d_skip, skip + f0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+		}
+		FrameBatch fb{ h->in_stage.p, stride, (long)spf, fmt, channels };
+		r = run_chunk(h, fb, n, d_skip, max_skip, h->payload.as<uint8_t>(), h->res.as<Result>(), true);
+		if (r)
+			return r;
+		HIP_OK(hipMemcpyAsync(payload_out + f0 * PAYLOAD_BYTES, h->payload.p, (size_t)n * PAYLOAD_BYTES,
+			hipMemcpyDeviceToHost, h->stream));
+		HIP_OK(hipMemcpyAsync(results + f0, h->res.p, (size_t)n * sizeof(Result), hipMemcpyDeviceToHost, h->stream));
+		HIP_OK(hipStreamSynchronize(h->stream));
+	}
+	return 0;
+}
+
+extern "C" int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t)
+{
+	if (!h || !t)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipStreamSynchronize(h->stream));
+	std::memset(&h->timing, 0, sizeof(h->timing));
+	for (const auto &sp : h->spans) {
+		if (sp.a == (size_t)-1 || sp.b == (size_t)-1)
+			continue;
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, h->ev_pool[sp.a], h->ev_pool[sp.b]) == hipSuccess) {
+			h->timing.ms[sp.stage] += ms;
+			h->timing.launches[sp.stage] += 1;
+		}
+	}
+	*t = h->timing;
+	return 0;
+}
+
+extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *dst, size_t dst_bytes)
+{
+	if (!h || !dst || frame >= (size_t)h->last_n)
+		return OFDMRX_E_ARG;
+	const void *src = nullptr;
+	size_t bytes = 0;
+	switch (tap) {
+	case OFDMRX_TAP_HDR_SOFT: src = h->hdr_soft.as<int8_t>() + frame * 256; bytes = 255; break;
+	case OFDMRX_TAP_CONS_RAW:   /* D5 rotates in place: the raw copy exists only with cfg.flags & 1 */
+		if (!(h->cfg.flags & 1))
+			return OFDMRX_E_ARG;
+		src = h->cons_raw.as<cf>() + frame * CONS_CNT; bytes = CONS_CNT * sizeof(cf); break;
+	case OFDMRX_TAP_CONS_ROT: src = h->cons.as<cf>() + frame * CONS_CNT; bytes = CONS_CNT * sizeof(cf); break;
+	case OFDMRX_TAP_SLOPE: src = h->slope.as<float>() + frame * CONS_ROWS; bytes = CONS_ROWS * 4; break;
+	case OFDMRX_TAP_YINT: src = h->yint.as<float>() + frame * CONS_ROWS; bytes = CONS_ROWS * 4; break;
+	case OFDMRX_TAP_PRECISION: src = h->precision.as<float>() + frame * CONS_ROWS; bytes = CONS_ROWS * 4; break;
+	case OFDMRX_TAP_LLR: src = h->llr.as<float>() + frame * CODE_LEN; bytes = CODE_LEN * 4; break;
+	case OFDMRX_TAP_METRIC: src = h->metric.as<float>() + frame * LIST; bytes = LIST * 4; break;
+	case OFDMRX_TAP_LANE_MESG: src = h->lane_mesg.as<uint8_t>() + frame * LIST * MESG_BYTES; bytes = LIST * MESG_BYTES; break;
+	case OFDMRX_TAP_ANALYTIC:
+		if (!h->last_mono)
+			return OFDMRX_E_ARG;
+		src = h->z.as<cf>() + frame * (size_t)h->last_spf;
+		bytes = 0;   /* caller-sized */
+		break;
+	default: return OFDMRX_E_ARG;
+	}
+	if (tap == OFDMRX_TAP_ANALYTIC)
+		bytes = dst_bytes;
+	if (dst_bytes < bytes)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipStreamSynchronize(h->stream));
+	HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// ---- single-stage entry points ------------------------------------------------------
+extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, uint8_t *lane_mesg, float *metric)
+{
+	if (!h || !llr || !n || n > (size_t)h->chunk)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	int r = ensure_capacity(h, (int)n, false, 0);
+	if (r)
+		return r;
+	std::vector<SyncState> st(n);
+	std::memset(st.data(), 0, n * sizeof(SyncState));
+	for (auto &s : st) { s.okay = 1; s.oper_mode = 6; }
+	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
+	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
+	launch_polar(h->stream, (int)n, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	launch_finish(h->stream, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, 0,
+		h->lane_mesg.as<uint8_t>(), h->payload.as<uint8_t>(), h->res.as<Result>());
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipStreamSynchronize(h->stream));
+	if (lane_mesg)
+		HIP_OK(hipMemcpy(lane_mesg, h->lane_mesg.p, n * LIST * MESG_BYTES, hipMemcpyDeviceToHost));
+	if (metric)
+		HIP_OK(hipMemcpy(metric, h->metric.p, n * LIST * sizeof(float), hipMemcpyDeviceToHost));
+	h->last_n = (int)n;
+	return 0;
+}
+
+extern "C" int ofdmrx_debug_theil_sen(ofdmrx_handle *h, const float *y, size_t rows, int cols, float *slope, float *yint)
+{
+	if (!h || !y || !rows || cols < 2 || cols > 510 || !slope || !yint)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	DevBuf dy, ds, di;
+	int r = dy.ensure(rows * cols * 4);
+	r = r ? r : ds.ensure(rows * 4);
+	r = r ? r : di.ensure(rows * 4);
+	if (!r) {
+		hipError_t e = hipMemcpy(dy.p, y, rows * cols * 4, hipMemcpyHostToDevice);
+		launch_theil_sen_raw(h->stream, (int)rows, cols, dy.as<float>(), ds.as<float>(), di.as<float>());
+		e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;
+		e = e == hipSuccess ? hipMemcpy(slope, ds.p, rows * 4, hipMemcpyDeviceToHost) : e;
+		e = e == hipSuccess ? hipMemcpy(yint, di.p, rows * 4, hipMemcpyDeviceToHost) : e;
+		if (e != hipSuccess) {
+			g_last_error = hipGetErrorString(e);
+			r = OFDMRX_E_HIP;
+		}
+	}
+	dy.release(); ds.release(); di.release();
+	return r;
+}
+
+extern "C" int ofdmrx_debug_osd(ofdmrx_handle *h, const int8_t *soft, size_t n, uint8_t *hard, int32_t *unique)
+{
+	if (!h || !soft || !n || !hard || !unique)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	DevBuf dsf, dh, du;
+	int r = dsf.ensure(n * 255);
+	r = r ? r : dh.ensure(n * 32);
+	r = r ? r : du.ensure(n * 4);
+	if (!r) {
+		hipError_t e = hipMemcpy(dsf.p, soft, n * 255, hipMemcpyHostToDevice);
+		launch_osd_only(h->stream, (int)n, h->dev, dsf.as<int8_t>(), dh.as<uint8_t>(), du.as<int32_t>());
+		e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;
+		e = e == hipSuccess ? hipMemcpy(hard, dh.p, n * 32, hipMemcpyDeviceToHost) : e;
+		e = e == hipSuccess ? hipMemcpy(unique, du.p, n * 4, hipMemcpyDeviceToHost) : e;
+		if (e != hipSuccess) {
+			g_last_error = hipGetErrorString(e);
+			r = OFDMRX_E_HIP;
+		}
+	}
+	dsf.release(); dh.release(); du.release();
+	return r;
+}
+
+extern "C" int ofdmrx_debug_fft(ofdmrx_handle *h, const float *in, size_t n, int len, int sign, float *out)
+{
+	if (!h || !in || !out || !n || (len != 1280 && len != 640) || (sign != 1 && sign != -1))
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	DevBuf di, dout;
+	size_t bytes = n * (size_t)len * sizeof(cf);
+	int r = di.ensure(bytes);
+	r = r ? r : dout.ensure(bytes);
+	if (!r) {
+		hipError_t e = hipMemcpy(di.p, in, bytes, hipMemcpyHostToDevice);
+		launch_fft_debug(h->stream, (int)n, len, sign, di.as<cf>(), dout.as<cf>(), h->dev);
+		e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;
+		e = e == hipSuccess ? hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost) : e;
+		if (e != hipSuccess) {
+			g_last_error = hipGetErrorString(e);
+			r = OFDMRX_E_HIP;
+		}
+	}
+	di.release(); dout.release();
+	return r;
+}
+
+extern "C" int ofdmrx_util_awgn_tile(ofdmrx_handle *h, const int16_t *d_base, size_t n_base, int16_t *d_out, size_t n_out,
+	size_t spf, float noise_db, uint64_t seed, uint64_t first_frame)
+{
+	if (!h || !d_base || !d_out || !n_base || !n_out || !spf)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	const float sigma = std::sqrt(0.5f * std::pow(10.f, noise_db / 10.f));
+	launch_awgn_tile(h->stream, d_base, n_base, d_out, n_out, spf, sigma, seed, first_frame);
+	HIP_OK(hipGetLastError());
+	return 0;
+}

@@ -1,0 +1,185 @@
+// tables.cpp -- host-side construction of the constant tables the kernels read.
+// Everything is generated from first principles (nothing is copied from the reference's
+// polar_tables.hh; nothing links against oracle/).
+#include "tables.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace rx {
+
+// ---- CODE::MLS (decode.cc:238,407): Galois LFSR, register starts at 1
+struct Mls {
+	int poly, test, reg;
+	explicit Mls(int p) : poly(p), reg(1)
+	{
+		unsigned n = (unsigned)p;
+		n |= n >> 1; n |= n >> 2; n |= n >> 4; n |= n >> 8; n |= n >> 16;
+		test = (int)((n ^ (n >> 1)) >> 1);
+	}
+	int next()
+	{
+		int fb = (reg & test) != 0;
+		reg <<= 1;
+		reg ^= fb * poly;
+		return fb;
+	}
+};
+
+// ---- frozen mask: freezer.cc:14-32 recipe (BEC construction in long double, the K most
+// reliable synthetic channels are unfrozen).  table 0 = (64800, 43072): polar_tables.hh:2
+static void frozen_mask(uint32_t *frozen)
+{
+	const int M = 16, LEN = 1 << M, N = 64800, K = 43040 + 32;
+	long double erasure_probability = (long double)(N - K) / N;
+	double design_SNR = 10 * std::log10(-std::log((double)erasure_probability));
+	double better_SNR = design_SNR + 1.59175;
+	long double p = expl(-(long double)std::pow(10.0, better_SNR / 10));
+	std::vector<long double> a(1, p), b;
+	for (int m = 0; m < M; ++m) {
+		b.resize(a.size() * 2);
+		for (size_t i = 0; i < a.size(); ++i) {
+			b[2 * i] = 2 * a[i] - a[i] * a[i];
+			b[2 * i + 1] = a[i] * a[i];
+		}
+		a.swap(b);
+	}
+	std::vector<int> idx(LEN);
+	std::iota(idx.begin(), idx.end(), 0);
+	std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return a[x] < a[y]; });
+	for (int i = 0; i < LEN / 32; ++i)
+		frozen[i] = 0xffffffffu;
+	for (int i = 0; i < K + LEN - N; ++i)
+		frozen[idx[i] / 32] &= ~(1u << (idx[i] % 32));
+}
+
+// ---- BCH(255,71): generator polynomial = product of the 24 minimal polynomials of
+// decode.cc:379-384; systematic generator rows = [e_j | (x^184 e_j(x)) mod g(x)]
+static void bch_genmat_bits(uint32_t *rows /*71*8*/)
+{
+	static const int minpolys[24] = {
+		0x11d, 0x177, 0x1f3, 0x169, 0x1bd, 0x1e7, 0x12b, 0x1d7, 0x013, 0x165, 0x18b, 0x163,
+		0x11b, 0x13f, 0x18d, 0x12d, 0x15f, 0x1f9, 0x1c3, 0x139, 0x1a9, 0x01f, 0x187, 0x1b1 };
+	const int NP = 184, K = 71;
+	std::vector<uint8_t> g(NP + 1, 0);
+	g[0] = 1;
+	int deg = 0;
+	for (int p = 0; p < 24; ++p) {
+		int m = minpolys[p], md = 0;
+		while (m >> (md + 1)) ++md;
+		std::vector<uint8_t> t(NP + 1, 0);
+		for (int i = 0; i <= deg; ++i)
+			if (g[i])
+				for (int j = 0; j <= md; ++j)
+					if ((m >> j) & 1) t[i + j] ^= 1;
+		deg += md;
+		g = t;
+	}
+	std::memset(rows, 0, sizeof(uint32_t) * K * 8);
+	for (int j = 0; j < K; ++j) {
+		// message bit j = coefficient of x^(K-1-j); remainder of x^(NP + K-1-j) mod g
+		std::vector<uint8_t> r(NP, 0);
+		for (int i = 0; i < K; ++i) {
+			int fb = (i == j) ^ r[NP - 1];
+			for (int d = NP - 1; d > 0; --d) r[d] = r[d - 1];
+			r[0] = 0;
+			if (fb)
+				for (int d = 0; d < NP; ++d) r[d] ^= g[d];
+		}
+		auto set = [&](int col) { rows[j * 8 + (col >> 5)] |= 1u << (col & 31); };
+		set(j);
+		for (int i = 0; i < NP; ++i)
+			if (r[NP - 1 - i]) set(K + i);
+	}
+}
+
+static double bessel_i0(double x)
+{
+	double sum = 1.0, term = 1.0;
+	for (int k = 1; k < 64; ++k) {
+		term *= (x / (2.0 * k)) * (x / (2.0 * k));
+		sum += term;
+		if (term < 1e-20 * sum) break;
+	}
+	return sum;
+}
+static double kaiser(double a, int n, int N)
+{
+	double t = 2.0 * n / (double)(N - 1) - 1.0;
+	return bessel_i0(M_PI * a * std::sqrt(1.0 - t * t)) / bessel_i0(M_PI * a);
+}
+
+void build_tables(HostTables &t)
+{
+	t.tw1280.resize(1280);
+	for (int k = 0; k < 1280; ++k) {
+		double a = -2.0 * M_PI * k / 1280.0;
+		t.tw1280[k].re = (float)std::cos(a);
+		t.tw1280[k].im = (float)std::sin(a);
+	}
+	// decode.cc:236-244 mls0_seq + decode.cc:80-82: kern = conj(FFT640(seq))/640
+	{
+		std::vector<double> seq(640, 0.0);
+		Mls m0(0x89);
+		const int mls0_off = -127 + 1;
+		for (int i = 0; i < 127; ++i)
+			seq[(i + mls0_off / 2 + 640) % 640] = 1 - 2 * m0.next();
+		t.sc_kern.resize(640);
+		for (int k = 0; k < 640; ++k) {
+			double re = 0, im = 0;
+			for (int n = 0; n < 640; ++n) {
+				double a = -2.0 * M_PI * ((long)k * n % 640) / 640.0;
+				re += seq[n] * std::cos(a);
+				im += seq[n] * std::sin(a);
+			}
+			t.sc_kern[k].re = (float)(re / 640.0);
+			t.sc_kern[k].im = (float)(-im / 640.0);
+		}
+	}
+	{
+		Mls m1(0x12b);
+		t.mls1_nrz.resize(256, 1.f);
+		for (int i = 0; i < 255; ++i)
+			t.mls1_nrz[i] = (float)(1 - 2 * m1.next());
+	}
+	t.frozen.resize(2048);
+	frozen_mask(t.frozen.data());
+	t.info_pos.clear();
+	for (int i = 0; i < 65536; ++i)
+		if (!((t.frozen[i / 32] >> (i % 32)) & 1))
+			t.info_pos.push_back((uint16_t)i);
+	t.genmat_bits.resize(71 * 8);
+	bch_genmat_bits(t.genmat_bits.data());
+	t.osd_pairs.clear();
+	for (int a = 0; a < 71; ++a)
+		for (int b = a + 1; b < 71; ++b) {
+			t.osd_pairs.push_back((uint8_t)a);
+			t.osd_pairs.push_back((uint8_t)b);
+		}
+	t.crc32_tab.resize(256);
+	for (uint32_t j = 0; j < 256; ++j) {
+		uint32_t c = j;
+		for (int i = 0; i < 8; ++i)
+			c = (c >> 1) ^ ((c & 1) * 0xD419CC15u);   // CRC<uint32_t>(0xD419CC15), decode.cc:198
+		t.crc32_tab[j] = c;
+	}
+	t.scramble.resize(5380);
+	{
+		uint32_t y = 2463534242u;   // CODE::Xorshift32 default seed, decode.cc:613
+		for (int i = 0; i < 5380; ++i) {
+			y ^= y << 13; y ^= y >> 17; y ^= y << 5;
+			t.scramble[i] = (uint8_t)y;
+		}
+	}
+	// BlockDC::samples(2*(1280+160)) decode.cc:386 ; Hilbert<cmplx,21> decode.cc:193
+	const float s = 2880.f;
+	t.front.dc_a = (s - 1.f) / s;
+	t.front.dc_b = (1.f + t.front.dc_a) / 2.f;
+	const int TAPS = 21;
+	t.front.reco = (float)kaiser(2.0, (TAPS - 1) / 2, TAPS);
+	for (int i = 0; i < 5; ++i)
+		t.front.imco[i] = (float)(kaiser(2.0, (2 * i + 1) + (TAPS - 1) / 2, TAPS) * 2.0 / ((2 * i + 1) * M_PI));
+}
+
+}  // namespace rx

@@ -1,0 +1,20 @@
+// tables.h -- host-side constant tables (see tables.cpp)
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "kernels.h"
+
+namespace rx {
+
+struct HostTables {
+	std::vector<cf> tw1280, sc_kern;
+	std::vector<float> mls1_nrz;
+	std::vector<uint32_t> frozen, genmat_bits, crc32_tab;
+	std::vector<uint16_t> info_pos;
+	std::vector<uint8_t> osd_pairs, scramble;
+	FrontCoef front;
+};
+
+void build_tables(HostTables &t);
+
+}  // namespace rx

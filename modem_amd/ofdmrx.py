@@ -1,0 +1,222 @@
+"""ctypes mirror of include/ofdmrx.h (the drop-in boundary for decode.cc's Decoder seam)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+
+FMT_S16, FMT_U8, FMT_F32 = 0, 1, 2
+PAYLOAD_BYTES = 5380
+CODE_LEN = 65536
+FRAME_SAMPLES = 95200
+MESG_BYTES = 5476
+STATUS_NAMES = ["OK", "NO_SYNC", "OSD_ERROR", "HEADER_CRC", "BAD_MODE", "BAD_CALLSIGN", "PAYLOAD_CRC"]
+TAPS = dict(HDR_SOFT=1, CONS_RAW=2, CONS_ROT=3, SLOPE=4, YINT=5, PRECISION=6, LLR=7, METRIC=8, LANE_MESG=9, ANALYTIC=10)
+STAGES = ["front", "sync", "header", "demod", "theilsen", "llr", "polar", "finish", "total"]
+
+# every symbol include/ofdmrx.h declares
+EXPORTS = [
+    "ofdmrx_abi_version", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
+    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames",
+    "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
+    "ofdmrx_util_awgn_tile",
+]
+
+
+class OfdmRxError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("sample_rate", C.c_int32), ("list_size", C.c_int32),
+                ("device", C.c_int32), ("chunk_frames", C.c_int32), ("max_samples", C.c_int32),
+                ("descramble", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("symbol_pos", C.c_int32), ("sc_start", C.c_int64),
+                ("cfo_rad", C.c_float), ("cfo_fine", C.c_float), ("sfo_slope", C.c_float),
+                ("oper_mode", C.c_int32), ("call_sign", C.c_uint64), ("best_lane", C.c_int32),
+                ("bit_flips", C.c_int32), ("esn0_db_last", C.c_float), ("n_sync_rejects", C.c_int32)]
+
+
+RESULT_DTYPE = np.dtype([("status", "<i4"), ("symbol_pos", "<i4"), ("sc_start", "<i8"), ("cfo_rad", "<f4"),
+                         ("cfo_fine", "<f4"), ("sfo_slope", "<f4"), ("oper_mode", "<i4"), ("call_sign", "<u8"),
+                         ("best_lane", "<i4"), ("bit_flips", "<i4"), ("esn0_db_last", "<f4"),
+                         ("n_sync_rejects", "<i4")], align=True)
+assert RESULT_DTYPE.itemsize == C.sizeof(FrameResult)
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms", C.c_float * 9), ("launches", C.c_int32 * 9)]
+
+
+def lib_path():
+    return os.path.join(HERE, "lib", "libofdmrx.so")
+
+
+def build(force=False):
+    """compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)"""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "-j8", "all"], stdout=subprocess.DEVNULL)
+    return lib_path()
+
+
+_LIB = None
+
+
+def load_library():
+    """dlopen libofdmrx.so; fails loudly when the HIP extension has not been built"""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise OfdmRxError("libofdmrx.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "-- the receive path has no CPU fallback" % path)
+    L = C.CDLL(path)
+    L.ofdmrx_abi_version.restype = C.c_int
+    L.ofdmrx_strerror.restype = C.c_char_p
+    L.ofdmrx_strerror.argtypes = [C.c_int]
+    L.ofdmrx_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.ofdmrx_destroy.argtypes = [C.c_void_p]
+    L.ofdmrx_destroy.restype = None
+    batch = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ofdmrx_decode_batch.argtypes = batch
+    L.ofdmrx_decode_batch_device.argtypes = batch
+    L.ofdmrx_synchronize.argtypes = [C.c_void_p]
+    L.ofdmrx_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+    L.ofdmrx_chunk_frames.argtypes = [C.c_void_p]
+    L.ofdmrx_debug_dump.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.ofdmrx_debug_polar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ofdmrx_debug_theil_sen.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    L.ofdmrx_debug_osd.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ofdmrx_debug_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    L.ofdmrx_util_awgn_tile.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                        C.c_float, C.c_uint64, C.c_uint64]
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Receiver:
+    """Batch counterpart of `new Decoder<float, Complex<float>, 8000>(out, pcm, skip)` (decode.cc:592).
+
+    decode(pcm) takes raw PCM frames [n_frames, samples, channels] (int16 / uint8 / float32, what
+    DSP::ReadWAV would deliver) and returns (payload[n_frames, 5380] uint8, results structured array).
+    """
+
+    def __init__(self, device=0, chunk_frames=0, max_samples=0, descramble=True, keep_raw_cons=False, stream=None):
+        self._lib = load_library()
+        if self._lib.ofdmrx_abi_version() != 1:
+            raise OfdmRxError("ABI mismatch")
+        cfg = Config(1, 8000, 8, device, chunk_frames, max_samples, 1 if descramble else 0,
+                     1 if keep_raw_cons else 0, stream)
+        self._h = C.c_void_p()
+        self._check(self._lib.ofdmrx_create(C.byref(cfg), C.byref(self._h)))
+
+    def _check(self, r):
+        if r != 0:
+            raise OfdmRxError("ofdmrx: %s (%d)" % (self._lib.ofdmrx_strerror(r).decode(), r))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ofdmrx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def chunk_frames(self):
+        return self._lib.ofdmrx_chunk_frames(self._h)
+
+    @staticmethod
+    def _fmt(dtype):
+        return {np.dtype(np.int16): FMT_S16, np.dtype(np.uint8): FMT_U8, np.dtype(np.float32): FMT_F32}[np.dtype(dtype)]
+
+    def decode(self, pcm, skip=None):
+        pcm = np.ascontiguousarray(pcm)
+        if pcm.ndim == 2:
+            pcm = pcm[None]
+        n, spf, ch = pcm.shape
+        stride = spf * ch * pcm.dtype.itemsize
+        if stride % 4:
+            pad = np.zeros((n, (stride + 3) // 4 * 4), np.uint8)
+            pad[:, :stride] = pcm.reshape(n, -1).view(np.uint8)
+            buf, stride = pad, pad.shape[1]
+        else:
+            buf = pcm
+        out = np.zeros((n, PAYLOAD_BYTES), np.uint8)
+        res = np.zeros(n, RESULT_DTYPE)
+        sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.int32)
+        self._check(self._lib.ofdmrx_decode_batch(self._h, _ptr(buf), self._fmt(pcm.dtype), ch, spf, stride, n,
+                                                  _ptr(sk) if sk is not None else None, _ptr(out), _ptr(res)))
+        return out, res
+
+    def decode_device(self, d_samples, fmt, channels, spf, stride, n, d_payload, d_results, d_skip=None):
+        """device pointers (ints); asynchronous on the handle's stream"""
+        self._check(self._lib.ofdmrx_decode_batch_device(self._h, d_samples, fmt, channels, spf, stride, n,
+                                                         d_skip, d_payload, d_results))
+
+    def synchronize(self):
+        self._check(self._lib.ofdmrx_synchronize(self._h))
+
+    def timing(self):
+        t = Timing()
+        self._check(self._lib.ofdmrx_get_timing(self._h, C.byref(t)))
+        return {s: (t.ms[i], t.launches[i]) for i, s in enumerate(STAGES)}
+
+    def tap(self, name, frame, samples=None):
+        shapes = dict(HDR_SOFT=((255,), np.int8), CONS_RAW=((21600, 2), np.float32), CONS_ROT=((21600, 2), np.float32),
+                      SLOPE=((50,), np.float32), YINT=((50,), np.float32), PRECISION=((50,), np.float32),
+                      LLR=((CODE_LEN,), np.float32), METRIC=((8,), np.float32), LANE_MESG=((8, MESG_BYTES), np.uint8),
+                      ANALYTIC=((samples or 0, 2), np.float32))
+        shape, dt = shapes[name]
+        a = np.zeros(shape, dt)
+        self._check(self._lib.ofdmrx_debug_dump(self._h, TAPS[name], frame, _ptr(a), a.nbytes))
+        return a
+
+    # ---- single-stage entry points (parity tests)
+    def polar(self, llr):
+        llr = np.ascontiguousarray(llr, dtype=np.float32).reshape(-1, CODE_LEN)
+        n = llr.shape[0]
+        mesg = np.zeros((n, 8, MESG_BYTES), np.uint8)
+        metric = np.zeros((n, 8), np.float32)
+        self._check(self._lib.ofdmrx_debug_polar(self._h, _ptr(llr), n, _ptr(mesg), _ptr(metric)))
+        return mesg, metric
+
+    def theil_sen(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        rows, cols = y.shape
+        s, i = np.zeros(rows, np.float32), np.zeros(rows, np.float32)
+        self._check(self._lib.ofdmrx_debug_theil_sen(self._h, _ptr(y), rows, cols, _ptr(s), _ptr(i)))
+        return s, i
+
+    def osd(self, soft):
+        soft = np.ascontiguousarray(soft, dtype=np.int8).reshape(-1, 255)
+        n = soft.shape[0]
+        hard, uniq = np.zeros((n, 32), np.uint8), np.zeros(n, np.int32)
+        self._check(self._lib.ofdmrx_debug_osd(self._h, _ptr(soft), n, _ptr(hard), _ptr(uniq)))
+        return hard, uniq
+
+    def fft(self, x, sign=-1):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        if x.ndim == 1:
+            x = x[None]
+        out = np.zeros_like(x)
+        self._check(self._lib.ofdmrx_debug_fft(self._h, _ptr(x), x.shape[0], x.shape[1], sign, _ptr(out)))
+        return out
+
+    def awgn_tile(self, d_base, n_base, d_out, n_out, spf, noise_db, seed, first_frame=0):
+        self._check(self._lib.ofdmrx_util_awgn_tile(self._h, d_base, n_base, d_out, n_out, spf, noise_db, seed, first_frame))

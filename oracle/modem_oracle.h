@@ -137,6 +137,9 @@ void orc_polar_enc(int8_t *code, const int8_t *mesg, const uint32_t *frozen, int
 int orc_polar_list_decode(float *metric_out, int8_t *mesg_out, const float *llr,
 	const uint32_t *frozen, int level, int L);
 
+int orc_polar_lane_mesg(const float *llr, const uint32_t *frozen, int level, int L,
+	uint8_t *lane_mesg, int mesg_bytes, float *metric);
+
 /* ---- BCH(255,71) + OSD --------------------------------------------------- */
 void orc_bch_encode(const uint8_t *data /*9 B*/, uint8_t *parity /*23 B*/); /* encode.cc:164 */
 void orc_bch_genmat(int8_t *genmat /*255*71*/);                              /* decode.cc:378-384 */

@@ -253,3 +253,31 @@ int orc_polar_list_decode(float *metric_out, int8_t *mesg_out, const float *llr,
 	free(s.maps);
 	return count;
 }
+
+/* test helper: D9 + systematic() (decode.cc:530-531, 254-261) from raw LLRs:
+ * per-lane systematic message bits, LE packed, lane_mesg[L][mesg_bytes] */
+int orc_polar_lane_mesg(const float *llr, const uint32_t *frozen, int level, int L,
+	uint8_t *lane_mesg, int mesg_bytes, float *metric)
+{
+	const int N = 1 << level;
+	int8_t *mesg = (int8_t *)malloc((size_t)N * L);
+	int8_t *u = (int8_t *)malloc((size_t)N);
+	int8_t *x = (int8_t *)malloc((size_t)N);
+	int count = orc_polar_list_decode(metric, mesg, llr, frozen, level, L);
+	memset(lane_mesg, 0, (size_t)L * mesg_bytes);
+	for (int k = 0; k < L; ++k) {
+		for (int i = 0; i < count; ++i)
+			u[i] = mesg[(size_t)i * L + k];
+		orc_polar_enc(x, u, frozen, level);
+		for (int i = 0, j = 0; i < N && j < count; ++i)
+			if (!is_frozen(frozen, i)) {
+				if (x[i] < 0)
+					lane_mesg[(size_t)k * mesg_bytes + j / 8] |= (uint8_t)(1 << (j % 8));
+				++j;
+			}
+	}
+	free(mesg);
+	free(u);
+	free(x);
+	return count;
+}

@@ -71,6 +71,8 @@ def lib():
                                        C.c_void_p, C.c_void_p, C.c_int]
         L.orc_polar_list_decode.restype = C.c_int
         L.orc_polar_list_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_polar_lane_mesg.restype = C.c_int
+        L.orc_polar_lane_mesg.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_frozen_get.restype = C.POINTER(C.c_uint32)
         L.orc_frozen_get.argtypes = [C.c_int]
         L.orc_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -199,3 +201,30 @@ def impair(pcm2, noise_db=None, cfo_hz=0.0, sfo_ppm=0.0, multipath=None, seed=1,
     if noise_db is not None:
         lib().orc_chan_awgn(ptr(z), n, noise_db, seed, frame)
     return quantise(z, bits, 2)
+
+
+def polar_lane_mesg(llr, L=8, table=0):
+    """oracle D9 + systematic(): per-lane systematic message bits [L, 5476] and metrics [L]"""
+    llr = np.ascontiguousarray(llr, dtype=np.float32)
+    fr = frozen(table)
+    mesg = np.zeros((L, 5476), np.uint8)
+    metric = np.zeros(L, np.float32)
+    lib().orc_polar_lane_mesg(ptr(llr), ptr(fr), 16, L, ptr(mesg), 5476, ptr(metric))
+    return mesg, metric
+
+
+def theil_sen(y):
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    x = (np.arange(y.size) - y.size // 2).astype(np.float32)
+    s, i = C.c_float(), C.c_float()
+    lib().orc_theil_sen(ptr(x), ptr(y), y.size, C.byref(s), C.byref(i))
+    return s.value, i.value
+
+
+def osd(soft):
+    g = np.zeros((71, 255), np.int8)
+    lib().orc_bch_genmat(ptr(g))
+    soft = np.ascontiguousarray(soft, dtype=np.int8)
+    hard = np.zeros(32, np.uint8)
+    u = lib().orc_osd_decode(ptr(hard), ptr(soft), ptr(g))
+    return hard, u

@@ -1,0 +1,123 @@
+"""CPU-side checks of the drop-in boundary: libofdmrx.so builds for gfx950, loads, exports every
+symbol include/ofdmrx.h declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import modem_amd
+    modem_amd.build()
+    return modem_amd.load_library()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ofdmrx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ofdmrx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_all_exported(lib):
+    import modem_amd.ofdmrx as M
+    names = _declared()
+    assert len(names) >= 15 and sorted(M.EXPORTS) == names
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.ofdmrx_abi_version() == 1
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    c = tmp_path / "t.c"
+    c.write_text('#include "ofdmrx.h"\nint main(void){ofdmrx_config c; ofdmrx_frame_result r; (void)c; (void)r; '
+                 'return sizeof(ofdmrx_frame_result) == 56 ? 0 : 1;}\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
+
+
+def test_result_struct_layout_matches_numpy_and_oracle():
+    import modem_amd.ofdmrx as M
+    import oracle_lib as O
+    assert C.sizeof(M.FrameResult) == M.RESULT_DTYPE.itemsize == 56 == C.sizeof(O.Result)
+    for (name, _), (oname, _) in zip(M.FrameResult._fields_, O.Result._fields_):
+        assert name == oname
+        assert getattr(M.FrameResult, name).offset == getattr(O.Result, name).offset == M.RESULT_DTYPE.fields[name][1]
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import modem_amd
+    with pytest.raises(modem_amd.OfdmRxError, match="no usable HIP device"):
+        modem_amd.Receiver()
+    assert lib.ofdmrx_strerror(-4).decode().startswith("no usable HIP device")
+
+
+def test_argument_validation_without_device(lib):
+    # NULL handle / bad arguments are API errors (negative), never crashes
+    assert lib.ofdmrx_decode_batch(None, None, 0, 1, 10, 20, 1, None, None, None) == -1
+    assert lib.ofdmrx_chunk_frames(None) == -1
+    bad = (C.c_int32 * 16)()
+    h = C.c_void_p()
+    import modem_amd.ofdmrx as M
+    cfg = M.Config(2, 8000, 8, 0, 0, 0, 1, 0, None)      # wrong ABI version
+    assert lib.ofdmrx_create(C.byref(cfg), C.byref(h)) == -1
+    cfg = M.Config(1, 48000, 8, 0, 0, 0, 1, 0, None)     # decode.cc:599-601 rate this build does not cover
+    assert lib.ofdmrx_create(C.byref(cfg), C.byref(h)) == -5
+
+
+def test_product_does_not_reference_the_oracle():
+    """the product path must never route through oracle/: no include, no link, no dlopen"""
+    csrc = os.path.join(ROOT, "modem_amd")
+    for dp, _, fs in os.walk(csrc):
+        for f in fs:
+            if f.endswith((".hip", ".cpp", ".h", ".py", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "modem_oracle" not in txt and "oracle_lib" not in txt and "liboracle" not in txt, f
+    out = subprocess.run(["ldd", os.path.join(csrc, "lib", "libofdmrx.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_host_tables_match_oracle_constants(lib):
+    """the product builds its own frozen mask / BCH generator (tables.cpp); they must equal the
+    oracle's, which is pinned to the reference's polar_tables.hh by SHA-256"""
+    import oracle_lib as O
+    exe_src = r'''
+#include "tables.h"
+#include <cstdio>
+int main(){ rx::HostTables t; rx::build_tables(t);
+  fwrite(t.frozen.data(),4,2048,stdout); fwrite(t.genmat_bits.data(),4,71*8,stdout);
+  fwrite(t.scramble.data(),1,5380,stdout); fwrite(t.crc32_tab.data(),4,256,stdout); return 0; }
+'''
+    import tempfile
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "m.cpp"), "w").write(exe_src)
+    csrc = os.path.join(ROOT, "modem_amd", "csrc")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-I", csrc, os.path.join(d, "m.cpp"),
+                           os.path.join(csrc, "tables.cpp"), "-o", os.path.join(d, "m")])
+    raw = subprocess.check_output([os.path.join(d, "m")])
+    fr = np.frombuffer(raw[:8192], np.uint32)
+    assert (fr == O.frozen(0)).all()
+    gm = np.frombuffer(raw[8192:8192 + 71 * 32], np.uint32).reshape(71, 8)
+    g = np.zeros((71, 255), np.int8)
+    O.lib().orc_bch_genmat(O.ptr(g))
+    bits = np.unpackbits(gm.view(np.uint8), bitorder="little").reshape(71, 256)[:, :255]
+    assert (bits == g).all()
+    scr = np.frombuffer(raw[8192 + 71 * 32:8192 + 71 * 32 + 5380], np.uint8).copy()
+    z = np.zeros(5380, np.uint8)
+    O.lib().orc_scramble(O.ptr(z), 5380)
+    assert (scr == z).all()
+    tab = np.frombuffer(raw[8192 + 71 * 32 + 5380:], np.uint32)
+    data = O.payload_for(1)
+    crc = 0
+    for b in data[:64]:
+        crc = (crc >> 8) ^ int(tab[(crc ^ int(b)) & 255])
+    assert crc == O.lib().orc_crc32_bytes(0xD419CC15, O.ptr(data), 64)

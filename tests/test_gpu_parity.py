@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/ofdmrx.h) against the CPU oracle.
+
+Bars (north_star): decoded bits / integer decisions bit-exact; complex / fp32 intermediates
+within 1e-5 relative (relative to the largest magnitude of the compared array, stated per test).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5   # north_star tolerance on fp32 intermediates
+
+
+@pytest.fixture(scope="module")
+def rx():
+    import modem_amd
+    r = modem_amd.Receiver(device=0, chunk_frames=64, keep_raw_cons=True)
+    yield r
+    r.close()
+
+
+def _close(a, b, rel=REL, what=""):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max() / scale
+    assert err <= rel, "%s: max rel err %.3g > %.1g" % (what, err, rel)
+
+
+# ---------------------------------------------------------------- single stages
+@pytest.mark.parametrize("n", [1280, 640])
+def test_fft_matches_double_dft(rx, n):
+    """DSP::FastFourierTransform<1280|640,cmplx,-1|+1> (decode.cc:191,43-44): unnormalised, natural order"""
+    rng = np.random.default_rng(n)
+    x = (rng.normal(size=(5, n)) + 1j * rng.normal(size=(5, n))).astype(np.complex64)
+    x[4] = 0
+    x[4, 3] = 1      # impulse: exposes index-order mistakes
+    for sign in (-1, 1):
+        y = rx.fft(x, sign)
+        ref = np.fft.fft(x.astype(np.complex128), axis=1) if sign < 0 else np.fft.ifft(x.astype(np.complex128), axis=1) * n
+        for r in range(5):
+            assert np.abs(y[r] - ref[r]).max() <= REL * np.abs(ref[r]).max()
+        # and against the oracle's own fp32 FFT
+        o = np.zeros(n, np.complex64)
+        O.lib().orc_fft(O.ptr(o), O.ptr(x[0]), n, sign)
+        assert np.abs(y[0] - o).max() <= REL * np.abs(o).max()
+
+
+def test_theil_sen_bit_exact(rx):
+    """DSP::TheilSenEstimator::compute (decode.cc:488): exact median selection, bit-identical to the oracle"""
+    rng = np.random.default_rng(3)
+    rows = []
+    x = np.arange(-216, 216, dtype=np.float32)
+    for r in range(12):
+        y = (rng.normal(0, 0.002) * x + rng.normal(0, 0.2) + rng.normal(0, 0.1 + 0.05 * r, 432)).astype(np.float32)
+        if r % 3 == 0:
+            y[rng.integers(0, 432, 40)] += rng.normal(0, 2, 40).astype(np.float32)   # outliers
+        rows.append(y)
+    rows.append(np.zeros(432, np.float32))                       # all slopes equal (ties everywhere)
+    rows.append((np.float32(0.01) * x).astype(np.float32))       # exact line
+    rows = np.stack(rows)
+    s, yi = rx.theil_sen(rows)
+    for r in range(rows.shape[0]):
+        os_, oy = O.theil_sen(rows[r])
+        assert s[r] == np.float32(os_) and yi[r] == np.float32(oy), (r, s[r], os_, yi[r], oy)
+    # odd / small sizes exercise the pair folding
+    for cols in (5, 64, 255, 400):
+        y = rng.normal(0, 1, (3, cols)).astype(np.float32)
+        s, yi = rx.theil_sen(y)
+        for r in range(3):
+            os_, oy = O.theil_sen(y[r])
+            assert s[r] == np.float32(os_) and yi[r] == np.float32(oy)
+
+
+def _bch_codeword(rng):
+    data = rng.integers(0, 256, 9, dtype=np.uint8)
+    data[8] &= 0xfe
+    par = np.zeros(23, np.uint8)
+    O.lib().orc_bch_encode(O.ptr(data), O.ptr(par))
+    return np.concatenate([np.unpackbits(data)[:71], np.unpackbits(par)[:184]])
+
+
+def test_osd_bit_exact(rx):
+    """CODE::OrderedStatisticsDecoder<255,71,4> (decode.cc:417): same codeword and uniqueness flag"""
+    rng = np.random.default_rng(4)
+    softs = []
+    for t in range(10):
+        cw = _bch_codeword(rng)
+        amp = [127, 60, 30, 20, 14, 10, 8, 6, 5, 4][t]
+        s = amp * (1 - 2 * cw.astype(np.int32)) + rng.normal(0, 10 + 2 * t, 255)
+        softs.append(np.clip(np.rint(s), -128, 127).astype(np.int8))
+    softs.append(np.zeros(255, np.int8))                          # everything ties: not unique
+    softs.append(np.full(255, -128, np.int8))                     # clamp path (-128 -> -127)
+    softs = np.stack(softs)
+    hard, uniq = rx.osd(softs)
+    for i in range(softs.shape[0]):
+        oh, ou = O.osd(softs[i])
+        assert int(uniq[i]) == int(ou), i
+        if ou:
+            assert (hard[i] == oh).all(), i
+
+
+def test_polar_list_decoder_bit_exact(rx):
+    """CODE::PolarListDecoder<SIMD<float,8>,16> + systematic() (decode.cc:530-531): all 8 lanes'
+    messages and path metrics bit-exact on identical LLRs (clean, noisy near threshold, garbage)"""
+    llrs = []
+    for i, db in enumerate((None, -30, -20, -17, -15, -13)):
+        p = O.payload_for(40 + i)
+        pcm = O.encode_pcm(p, channels=2)
+        if db is not None:
+            pcm = O.impair(pcm, noise_db=db, seed=9, frame=i)
+        _, res, tb = O.decode(pcm, taps=True)
+        assert res.oper_mode == 6
+        llrs.append(tb.llr.copy())
+    rng = np.random.default_rng(6)
+    g = rng.normal(0, 5, 65536).astype(np.float32)
+    g[64800:] = 9000
+    llrs.append(g)                                                # not a codeword at all
+    z = np.zeros(65536, np.float32)
+    z[64800:] = 9000
+    llrs.append(z)                                                # all-erased payload: every metric ties
+    llrs = np.stack(llrs)
+    mesg, metric = rx.polar(llrs)
+    for i in range(llrs.shape[0]):
+        om, omet = O.polar_lane_mesg(llrs[i])
+        assert (metric[i] == omet).all(), (i, metric[i], omet)
+        assert (mesg[i] == om).all(), i
+
+
+# ---------------------------------------------------------------- whole path
+def _frames(kinds):
+    pcms, pays = [], []
+    for i, (ch, db, extra) in enumerate(kinds):
+        p = O.payload_for(100 + i)
+        pcm = O.encode_pcm(p, channels=ch, call_sign="ANONYMOUS")
+        if ch == 2 and (db is not None or extra):
+            pcm = O.impair(pcm, noise_db=db, seed=21, frame=i, **extra)
+        pcms.append(pcm)
+        pays.append(p)
+    return pcms, pays
+
+
+def _check_against_oracle(rx, pcm, payload, expect_ok=True):
+    out, res = rx.decode(pcm[None])
+    oout, ores, tb = O.decode(pcm, taps=True)
+    r = res[0]
+    assert int(r["status"]) == ores.status
+    assert (out[0] == oout).all()                                 # bit-exact vs the oracle
+    if expect_ok:
+        assert ores.status == 0 and (out[0] == payload).all()     # and vs the transmitted payload
+    if ores.sc_start >= 0:
+        assert int(r["sc_start"]) == ores.sc_start and int(r["symbol_pos"]) == ores.symbol_pos
+        assert abs(float(r["cfo_rad"]) - ores.cfo_rad) <= REL
+        assert int(r["n_sync_rejects"]) == ores.n_sync_rejects
+    if ores.status in (0, 6):
+        assert int(r["oper_mode"]) == ores.oper_mode and int(r["call_sign"]) == ores.call_sign
+        hs = rx.tap("HDR_SOFT", 0).astype(np.int32)
+        assert np.abs(hs - tb.hdr_soft).max() <= 1               # int8 rounding of an fp32 value
+        _close(rx.tap("CONS_RAW", 0), tb.cons_raw[:21600], what="cons_raw (decode.cc:464-477)")
+        _close(rx.tap("SLOPE", 0), tb.slope[:50], rel=1e-4, what="Theil-Sen slope")
+        assert np.abs(rx.tap("YINT", 0) - tb.yint[:50]).max() <= 2e-6
+        _close(rx.tap("CONS_ROT", 0), tb.cons_rot[:21600], what="cons_rot (decode.cc:481-495)")
+        _close(rx.tap("PRECISION", 0), tb.precision[:50], what="precision (decode.cc:516)")
+        _close(rx.tap("LLR", 0)[:64800], tb.llr[:64800], what="llr (decode.cc:520-529)")
+        assert (rx.tap("LLR", 0)[64800:] == 9000).all()
+        assert abs(float(r["cfo_fine"]) - ores.cfo_fine) <= REL and abs(float(r["esn0_db_last"]) - ores.esn0_db_last) < 1e-3
+    if ores.status == 0:
+        assert int(r["bit_flips"]) == ores.bit_flips
+        best = int(r["best_lane"])
+        assert (rx.tap("LANE_MESG", 0)[best][:5380] ^ 0 == tb.lane_mesg[ores.best_lane][:5380]).all()
+    return r, ores
+
+
+def test_clean_frames_mono_and_analytic(rx):
+    """config 2 flavour: clean mode-6 frames, 16-bit mono (front end D1) and 2-channel analytic"""
+    pcms, pays = _frames([(1, None, {}), (2, None, {})])
+    for pcm, p in zip(pcms, pays):
+        r, o = _check_against_oracle(rx, pcm, p)
+        assert int(r["bit_flips"]) == 0
+
+
+def test_mono_front_end_matches_oracle(rx):
+    """D1: BlockDC + Hilbert (decode.cc:294-301) within 1e-5 of the sequential CPU recurrence"""
+    p = O.payload_for(5)
+    pcm = O.encode_pcm(p, channels=1)
+    rx.decode(pcm[None])
+    z = rx.tap("ANALYTIC", 0, samples=pcm.shape[0])
+    ref = np.zeros((pcm.shape[0], 2), np.float32)
+    O.lib().orc_front_end(O.ptr(pcm), O.FMT_S16, 1, pcm.shape[0], O.ptr(ref))
+    _close(z, ref, what="analytic signal")
+
+
+def test_8bit_input(rx):
+    p = O.payload_for(8)
+    pcm = O.encode_pcm(p, bits=8, channels=1)                     # `make test` format (Makefile:14)
+    _check_against_oracle(rx, pcm, p)
+
+
+@pytest.mark.parametrize("db", [-30, -22, -18])
+def test_awgn_frames(rx, db):
+    """config 3 flavour: analytic frames with AWGN at a noise LEVEL (README.md:49 uses -30)"""
+    pcms, pays = _frames([(2, db, {}), (2, db, {})])
+    for pcm, p in zip(pcms, pays):
+        _check_against_oracle(rx, pcm, p)
+
+
+def test_full_impairment_chain(rx):
+    """config 4 flavour (README.md:49): multipath + CFO 234.567 Hz + SFO 147 ppm + AWGN -30 dB"""
+    extra = dict(cfo_hz=234.567, sfo_ppm=147.0, multipath=[(0, 1 + 0j), (7, 0.3 - 0.2j), (19, -0.1 + 0.15j)])
+    pcms, pays = _frames([(2, -30, extra)])
+    r, o = _check_against_oracle(rx, pcms[0], pays[0])
+    assert abs(float(r["cfo_fine"]) * 8000 / (2 * np.pi) - 2234.567) < 1.0
+
+
+def test_failure_statuses_match_reference_exits(rx):
+    """every exit of Decoder::Decoder (decode.cc:393,419,430,435,440,543) is data, never an API error"""
+    silence = np.zeros((30000, 2), np.int16)
+    out, res = rx.decode(silence[None])
+    assert int(res["status"][0]) == 1 and not out.any() and int(res["sc_start"][0]) == -1
+    p = O.payload_for(9)
+    pcm = O.encode_pcm(p, channels=2)
+    _check_against_oracle(rx, O.impair(pcm, noise_db=-6, seed=2), p, expect_ok=False)    # hopeless SNR
+    y = pcm.copy()
+    s = 8000 + 4 * 1440
+    y[s + 10 * 1440: s + 40 * 1440] = 0                           # header fine, payload destroyed
+    r, o = _check_against_oracle(rx, y, p, expect_ok=False)
+    assert int(r["status"]) == 6 and int(r["best_lane"]) == -1
+    trunc = pcm[:40000]                                           # stream ends inside the payload
+    _check_against_oracle(rx, trunc, p, expect_ok=False)
+    m7 = O.encode_pcm(p, channels=2, mode=7)                      # valid header, mode this build does not decode
+    out, res = rx.decode(m7[None])
+    assert int(res["status"][0]) == 4 and int(res["oper_mode"][0]) == 7 and not out.any()
+
+
+def test_skip_count_selects_second_frame(rx):
+    """decode.cc:448 `while (skip_count--)`: SKIP=1 decodes the second frame of a stream"""
+    p = O.payload_for(30, count=2)
+    pcm = O.encode_pcm(p, channels=2)
+    out, res = rx.decode(np.stack([pcm, pcm]), skip=[0, 1])
+    assert (res["status"] == 0).all()
+    assert (out[0] == p[:5380]).all() and (out[1] == p[5380:]).all()
+    o1, r1 = O.decode(pcm, skip=1)
+    assert int(res["sc_start"][1]) == r1.sc_start and (out[1] == o1).all()
+
+
+def test_batch_is_frame_independent_and_ragged(rx):
+    """batching must not couple frames: a mixed batch (clean / noisy / silent / failing) returns, per
+    frame, exactly what each frame returns alone; the batch spans several resident chunks"""
+    kinds = [(2, None, {}), (2, -30, {}), (2, -18, {}), (2, -25, {}), (2, None, {})]
+    pcms, pays = _frames(kinds)
+    pcms.append(np.zeros_like(pcms[0]))
+    pcms.append(O.impair(pcms[0], noise_db=-5, seed=4))
+    batch = np.stack(pcms * 20)                                   # 140 frames > chunk_frames=64
+    out, res = rx.decode(batch)
+    for i, pcm in enumerate(pcms):
+        o, r = O.decode(pcm)
+        for rep in range(20):
+            k = rep * len(pcms) + i
+            assert int(res["status"][k]) == r.status and (out[k] == o).all()
+    assert (out[:5] == np.stack(pays)).all()
+
+
+def test_device_pointer_api_and_awgn_tile_roundtrip(rx):
+    """inputs resident in HBM (bench path): tile 3 base frames to 96 with on-device AWGN at -30 dB,
+    decode through ofdmrx_decode_batch_device; every frame must return its base payload
+    (encode -> channel -> decode round trip, size-independent property)"""
+    import torch
+    import modem_amd.ofdmrx as M
+    pays = [O.payload_for(60 + i) for i in range(3)]
+    base = np.stack([O.encode_pcm(p, channels=2) for p in pays])
+    spf = base.shape[1]
+    dev = torch.device("cuda:0")
+    d_base = torch.from_numpy(base).to(dev)
+    n = 96
+    d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+    d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+    d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    rx.awgn_tile(d_base.data_ptr(), 3, d_in.data_ptr(), n, spf, -30.0, 77)
+    rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+    rx.synchronize()
+    out = d_out.cpu().numpy()
+    res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+    assert (res["status"] == 0).all()
+    for k in range(n):
+        assert (out[k] == pays[k % 3]).all()
+    assert 20.0 < res["esn0_db_last"].mean() < 24.0
+    noisy = d_in.cpu().numpy()
+    assert not (noisy[0] == noisy[3]).all()                       # distinct noise per frame
+    o, r = O.decode(noisy[5])                                     # oracle on the device-made frame
+    assert r.status == 0 and (o == out[5]).all() and r.sc_start == int(res["sc_start"][5])
+    t = rx.timing()
+    assert t["polar"][0] > 0 and t["total"][0] >= t["polar"][0]
