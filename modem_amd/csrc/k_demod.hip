@@ -80,6 +80,15 @@ struct TsShared {
 	int rank;
 };
 
+// y - s*x with the product rounded on its own (HIP's __fmul_rn is a plain '*' and would be
+// contracted into an FMA): keeps the intercepts bit-identical to the CPU's
+__device__ __forceinline__ float sub_mul_nofma(float y, float s, float x)
+{
+	#pragma clang fp contract(off)
+	float p = s * x;
+	return y - p;
+}
+
 __device__ __forceinline__ unsigned fkey(float v)
 {
 	unsigned b = __float_as_uint(v);
@@ -152,7 +161,7 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 	slope = fkey_inv(s.prefix);
 	const int xoff = n / 2;
 	for (int i = tid; i < n; i += 256)
-		s.ic[i] = __fsub_rn(s.y[i], __fmul_rn(slope, (float)(i - xoff)));   // no FMA contraction: bit-exact vs CPU
+		s.ic[i] = sub_mul_nofma(s.y[i], slope, (float)(i - xoff));
 	__syncthreads();
 	// value at sorted position n/2 of the intercepts: rank counting
 	for (int i = tid; i < n; i += 256) {

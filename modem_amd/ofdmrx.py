@@ -74,6 +74,14 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own HIP runtime (same SONAME libamdhip64.so.7).  Two HIP runtimes in one
+    # process cannot both see the GPU, so when torch is importable it is loaded FIRST and libofdmrx
+    # binds to the runtime already in the process.  MODEM_AMD_NO_TORCH=1 skips this (pure C ABI use).
+    if not os.environ.get("MODEM_AMD_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = lib_path()
     if not os.path.exists(path):
         raise OfdmRxError("libofdmrx.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
