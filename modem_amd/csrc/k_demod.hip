@@ -73,21 +73,16 @@ __global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restri
 // the CPU's.
 struct TsShared {
 	float y[512];
-	float ic[512];
+	float rcp[512];            // correctly rounded 1/d
+	float buf[8192];           // sample of exact slopes, then the list of bracketed exact slopes
 	int hist[2048];
 	int part[256];
+	int red[4];
 	unsigned prefix;
 	int rank;
+	int list_n;
+	float pick;
 };
-
-// y - s*x with the product rounded on its own (HIP's __fmul_rn is a plain '*' and would be
-// contracted into an FMA): keeps the intercepts bit-identical to the CPU's
-__device__ __forceinline__ float sub_mul_nofma(float y, float s, float x)
-{
-	#pragma clang fp contract(off)
-	float p = s * x;
-	return y - p;
-}
 
 __device__ __forceinline__ unsigned fkey(float v)
 {
@@ -103,31 +98,38 @@ __device__ __forceinline__ float fkey_inv(unsigned k)
 template <typename F>
 __device__ __forceinline__ void for_each_pair(int n, int tid, F fn)
 {
-	// fold distance q with n-q so every fold has n items (i, d): all i<j pairs exactly once
-	const int folds = (n - 1) / 2;
+	// fold distance q with n-q so every fold has n items (i, d): all i<j pairs exactly once.
+	// Every thread runs the same trip counts (fn gets a `valid` flag) so wave-level ballots inside
+	// fn see all 64 lanes.
+	const int folds = (n - 1) / 2, n_up = (n + 255) & ~255;
 	for (int q = 1; q <= folds; ++q)
-		for (int e = tid; e < n; e += 256) {
+		for (int e = tid; e < n_up; e += 256) {
 			int i, d;
 			if (e < n - q) { i = e; d = q; }
 			else { i = e - (n - q); d = n - q; }
-			fn(i, d);
+			const bool valid = e < n;
+			fn(valid ? i : 0, valid ? d : 1, valid);
 		}
 	if ((n & 1) == 0) {
-		int d = n / 2;
-		for (int e = tid; e < n - d; e += 256)
-			fn(e, d);
+		const int d = n / 2;
+		for (int e = tid; e < n_up; e += 256) {
+			const bool valid = e < n - d;
+			fn(valid ? e : 0, d, valid);
+		}
 	}
 }
 
-__device__ void radix_pass(TsShared &s, int n, int tid, int shift, int bits, unsigned mask_hi)
+// one radix digit of a rank selection: histogram `bits` bits at `shift` of the keys produced by
+// `each` that match the prefix found so far, then narrow (prefix, rank) to the digit's bin
+template <typename Each>
+__device__ void radix_digit(TsShared &s, int tid, int shift, int bits, unsigned mask_hi, Each each)
 {
 	for (int i = tid; i < 2048; i += 256)
 		s.hist[i] = 0;
 	__syncthreads();
 	const unsigned prefix = s.prefix, bmask = (1u << bits) - 1;
-	for_each_pair(n, tid, [&](int i, int d) {
-		float sl = (s.y[i + d] - s.y[i]) / (float)d;
-		unsigned k = fkey(sl);
+	each([&](float v) {
+		unsigned k = fkey(v);
 		if ((k & mask_hi) == prefix)
 			atomicAdd(&s.hist[(k >> shift) & bmask], 1);
 	});
@@ -136,48 +138,214 @@ __device__ void radix_pass(TsShared &s, int n, int tid, int shift, int bits, uns
 	int acc = 0;
 	for (int q = 0; q < per; ++q)
 		acc += s.hist[tid * per + q];
-	s.part[tid] = acc;
+	// block-wide exclusive scan of the 256 partial counts; the thread whose span holds the rank
+	// walks its own <= 8 bins (no serial scan over the histogram)
+	const int lane = tid & 63, wave = tid >> 6;
+	int incl = acc;
+	#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		int o = __shfl_up(incl, d);
+		if (lane >= d)
+			incl += o;
+	}
+	if (lane == 63)
+		s.red[wave] = incl;
+	const int r = s.rank;
 	__syncthreads();
-	if (tid == 0) {
-		int r = s.rank, t = 0;
-		while (t < 255 && r >= s.part[t]) { r -= s.part[t]; ++t; }
-		int b = t * per;
-		while (b < nb - 1 && r >= s.hist[b]) { r -= s.hist[b]; ++b; }
-		s.rank = r;
+	int off = 0;
+	for (int w = 0; w < wave; ++w)
+		off += s.red[w];
+	const int excl = incl - acc + off;
+	if (r >= excl && r < excl + acc) {
+		int rr = r - excl, b = tid * per;
+		while (rr >= s.hist[b]) { rr -= s.hist[b]; ++b; }
+		s.rank = rr;
 		s.prefix = prefix | ((unsigned)b << shift);
 	}
 	__syncthreads();
 }
+// value at sorted position `rank` of the multiset enumerated by `each` (exact, 3 digits 11+11+10)
+template <typename Each>
+__device__ float select_rank(TsShared &s, int tid, int rank, Each each)
+{
+	if (tid == 0) { s.prefix = 0; s.rank = rank; }
+	__syncthreads();
+	radix_digit(s, tid, 21, 11, 0u, each);
+	radix_digit(s, tid, 10, 11, 0xffe00000u, each);
+	radix_digit(s, tid, 0, 10, 0xfffffc00u, each);
+	float v = fkey_inv(s.prefix);
+	__syncthreads();
+	return v;
+}
+
+// y - s*x with the product rounded on its own (HIP's __fmul_rn is a plain '*' and would be
+// contracted into an FMA): keeps the intercepts bit-identical to the CPU's
+__device__ __forceinline__ float sub_mul_nofma(float y, float s, float x)
+{
+	#pragma clang fp contract(off)
+	float p = s * x;
+	return y - p;
+}
+
+constexpr int TS_SAMPLE_STEP = 12;   // sample = all pairs whose distance is a multiple of 12
+constexpr int TS_LIST_CAP = 8192;
 
 // y[0..n) in s.y ; x[i] = i - n/2.  Returns slope and yint in all threads.
+// Exact median of the n(n-1)/2 pairwise slopes (decode.cc:488, rank count/2):
+//  1. a ~8% sample of the pairs (exact fp32 divisions) brackets the median: [T_lo, T_hi] =
+//     sample order statistics +-4.5 sigma around the sample median;
+//  2. ONE pass over all pairs with the cheap slope a*rcp(d) (relative error < 2^-22 of the
+//     correctly rounded quotient): pairs certainly below T_lo are counted, pairs certainly
+//     above T_hi are dropped, the rest (~5%) get the exact division and go to an LDS list;
+//  3. the wanted order statistic is selected exactly inside the list.  The result is accepted only
+//     if it lies in [T_lo, T_hi] (then its rank is provably exact); otherwise, or when the list
+//     overflows (ties), the exact 3-digit radix select over all pairs runs instead.
 __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float &yint)
 {
-	const int count = n * (n - 1) / 2;
-	if (tid == 0) { s.prefix = 0; s.rank = count / 2; }
+	const int count = n * (n - 1) / 2, target = count / 2;
+	for (int d = tid; d < 512; d += 256)
+		s.rcp[d] = d ? 1.f / (float)d : 0.f;
 	__syncthreads();
-	radix_pass(s, n, tid, 21, 11, 0u);
-	radix_pass(s, n, tid, 10, 11, 0xffe00000u);
-	radix_pass(s, n, tid, 0, 10, 0xfffffc00u);
-	slope = fkey_inv(s.prefix);
+	auto all_pairs_exact = [&](auto emit) {
+		for_each_pair(n, tid, [&](int i, int d, bool valid) { if (valid) emit((s.y[i + d] - s.y[i]) / (float)d); });
+	};
+	bool done = false;
+	// ---- 1. sample
+	int m = 0;
+	for (int d = TS_SAMPLE_STEP; d < n; d += TS_SAMPLE_STEP)
+		m += n - d;
+	if (m >= 512 && m <= TS_LIST_CAP) {
+		int base = 0;
+		for (int d = TS_SAMPLE_STEP; d < n; d += TS_SAMPLE_STEP) {
+			for (int i = tid; i < n - d; i += 256)
+				s.buf[base + i] = (s.y[i + d] - s.y[i]) / (float)d;
+			base += n - d;
+		}
+		__syncthreads();
+		auto sample = [&](auto emit) { for (int i = tid; i < m; i += 256) emit(s.buf[i]); };
+		int K = (int)(2.25f * sqrtf((float)m)) + 2;           // 4.5 sigma of Binomial(m, 1/2)
+		int rlo = m / 2 - K, rhi = m / 2 + K;
+		if (rlo < 0) rlo = 0;
+		if (rhi > m - 1) rhi = m - 1;
+#ifdef TS_PROBE_SKIP_SAMPLE_SELECT
+		const float T_lo = -1e-3f, T_hi = 1e-3f;
+#else
+		const float T_lo = select_rank(s, tid, rlo, sample);
+		const float T_hi = select_rank(s, tid, rhi, sample);
+#endif
+		// ---- 2. classify every pair.  Appends go to a per-wave segment of the list; the fill count of
+		// a segment lives in a wave-uniform register (ballot + popcount), so there is no LDS atomic.
+		__syncthreads();
+		const int lane = tid & 63, wave = tid >> 6;
+		constexpr int SEG = TS_LIST_CAP / 4;
+		int below = 0, fill = 0;
+		unsigned *seg = (unsigned *)s.buf + wave * SEG;
+		// q = a*rcp(d) is within 3*2^-24 relative of the correctly rounded quotient; thresholds moved
+		// outwards by 1e-6 relative (+ an absolute floor) make "q < T_lo_m" imply "exact < T_lo"
+		const float T_lo_m = T_lo - (1e-6f * fabsf(T_lo) + 1e-36f);
+		const float T_hi_m = T_hi + (1e-6f * fabsf(T_hi) + 1e-36f);
+#ifndef TS_PROBE_SKIP_MAIN
+		{
+			// folds q (distance q paired with n-q) are taken 4 at a time and both halves e = tid,
+			// tid+256 together, so 16 LDS reads are in flight before the first classification
+			const int folds = (n - 1) / 2, extra = (n & 1) == 0 ? 1 : 0;   // extra fold: d = n/2 alone
+			constexpr int QB = 4;
+			for (int q0 = 1; q0 <= folds + extra; q0 += QB) {
+				float a[2 * QB], rc[2 * QB];
+				unsigned pk[2 * QB];
+				bool vv[2 * QB];
+				#pragma unroll
+				for (int u = 0; u < QB; ++u) {
+					const int q = q0 + u;
+					#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const int e = tid + 256 * h, x = 2 * u + h;
+						int i, d;
+						bool valid;
+						if (q <= folds) {
+							if (e < n - q) { i = e; d = q; } else { i = e - (n - q); d = n - q; }
+							valid = e < n;
+						} else {
+							i = e; d = n / 2;
+							valid = q == folds + 1 && extra && e < n - d;
+						}
+						if (!valid) { i = 0; d = 1; }
+						a[x] = s.y[i + d] - s.y[i];
+						rc[x] = __builtin_amdgcn_rcpf((float)d);   // 1 ulp reciprocal: inside the margin
+						pk[x] = (unsigned)i | ((unsigned)d << 16);
+						vv[x] = valid;
+					}
+				}
+				#pragma unroll
+				for (int x = 0; x < 2 * QB; ++x) {
+					const float q = a[x] * rc[x];
+					const bool lo = vv[x] && q < T_lo_m;      // certainly below T_lo even after rounding
+					const bool keep = vv[x] && !lo && !(q > T_hi_m);
+					below += lo;
+					const unsigned long long bal = __ballot(keep);
+					if (keep) {   // remember the pair; its exact quotient is computed once, after the pass
+						int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+						if (slot < SEG)
+							seg[slot] = pk[x];
+					}
+					fill += __popcll(bal);
+				}
+			}
+		}
+#endif
+		#pragma unroll
+		for (int mm = 32; mm; mm >>= 1)
+			below += __shfl_xor(below, mm);
+		if (lane == 0) {
+			s.red[wave] = below;
+			s.part[wave] = fill;
+		}
+		__syncthreads();
+		below = s.red[0] + s.red[1] + s.red[2] + s.red[3];
+		const int f0 = s.part[0], f1 = s.part[1], f2 = s.part[2], f3 = s.part[3];
+		const int ln = (f0 > SEG || f1 > SEG || f2 > SEG || f3 > SEG) ? TS_LIST_CAP + 1 : f0 + f1 + f2 + f3;
+		const int r = target - below;
+		{
+			const int fs[4] = { f0, f1, f2, f3 };
+			#pragma unroll
+			for (int w4 = 0; w4 < 4; ++w4)
+				for (int i = tid; i < fs[w4] && i < SEG; i += 256) {
+					unsigned pk = ((const unsigned *)s.buf)[w4 * SEG + i];
+					int pi = pk & 0xffff, pd = pk >> 16;
+					s.buf[w4 * SEG + i] = (s.y[pi + pd] - s.y[pi]) / (float)pd;
+				}
+		}
+		__syncthreads();
+		if (ln <= TS_LIST_CAP && r >= 0 && r < ln) {
+			auto list = [&](auto emit) {
+				for (int i = tid; i < f0; i += 256) emit(s.buf[i]);
+				for (int i = tid; i < f1; i += 256) emit(s.buf[SEG + i]);
+				for (int i = tid; i < f2; i += 256) emit(s.buf[2 * SEG + i]);
+				for (int i = tid; i < f3; i += 256) emit(s.buf[3 * SEG + i]);
+			};
+			float v = select_rank(s, tid, r, list);
+			if (v >= T_lo && v <= T_hi) {
+				slope = v;
+				done = true;
+			}
+		}
+	}
+#ifdef TS_PROBE_COUNT
+	if (!done && tid == 0) atomicAdd(TS_PROBE_COUNT, 1);
+#endif
+#ifdef TS_PROBE_NO_FALLBACK
+	if (!done) { slope = 0.f; done = true; }
+#endif
+	if (!done)   // wave-uniform: every thread computed the same decision
+		slope = select_rank(s, tid, target, all_pairs_exact);
+	// ---- intercepts y - slope*x, median (rank n/2)
 	const int xoff = n / 2;
 	for (int i = tid; i < n; i += 256)
-		s.ic[i] = sub_mul_nofma(s.y[i], slope, (float)(i - xoff));
+		s.buf[i] = sub_mul_nofma(s.y[i], slope, (float)(i - xoff));
 	__syncthreads();
-	// value at sorted position n/2 of the intercepts: rank counting
-	for (int i = tid; i < n; i += 256) {
-		float v = s.ic[i];
-		int less = 0, eq = 0;
-		for (int j = 0; j < n; ++j) {
-			float o = s.ic[j];
-			less += o < v;
-			eq += o == v;
-		}
-		if (less <= n / 2 && n / 2 < less + eq)
-			s.y[511] = v;   // every qualifying thread writes the same value
-	}
-	__syncthreads();
-	yint = s.y[511];
-	__syncthreads();
+	auto icpt = [&](auto emit) { for (int i = tid; i < n; i += 256) emit(s.buf[i]); };
+	yint = select_rank(s, tid, n / 2, icpt);
+	// the key order treats -0 < +0; nth_element would return whichever sits there: same value
 }
 
 // decode.cc:479-504: one workgroup per (frame, row)

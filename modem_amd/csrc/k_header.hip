@@ -14,10 +14,13 @@
 namespace rx {
 
 constexpr int NPAIRS = BCH_K * (BCH_K - 1) / 2;   // 2485
+constexpr int NTRIPLES = BCH_K * (BCH_K - 1) * (BCH_K - 2) / 6;   // 57155
 
 struct OsdShared {
-	uint32_t G[BCH_K][8];
-	short T[32][256];          // T[g][byte] = sum of x over set bits of byte g
+	uint32_t G[BCH_K][9];      // 8 words + 1 pad: row stride 9 words spreads rows over the LDS banks
+	uint32_t plane[8][8];      // plane[b][w]: bit i = bit b of the two's-complement byte of x[32w+i]
+	short ax[BCH_K];           // |x| of the 71 most reliable (systematic) positions
+	int S0;                    // sum of x over the set bits of the order-0 codeword's systematic part
 	short x[256];
 	short perm[256];
 	unsigned char rel[256];
@@ -29,19 +32,27 @@ struct OsdShared {
 	int X;
 };
 
-__device__ __forceinline__ int lut_sum(const OsdShared &s, const uint32_t *e)
-{
-	int acc = 0;
-	#pragma unroll
-	for (int w = 0; w < 8; ++w) {
-		uint32_t v = e[w];
-		acc += s.T[4 * w + 0][v & 255];
-		acc += s.T[4 * w + 1][(v >> 8) & 255];
-		acc += s.T[4 * w + 2][(v >> 16) & 255];
-		acc += s.T[4 * w + 3][v >> 24];
+// After Gauss-Jordan the permuted generator is [I | P]: a candidate differs from the order-0
+// codeword in exactly its flipped systematic positions (each adds |x| to S) plus the XOR of
+// the rows' parity parts.  S over the 184 parity positions (words 2..7, word 2 bits >= 7) is a
+// weighted popcount over the 8 bit planes of x: 48 AND + 48 BCNT, registers only.
+constexpr int PW = 6;   // parity words 2..7
+struct Planes {
+	uint32_t v[8][PW];
+	__device__ __forceinline__ int eval(const uint32_t *e) const
+	{
+		int acc = 0;
+		#pragma unroll
+		for (int b = 0; b < 8; ++b) {
+			int c = 0;
+			#pragma unroll
+			for (int w = 0; w < PW; ++w)
+				c += __popc(e[w] & v[b][w]);
+			acc += b == 7 ? -(c << 7) : (c << b);
+		}
+		return acc;
 	}
-	return acc;
-}
+};
 
 struct Track {
 	int best, next, id;
@@ -54,6 +65,7 @@ struct Track {
 
 // soft[255] in s.soft must be valid; returns unique flag, writes hard bits (BE) to hard_out[32] (thread 0)
 __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bits, const uint8_t *__restrict__ pairs,
+	const uint8_t *__restrict__ triples,
 	uint8_t *hard_out /* LDS or global, 32 B */, int tid)
 {
 	// reliabilities, stable descending sort by rank counting
@@ -142,13 +154,17 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 	if (tid < 256)
 		s.x[tid] = tid < BCH_N ? (short)max((int)s.soft[s.perm[tid]], -127) : 0;
 	__syncthreads();
-	for (int it = tid; it < 32 * 256; it += 256) {
-		int g = it >> 8, b = it & 255, acc = 0;
-		for (int q = 0; q < 8; ++q)
-			if ((b >> q) & 1)
-				acc += s.x[8 * g + q];
-		s.T[g][b] = (short)acc;
+	if (tid < 64) {   // bit planes of x (two's complement bytes)
+		int b = tid >> 3, w = tid & 7;
+		uint32_t v = 0;
+		for (int i = 0; i < 32; ++i)
+			v |= (uint32_t)(((int)s.x[32 * w + i] >> b) & 1) << i;
+		if (w == 2)
+			v &= ~((1u << (BCH_K - 64)) - 1);   // positions 64..70 are systematic
+		s.plane[b][w] = v;
 	}
+	if (tid < BCH_K)
+		s.ax[tid] = (short)abs((int)s.x[tid]);
 	if (tid < 8) {   // order-0 codeword: hard decisions on the 71 most reliable positions
 		uint32_t v = 0;
 		for (int i = 0; i < BCH_K; ++i)
@@ -157,55 +173,74 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 		s.cw[tid] = v;
 	}
 	if (tid == 0) {
-		int X = 0;
+		int X = 0, S0 = 0;
 		for (int i = 0; i < BCH_N; ++i)
 			X += s.x[i];
+		for (int i = 0; i < BCH_K; ++i)
+			if (s.x[i] < 0)
+				S0 += s.x[i];
 		s.X = X;
+		s.S0 = S0;
 		s.next_item = 0;
 	}
 	__syncthreads();
-	const int X = s.X;
-	uint32_t base[8];
+	const int X = s.X, S0 = s.S0;
+	Planes pl;
 	#pragma unroll
-	for (int w = 0; w < 8; ++w)
-		base[w] = s.cw[w];
+	for (int b = 0; b < 8; ++b)
+		#pragma unroll
+		for (int w = 0; w < PW; ++w)
+			pl.v[b][w] = s.plane[b][w + 2];
+	uint32_t base[PW];
+	#pragma unroll
+	for (int w = 0; w < PW; ++w)
+		base[w] = s.cw[w + 2];
 	Track tr;
-	tr.best = X - 2 * lut_sum(s, base);   // candidate id 0 = no flips
+	tr.best = X - 2 * (S0 + pl.eval(base));   // candidate id 0 = no flips
 	tr.next = -1;
 	tr.id = 0;
 	if (tid != 0) { tr.best = -0x7fffffff; tr.next = -0x7fffffff; }
 	// ids: singles 1+a ; pairs/triples/quads packed as (a+1) | (b+1)<<7 | (c+1)<<14 | (d+1)<<21
 	if (tid < BCH_K) {
-		uint32_t e[8];
+		uint32_t e[PW];
 		#pragma unroll
-		for (int w = 0; w < 8; ++w)
-			e[w] = base[w] ^ s.G[tid][w];
-		tr.update(X - 2 * lut_sum(s, e), tid + 1);
+		for (int w = 0; w < PW; ++w)
+			e[w] = base[w] ^ s.G[tid][w + 2];
+		tr.update(X - 2 * (S0 + s.ax[tid] + pl.eval(e)), tid + 1);
 	}
-	for (;;) {
-		int item = atomicAdd(&s.next_item, 1);
-		if (item >= NPAIRS)
-			break;
+	// pairs: one candidate each, strided over the threads
+	for (int item = tid; item < NPAIRS; item += 256) {
 		const int a = pairs[2 * item], b = pairs[2 * item + 1];
-		uint32_t eab[8], eabc[8], e[8];
+		uint32_t e[PW];
 		#pragma unroll
-		for (int w = 0; w < 8; ++w)
-			eab[w] = base[w] ^ s.G[a][w] ^ s.G[b][w];
-		const int idab = (a + 1) | ((b + 1) << 7);
-		tr.update(X - 2 * lut_sum(s, eab), idab);
-		for (int c = b + 1; c < BCH_K; ++c) {
+		for (int w = 0; w < PW; ++w)
+			e[w] = base[w] ^ s.G[a][w + 2] ^ s.G[b][w + 2];
+		tr.update(X - 2 * (S0 + s.ax[a] + s.ax[b] + pl.eval(e)), (a + 1) | ((b + 1) << 7));
+	}
+	// triples (a<b<c) sorted by c: item = the triple itself plus its d-loop (d > c).  Consecutive
+	// items have equal trip counts, so the 64 lanes of a wave stay converged.
+#ifdef OSD_PROBE_SKIP_TRIPLES
+	for (int item = tid; item < 0; item += 256) {
+#else
+	for (int item = tid; item < NTRIPLES; item += 256) {
+#endif
+		const int a = triples[3 * item], b = triples[3 * item + 1], c = triples[3 * item + 2];
+		uint32_t eabc[PW], e[PW];
+		#pragma unroll
+		for (int w = 0; w < PW; ++w)
+			eabc[w] = base[w] ^ s.G[a][w + 2] ^ s.G[b][w + 2] ^ s.G[c][w + 2];
+		const int idabc = (a + 1) | ((b + 1) << 7) | ((c + 1) << 14);
+		const int sabc = S0 + s.ax[a] + s.ax[b] + s.ax[c];
+		tr.update(X - 2 * (sabc + pl.eval(eabc)), idabc);
+#ifndef OSD_PROBE_SKIP_DLOOP
+		#pragma unroll 2
+		for (int d = c + 1; d < BCH_K; ++d) {
 			#pragma unroll
-			for (int w = 0; w < 8; ++w)
-				eabc[w] = eab[w] ^ s.G[c][w];
-			const int idabc = idab | ((c + 1) << 14);
-			tr.update(X - 2 * lut_sum(s, eabc), idabc);
-			for (int d = c + 1; d < BCH_K; ++d) {
-				#pragma unroll
-				for (int w = 0; w < 8; ++w)
-					e[w] = eabc[w] ^ s.G[d][w];
-				tr.update(X - 2 * lut_sum(s, e), idabc | ((d + 1) << 21));
-			}
+			for (int w = 0; w < PW; ++w)
+				e[w] = eabc[w] ^ s.G[d][w + 2];
+			tr.update(X - 2 * (sabc + s.ax[d] + pl.eval(e)), idabc | ((d + 1) << 21));
 		}
+#endif
 	}
 	s.red_best[tid] = tr.best;
 	s.red_next[tid] = tr.next;
@@ -253,7 +288,7 @@ __device__ __forceinline__ unsigned crc16_u64(unsigned long long data)
 	return crc & 0xffffu;
 }
 
-__global__ __launch_bounds__(256) void k_header(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
+__global__ __launch_bounds__(256, 2) void k_header(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
 	SyncState *__restrict__ st_all, int8_t *__restrict__ hdr_soft)
 {
 	const int f = blockIdx.x, tid = threadIdx.x;
@@ -294,7 +329,7 @@ __global__ __launch_bounds__(256) void k_header(FrameBatch fb, const cf *__restr
 	if (tid == 255)
 		s.soft[255] = 0;
 	__syncthreads();
-	bool unique = osd_decode(s, tb.genmat_bits, tb.osd_pairs, hard, tid);
+	bool unique = osd_decode(s, tb.genmat_bits, tb.osd_pairs, tb.osd_triples, hard, tid);
 	if (tid == 0) {
 		int status = 0;
 		unsigned long long md = 0;
@@ -329,7 +364,7 @@ __global__ __launch_bounds__(256) void k_header(FrameBatch fb, const cf *__restr
 }
 
 // parity-test entry: OSD alone on caller-provided soft values
-__global__ __launch_bounds__(256) void k_osd_only(Tables tb, const int8_t *__restrict__ soft, uint8_t *__restrict__ hard_out,
+__global__ __launch_bounds__(256, 2) void k_osd_only(Tables tb, const int8_t *__restrict__ soft, uint8_t *__restrict__ hard_out,
 	int32_t *__restrict__ unique_out)
 {
 	const int f = blockIdx.x, tid = threadIdx.x;
@@ -338,7 +373,7 @@ __global__ __launch_bounds__(256) void k_osd_only(Tables tb, const int8_t *__res
 	if (tid < 256)
 		s.soft[tid] = tid < BCH_N ? soft[(size_t)f * BCH_N + tid] : 0;
 	__syncthreads();
-	bool u = osd_decode(s, tb.genmat_bits, tb.osd_pairs, hard, tid);
+	bool u = osd_decode(s, tb.genmat_bits, tb.osd_pairs, tb.osd_triples, hard, tid);
 	if (tid < 32)
 		hard_out[(size_t)f * 32 + tid] = hard[tid];
 	if (tid == 0)

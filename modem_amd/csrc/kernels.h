@@ -43,7 +43,8 @@ struct Tables {                    // device-resident constants, built once per 
 	const uint32_t *frozen;        // 2048 words, bit set = frozen (polar_tables.hh data, regenerated)
 	const uint16_t *info_pos;      // ascending unfrozen positions [43808]
 	const uint32_t *genmat_bits;   // BCH(255,71) systematic generator, [71][8] words, bit i of row j
-	const uint8_t *osd_pairs;      // [2485][2] (a,b) enumeration order
+	const uint8_t *osd_pairs;      // [2485][2] (a,b)
+	const uint8_t *osd_triples;    // [57155][3] (a,b,c) sorted by c (equal d-loop lengths are adjacent)
 	const uint32_t *crc32_tab;     // 256-entry byte table of CRC<uint32_t>(0xD419CC15)
 	const uint8_t *scramble;       // 5380 bytes of the Xorshift32 stream (decode.cc:613-615)
 };

@@ -146,6 +146,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.info_pos, &h->dev.info_pos);
 	r = r ? r : upload(h, h->host.genmat_bits, &h->dev.genmat_bits);
 	r = r ? r : upload(h, h->host.osd_pairs, &h->dev.osd_pairs);
+	r = r ? r : upload(h, h->host.osd_triples, &h->dev.osd_triples);
 	r = r ? r : upload(h, h->host.crc32_tab, &h->dev.crc32_tab);
 	r = r ? r : upload(h, h->host.scramble, &h->dev.scramble);
 	if (r) {

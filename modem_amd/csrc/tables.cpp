@@ -157,6 +157,14 @@ void build_tables(HostTables &t)
 			t.osd_pairs.push_back((uint8_t)a);
 			t.osd_pairs.push_back((uint8_t)b);
 		}
+	t.osd_triples.clear();
+	for (int c = 2; c < 71; ++c)
+		for (int a = 0; a < c; ++a)
+			for (int b = a + 1; b < c; ++b) {
+				t.osd_triples.push_back((uint8_t)a);
+				t.osd_triples.push_back((uint8_t)b);
+				t.osd_triples.push_back((uint8_t)c);
+			}
 	t.crc32_tab.resize(256);
 	for (uint32_t j = 0; j < 256; ++j) {
 		uint32_t c = j;

@@ -1,0 +1,28 @@
+// ts_probe.cpp -- timing probe for the Theil-Sen kernel (tools only)
+#include <hip/hip_runtime.h>
+__device__ int g_fallbacks;
+#define TS_PROBE_COUNT (&g_fallbacks)
+#include "../modem_amd/csrc/k_demod.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+using namespace rx;
+int main()
+{
+	const int rows = 50 * 1024, cols = 432;
+	std::mt19937 rng(1); std::normal_distribution<float> nd(0.f, 0.1f);
+	std::vector<float> y((size_t)rows * cols);
+	for (int r = 0; r < rows; ++r) for (int i = 0; i < cols; ++i) y[(size_t)r * cols + i] = 1e-4f * (i - 216) + 0.02f + nd(rng);
+	float *dy, *ds, *di; hipMalloc(&dy, y.size() * 4); hipMalloc(&ds, rows * 4); hipMalloc(&di, rows * 4);
+	hipMemcpy(dy, y.data(), y.size() * 4, hipMemcpyHostToDevice);
+	int zero = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_fallbacks), &zero, 4);
+	for (int rep = 0; rep < 2; ++rep) {
+		hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a);
+		launch_theil_sen_raw(0, rows, cols, dy, ds, di);
+		hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
+		int fb; hipMemcpyFromSymbol(&fb, HIP_SYMBOL(g_fallbacks), 4);
+		printf("%s: %d rows %.2f ms (fallbacks so far %d)\n", VARIANT, rows, ms, fb);
+	}
+	return 0;
+}
