@@ -31,6 +31,42 @@ __device__ __forceinline__ float f_minsum(float a, float b)
 }
 __device__ __forceinline__ float g_add(float a, float b, int u) { return u ? b - a : a + b; }
 
+// ---- cheap cross-lane exchanges (no LDS crossbar): lane ^ 8 (DPP row_ror:8), lane ^ 16 and
+// lane ^ 32 (gfx950 v_permlane16_swap / v_permlane32_swap)
+__device__ __forceinline__ int xor8_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); }
+__device__ __forceinline__ int xor16_i(int v, int lane)
+{
+	auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+	return (int)((lane & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ int xor32_i(int v, int lane)
+{
+	auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+	return (int)((lane & 32) ? r[0] : r[1]);
+}
+// exchange with the lane whose butterfly index j differs in bit zz (zz = 0,1,2)
+template <int ZZ> __device__ __forceinline__ float xj(float v, int lane)
+{
+	int i = __float_as_int(v);
+	i = ZZ == 0 ? xor8_i(i) : (ZZ == 1 ? xor16_i(i, lane) : xor32_i(i, lane));
+	return __int_as_float(i);
+}
+// min / max over the 8 paths (lanes k = 0..7 of a group); result in every lane
+__device__ __forceinline__ float group8_min(float v)
+{
+	v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+	v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+	v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+	return v;
+}
+__device__ __forceinline__ float group8_max(float v)
+{
+	v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));
+	v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));
+	v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));
+	return v;
+}
+
 constexpr uint32_t ID0 = 0x09249249u;   // 10 fields of 3 bits, each = 1
 constexpr uint32_t ID1 = 0x00049249u;   //  7 fields
 
@@ -50,85 +86,39 @@ struct Maps {
 	}
 };
 
-constexpr int UB = 8;   // iterations batched per pass so that 2*UB loads are in flight per lane
+constexpr int UB = 8;      // iterations batched per pass so that 2*UB loads are in flight per lane
+constexpr int LDS_TOP = 7; // tree levels 4..7 (sub-trees of <= 128 leaves) live in LDS
 
-// level m+1 -> level m (left child), both in memory; m >= 4
-__device__ __forceinline__ void pass_f_mem(const float *__restrict__ src, float *__restrict__ dst, int m, int lane)
-{
-	const int half = 1 << m, iters = half >> 3;
-	for (int it0 = 0; it0 < iters; it0 += UB) {
-		float a[UB], b[UB];
-		#pragma unroll
-		for (int u = 0; u < UB; ++u)
-			if (it0 + u < iters) {
-				int idx = (it0 + u) * 64 + lane;
-				a[u] = src[idx];
-				b[u] = src[idx + half * 8];
-			}
-		#pragma unroll
-		for (int u = 0; u < UB; ++u)
-			if (it0 + u < iters)
-				dst[(it0 + u) * 64 + lane] = f_minsum(a[u], b[u]);
-	}
-}
-// level 16 (shared channel LLRs) -> level 15, left child
-__device__ __forceinline__ void pass_f_top(const float *__restrict__ llr, float *__restrict__ dst, int lane)
-{
-	const int half = 1 << 15, iters = half >> 3, j = lane >> 3;
-	for (int it0 = 0; it0 < iters; it0 += UB) {
-		float a[UB], b[UB];
-		#pragma unroll
-		for (int u = 0; u < UB; ++u) {
-			int i = (it0 + u) * 8 + j;
-			a[u] = llr[i];
-			b[u] = llr[i + half];
-		}
-		#pragma unroll
-		for (int u = 0; u < UB; ++u)
-			dst[(it0 + u) * 64 + lane] = f_minsum(a[u], b[u]);
-	}
-}
-// right child of the level-(m+1) node: level m from level m+1 with partial sums hard[o..o+2^m)
-// and lane map lk (per lane: source path of path k).  m >= 4, level m+1 <= 15.
-__device__ __forceinline__ void pass_g_mem(const float *__restrict__ src, float *__restrict__ dst,
-	const uint8_t *__restrict__ hard_o, int m, int lane, int lk)
+// One pass of the tree: level m (2^m positions x 8 paths) from level m+1.
+//   G = false: left child  f(a, b)
+//   G = true : right child g(a, b, u) with partial sums hb[i] (bit k) and the lane map (gl = source lane)
+// SRC_TOP: level m+1 is the shared channel LLR vector (m = 15).  Pointers may be global or LDS.
+template <bool G, bool SRC_TOP>
+__device__ __forceinline__ void tree_pass(const float *src, float *dst, const uint8_t *hb, int m, int lane, int gl)
 {
 	const int half = 1 << m, iters = half >> 3, j = lane >> 3, k = lane & 7;
-	const int gl = (j << 3) | lk;
 	for (int it0 = 0; it0 < iters; it0 += UB) {
 		float a[UB], b[UB];
 		int h[UB];
 		#pragma unroll
 		for (int u = 0; u < UB; ++u)
 			if (it0 + u < iters) {
-				int base = (it0 + u) * 64;
-				a[u] = src[base + gl];
-				b[u] = src[base + gl + half * 8];
-				h[u] = hard_o[(it0 + u) * 8 + j];
+				if (SRC_TOP) {
+					int i = (it0 + u) * 8 + j;
+					a[u] = src[i];
+					b[u] = src[i + half];
+				} else {
+					int base = (it0 + u) * 64 + (G ? gl : lane);
+					a[u] = src[base];
+					b[u] = src[base + half * 8];
+				}
+				if (G)
+					h[u] = hb[(it0 + u) * 8 + j];
 			}
 		#pragma unroll
 		for (int u = 0; u < UB; ++u)
 			if (it0 + u < iters)
-				dst[(it0 + u) * 64 + lane] = g_add(a[u], b[u], (h[u] >> k) & 1);
-	}
-}
-__device__ __forceinline__ void pass_g_top(const float *__restrict__ llr, float *__restrict__ dst,
-	const uint8_t *__restrict__ hard_o, int lane)
-{
-	const int half = 1 << 15, iters = half >> 3, j = lane >> 3, k = lane & 7;
-	for (int it0 = 0; it0 < iters; it0 += UB) {
-		float a[UB], b[UB];
-		int h[UB];
-		#pragma unroll
-		for (int u = 0; u < UB; ++u) {
-			int i = (it0 + u) * 8 + j;
-			a[u] = llr[i];
-			b[u] = llr[i + half];
-			h[u] = hard_o[i];
-		}
-		#pragma unroll
-		for (int u = 0; u < UB; ++u)
-			dst[(it0 + u) * 64 + lane] = g_add(a[u], b[u], (h[u] >> k) & 1);
+				dst[(it0 + u) * 64 + lane] = G ? g_add(a[u], b[u], (h[u] >> k) & 1) : f_minsum(a[u], b[u]);
 	}
 }
 
@@ -137,48 +127,53 @@ __global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all,
 {
 	const int cw = blockIdx.x, lane = threadIdx.x, j = lane >> 3, k = lane & 7;
 	const float *llr = llr_all + (size_t)cw * CODE_LEN;
-	float *soft = soft_all + (size_t)cw * (8 * CODE_LEN);     // level m at soft + 8*2^m
+	float *soft = soft_all + (size_t)cw * (8 * CODE_LEN);     // level m >= 8 at soft + 8*2^m
 	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;
-	#define LV(m) (soft + (8 << (m)))
+	__shared__ float ls[8 << (LDS_TOP + 1)];                  // level m <= 7 at ls + 8*2^m
+	__shared__ __attribute__((aligned(8))) uint8_t lh[1 << LDS_TOP];   // partial sums of the current 128-leaf sub-tree
+	auto LV = [&](int m) -> float * { return (m > LDS_TOP ? soft : ls) + (8 << m); };
 	float M = k ? 1000.f : 0.f;                               // lane 0 carries the only real path
 	Maps A;
 	A.w0 = ID0 * (uint32_t)k;
 	A.w1 = ID1 * (uint32_t)k;
-	float r3 = 0.f, r2, r1, r0;
-	int hb = 0;
+	float r3 = 0.f, r2 = 0.f, r1 = 0.f, r0 = 0.f;
+	const int tmask = 0;
+	(void)tmask;
 
 	for (int t8 = 0; t8 < CODE_LEN / 8; ++t8) {
 		const int t = t8 * 8;
 		// ---------------- LLRs of this 8-leaf sub-tree into r3
+		int zf;                                               // f-passes run from level zf-1 down to 4
 		if (t == 0) {
-			pass_f_top(llr, LV(15), lane);
+			tree_pass<false, true>(llr, LV(15), nullptr, 15, lane, lane);
 			__syncthreads();
-			for (int m = 14; m >= 4; --m) {
-				pass_f_mem(LV(m + 1), LV(m), m, lane);
-				__syncthreads();
-			}
-			r3 = f_minsum(LV(4)[lane], LV(4)[lane + 64]);
+			zf = 15;
 		} else {
 			const int z = __builtin_ctz(t);                   // right child of the level-(z+1) node starts here
 			const int lk = A.get(z + 1);
-			const uint8_t *ho = hard + (t - (1 << z));
+			const int gl = (j << 3) | lk;
+			const uint8_t *ho = z <= LDS_TOP - 1 ? lh + ((t - (1 << z)) & ((1 << LDS_TOP) - 1)) : hard + (t - (1 << z));
 			if (z == 3) {
-				const int gl = (j << 3) | lk;
 				float a = LV(4)[gl], b = LV(4)[gl + 64];
 				r3 = g_add(a, b, (ho[j] >> k) & 1);
+				zf = 3;
 			} else {
-				if (z == 15) pass_g_top(llr, LV(15), ho, lane);
-				else pass_g_mem(LV(z + 1), LV(z), ho, z, lane, lk);
+				if (z == 15) tree_pass<true, true>(llr, LV(15), ho, 15, lane, gl);
+				else tree_pass<true, false>(LV(z + 1), LV(z), ho, z, lane, gl);
 				__syncthreads();
-				for (int m = z - 1; m >= 4; --m) {
-					pass_f_mem(LV(m + 1), LV(m), m, lane);
-					__syncthreads();
-				}
-				r3 = f_minsum(LV(4)[lane], LV(4)[lane + 64]);
+				zf = z;
 			}
 		}
+		if (zf > 3) {
+			for (int m = zf - 1; m >= 4; --m) {
+				tree_pass<false, false>(LV(m + 1), LV(m), nullptr, m, lane, lane);
+				__syncthreads();
+			}
+			r3 = f_minsum(LV(4)[lane], LV(4)[lane + 64]);
+		}
 		const uint32_t fz = (frozen[t >> 5] >> (t & 31)) & 0xffu;
-		hb = 0;
+		// H: partial sums of the 8 leaves, one bit per position, for THIS lane's path (same in all j)
+		int H = 0;
 		// ---------------- the 8 leaves, all in registers
 		#pragma unroll
 		for (int p = 0; p < 8; ++p) {
@@ -186,24 +181,28 @@ __global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all,
 			A.reset_upto(tt ? __builtin_ctz(tt) : 16, k);
 			// LLRs down to the leaf
 			if (p == 0) {
-				r2 = f_minsum(r3, __shfl_xor(r3, 32));
-				r1 = f_minsum(r2, __shfl_xor(r2, 16));
-				r0 = f_minsum(r1, __shfl_xor(r1, 8));
+				r2 = f_minsum(r3, xj<2>(r3, lane));
+				r1 = f_minsum(r2, xj<1>(r2, lane));
+				r0 = f_minsum(r1, xj<0>(r1, lane));
 			} else {
+				constexpr int dummy = 0;
+				(void)dummy;
 				const int zz = __builtin_ctz(p);              // 0,1,2 : g at level zz+1
 				const int mg = zz + 1;
 				const int hbit = 1 << zz;                     // half size of the level-mg node
 				const int q = p - hbit;                       // first leaf of the left child
 				const int lk = A.get(mg);
 				const float rsrc = mg == 3 ? r3 : (mg == 2 ? r2 : r1);
-				const float own = __shfl(rsrc, (j << 3) | lk);
-				const float oth = __shfl(rsrc, ((j ^ hbit) << 3) | lk);
+				float own = rsrc;
+				if (__ballot(lk != k))                        // lane map since the node started is not the identity
+					own = __shfl(rsrc, (j << 3) | lk);
+				const float oth = zz == 0 ? xj<0>(own, lane) : (zz == 1 ? xj<1>(own, lane) : xj<2>(own, lane));
 				const bool hi = (j >> zz) & 1;
 				const float a = hi ? oth : own, b = hi ? own : oth;
-				const int ub = __shfl(hb, ((q + (j & (hbit - 1))) << 3) | k);
+				const int ub = (H >> (q + (j & (hbit - 1)))) & 1;
 				const float v = g_add(a, b, ub);
-				if (mg == 3) { r2 = v; r1 = f_minsum(r2, __shfl_xor(r2, 16)); r0 = f_minsum(r1, __shfl_xor(r1, 8)); }
-				else if (mg == 2) { r1 = v; r0 = f_minsum(r1, __shfl_xor(r1, 8)); }
+				if (mg == 3) { r2 = v; r1 = f_minsum(r2, xj<1>(r2, lane)); r0 = f_minsum(r1, xj<0>(r1, lane)); }
+				else if (mg == 2) { r1 = v; r0 = f_minsum(r1, xj<0>(r1, lane)); }
 				else { r0 = v; }
 			}
 			// leaf decision
@@ -212,60 +211,71 @@ __global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all,
 				if (r0 < 0.f)
 					M -= r0;
 			} else {
-				float v0 = M, v1 = M;
-				if (r0 < 0.f) v0 = M - r0; else v1 = M + r0;
-				const int umine = j & 1;
-				const float val = umine ? v1 : v0;
-				const int cidx = 2 * k + umine;
-				int rank = 0;
-				#pragma unroll
-				for (int kk = 0; kk < 8; ++kk) {
-					const float o0 = __shfl(v0, kk), o1 = __shfl(v1, kk);
-					rank += (2 * kk < cidx) ? (o0 <= val) : (o0 < val);
-					rank += (2 * kk + 1 < cidx) ? (o1 <= val) : (o1 < val);
+				// stable-list fast path: paths already sorted by metric and every penalised
+				// continuation is worse than every free one -> each path just takes its own sign bit
+				const float P = M + fabsf(r0);
+				const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
+				const bool ok = (k == 0 || Mprev <= M) && group8_max(M) < group8_min(P);
+				if (__ballot(!ok) == 0) {
+					ubit = r0 < 0.f;
+				} else {
+					float v0 = M, v1 = M;
+					if (r0 < 0.f) v0 = M - r0; else v1 = M + r0;
+					const int umine = j & 1;
+					const float val = umine ? v1 : v0;
+					const int cidx = 2 * k + umine;
+					int rank = 0;
+					#pragma unroll
+					for (int kk = 0; kk < 8; ++kk) {
+						const float o0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), kk));
+						const float o1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), kk));
+						rank += (o0 < val) | ((o0 == val) & (2 * kk < cidx));
+						rank += (o1 < val) | ((o1 == val) & (2 * kk + 1 < cidx));
+					}
+					// every row of 16 lanes holds the 16 candidates at position (u << 3) | k: scatter inside the row
+					const int dst = (lane & 48) | rank;
+					int rc = __builtin_amdgcn_ds_permute(dst << 2, cidx);
+					int rv = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(val));
+					const int rcx = xor8_i(rc), rvx = xor8_i(rv);   // odd j sit at row position 8+k: take position k
+					if (j & 1) { rc = rcx; rv = rvx; }
+					M = __int_as_float(rv);
+					const int parent = rc >> 1;
+					ubit = rc & 1;
+					if (__ballot(parent != k)) {
+						A.w0 = __shfl((int)A.w0, (j << 3) | parent);
+						A.w1 = __shfl((int)A.w1, (j << 3) | parent);
+					}
 				}
-				const int dst = lane < 16 ? rank : lane;      // lanes 0..15 hold the 16 candidates
-				const int rc = __builtin_amdgcn_ds_permute(dst << 2, cidx);
-				const int rv = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(val));
-				const int mine = __shfl(rc, k);               // lane r (< 8) received the rank-r candidate
-				M = __int_as_float(__shfl(rv, k));
-				const int parent = mine >> 1;
-				ubit = mine & 1;
-				A.w0 = __shfl((int)A.w0, (j << 3) | parent);
-				A.w1 = __shfl((int)A.w1, (j << 3) | parent);
 			}
-			if (j == p)
-				hb = ubit;
+			H = (H & ~(1 << p)) | (ubit << p);
 			// partial-sum combines that complete at this leaf (levels 1..3)
 			#pragma unroll
 			for (int m = 1; m <= 3; ++m) {
 				if (((p + 1) & ((1 << m) - 1)) == 0) {
 					const int hh = 1 << (m - 1), q = p + 1 - (1 << m);
+					const int lmask = ((1 << hh) - 1) << q;
 					const int rm = A.get(m - 1);
-					const int lft = __shfl(hb, (j << 3) | rm);
-					const int rgt = __shfl(hb, (((j + hh) & 7) << 3) | k);
-					if (j >= q && j < q + hh)
-						hb = lft ^ rgt;
+					int L = H;
+					if (__ballot(rm != k))
+						L = __shfl(H, (j << 3) | rm);
+					H = (H & ~lmask) | ((L ^ (H >> hh)) & lmask);
 				}
 			}
 		}
-		// ---------------- partial sums of the sub-tree to memory, then the combines above
+		// ---------------- partial sums of the sub-tree: bytes (bit k = path k) via ballot
 		{
-			const unsigned long long bal = __ballot(hb != 0);
+			const unsigned long long bal = __ballot((H >> j) & 1);
 			if (lane == 0)
-				*(unsigned long long *)(hard + t) = bal;
+				*(unsigned long long *)(lh + (t & ((1 << LDS_TOP) - 1))) = bal;
 		}
-		for (int m = 4; m <= 16 && ((t + 8) & ((1 << m) - 1)) == 0; ++m) {
-			__syncthreads();
-			const int hh = 1 << (m - 1), o = t + 8 - (1 << m);
-			const int rm = A.get(m - 1);
+		auto combine = [&](uint8_t *hp, int hh, int rm) {     // hard[i] = perm(hard[i], rm) ^ hard[i + hh]
 			for (int it0 = 0; it0 < hh / 8; it0 += UB) {
 				int xl[UB], xr[UB];
 				#pragma unroll
 				for (int u = 0; u < UB; ++u)
 					if (it0 + u < hh / 8) {
-						xl[u] = hard[o + (it0 + u) * 8 + j];
-						xr[u] = hard[o + hh + (it0 + u) * 8 + j];
+						xl[u] = hp[(it0 + u) * 8 + j];
+						xr[u] = hp[hh + (it0 + u) * 8 + j];
 					}
 				#pragma unroll
 				for (int u = 0; u < UB; ++u)
@@ -273,15 +283,27 @@ __global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all,
 						const int bit = ((xl[u] >> rm) ^ (xr[u] >> k)) & 1;
 						const unsigned long long bal = __ballot(bit != 0);
 						if (lane == 0)
-							*(unsigned long long *)(hard + o + (it0 + u) * 8) = bal;
+							*(unsigned long long *)(hp + (it0 + u) * 8) = bal;
 					}
+			}
+		};
+		const int tn = t + 8;
+		for (int m = 4; m <= LDS_TOP && (tn & ((1 << m) - 1)) == 0; ++m) {
+			__syncthreads();
+			combine(lh + ((tn - (1 << m)) & ((1 << LDS_TOP) - 1)), 1 << (m - 1), A.get(m - 1));
+		}
+		if ((tn & ((1 << LDS_TOP) - 1)) == 0) {               // a 128-leaf sub-tree is complete: publish its bytes
+			__syncthreads();
+			((unsigned short *)(hard + tn - (1 << LDS_TOP)))[lane] = ((const unsigned short *)lh)[lane];
+			for (int m = LDS_TOP + 1; m <= 16 && (tn & ((1 << m) - 1)) == 0; ++m) {
+				__syncthreads();
+				combine(hard + tn - (1 << m), 1 << (m - 1), A.get(m - 1));
 			}
 		}
 		__syncthreads();
 	}
 	if (j == 0)
 		metric_all[(size_t)cw * LIST + k] = M;
-	#undef LV
 }
 
 // ---------------------------------------------------------------- D10
