@@ -294,3 +294,29 @@ def test_device_pointer_api_and_awgn_tile_roundtrip(rx):
     assert r.status == 0 and (o == out[5]).all() and r.sc_start == int(res["sc_start"][5])
     t = rx.timing()
     assert t["polar"][0] > 0 and t["total"][0] >= t["polar"][0]
+
+
+def test_decode_cli_is_a_drop_in(tmp_path):
+    """`decode OUTPUT INPUT [SKIP]` (decode.cc:559-620): same argv, same 5380-byte output, exit code 0"""
+    import os
+    import subprocess
+    exe = os.path.join(O.ROOT, "modem_amd", "bin", "decode")
+    enc = os.path.join(O.ORACLE_DIR, "encode")
+    a, b = tmp_path / "a.dat", tmp_path / "b.dat"
+    a.write_bytes(bytes(O.payload_for(71)))
+    b.write_bytes(bytes(O.payload_for(72)))
+    wav, out = tmp_path / "e.wav", tmp_path / "d.dat"
+    subprocess.check_call([enc, str(wav), "8000", "16", "1", "2000", "6", "CALLSIGN", str(a), str(b)])
+    for skip, want in ((None, a), ("1", b)):
+        cmd = [exe, str(out), str(wav)] + ([skip] if skip else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MODEM_AMD_NO_TORCH="1"))
+        assert r.returncode == 0, r.stderr
+        assert out.read_bytes() == want.read_bytes()
+        assert "call sign:  CALLSIGN" in r.stderr and "bit flips: 0" in r.stderr and "oper mode: 6" in r.stderr
+    assert subprocess.run([exe], capture_output=True).returncode == 1            # usage
+    r = subprocess.run([exe, str(out), str(tmp_path / "missing.wav")], capture_output=True)
+    assert r.returncode == 1
+    # 8-bit `make test` format through the CLI, stdin/stdout as "-"
+    subprocess.check_call([enc, str(wav), "8000", "8", "1", "2000", "6", "ANONYMOUS", str(a)])
+    r = subprocess.run([exe, "-", "-"], stdin=open(wav, "rb"), capture_output=True)
+    assert r.returncode == 0 and r.stdout == a.read_bytes()
