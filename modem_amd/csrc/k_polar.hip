@@ -122,6 +122,70 @@ __device__ __forceinline__ void tree_pass(const float *src, float *dst, const ui
 	}
 }
 
+// Fused pass: levels m, m-1, ..., m-D+1 from level m+1 in one sweep.  A lane owns butterfly column
+// (j, k) at EVERY level (position i = x*8 + j, local index x), and the partner of local index x at
+// level L is x + 2^(L-4): the whole f-chain below the first step is lane-local, so the intermediate
+// levels are produced in registers and each level is written exactly once, never re-read.
+//   KIND 0: first step f from level m+1      KIND 1: first step g (partial sums hb, lane map gl)
+//   KIND 2: first step f from the shared channel LLRs   KIND 3: first step g from the shared channel LLRs
+// Address spaces are compile-time: the NG highest produced levels (and the source iff SRC_G) are
+// in global memory (gs = base of the codeword's soft array), the rest in LDS (ls); flat
+// addressing would serialise the two memory pipes.  Level L starts at element 8 << L in either.
+template <int D, int KIND, int NG, bool SRC_G>
+__device__ __forceinline__ void fused_pass(const float *__restrict__ llr, float *__restrict__ gs, float *ls,
+	const uint8_t *__restrict__ hb_g, const uint8_t *hb_l, int m, int lane, int gl)
+{
+	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
+	constexpr int XB = D == 3 ? 2 : (D == 2 ? 4 : 8);   // columns batched: 16 loads in flight
+	const int S = 1 << (m - D + 1 - 3);       // local indices at the lowest produced level
+	const int half = 1 << (m - 3);            // partner distance (local) at level m+1
+	const int j = lane >> 3, k = lane & 7;
+	const float *src = SRC_G ? gs + (8 << (m + 1)) : ls + (8 << (m + 1));
+	#pragma unroll 1
+	for (int x0 = 0; x0 < S; x0 += XB) {
+		float a[XB][NT], b[XB][NT];
+		int h[XB][NT];
+		#pragma unroll
+		for (int xb = 0; xb < XB; ++xb)
+			#pragma unroll
+			for (int s2 = 0; s2 < NT; ++s2)
+				if (x0 + xb < S) {
+					const int x = x0 + xb + s2 * S;
+					if (KIND >= 2) {
+						a[xb][s2] = llr[x * 8 + j];
+						b[xb][s2] = llr[(x + half) * 8 + j];
+					} else {
+						const int o = KIND == 1 ? gl : lane;
+						a[xb][s2] = src[x * 64 + o];
+						b[xb][s2] = src[(x + half) * 64 + o];
+					}
+					if (KIND & 1)
+						h[xb][s2] = (SRC_G || KIND == 3) ? hb_g[x * 8 + j] : hb_l[x * 8 + j];
+				}
+		#pragma unroll
+		for (int xb = 0; xb < XB; ++xb)
+			if (x0 + xb < S) {
+				float v[NT];
+				#pragma unroll
+				for (int s2 = 0; s2 < NT; ++s2) {
+					v[s2] = (KIND & 1) ? g_add(a[xb][s2], b[xb][s2], (h[xb][s2] >> k) & 1) : f_minsum(a[xb][s2], b[xb][s2]);
+					const int idx = (8 << m) + (x0 + xb + s2 * S) * 64 + lane;
+					if (NG > 0) gs[idx] = v[s2]; else ls[idx] = v[s2];
+				}
+				#pragma unroll
+				for (int d = 1; d < D; ++d) {
+					const int n = NT >> d;
+					#pragma unroll
+					for (int s2 = 0; s2 < n; ++s2) {
+						v[s2] = f_minsum(v[s2], v[s2 + n]);
+						const int idx = (8 << (m - d)) + (x0 + xb + s2 * S) * 64 + lane;
+						if (NG > d) gs[idx] = v[s2]; else ls[idx] = v[s2];
+					}
+				}
+			}
+	}
+}
+
 __global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all, float *__restrict__ soft_all,
 	uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen, float *__restrict__ metric_all)
 {
@@ -131,7 +195,6 @@ __global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all,
 	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;
 	__shared__ float ls[8 << (LDS_TOP + 1)];                  // level m <= 7 at ls + 8*2^m
 	__shared__ __attribute__((aligned(8))) uint8_t lh[1 << LDS_TOP];   // partial sums of the current 128-leaf sub-tree
-	auto LV = [&](int m) -> float * { return (m > LDS_TOP ? soft : ls) + (8 << m); };
 	float M = k ? 1000.f : 0.f;                               // lane 0 carries the only real path
 	Maps A;
 	A.w0 = ID0 * (uint32_t)k;
@@ -143,33 +206,43 @@ __global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all,
 	for (int t8 = 0; t8 < CODE_LEN / 8; ++t8) {
 		const int t = t8 * 8;
 		// ---------------- LLRs of this 8-leaf sub-tree into r3
-		int zf;                                               // f-passes run from level zf-1 down to 4
-		if (t == 0) {
-			tree_pass<false, true>(llr, LV(15), nullptr, 15, lane, lane);
-			__syncthreads();
-			zf = 15;
-		} else {
-			const int z = __builtin_ctz(t);                   // right child of the level-(z+1) node starts here
-			const int lk = A.get(z + 1);
-			const int gl = (j << 3) | lk;
-			const uint8_t *ho = z <= LDS_TOP - 1 ? lh + ((t - (1 << z)) & ((1 << LDS_TOP) - 1)) : hard + (t - (1 << z));
-			if (z == 3) {
-				float a = LV(4)[gl], b = LV(4)[gl + 64];
-				r3 = g_add(a, b, (ho[j] >> k) & 1);
-				zf = 3;
+		{
+			int cur, kind;                                    // next level to produce and how its first step works
+			const uint8_t *ho_g = hard, *ho_l = lh;
+			int gl = lane;
+			if (t == 0) {
+				cur = 15; kind = 2;
 			} else {
-				if (z == 15) tree_pass<true, true>(llr, LV(15), ho, 15, lane, gl);
-				else tree_pass<true, false>(LV(z + 1), LV(z), ho, z, lane, gl);
-				__syncthreads();
-				zf = z;
+				const int z = __builtin_ctz(t);               // right child of the level-(z+1) node starts here
+				gl = (j << 3) | A.get(z + 1);
+				ho_g = hard + (t - (1 << z));                 // left child's partial sums: global for sub-trees >= 128 leaves,
+				ho_l = lh + ((t - (1 << z)) & ((1 << LDS_TOP) - 1));   // else inside the current LDS block
+				cur = z; kind = z == 15 ? 3 : 1;
 			}
-		}
-		if (zf > 3) {
-			for (int m = zf - 1; m >= 4; --m) {
-				tree_pass<false, false>(LV(m + 1), LV(m), nullptr, m, lane, lane);
-				__syncthreads();
+			if (cur == 3) {
+				float a = ls[(8 << 4) + gl], b = ls[(8 << 4) + gl + 64];
+				r3 = g_add(a, b, (ho_l[j] >> k) & 1);
+			} else {
+				while (cur >= 4) {
+					#define FP(DD, KK, NGG, SG) fused_pass<DD, KK, NGG, SG>(llr, soft, ls, ho_g, ho_l, cur, lane, gl)
+					#define FPK(DD, NGG, SG) do { if (kind == 0) FP(DD, 0, NGG, SG); else FP(DD, 1, NGG, SG); } while (0)
+					int D = 3;
+					if (cur == 15) { if (kind == 2) FP(3, 2, 3, true); else FP(3, 3, 3, true); }
+					else if (cur >= 10) FPK(3, 3, true);
+					else if (cur == 9) FPK(3, 2, true);
+					else if (cur == 8) FPK(3, 1, true);
+					else if (cur == 7) FPK(3, 0, true);
+					else if (cur == 6) FPK(3, 0, false);
+					else if (cur == 5) { FPK(2, 0, false); D = 2; }
+					else { FPK(1, 0, false); D = 1; }
+					#undef FPK
+					#undef FP
+					__syncthreads();
+					cur -= D;
+					kind = 0;
+				}
+				r3 = f_minsum(ls[(8 << 4) + lane], ls[(8 << 4) + lane + 64]);
 			}
-			r3 = f_minsum(LV(4)[lane], LV(4)[lane + 64]);
 		}
 		const uint32_t fz = (frozen[t >> 5] >> (t & 31)) & 0xffu;
 		// H: partial sums of the 8 leaves, one bit per position, for THIS lane's path (same in all j)
@@ -268,7 +341,8 @@ __global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all,
 			if (lane == 0)
 				*(unsigned long long *)(lh + (t & ((1 << LDS_TOP) - 1))) = bal;
 		}
-		auto combine = [&](uint8_t *hp, int hh, int rm) {     // hard[i] = perm(hard[i], rm) ^ hard[i + hh]
+		auto combine = [&](int off, int hh, int rm) {        // LDS block: lh[i] = perm(lh[i], rm) ^ lh[i + hh]
+			uint8_t *hp = lh + off;
 			for (int it0 = 0; it0 < hh / 8; it0 += UB) {
 				int xl[UB], xr[UB];
 				#pragma unroll
@@ -287,17 +361,47 @@ __global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all,
 					}
 			}
 		};
+		// same for sub-trees of >= 256 leaves (hh >= 128): one dword (4 positions) per lane, 256 B per sweep
+		auto combine_wide = [&](uint8_t *hp, int hh, int rm) {
+			int rmk[8];
+			#pragma unroll
+			for (int kk = 0; kk < 8; ++kk)
+				rmk[kk] = __builtin_amdgcn_readlane(rm, kk);   // lanes 0..7 hold paths 0..7
+			const bool ident = __ballot(rm != k) == 0;
+			uint32_t *pl = (uint32_t *)hp, *pr = (uint32_t *)(hp + hh);
+			for (int i0 = 0; i0 < hh / 4; i0 += 64 * 4) {
+				uint32_t xl[4], xr[4];
+				#pragma unroll
+				for (int u = 0; u < 4; ++u)
+					if (i0 + u * 64 + lane < hh / 4) {
+						xl[u] = pl[i0 + u * 64 + lane];
+						xr[u] = pr[i0 + u * 64 + lane];
+					}
+				#pragma unroll
+				for (int u = 0; u < 4; ++u)
+					if (i0 + u * 64 + lane < hh / 4) {
+						uint32_t y = xl[u];
+						if (!ident) {                         // out bit k of every byte = in bit rm[k]
+							y = 0;
+							#pragma unroll
+							for (int kk = 0; kk < 8; ++kk)
+								y |= ((xl[u] >> rmk[kk]) & 0x01010101u) << kk;
+						}
+						pl[i0 + u * 64 + lane] = y ^ xr[u];
+					}
+			}
+		};
 		const int tn = t + 8;
 		for (int m = 4; m <= LDS_TOP && (tn & ((1 << m) - 1)) == 0; ++m) {
 			__syncthreads();
-			combine(lh + ((tn - (1 << m)) & ((1 << LDS_TOP) - 1)), 1 << (m - 1), A.get(m - 1));
+			combine((tn - (1 << m)) & ((1 << LDS_TOP) - 1), 1 << (m - 1), A.get(m - 1));
 		}
 		if ((tn & ((1 << LDS_TOP) - 1)) == 0) {               // a 128-leaf sub-tree is complete: publish its bytes
 			__syncthreads();
 			((unsigned short *)(hard + tn - (1 << LDS_TOP)))[lane] = ((const unsigned short *)lh)[lane];
 			for (int m = LDS_TOP + 1; m <= 16 && (tn & ((1 << m) - 1)) == 0; ++m) {
 				__syncthreads();
-				combine(hard + tn - (1 << m), 1 << (m - 1), A.get(m - 1));
+				combine_wide(hard + tn - (1 << m), 1 << (m - 1), A.get(m - 1));
 			}
 		}
 		__syncthreads();

@@ -55,7 +55,8 @@ class Timing(C.Structure):
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libofdmrx.so")
+    """MODEM_AMD_LIB selects an alternative build of the same library (A/B runs of kernel variants)"""
+    return os.environ.get("MODEM_AMD_LIB") or os.path.join(HERE, "lib", "libofdmrx.so")
 
 
 def build(force=False):
