@@ -25,7 +25,7 @@ B_FRAME_2CH = 95200 * 2 * 2 + 5380      # algorithmic bytes per frame, SURVEY 8(
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def cpu_baseline(pcm_sample, payload_ref, threads):
+def cpu_baseline(pcm_sample, payload_ref, threads, ch=2):
     """the oracle (CPU restatement of decode.cc; the reference's own deps are absent) timed on the
     host cores on a bounded sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -37,7 +37,7 @@ def cpu_baseline(pcm_sample, payload_ref, threads):
     lib = O.lib()
     pcm_sample = np.ascontiguousarray(pcm_sample)
     t0 = time.perf_counter()
-    used = lib.orc_decode_batch(O.ptr(pcm_sample), O.FMT_S16, 2, pcm_sample.shape[1], pcm_sample.shape[1] * 4,
+    used = lib.orc_decode_batch(O.ptr(pcm_sample), O.FMT_S16, ch, pcm_sample.shape[1], pcm_sample.shape[1] * 2 * ch,
                                 n, 8, O.ptr(out), O.ptr(res), threads)
     dt = time.perf_counter() - t0
     ok = int((out == payload_ref).all(axis=1).sum())
@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="resident frames per pass (0 = library default)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="cpu_baseline sample size (-1 auto, 0 off)")
     ap.add_argument("--seed", type=int, default=2021)
+    ap.add_argument("--channels", type=int, default=2, choices=[1, 2],
+                    help="2 = configs[2] (analytic + AWGN, the headline workload); 1 = configs[1] flavour: clean 16-bit mono frames "
+                         "(exercises the D1 front end)")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,16 +84,22 @@ def main():
     B = args.frames
     rx = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=torch.cuda.current_stream().cuda_stream)
     d_base = torch.from_numpy(base).to(dev)
-    d_in = torch.empty((B, spf, 2), dtype=torch.int16, device=dev)
+    ch = args.channels
+    d_in = torch.empty((B, spf, ch), dtype=torch.int16, device=dev)
     d_out = torch.zeros((B, 5380), dtype=torch.uint8, device=dev)
     d_res = torch.zeros((B, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     # synthetic batch: frame f = base[f % n_base] + AWGN(noise level) keyed by the GLOBAL frame index
-    rx.awgn_tile(d_base.data_ptr(), n_base, d_in.data_ptr(), B, spf, args.noise_db, args.seed,
-                 shard.frame_seed_offset(B, rank))
+    if ch == 2:
+        rx.awgn_tile(d_base.data_ptr(), n_base, d_in.data_ptr(), B, spf, args.noise_db, args.seed,
+                     shard.frame_seed_offset(B, rank))
+    else:   # a 1-channel WAV from encode is the real part of the same stream (encode.cc:127-128)
+        idx = torch.arange(B, device=dev) % n_base
+        for lo in range(0, B, 4096):
+            d_in[lo:lo + 4096, :, 0] = d_base[idx[lo:lo + 4096], :, 0]
     torch.cuda.synchronize()
 
     def step():
-        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, B, d_out.data_ptr(), d_res.data_ptr())
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out.data_ptr(), d_res.data_ptr())
 
     for _ in range(args.warmup):
         step()
@@ -127,22 +136,24 @@ def main():
         value = frames_total / secs
         frames_per_launch = B * args.steps / max(polar_launches, 1)
         avg_launch_s = polar_ms / 1e3 / max(polar_launches, 1)
-        achieved = B_FRAME_2CH * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        achieved = (B_FRAME_2CH if ch == 2 else 95200 * 2 + 5380) * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         line = {
             "metric": "decoded frames/sec + BER, mode-6 8kHz OFDM, batch 65536, 1/2/4/8 MI355X",
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: batch %d analytic (2-ch int16) mode-6 8 kHz frames per GPU, AWGN noise "
-                                   "level %g dB, inputs resident in HBM; %d base frames x on-device noise keyed by frame index"
-                                   % (B, args.noise_db, n_base),
+            "config": {"workload": ("configs[2]: batch %d analytic (2-ch int16) mode-6 8 kHz frames per GPU, AWGN noise "
+                                    "level %g dB, inputs resident in HBM; %d base frames x on-device noise keyed by frame index"
+                                    % (B, args.noise_db, n_base)) if ch == 2 else
+                                   ("configs[1] flavour: batch %d clean 16-bit mono mode-6 8 kHz frames per GPU, inputs resident "
+                                    "in HBM; %d base frames tiled" % (B, n_base)),
                        "frames_per_gpu": B, "list_size": 8, "chunk_frames": rx.chunk_frames, "parallelism": "frames x%d" % n_gpus},
             "ber": bit_err / (43040.0 * B * n_gpus), "fer": frame_err / float(B * n_gpus),
             "frames_ok": ok_status, "frames": B * n_gpus,
             "roofline": {"bound": "hbm", "kernel": "k_polar (D9 SCL)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "frames_per_launch": frames_per_launch, "avg_launch_ms": 1e3 * avg_launch_s,
-                         "algorithmic_bytes_per_frame": B_FRAME_2CH},
+                         "algorithmic_bytes_per_frame": B_FRAME_2CH if ch == 2 else 95200 * 2 + 5380},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
         }
         ncpu = args.cpu_frames
@@ -152,7 +163,7 @@ def main():
                 ncpu = 4 * threads
             ncpu = min(ncpu, B)
             sample = d_in[:ncpu].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(sample, ref[:ncpu], threads)
+            line["cpu_baseline"] = cpu_baseline(sample, ref[:ncpu], threads, ch)
         print(json.dumps(line), flush=True)
     rx.close()
     if dist:

@@ -17,56 +17,117 @@
 namespace rx {
 
 // ---------------------------------------------------------------- D1 front end
+// Decoder::next_sample (decode.cc:294-301) for mono input: y = BlockDC(x), z = Hilbert<cmplx,21>(y).
+// One workgroup per frame walks the stream in tiles of 4096 samples (16 consecutive samples per
+// thread, 32 contiguous bytes per lane).  The DC blocker y[n] = b(x[n]-x[n-1]) + a y[n-1] is a linear
+// recurrence: each thread runs its 16 samples from a zero state, the 256 end states are combined by a
+// weighted inclusive scan (v[t] += A^d v[t-d], A = a^16) inside each wave and across the 4 waves, and
+// every sample is corrected by a^(k+1) * carry.  The tile of y (plus a 20-sample history) sits in LDS
+// for the 21-tap Hilbert FIR; z is written as 128 contiguous bytes per lane.
+constexpr int FE_PER = 16, FE_TILE = 256 * FE_PER, FE_HIST = 32;
+
 __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, float *__restrict__ dc_all, cf *__restrict__ z_all)
 {
-	const int f = blockIdx.x, tid = threadIdx.x;
+	const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const long n = fb.samples_per_frame;
 	const char *base = (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes;
 	SampleSrc src{ base, fb.fmt, 1, n, nullptr };
-	float *dc = dc_all + (size_t)f * fb.samples_per_frame;
 	cf *z = z_all + (size_t)f * fb.samples_per_frame;
-	__shared__ float carry_end[256], carry_pow[256], carry_in[256];
-	const long chunk = (n + 255) / 256;
-	const long s0 = min((long)tid * chunk, n), s1 = min(s0 + chunk, n);
+	(void)dc_all;
+	__shared__ float ydc[FE_HIST + FE_TILE];   // [0, FE_HIST) = tail of the previous tile
+	__shared__ float wave_end[4];
+	__shared__ float tile_carry;
 	const float a = co.dc_a, b = co.dc_b;
-	float x1 = s0 > 0 ? src.scalar(s0 - 1) : 0.f, y1 = 0.f, pw = 1.f;
-	for (long i = s0; i < s1; ++i) {
-		float x0 = src.scalar(i);
-		float y0 = b * (x0 - x1) + a * y1;
-		x1 = x0;
-		y1 = y0;
-		dc[i] = y0;
-		pw *= a;
-	}
-	carry_end[tid] = y1;
-	carry_pow[tid] = pw;
+	// powers of a: a^1..a^16 in registers, A^(2^s) = a^(16*2^s) for the scan steps
+	float apow[FE_PER];
+	apow[0] = a;
+	#pragma unroll
+	for (int i = 1; i < FE_PER; ++i)
+		apow[i] = apow[i - 1] * a;
+	float Apow[7];   // A^1, A^2, A^4, ... A^64
+	Apow[0] = apow[FE_PER - 1];
+	#pragma unroll
+	for (int sft = 1; sft < 7; ++sft)
+		Apow[sft] = Apow[sft - 1] * Apow[sft - 1];
+	if (tid < FE_HIST)
+		ydc[tid] = 0.f;
+	if (tid == 0)
+		tile_carry = 0.f;
 	__syncthreads();
-	if (tid == 0) {
-		float y = 0.f;
-		for (int t = 0; t < 256; ++t) {
-			carry_in[t] = y;
-			y = carry_end[t] + carry_pow[t] * y;
+	for (long t0 = 0; t0 < n; t0 += FE_TILE) {
+		const long s0 = t0 + (long)tid * FE_PER;
+		float x[FE_PER + 1], y[FE_PER];
+		x[0] = (s0 - 1 >= 0 && s0 - 1 < n) ? src.scalar(s0 - 1) : 0.f;
+		if (fb.fmt == 0 && s0 + FE_PER <= n && (((size_t)base + (size_t)s0 * 2) & 15) == 0) {
+			const int4 *p = (const int4 *)((const int16_t *)base + s0);
+			int4 v0 = p[0], v1 = p[1];
+			const int w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+			#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				x[1 + 2 * q] = (float)(short)(w[q] & 0xffff) / 32767.f;
+				x[2 + 2 * q] = (float)(short)(w[q] >> 16) / 32767.f;
+			}
+		} else {
+			#pragma unroll
+			for (int i = 0; i < FE_PER; ++i)
+				x[1 + i] = s0 + i < n ? src.scalar(s0 + i) : 0.f;
 		}
-	}
-	__syncthreads();
-	{
-		float cin = carry_in[tid], p = a;
-		for (long i = s0; i < s1; ++i) {
-			dc[i] += p * cin;
-			p *= a;
-		}
-	}
-	__syncthreads();
-	// Hilbert<cmplx,21>: centre tap 10 back, odd taps +-1,3,5,7,9 around it
-	for (long i = tid; i < n; i += 256) {
-		long c = i - 10;
-		auto D = [&](long k) { return k >= 0 ? dc[k] : 0.f; };
-		float re = co.reco * D(c);
-		float im = co.imco[0] * (D(c - 1) - D(c + 1));
+		float yl = 0.f;
 		#pragma unroll
-		for (int k = 1; k < 5; ++k)
-			im += co.imco[k] * (D(c - (2 * k + 1)) - D(c + (2 * k + 1)));
-		z[i] = mk(re, im);
+		for (int i = 0; i < FE_PER; ++i) {
+			yl = b * (x[i + 1] - x[i]) + a * yl;
+			y[i] = yl;
+		}
+		// weighted inclusive scan of the chunk end states over the 64 lanes of the wave
+		float v = yl;
+		#pragma unroll
+		for (int sft = 0; sft < 6; ++sft) {
+			float o = __shfl_up(v, 1 << sft);
+			if (lane >= (1 << sft))
+				v += Apow[sft] * o;
+		}
+		if (lane == 63)
+			wave_end[wave] = v;
+		__syncthreads();
+		// carry into this thread = state after the previous thread's last sample
+		float cin = tile_carry;                       // state at the end of the previous tile
+		{
+			// state at the end of the previous waves of this tile: fold them in order
+			float st = cin;
+			for (int w2 = 0; w2 < wave; ++w2)
+				st = wave_end[w2] + Apow[6] * st;     // A^64 decays a whole wave (1024 samples)
+			// within the wave: exclusive value = inclusive of lane-1 (decayed state of lanes < lane)
+			float prev = __shfl_up(v, 1);
+			float decay = 1.f;                        // A^lane
+			#pragma unroll
+			for (int sft = 0; sft < 6; ++sft)
+				if (lane & (1 << sft))
+					decay *= Apow[sft];
+			cin = (lane ? prev : 0.f) + decay * st;
+		}
+		#pragma unroll
+		for (int i = 0; i < FE_PER; ++i)
+			ydc[FE_HIST + tid * FE_PER + i] = y[i] + apow[i] * cin;
+		__syncthreads();
+		if (tid == 255)
+			tile_carry = ydc[FE_HIST + FE_TILE - 1];
+		// Hilbert<cmplx,21>: centre tap 10 back, odd taps +-1,3,5,7,9 around it
+		#pragma unroll 4
+		for (int i = 0; i < FE_PER; ++i) {
+			const int li = FE_HIST + tid * FE_PER + i;        // index of sample s0+i ; centre at li-10
+			const int c = li - 10;
+			float re = co.reco * ydc[c];
+			float im = co.imco[0] * (ydc[c - 1] - ydc[c + 1]);
+			#pragma unroll
+			for (int k = 1; k < 5; ++k)
+				im += co.imco[k] * (ydc[c - (2 * k + 1)] - ydc[c + (2 * k + 1)]);
+			if (s0 + i < n)
+				z[s0 + i] = mk(re, im);
+		}
+		__syncthreads();
+		if (tid < FE_HIST)
+			ydc[tid] = ydc[FE_TILE + tid];            // keep the last 32 samples as history
+		__syncthreads();
 	}
 }
 
