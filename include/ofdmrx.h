@@ -165,6 +165,18 @@ int ofdmrx_util_awgn_tile(ofdmrx_handle *h, const int16_t *d_base, size_t n_base
 	int16_t *d_out, size_t n_out, size_t samples_per_frame, float noise_db,
 	uint64_t seed, uint64_t first_frame);
 
+/* deterministic part of the README.md:49 chain (multipath | cfo | sfo), applied to n 2-channel int16 frames on the
+ * device (n <= 65535); ofdmrx_util_awgn_tile then adds the independent noise.  Definitions: DESIGN.md / oracle/channel.c */
+typedef struct {
+	float cfo_hz;              /* carrier frequency offset, Hz at 8 kHz */
+	float sfo_ppm;             /* sampling frequency offset, ppm */
+	int32_t ntaps;             /* multipath taps (0..8); 0 = pass-through */
+	int32_t delays[8];         /* samples */
+	float gains_re[8], gains_im[8];
+} ofdmrx_channel;
+int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_t *d_out, size_t n_frames,
+	size_t samples_per_frame, const ofdmrx_channel *ch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -552,3 +552,82 @@ void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t
 }
 
 }  // namespace rx
+
+// ---------------------------------------------------------------- build-owned channel chain (N3)
+// README.md:49 pipes encode through aicodix/disorders: multipath | cfo | sfo | awgn.  That repository is
+// absent; the definitions here are this build's own (same as oracle/channel.c, checked against it):
+//   multipath: FIR with integer delays and complex gains;   cfo: x[m] * e^{j 2 pi hz m / 8000};
+//   sfo: out[i] = resample at t = i (1 + ppm 1e-6), 32-tap Hann-windowed sinc;   awgn: k_awgn_tile.
+// 2-channel int16 in and out.  The chain is deterministic, so it is applied to the base frames once
+// and k_awgn_tile then adds independent noise per frame.
+namespace rx {
+
+struct ChannelParams {
+	float cfo_hz, sfo_ppm;
+	int ntaps;
+	int delays[8];
+	float gre[8], gim[8];
+};
+
+__global__ __launch_bounds__(256) void k_channel(const short2 *__restrict__ in, short2 *__restrict__ out, size_t spf, ChannelParams cp)
+{
+	const size_t f = blockIdx.y;
+	const short2 *src = in + f * spf;
+	short2 *dst = out + f * spf;
+	const double step = 1.0 + (double)cp.sfo_ppm * 1e-6;
+	const double w0 = 2.0 * 3.14159265358979323846 * (double)cp.cfo_hz / 8000.0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < spf; i += (size_t)gridDim.x * 256) {
+		auto stage12 = [&](long m) -> cf {   // multipath then cfo at integer sample m
+			float re = 0.f, im = 0.f;
+			for (int t = 0; t < cp.ntaps; ++t) {
+				long idx = m - cp.delays[t];
+				if (idx < 0)
+					continue;
+				short2 v = src[idx];
+				float xr = (float)v.x / 32767.f, xi = (float)v.y / 32767.f;
+				re += xr * cp.gre[t] - xi * cp.gim[t];
+				im += xr * cp.gim[t] + xi * cp.gre[t];
+			}
+			if (cp.cfo_hz != 0.f) {
+				double a = w0 * (double)m;
+				float c = (float)cos(a), s = (float)sin(a);
+				float r2 = re * c - im * s, i2 = re * s + im * c;
+				re = r2; im = i2;
+			}
+			return mk(re, im);
+		};
+		float ore, oim;
+		if (cp.sfo_ppm == 0.f) {
+			cf v = stage12((long)i);
+			ore = v.re; oim = v.im;
+		} else {
+			const int HALF = 16;
+			double t = (double)i * step;
+			long t0 = (long)floor(t);
+			double fr = t - (double)t0, re = 0.0, im = 0.0;
+			for (int k = -HALF + 1; k <= HALF; ++k) {
+				long idx = t0 + k;
+				if (idx < 0 || (size_t)idx >= spf)
+					continue;
+				double x = (double)k - fr;
+				double sinc = fabs(x) < 1e-12 ? 1.0 : sin(3.14159265358979323846 * x) / (3.14159265358979323846 * x);
+				double w = 0.5 * (1.0 + cos(3.14159265358979323846 * x / (double)HALF));
+				cf v = stage12(idx);
+				re += sinc * w * v.re;
+				im += sinc * w * v.im;
+			}
+			ore = (float)re; oim = (float)im;
+		}
+		ore = fminf(fmaxf(ore, -1.f), 1.f);
+		oim = fminf(fmaxf(oim, -1.f), 1.f);
+		dst[i] = make_short2((short)nearbyintf(32767.f * ore), (short)nearbyintf(32767.f * oim));
+	}
+}
+
+void launch_channel(hipStream_t s, const int16_t *in, int16_t *out, size_t n, size_t spf, const void *params)
+{
+	ChannelParams cp = *(const ChannelParams *)params;
+	hipLaunchKernelGGL(k_channel, dim3(128, (unsigned)n), dim3(256), 0, s, (const short2 *)in, (short2 *)out, spf, cp);
+}
+
+}  // namespace rx

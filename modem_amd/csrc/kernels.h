@@ -77,6 +77,7 @@ void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, 
 void launch_fft_debug(hipStream_t s, int n, int len, int sign, const cf *in, cf *out, Tables tb);
 void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t *out, size_t n_out,
 	size_t spf, float sigma, uint64_t seed, uint64_t first_frame);
+void launch_channel(hipStream_t s, const int16_t *in, int16_t *out, size_t n, size_t spf, const void *params);
 void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts);
 
 }  // namespace rx

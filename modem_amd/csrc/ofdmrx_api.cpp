@@ -540,3 +540,20 @@ extern "C" int ofdmrx_util_awgn_tile(ofdmrx_handle *h, const int16_t *d_base, si
 	HIP_OK(hipGetLastError());
 	return 0;
 }
+
+extern "C" int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_t *d_out, size_t n_frames, size_t spf,
+	const ofdmrx_channel *ch)
+{
+	if (!h || !d_in || !d_out || !n_frames || n_frames > 65535 || !spf || !ch || ch->ntaps < 0 || ch->ntaps > 8 || d_in == d_out)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	struct { float cfo_hz, sfo_ppm; int ntaps; int delays[8]; float gre[8], gim[8]; } cp;
+	cp.cfo_hz = ch->cfo_hz;
+	cp.sfo_ppm = ch->sfo_ppm;
+	cp.ntaps = ch->ntaps;
+	for (int i = 0; i < 8; ++i) { cp.delays[i] = ch->delays[i]; cp.gre[i] = ch->gains_re[i]; cp.gim[i] = ch->gains_im[i]; }
+	if (cp.ntaps == 0) { cp.ntaps = 1; cp.delays[0] = 0; cp.gre[0] = 1.f; cp.gim[0] = 0.f; }
+	launch_channel(h->stream, d_in, d_out, n_frames, spf, &cp);
+	HIP_OK(hipGetLastError());
+	return 0;
+}

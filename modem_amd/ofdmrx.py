@@ -22,7 +22,7 @@ EXPORTS = [
     "ofdmrx_abi_version", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
     "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames",
     "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
-    "ofdmrx_util_awgn_tile",
+    "ofdmrx_util_awgn_tile", "ofdmrx_util_channel",
 ]
 
 
@@ -48,6 +48,11 @@ RESULT_DTYPE = np.dtype([("status", "<i4"), ("symbol_pos", "<i4"), ("sc_start", 
                          ("best_lane", "<i4"), ("bit_flips", "<i4"), ("esn0_db_last", "<f4"),
                          ("n_sync_rejects", "<i4")], align=True)
 assert RESULT_DTYPE.itemsize == C.sizeof(FrameResult)
+
+
+class Channel(C.Structure):
+    _fields_ = [("cfo_hz", C.c_float), ("sfo_ppm", C.c_float), ("ntaps", C.c_int32), ("delays", C.c_int32 * 8),
+                ("gains_re", C.c_float * 8), ("gains_im", C.c_float * 8)]
 
 
 class Timing(C.Structure):
@@ -107,6 +112,7 @@ def load_library():
     L.ofdmrx_debug_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
     L.ofdmrx_util_awgn_tile.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                         C.c_float, C.c_uint64, C.c_uint64]
+    L.ofdmrx_util_channel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(Channel)]
     _LIB = L
     return L
 
@@ -229,3 +235,11 @@ class Receiver:
 
     def awgn_tile(self, d_base, n_base, d_out, n_out, spf, noise_db, seed, first_frame=0):
         self._check(self._lib.ofdmrx_util_awgn_tile(self._h, d_base, n_base, d_out, n_out, spf, noise_db, seed, first_frame))
+
+    def channel(self, d_in, d_out, n, spf, cfo_hz=0.0, sfo_ppm=0.0, multipath=()):
+        """multipath | cfo | sfo on n device-resident 2-channel int16 frames (multipath = [(delay, complex gain), ...])"""
+        ch = Channel()
+        ch.cfo_hz, ch.sfo_ppm, ch.ntaps = cfo_hz, sfo_ppm, len(multipath)
+        for i, (d, g) in enumerate(multipath):
+            ch.delays[i], ch.gains_re[i], ch.gains_im[i] = int(d), float(complex(g).real), float(complex(g).imag)
+        self._check(self._lib.ofdmrx_util_channel(self._h, d_in, d_out, n, spf, C.byref(ch)))

@@ -351,3 +351,27 @@ def test_config4_full_impairments_at_scale(rx):
     assert (out == np.stack(pays)[np.arange(n) % 6]).all()
     hz = res["cfo_fine"] * 8000 / (2 * np.pi)
     assert np.abs(np.abs(hz - 2000) - 234.567).max() < 1.5
+
+
+def test_device_channel_chain_matches_oracle_models(rx):
+    """N3: multipath | cfo | sfo on the device (README.md:49 order) against oracle/channel.c: +-1 LSB of int16
+    (float rounding at the quantiser), and the impaired frame decodes to the same payload / sync on both"""
+    import torch
+    p = O.payload_for(55)
+    pcm = O.encode_pcm(p, channels=2)
+    taps = [(0, 1 + 0j), (7, 0.3 - 0.2j), (19, -0.1 + 0.15j)]
+    spf = pcm.shape[0]
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(pcm[None]).to(dev)
+    d_out = torch.empty_like(d_in)
+    torch.cuda.synchronize()
+    for kw in (dict(cfo_hz=234.567), dict(multipath=taps), dict(sfo_ppm=147.0), dict(cfo_hz=-100.25, sfo_ppm=-80.0, multipath=taps)):
+        rx.channel(d_in.data_ptr(), d_out.data_ptr(), 1, spf, **kw)
+        rx.synchronize()
+        got = d_out.cpu().numpy()[0].astype(np.int32)
+        ref = O.impair(pcm, noise_db=None, **kw).astype(np.int32)
+        assert np.abs(got - ref).max() <= 1, kw
+        assert (np.abs(got - ref) > 0).mean() < 0.02
+    out, res = rx.decode(d_out.cpu().numpy())
+    o, r = O.decode(d_out.cpu().numpy()[0])
+    assert res["status"][0] == 0 == r.status and (out[0] == p).all() and int(res["sc_start"][0]) == r.sc_start
