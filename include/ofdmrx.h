@@ -47,7 +47,7 @@ enum {
 	OFDMRX_NO_SYNC = 1,        /* decode.cc:393-394  stream ended while searching */
 	OFDMRX_OSD_ERROR = 2,      /* decode.cc:418-421 */
 	OFDMRX_HEADER_CRC = 3,     /* decode.cc:429-432 */
-	OFDMRX_BAD_MODE = 4,       /* decode.cc:434-437 (this build decodes mode 6 payloads) */
+	OFDMRX_BAD_MODE = 4,       /* decode.cc:434-437 (modes 6..13 are decoded) */
 	OFDMRX_BAD_CALLSIGN = 5,   /* decode.cc:439-442 */
 	OFDMRX_PAYLOAD_CRC = 6     /* decode.cc:542-545 */
 };
@@ -133,11 +133,11 @@ int ofdmrx_chunk_frames(ofdmrx_handle *h);
  * chunk's first frame). */
 enum {
 	OFDMRX_TAP_HDR_SOFT = 1,   /* int8  [255]      decode.cc:413-416 */
-	OFDMRX_TAP_CONS_RAW = 2,   /* cf32  [21600]    decode.cc:464-477 */
-	OFDMRX_TAP_CONS_ROT = 3,   /* cf32  [21600]    decode.cc:481-495 */
-	OFDMRX_TAP_SLOPE = 4,      /* f32   [50] */
-	OFDMRX_TAP_YINT = 5,       /* f32   [50] */
-	OFDMRX_TAP_PRECISION = 6,  /* f32   [50]       decode.cc:517 */
+	OFDMRX_TAP_CONS_RAW = 2,   /* cf32  [cons_cnt <= 32400] decode.cc:464-477 (21600 in mode 6) */
+	OFDMRX_TAP_CONS_ROT = 3,   /* cf32  [cons_cnt]          decode.cc:481-495 */
+	OFDMRX_TAP_SLOPE = 4,      /* f32   [rows <= 126]       (50 in mode 6) */
+	OFDMRX_TAP_YINT = 5,       /* f32   [rows] */
+	OFDMRX_TAP_PRECISION = 6,  /* f32   [rows]              decode.cc:517 */
 	OFDMRX_TAP_LLR = 7,        /* f32   [65536]    decode.cc:529 */
 	OFDMRX_TAP_METRIC = 8,     /* f32   [8] */
 	OFDMRX_TAP_LANE_MESG = 9,  /* u8    [8][5476]  systematic message bits per lane, LE packed */

@@ -14,7 +14,7 @@ constexpr int BUFFER_LEN = 8640;    // decode.cc:188
 constexpr int SEARCH_POS = 2880;    // decode.cc:189
 constexpr int MATCH_LEN = 161;      // decode.cc:41
 constexpr int MATCH_DEL = 80;       // decode.cc:42
-constexpr int CONS_COLS = 432;      // decode.cc:306 (mode 6)
+constexpr int CONS_COLS = 432;      // decode.cc:306 (mode 6; other modes via mode_desc)
 constexpr int CONS_ROWS = 50;       // decode.cc:453
 constexpr int CONS_CNT = 21600;     // decode.cc:372
 constexpr int CONS_BITS = 64800;    // decode.cc:310
@@ -30,6 +30,34 @@ constexpr int BCH_N = 255, BCH_K = 71;
 
 constexpr float TWO_PI_F = 6.28318530717958647692f;
 constexpr float PI_F = 3.14159265358979323846f;
+
+constexpr int CONS_MAX = 32400;     // decode.cc:178 cons_max
+constexpr int ROWS_MAX = 126;       // decode.cc:181 rows_max
+constexpr int COLS_MAX = 512;       // decode.cc:180
+constexpr int MESG_BITS_MAX = 44096;
+constexpr int MESG_BYTES_MAX = 5512;
+
+// decode.cc:302-374 prepare(): the mode table
+struct ModeDesc { int cols, rows, mod_bits, cons_bits, mesg_bits, table; };
+__host__ __device__ inline ModeDesc mode_desc(int mode)
+{
+	ModeDesc m;
+	m.table = mode >= 10;                       // 0: frozen_64800_43072, 1: frozen_64512_43072
+	m.cons_bits = m.table ? 64512 : 64800;
+	m.mesg_bits = m.table ? 44096 : 43808;
+	switch (mode) {
+	case 6: m.cols = 432; m.mod_bits = 3; break;    // decode.cc:305-312
+	case 7: m.cols = 400; m.mod_bits = 3; break;    // decode.cc:313-320
+	case 8: m.cols = 400; m.mod_bits = 2; break;    // decode.cc:321-328
+	case 9: m.cols = 360; m.mod_bits = 2; break;    // decode.cc:329-336
+	case 10: m.cols = 512; m.mod_bits = 3; break;   // decode.cc:337-344
+	case 11: m.cols = 384; m.mod_bits = 3; break;   // decode.cc:345-352
+	case 12: m.cols = 384; m.mod_bits = 2; break;   // decode.cc:353-360
+	default: m.cols = 256; m.mod_bits = 2; break;   // 13: decode.cc:361-368
+	}
+	m.rows = (m.cons_bits / m.mod_bits) / m.cols;   // decode.cc:372,453
+	return m;
+}
 
 struct cf { float re, im; };
 

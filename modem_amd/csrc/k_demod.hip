@@ -6,6 +6,12 @@
 namespace rx {
 
 // ---- psk.hh:90-140 PhaseShiftKeying<8, cmplx, float> ---------------------------------
+// psk.hh:49-88 PhaseShiftKeying<4>: map(hard(c)) (psk.hh:70-74,82-85)
+__device__ __forceinline__ cf psk4_hard_map(cf c)
+{
+	const float r = 0.70710678118654752440f;
+	return mk(r * (c.re < 0.f ? -1.f : 1.f), r * (c.im < 0.f ? -1.f : 1.f));
+}
 __device__ __forceinline__ cf psk8_hard_map(cf c)   // map(hard(c)): psk.hh:118-123,132-139
 {
 	const float cos_pi_8 = 0.92387953251128675613f, sin_pi_8 = 0.38268343236508977173f;
@@ -19,7 +25,7 @@ __device__ __forceinline__ cf psk8_hard_map(cf c)   // map(hard(c)): psk.hh:118-
 // ---------------------------------------------------------------- D4
 struct DemodShared {
 	cf fft[4][SYMBOL_LEN];
-	cf carr[8][CONS_COLS];
+	cf carr[8][COLS_MAX];
 };
 
 // decode.cc:453-477.  One workgroup (4 waves) per frame; wave w transforms symbol 4g+w of
@@ -36,13 +42,15 @@ __global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restri
 	__shared__ DemodShared sh;
 	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, fb.samples_per_frame,
 		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
-	cf *cons = cons_all + (size_t)f * CONS_CNT;
+	const ModeDesc md = mode_desc(st.oper_mode);
+	cf *cons = cons_all + (size_t)f * CONS_MAX;
 	const long body0 = st.sc_start + 2 * SYM_STRIDE;          // pilot body, decode.cc:456-459
 	const float omega = -st.cfo_rad;                          // decode.cc:403
-	const int code_off = -CONS_COLS / 2;                      // decode.cc:454
-	for (int g = 0; g < 13; ++g) {
-		const int s = 4 * g + wave;                           // 0 = pilot, 1..50 = data rows
-		const bool valid = s <= CONS_ROWS;
+	const int code_off = -md.cols / 2;                        // decode.cc:454
+	const int groups = (md.rows + 1 + 3) / 4;
+	for (int g = 0; g < groups; ++g) {
+		const int s = 4 * g + wave;                           // 0 = pilot, 1..rows = data rows
+		const bool valid = s <= md.rows;
 		cf *buf = sh.fft[wave];
 		#pragma unroll 4
 		for (int q = 0; q < SYMBOL_LEN / 64; ++q) {
@@ -55,12 +63,12 @@ __global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restri
 		__syncthreads();
 		fft1280<64>(buf, tb.tw1280, lane);
 		if (valid)
-			for (int i = lane; i < CONS_COLS; i += 64)
+			for (int i = lane; i < md.cols; i += 64)
 				sh.carr[s & 7][i] = buf[(i + code_off + SYMBOL_LEN) % SYMBOL_LEN];
 		__syncthreads();
 		if (valid && s >= 1)
-			for (int i = lane; i < CONS_COLS; i += 64)      // decode.cc:474-475
-				cons[(s - 1) * CONS_COLS + i] = demod_or_erase(sh.carr[s & 7][i], sh.carr[(s - 1) & 7][i]);
+			for (int i = lane; i < md.cols; i += 64)        // decode.cc:474-475
+				cons[(s - 1) * md.cols + i] = demod_or_erase(sh.carr[s & 7][i], sh.carr[(s - 1) & 7][i]);
 		__syncthreads();
 	}
 }
@@ -187,8 +195,9 @@ __device__ __forceinline__ float sub_mul_nofma(float y, float s, float x)
 	return y - p;
 }
 
-constexpr int TS_SAMPLE_STEP = 12;   // sample = all pairs whose distance is a multiple of 12
+
 constexpr int TS_LIST_CAP = 8192;
+constexpr int TS_GRID_ROWS = 50;
 
 // y[0..n) in s.y ; x[i] = i - n/2.  Returns slope and yint in all threads.
 // Exact median of the n(n-1)/2 pairwise slopes (decode.cc:488, rank count/2):
@@ -211,6 +220,7 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 	};
 	bool done = false;
 	// ---- 1. sample
+	const int TS_SAMPLE_STEP = n > 448 ? 16 : 12;         // sample = all pairs whose distance is a multiple of this
 	int m = 0;
 	for (int d = TS_SAMPLE_STEP; d < n; d += TS_SAMPLE_STEP)
 		m += n - d;
@@ -352,28 +362,36 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 __global__ __launch_bounds__(256) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
 	float *__restrict__ slope_all, float *__restrict__ yint_all)
 {
-	const int f = blockIdx.x / CONS_ROWS, j = blockIdx.x % CONS_ROWS, tid = threadIdx.x;
+	// grid = frames x 50 (mode 6 has exactly 50 rows: one row per block); modes with more rows loop
+	const int f = blockIdx.x / TS_GRID_ROWS, tid = threadIdx.x;
 	if (!st_all[f].okay)
 		return;
+	const ModeDesc md = mode_desc(st_all[f].oper_mode);
 	__shared__ TsShared s;
-	cf *row = cons_all + (size_t)f * CONS_CNT + (size_t)j * CONS_COLS;
-	for (int i = tid; i < CONS_COLS; i += 256) {              // decode.cc:482-487
-		cf c = row[i];
-		cf d = cmul(c, cconj(psk8_hard_map(c)));
-		s.y[i] = atan2f(d.im, d.re);
-	}
-	__syncthreads();
-	float slope, yint;
-	theil_sen_block(s, CONS_COLS, tid, slope, yint);
-	for (int i = tid; i < CONS_COLS; i += 256) {              // decode.cc:493-494
-		float a = -(yint + slope * (float)(i - CONS_COLS / 2));
-		float sn, cs;
-		sincosf(a, &sn, &cs);
-		row[i] = cmul(row[i], mk(cs, sn));
-	}
-	if (tid == 0) {
-		slope_all[(size_t)f * CONS_ROWS + j] = slope;
-		yint_all[(size_t)f * CONS_ROWS + j] = yint;
+	for (int j = blockIdx.x % TS_GRID_ROWS; j < md.rows; j += TS_GRID_ROWS) {
+		cf *row = cons_all + (size_t)f * CONS_MAX + (size_t)j * md.cols;
+		for (int i = tid; i < md.cols; i += 256) {            // decode.cc:482-487
+			cf c = row[i];
+			cf d = cmul(c, cconj(md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c)));
+			s.y[i] = atan2f(d.im, d.re);
+		}
+		__syncthreads();
+		float slope, yint;
+		if (md.cols == CONS_COLS)                             // mode 6: compile-time trip counts
+			theil_sen_block(s, CONS_COLS, tid, slope, yint);
+		else
+			theil_sen_block(s, md.cols, tid, slope, yint);
+		for (int i = tid; i < md.cols; i += 256) {            // decode.cc:493-494
+			float a = -(yint + slope * (float)(i - md.cols / 2));
+			float sn, cs;
+			sincosf(a, &sn, &cs);
+			row[i] = cmul(row[i], mk(cs, sn));
+		}
+		if (tid == 0) {
+			slope_all[(size_t)f * ROWS_MAX + j] = slope;
+			yint_all[(size_t)f * ROWS_MAX + j] = yint;
+		}
+		__syncthreads();
 	}
 }
 
@@ -403,21 +421,22 @@ __global__ __launch_bounds__(256) void k_llr(const SyncState *__restrict__ st_al
 	if (!st.okay)
 		return;
 	__shared__ double red[2][4];
-	const cf *cons = cons_all + (size_t)f * CONS_CNT;
+	const ModeDesc md = mode_desc(st.oper_mode);
+	const cf *cons = cons_all + (size_t)f * CONS_MAX;
 	float *llr = llr_all + (size_t)f * CODE_LEN;
-	const float DIST = 2.f * 0.38268343236508977173f;         // psk.hh:106
-	const float rcp_sqrt_2 = 0.70710678118654752440f;         // psk.hh:104
+	const float rcp_sqrt_2 = 0.70710678118654752440f;         // psk.hh:57,104
+	const float DIST = md.mod_bits == 3 ? 2.f * 0.38268343236508977173f : 2.f * rcp_sqrt_2;   // psk.hh:106 / psk.hh:59
 	float sp = 0.f, np = 0.f, precision = 0.f;
-	for (int j = 0; j < CONS_ROWS; ++j) {
+	for (int j = 0; j < md.rows; ++j) {
 		double dsp = 0.0, dnp = 0.0;
 		cf c[2];
 		#pragma unroll
 		for (int q = 0; q < 2; ++q) {
 			int i = tid + 256 * q;
 			c[q] = mk(0.f, 0.f);
-			if (i < CONS_COLS) {
-				c[q] = cons[j * CONS_COLS + i];
-				cf h = psk8_hard_map(c[q]);                   // decode.cc:509-511
+			if (i < md.cols) {
+				c[q] = cons[j * md.cols + i];
+				cf h = md.mod_bits == 3 ? psk8_hard_map(c[q]) : psk4_hard_map(c[q]);   // decode.cc:509-511
 				double er = (double)c[q].re - h.re, ei = (double)c[q].im - h.im;
 				dsp += (double)h.re * h.re + (double)h.im * h.im;
 				dnp += er * er + ei * ei;
@@ -434,31 +453,36 @@ __global__ __launch_bounds__(256) void k_llr(const SyncState *__restrict__ st_al
 		np = (float)((double)np + dnp);
 		precision = sp / np;                                  // decode.cc:516
 		if (tid == 0)
-			precision_all[(size_t)f * CONS_ROWS + j] = precision;
+			precision_all[(size_t)f * ROWS_MAX + j] = precision;
 		#pragma unroll
 		for (int q = 0; q < 2; ++q) {
 			int i = tid + 256 * q;
-			if (i < CONS_COLS) {                              // psk.hh:125-130, decode.cc:520-521
-				float *b = llr + 3 * (j * CONS_COLS + i);
+			if (i < md.cols) {                                // psk.hh:76-80,125-130, decode.cc:520-521
+				float *b = llr + md.mod_bits * (j * md.cols + i);
 				float sc = DIST * precision;
-				b[1] = c[q].re * sc;
-				b[2] = c[q].im * sc;
-				b[0] = (rcp_sqrt_2 * (fabsf(c[q].re) - fabsf(c[q].im))) * sc;
+				if (md.mod_bits == 3) {
+					b[1] = c[q].re * sc;
+					b[2] = c[q].im * sc;
+					b[0] = (rcp_sqrt_2 * (fabsf(c[q].re) - fabsf(c[q].im))) * sc;
+				} else {
+					b[0] = c[q].re * sc;
+					b[1] = c[q].im * sc;
+				}
 			}
 		}
 	}
-	// lengthen(): the shortened positions are the index tail [64800,65536), +9000
-	for (int i = CONS_BITS + tid; i < CODE_LEN; i += 256)
+	// lengthen(): the shortened positions are the index tail [cons_bits, 65536) for both tables
+	for (int i = md.cons_bits + tid; i < CODE_LEN; i += 256)
 		llr[i] = 9000.f;                                      // decode.cc:252
 	if (tid == 0) {
 		float sum_slope = 0.f, sum_yint = 0.f;
-		for (int j = 0; j < CONS_ROWS; ++j) {                 // decode.cc:491-492
-			sum_slope += slope_all[(size_t)f * CONS_ROWS + j];
-			sum_yint += yint_all[(size_t)f * CONS_ROWS + j];
+		for (int j = 0; j < md.rows; ++j) {                   // decode.cc:491-492
+			sum_slope += slope_all[(size_t)f * ROWS_MAX + j];
+			sum_yint += yint_all[(size_t)f * ROWS_MAX + j];
 		}
 		Result &r = res_all[f];
-		r.sfo_slope = sum_slope / (float)CONS_ROWS;
-		r.cfo_fine = st.cfo_rad + (sum_yint / (float)CONS_ROWS) / (float)SYM_STRIDE;   // decode.cc:501
+		r.sfo_slope = sum_slope / (float)md.rows;
+		r.cfo_fine = st.cfo_rad + (sum_yint / (float)md.rows) / (float)SYM_STRIDE;   // decode.cc:501
 		r.esn0_db_last = 10.f * log10f(precision);            // decode.cc:518
 	}
 }
@@ -485,7 +509,7 @@ void launch_demod(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, c
 }
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, float *slope, float *yint)
 {
-	hipLaunchKernelGGL(k_theil_sen, dim3(n * CONS_ROWS), dim3(256), 0, s, st, cons, slope, yint);
+	hipLaunchKernelGGL(k_theil_sen, dim3(n * TS_GRID_ROWS), dim3(256), 0, s, st, cons, slope, yint);
 }
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint)
 {

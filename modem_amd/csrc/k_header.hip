@@ -350,8 +350,6 @@ __global__ __launch_bounds__(256, 2) void k_header(FrameBatch fb, const cf *__re
 					status = 4;                               // decode.cc:434-437
 				else if ((md >> 8) == 0 || (md >> 8) >= 129961739795077ULL)
 					status = 5;                               // decode.cc:439-442
-				else if (st.oper_mode != 6)
-					status = 4;                               // payload path of this build: mode 6 only
 			}
 		}
 		st.status = status;

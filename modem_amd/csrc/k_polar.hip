@@ -186,10 +186,13 @@ __device__ __forceinline__ void fused_pass(const float *__restrict__ llr, float 
 	}
 }
 
-__global__ __launch_bounds__(64) void k_polar(const float *__restrict__ llr_all, float *__restrict__ soft_all,
-	uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen, float *__restrict__ metric_all)
+__global__ __launch_bounds__(64) void k_polar(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
+	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, float *__restrict__ metric_all)
 {
 	const int cw = blockIdx.x, lane = threadIdx.x, j = lane >> 3, k = lane & 7;
+	if (!st_all[cw].okay)
+		return;                                               // no header -> nothing to decode (decode.cc:450-451)
+	const uint32_t *frozen = frozen2 + (st_all[cw].oper_mode >= 10 ? 2048 : 0);   // decode.cc:312,344
 	const float *llr = llr_all + (size_t)cw * CODE_LEN;
 	float *soft = soft_all + (size_t)cw * (8 * CODE_LEN);     // level m >= 8 at soft + 8*2^m
 	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 	const int f = blockIdx.x, tid = threadIdx.x;
 	const SyncState st = st_all[f];
 	uint8_t *payload = payload_all + (size_t)f * PAYLOAD_BYTES;
-	__shared__ uint8_t mesg[LIST][MESG_BYTES];
+	__shared__ uint8_t mesg[LIST][MESG_BYTES_MAX];
 	__shared__ uint32_t crcs[LIST];
 	__shared__ int flips_red[4];
 	Result r = res_all[f];
@@ -446,12 +449,15 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 	}
 	const uint8_t *hard = hard_all + (size_t)f * CODE_LEN;
 	const float *llr = llr_all + (size_t)f * CODE_LEN;
+	const ModeDesc md = mode_desc(st.oper_mode);
+	const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
+	const int mesg_bytes = md.mesg_bits / 8;
 	// transpose: 8 code positions (one byte each, bit k = path k) -> one message byte per path
-	for (int bi = tid; bi < MESG_BYTES; bi += 256) {
+	for (int bi = tid; bi < mesg_bytes; bi += 256) {
 		uint32_t o[LIST] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 		#pragma unroll
 		for (int b = 0; b < 8; ++b) {
-			uint32_t x = hard[tb.info_pos[8 * bi + b]];
+			uint32_t x = hard[info_pos[8 * bi + b]];
 			#pragma unroll
 			for (int k = 0; k < LIST; ++k)
 				o[k] |= ((x >> k) & 1u) << b;
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 	}
 	int flips = 0;
 	for (int i = tid; i < DATA_BITS; i += 256) {              // decode.cc:546-554
-		int received = llr[tb.info_pos[i]] < 0.f;
+		int received = llr[info_pos[i]] < 0.f;
 		int decoded = (mesg[best][i >> 3] >> (i & 7)) & 1;
 		flips += received != decoded;
 	}
@@ -535,9 +541,9 @@ __global__ __launch_bounds__(256) void k_awgn_tile(const short2 *__restrict__ ba
 	}
 }
 
-void launch_polar(hipStream_t s, int n, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric)
+void launch_polar(hipStream_t s, int n, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric)
 {
-	hipLaunchKernelGGL(k_polar, dim3(n), dim3(64), 0, s, llr, soft, hard, tb.frozen, metric);
+	hipLaunchKernelGGL(k_polar, dim3(n), dim3(64), 0, s, st, llr, soft, hard, tb.frozen, metric);
 }
 void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
 	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res)

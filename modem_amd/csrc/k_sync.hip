@@ -14,6 +14,11 @@
 #include "dev_common.h"
 #include "kernels.h"
 
+// Decision-critical fp32 expressions (cfo_rad = shift*2pi/640 - frac_cfo sits at magnitude ~6 before the
+// wrap, so ONE ulp there is 5e-7 rad/sample = 7e-4 rad per symbol): no FMA contraction in this file, like
+// the strict-IEEE CPU restatement.
+#pragma clang fp contract(off)
+
 namespace rx {
 
 // ---------------------------------------------------------------- D1 front end

@@ -40,8 +40,8 @@ struct Tables {                    // device-resident constants, built once per 
 	const cf *tw1280;              // e^{-j 2 pi m / 1280}
 	const cf *sc_kern;             // conj(FFT640(mls0))/640, decode.cc:80-82
 	const float *mls1_nrz;         // +-1 descrambler, decode.cc:407-409
-	const uint32_t *frozen;        // 2048 words, bit set = frozen (polar_tables.hh data, regenerated)
-	const uint16_t *info_pos;      // ascending unfrozen positions [43808]
+	const uint32_t *frozen;        // [2][2048] words, bit set = frozen: frozen_64800_43072, frozen_64512_43072 (regenerated)
+	const uint16_t *info_pos;      // [2][44096] ascending unfrozen positions per table
 	const uint32_t *genmat_bits;   // BCH(255,71) systematic generator, [71][8] words, bit i of row j
 	const uint8_t *osd_pairs;      // [2485][2] (a,b)
 	const uint8_t *osd_triples;    // [57155][3] (a,b,c) sorted by c (equal d-loop lengths are adjacent)
@@ -71,7 +71,7 @@ void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, float
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
 void launch_llr(hipStream_t s, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, float *llr, Result *res);
-void launch_polar(hipStream_t s, int n, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric);
+void launch_polar(hipStream_t s, int n, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric);
 void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
 	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res);
 void launch_fft_debug(hipStream_t s, int n, int len, int sign, const cf *in, cf *out, Tables tb);

@@ -185,10 +185,10 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 		const size_t N = (size_t)n;
 		r = r ? r : h->st.ensure(N * sizeof(SyncState));
 		r = r ? r : h->hdr_soft.ensure(N * 256);
-		r = r ? r : h->cons.ensure(N * CONS_CNT * sizeof(cf));
-		r = r ? r : h->slope.ensure(N * CONS_ROWS * sizeof(float));
-		r = r ? r : h->yint.ensure(N * CONS_ROWS * sizeof(float));
-		r = r ? r : h->precision.ensure(N * CONS_ROWS * sizeof(float));
+		r = r ? r : h->cons.ensure(N * CONS_MAX * sizeof(cf));
+		r = r ? r : h->slope.ensure(N * ROWS_MAX * sizeof(float));
+		r = r ? r : h->yint.ensure(N * ROWS_MAX * sizeof(float));
+		r = r ? r : h->precision.ensure(N * ROWS_MAX * sizeof(float));
 		r = r ? r : h->llr.ensure(N * CODE_LEN * sizeof(float));
 		r = r ? r : h->soft.ensure(N * 8 * CODE_LEN * sizeof(float));
 		r = r ? r : h->hard.ensure(N * CODE_LEN);
@@ -197,7 +197,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 		r = r ? r : h->res.ensure(N * sizeof(Result));
 		r = r ? r : h->payload.ensure(N * PAYLOAD_BYTES);
 		if (h->cfg.flags & 1)
-			r = r ? r : h->cons_raw.ensure(N * CONS_CNT * sizeof(cf));
+			r = r ? r : h->cons_raw.ensure(N * CONS_MAX * sizeof(cf));
 		if (r)
 			return r;
 		h->cap = n;
@@ -254,14 +254,14 @@ static int run_chunk(ofdmrx_handle *h, FrameBatch fb, int n, const int32_t *d_sk
 	(void)e2;
 	launch_demod(s, n, fb, z, h->dev, st, h->cons.as<cf>());
 	if (h->cfg.flags & 1)
-		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_CNT * sizeof(cf), hipMemcpyDeviceToDevice, s));
+		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
 	size_t e4 = mark(h);
 	launch_theil_sen(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>());
 	size_t e5 = mark(h);
 	launch_llr(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
 		h->llr.as<float>(), d_res);
 	size_t e6 = mark(h);
-	launch_polar(s, n, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	launch_polar(s, n, st, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
 	size_t e7 = mark(h);
 	launch_finish(s, n, st, h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
 		want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res);
@@ -400,31 +400,29 @@ extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *
 		return OFDMRX_E_ARG;
 	const void *src = nullptr;
 	size_t bytes = 0;
+	size_t cap = 0;   // bytes available per frame; the copy is min(dst_bytes, cap)
 	switch (tap) {
-	case OFDMRX_TAP_HDR_SOFT: src = h->hdr_soft.as<int8_t>() + frame * 256; bytes = 255; break;
+	case OFDMRX_TAP_HDR_SOFT: src = h->hdr_soft.as<int8_t>() + frame * 256; cap = 255; break;
 	case OFDMRX_TAP_CONS_RAW:   /* D5 rotates in place: the raw copy exists only with cfg.flags & 1 */
 		if (!(h->cfg.flags & 1))
 			return OFDMRX_E_ARG;
-		src = h->cons_raw.as<cf>() + frame * CONS_CNT; bytes = CONS_CNT * sizeof(cf); break;
-	case OFDMRX_TAP_CONS_ROT: src = h->cons.as<cf>() + frame * CONS_CNT; bytes = CONS_CNT * sizeof(cf); break;
-	case OFDMRX_TAP_SLOPE: src = h->slope.as<float>() + frame * CONS_ROWS; bytes = CONS_ROWS * 4; break;
-	case OFDMRX_TAP_YINT: src = h->yint.as<float>() + frame * CONS_ROWS; bytes = CONS_ROWS * 4; break;
-	case OFDMRX_TAP_PRECISION: src = h->precision.as<float>() + frame * CONS_ROWS; bytes = CONS_ROWS * 4; break;
-	case OFDMRX_TAP_LLR: src = h->llr.as<float>() + frame * CODE_LEN; bytes = CODE_LEN * 4; break;
-	case OFDMRX_TAP_METRIC: src = h->metric.as<float>() + frame * LIST; bytes = LIST * 4; break;
-	case OFDMRX_TAP_LANE_MESG: src = h->lane_mesg.as<uint8_t>() + frame * LIST * MESG_BYTES; bytes = LIST * MESG_BYTES; break;
+		src = h->cons_raw.as<cf>() + frame * CONS_MAX; cap = CONS_MAX * sizeof(cf); break;
+	case OFDMRX_TAP_CONS_ROT: src = h->cons.as<cf>() + frame * CONS_MAX; cap = CONS_MAX * sizeof(cf); break;
+	case OFDMRX_TAP_SLOPE: src = h->slope.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
+	case OFDMRX_TAP_YINT: src = h->yint.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
+	case OFDMRX_TAP_PRECISION: src = h->precision.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
+	case OFDMRX_TAP_LLR: src = h->llr.as<float>() + frame * CODE_LEN; cap = CODE_LEN * 4; break;
+	case OFDMRX_TAP_METRIC: src = h->metric.as<float>() + frame * LIST; cap = LIST * 4; break;
+	case OFDMRX_TAP_LANE_MESG: src = h->lane_mesg.as<uint8_t>() + frame * LIST * MESG_BYTES; cap = LIST * MESG_BYTES; break;
 	case OFDMRX_TAP_ANALYTIC:
 		if (!h->last_mono)
 			return OFDMRX_E_ARG;
 		src = h->z.as<cf>() + frame * (size_t)h->last_spf;
-		bytes = 0;   /* caller-sized */
+		cap = (size_t)h->last_spf * sizeof(cf);
 		break;
 	default: return OFDMRX_E_ARG;
 	}
-	if (tap == OFDMRX_TAP_ANALYTIC)
-		bytes = dst_bytes;
-	if (dst_bytes < bytes)
-		return OFDMRX_E_ARG;
+	bytes = dst_bytes < cap ? dst_bytes : cap;
 	HIP_OK(hipStreamSynchronize(h->stream));
 	HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
 	return 0;
@@ -445,7 +443,7 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
-	launch_polar(h->stream, (int)n, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	launch_polar(h->stream, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
 	launch_finish(h->stream, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, 0,
 		h->lane_mesg.as<uint8_t>(), h->payload.as<uint8_t>(), h->res.as<Result>());
 	HIP_OK(hipGetLastError());
@@ -460,7 +458,7 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 
 extern "C" int ofdmrx_debug_theil_sen(ofdmrx_handle *h, const float *y, size_t rows, int cols, float *slope, float *yint)
 {
-	if (!h || !y || !rows || cols < 2 || cols > 510 || !slope || !yint)
+	if (!h || !y || !rows || cols < 2 || cols > 512 || !slope || !yint)
 		return OFDMRX_E_ARG;
 	HIP_OK(hipSetDevice(h->cfg.device));
 	DevBuf dy, ds, di;

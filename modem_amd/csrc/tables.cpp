@@ -28,10 +28,10 @@ struct Mls {
 };
 
 // ---- frozen mask: freezer.cc:14-32 recipe (BEC construction in long double, the K most
-// reliable synthetic channels are unfrozen).  table 0 = (64800, 43072): polar_tables.hh:2
-static void frozen_mask(uint32_t *frozen)
+// reliable synthetic channels are unfrozen).  N = 64800: polar_tables.hh:2 ; N = 64512: polar_tables.hh:1
+static void frozen_mask(uint32_t *frozen, int N)
 {
-	const int M = 16, LEN = 1 << M, N = 64800, K = 43040 + 32;
+	const int M = 16, LEN = 1 << M, K = 43040 + 32;
 	long double erasure_probability = (long double)(N - K) / N;
 	double design_SNR = 10 * std::log10(-std::log((double)erasure_probability));
 	double better_SNR = design_SNR + 1.59175;
@@ -143,12 +143,16 @@ void build_tables(HostTables &t)
 		for (int i = 0; i < 255; ++i)
 			t.mls1_nrz[i] = (float)(1 - 2 * m1.next());
 	}
-	t.frozen.resize(2048);
-	frozen_mask(t.frozen.data());
-	t.info_pos.clear();
-	for (int i = 0; i < 65536; ++i)
-		if (!((t.frozen[i / 32] >> (i % 32)) & 1))
-			t.info_pos.push_back((uint16_t)i);
+	t.frozen.resize(2 * 2048);
+	frozen_mask(t.frozen.data(), 64800);
+	frozen_mask(t.frozen.data() + 2048, 64512);
+	t.info_pos.assign(2 * 44096, 0);
+	for (int tab = 0; tab < 2; ++tab) {
+		int n = 0;
+		for (int i = 0; i < 65536; ++i)
+			if (!((t.frozen[tab * 2048 + i / 32] >> (i % 32)) & 1))
+				t.info_pos[tab * 44096 + n++] = (uint16_t)i;
+	}
 	t.genmat_bits.resize(71 * 8);
 	bch_genmat_bits(t.genmat_bits.data());
 	t.osd_pairs.clear();

@@ -192,9 +192,10 @@ class Receiver:
         self._check(self._lib.ofdmrx_get_timing(self._h, C.byref(t)))
         return {s: (t.ms[i], t.launches[i]) for i, s in enumerate(STAGES)}
 
-    def tap(self, name, frame, samples=None):
-        shapes = dict(HDR_SOFT=((255,), np.int8), CONS_RAW=((21600, 2), np.float32), CONS_ROT=((21600, 2), np.float32),
-                      SLOPE=((50,), np.float32), YINT=((50,), np.float32), PRECISION=((50,), np.float32),
+    def tap(self, name, frame, samples=None, cons_cnt=21600, rows=50):
+        """stage tap of the last resident chunk; cons_cnt / rows default to mode 6 (other modes: up to 32400 / 126)"""
+        shapes = dict(HDR_SOFT=((255,), np.int8), CONS_RAW=((cons_cnt, 2), np.float32), CONS_ROT=((cons_cnt, 2), np.float32),
+                      SLOPE=((rows,), np.float32), YINT=((rows,), np.float32), PRECISION=((rows,), np.float32),
                       LLR=((CODE_LEN,), np.float32), METRIC=((8,), np.float32), LANE_MESG=((8, MESG_BYTES), np.uint8),
                       ANALYTIC=((samples or 0, 2), np.float32))
         shape, dt = shapes[name]

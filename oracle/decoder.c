@@ -444,10 +444,10 @@ int orc_decode_cf(const orc_cf *z, size_t n, int skip_count, int list_size,
 				mesg[(size_t)(j++) * L + k] = mess[i];
 	}
 	if (taps && taps->lane_mesg) {
-		memset(taps->lane_mesg, 0, (size_t)L * 5476);
+		memset(taps->lane_mesg, 0, (size_t)L * 5512);
 		for (int k = 0; k < L; ++k)
 			for (int i = 0; i < md.mesg_bits; ++i)
-				orc_set_le_bit(taps->lane_mesg + (size_t)k * 5476, i, mesg[(size_t)i * L + k] < 0);
+				orc_set_le_bit(taps->lane_mesg + (size_t)k * 5512, i, mesg[(size_t)i * L + k] < 0);
 	}
 	int best = -1;
 	for (int k = 0; k < L; ++k) {                          /* decode.cc:532-541 */

@@ -206,7 +206,7 @@ typedef struct {
 	float *precision;      /* [rows]   decode.cc:517 */
 	float *llr;            /* [65536]  after lengthen, decode.cc:529 */
 	float *metric;         /* [L] */
-	uint8_t *lane_mesg;    /* [L][5476] systematic message bits, LE packed, per lane */
+	uint8_t *lane_mesg;    /* [L][5512] systematic message bits (<= 44096), LE packed, per lane */
 } orc_taps;
 
 /* samples: interleaved raw stream (the WAV body). payload: 5380 B, descrambled

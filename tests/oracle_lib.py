@@ -160,7 +160,7 @@ class TapBuffers:
         self.precision = np.zeros(126, np.float32)
         self.llr = np.zeros(CODE_LEN, np.float32)
         self.metric = np.zeros(8, np.float32)
-        self.lane_mesg = np.zeros((8, 5476), np.uint8)
+        self.lane_mesg = np.zeros((8, 5512), np.uint8)
         self.c = Taps(*[ptr(getattr(self, n)) for n, _ in Taps._fields_])
 
 
