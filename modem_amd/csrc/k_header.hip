@@ -26,6 +26,7 @@ struct OsdShared {
 	unsigned char rel[256];
 	signed char soft[256];
 	uint32_t cw[8];
+	uint32_t cw2[8];           // best codeword so far (permuted order)
 	int pivot_row, pivot_col;
 	int next_item;
 	int red_best[256], red_next[256], red_id[256];
@@ -62,6 +63,54 @@ struct Track {
 		else if (met > next) { next = met; }
 	}
 };
+
+// Exact optimality certificate.  For codewords c, c' : metric(c) - metric(c') = 2 * sum over the
+// positions where they differ of w_i(c), w_i(c) = (1 - 2 c_i) x_i.  The generator's roots include
+// alpha^1..alpha^58 (the 24 minimal polynomials of decode.cc:379-384), so by the BCH bound two distinct
+// codewords differ in >= 59 positions.  If -(sum of |w_i| over the n_neg positions with w_i < 0)
+// + (sum of the 59 - n_neg smallest non-negative w_i) > 0, every other codeword - hence every other
+// OSD candidate - has a strictly smaller metric: c is the result and it is unique (best != next), exactly
+// what the full enumeration of decode.cc:417 would return.  cwbits: 8 words in LDS (permuted order).
+__device__ bool osd_certify(OsdShared &s, const uint32_t *cwbits, int tid)
+{
+	const int DMIN = 59;
+	int w = 0;
+	if (tid < BCH_N) {
+		int c = (cwbits[tid >> 5] >> (tid & 31)) & 1;
+		w = c ? -(int)s.x[tid] : (int)s.x[tid];
+	}
+	s.red_id[tid] = w;
+	__syncthreads();
+	int neg = 0, nneg = 0;
+	for (int i = 0; i < BCH_N; ++i) {        // uniform loop, LDS broadcast reads
+		int v = s.red_id[i];
+		if (v < 0) { neg -= v; ++nneg; }
+	}
+	const int need = DMIN - nneg;
+	bool ok = false;
+	if (need > 0) {
+		int take = 0;
+		if (tid < BCH_N && w >= 0) {
+			int r = 0;
+			for (int i = 0; i < BCH_N; ++i) {
+				int v = s.red_id[i];
+				r += v >= 0 && (v < w || (v == w && i < tid));
+			}
+			if (r < need)
+				take = w;
+		}
+		#pragma unroll
+		for (int m = 32; m; m >>= 1)
+			take += __shfl_xor(take, m);
+		__syncthreads();
+		if ((tid & 63) == 0)
+			s.red_best[tid >> 6] = take;
+		__syncthreads();
+		ok = s.red_best[0] + s.red_best[1] + s.red_best[2] + s.red_best[3] > neg;
+	}
+	__syncthreads();
+	return ok;
+}
 
 // soft[255] in s.soft must be valid; returns unique flag, writes hard bits (BE) to hard_out[32] (thread 0)
 __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bits, const uint8_t *__restrict__ pairs,
@@ -217,13 +266,54 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 			e[w] = base[w] ^ s.G[a][w + 2] ^ s.G[b][w + 2];
 		tr.update(X - 2 * (S0 + s.ax[a] + s.ax[b] + pl.eval(e)), (a + 1) | ((b + 1) << 7));
 	}
+	// reduce the per-thread (best, runner-up, id) triples; thread 0 rebuilds the best codeword into s.cw2
+	auto reduce_tracks = [&]() {
+		s.red_best[tid] = tr.best;
+		s.red_next[tid] = tr.next;
+		s.red_id[tid] = tr.id;
+		__syncthreads();
+		if (tid == 0) {
+			int gb = -0x7fffffff, gi = 0, cnt = 0, gn = -1;
+			for (int t = 0; t < 256; ++t)
+				if (s.red_best[t] > gb) { gb = s.red_best[t]; gi = s.red_id[t]; }
+			for (int t = 0; t < 256; ++t) {
+				if (s.red_best[t] == gb) ++cnt;
+				else if (s.red_best[t] > gn) gn = s.red_best[t];
+				if (s.red_next[t] > gn) gn = s.red_next[t];
+			}
+			if (cnt > 1) gn = gb;
+			for (int w = 0; w < 8; ++w) s.cw2[w] = s.cw[w];
+			for (int q = 0; q < 4; ++q) {
+				int r = (gi >> (7 * q)) & 127;
+				if (r)
+					for (int w = 0; w < 8; ++w) s.cw2[w] ^= s.G[r - 1][w];
+			}
+			s.pivot_row = (gb != gn);
+		}
+		__syncthreads();
+	};
+	auto emit = [&](bool unique) {
+		if (tid == 0) {
+			for (int i = 0; i < 32; ++i) hard_out[i] = 0;
+			for (int i = 0; i < BCH_N; ++i) {
+				int p = s.perm[i];
+				if ((s.cw2[i >> 5] >> (i & 31)) & 1)
+					hard_out[p >> 3] |= (uint8_t)(0x80 >> (p & 7));
+			}
+			s.pivot_row = unique;
+		}
+		__syncthreads();
+		return s.pivot_row != 0;
+	};
+	// orders 0..2 are done (2557 candidates).  If their best is provably the unique optimum, stop here.
+	reduce_tracks();
+#ifndef OSD_NO_CERTIFICATE
+	if (osd_certify(s, s.cw2, tid))
+		return emit(true);
+#endif
 	// triples (a<b<c) sorted by c: item = the triple itself plus its d-loop (d > c).  Consecutive
 	// items have equal trip counts, so the 64 lanes of a wave stay converged.
-#ifdef OSD_PROBE_SKIP_TRIPLES
-	for (int item = tid; item < 0; item += 256) {
-#else
 	for (int item = tid; item < NTRIPLES; item += 256) {
-#endif
 		const int a = triples[3 * item], b = triples[3 * item + 1], c = triples[3 * item + 2];
 		uint32_t eabc[PW], e[PW];
 		#pragma unroll
@@ -232,7 +322,6 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 		const int idabc = (a + 1) | ((b + 1) << 7) | ((c + 1) << 14);
 		const int sabc = S0 + s.ax[a] + s.ax[b] + s.ax[c];
 		tr.update(X - 2 * (sabc + pl.eval(eabc)), idabc);
-#ifndef OSD_PROBE_SKIP_DLOOP
 		#pragma unroll 2
 		for (int d = c + 1; d < BCH_K; ++d) {
 			#pragma unroll
@@ -240,39 +329,9 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 				e[w] = eabc[w] ^ s.G[d][w + 2];
 			tr.update(X - 2 * (sabc + s.ax[d] + pl.eval(e)), idabc | ((d + 1) << 21));
 		}
-#endif
 	}
-	s.red_best[tid] = tr.best;
-	s.red_next[tid] = tr.next;
-	s.red_id[tid] = tr.id;
-	__syncthreads();
-	if (tid == 0) {
-		int gb = -0x7fffffff, gi = 0, cnt = 0, gn = -1;
-		for (int t = 0; t < 256; ++t)
-			if (s.red_best[t] > gb) { gb = s.red_best[t]; gi = s.red_id[t]; }
-		for (int t = 0; t < 256; ++t) {
-			if (s.red_best[t] == gb) ++cnt;
-			else if (s.red_best[t] > gn) gn = s.red_best[t];
-			if (s.red_next[t] > gn) gn = s.red_next[t];
-		}
-		if (cnt > 1) gn = gb;
-		uint32_t best[8];
-		for (int w = 0; w < 8; ++w) best[w] = s.cw[w];
-		for (int q = 0; q < 4; ++q) {
-			int r = (gi >> (7 * q)) & 127;
-			if (r)
-				for (int w = 0; w < 8; ++w) best[w] ^= s.G[r - 1][w];
-		}
-		for (int i = 0; i < 32; ++i) hard_out[i] = 0;
-		for (int i = 0; i < BCH_N; ++i) {
-			int p = s.perm[i];
-			if ((best[i >> 5] >> (i & 31)) & 1)
-				hard_out[p >> 3] |= (uint8_t)(0x80 >> (p & 7));
-		}
-		s.pivot_row = (gb != gn);
-	}
-	__syncthreads();
-	return s.pivot_row != 0;
+	reduce_tracks();
+	return emit(s.pivot_row != 0);
 }
 
 __device__ __forceinline__ int be_bit(const uint8_t *b, int i) { return (b[i >> 3] >> (7 - (i & 7))) & 1; }
