@@ -79,10 +79,13 @@ __global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restri
 // (11+11+10 bits of the order-preserving key) with the slopes recomputed on the fly from the
 // 432 phases held in LDS; fp32 division is correctly rounded so slopes are bit-identical to
 // the CPU's.
+#ifndef TS_LIST_CAP_V
+#define TS_LIST_CAP_V 4096   // 16 KB: with hist/part the block needs ~29 KB of LDS -> 5 workgroups per CU
+#endif
 struct TsShared {
 	float y[512];
 	float rcp[512];            // correctly rounded 1/d
-	float buf[8192];           // sample of exact slopes, then the list of bracketed exact slopes
+	float buf[TS_LIST_CAP_V];    // list of bracketed pairs -> their exact slopes; then the intercepts
 	int hist[2048];
 	int part[256];
 	int red[4];
@@ -172,16 +175,22 @@ __device__ void radix_digit(TsShared &s, int tid, int shift, int bits, unsigned 
 	}
 	__syncthreads();
 }
-// value at sorted position `rank` of the multiset enumerated by `each` (exact, 3 digits 11+11+10)
-template <typename Each>
+// value at sorted position `rank` of the multiset enumerated by `each` (exact, 3 digits 11+11+10).
+// EDGE = -1 / +1 stops after two digits and returns the lower / upper edge of the 22-bit key cell that
+// holds the rank (a value <= / >= the order statistic, within 2^-13 relative): enough for a bracket.
+template <int EDGE = 0, typename Each>
 __device__ float select_rank(TsShared &s, int tid, int rank, Each each)
 {
 	if (tid == 0) { s.prefix = 0; s.rank = rank; }
 	__syncthreads();
 	radix_digit(s, tid, 21, 11, 0u, each);
 	radix_digit(s, tid, 10, 11, 0xffe00000u, each);
-	radix_digit(s, tid, 0, 10, 0xfffffc00u, each);
-	float v = fkey_inv(s.prefix);
+	if (EDGE == 0)
+		radix_digit(s, tid, 0, 10, 0xfffffc00u, each);
+	unsigned key = s.prefix;
+	if (EDGE > 0)
+		key |= 0x3ffu;
+	float v = fkey_inv(key);
 	__syncthreads();
 	return v;
 }
@@ -196,7 +205,7 @@ __device__ __forceinline__ float sub_mul_nofma(float y, float s, float x)
 }
 
 
-constexpr int TS_LIST_CAP = 8192;
+constexpr int TS_LIST_CAP = TS_LIST_CAP_V;
 constexpr int TS_GRID_ROWS = 50;
 
 // y[0..n) in s.y ; x[i] = i - n/2.  Returns slope and yint in all threads.
@@ -220,120 +229,130 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 	};
 	bool done = false;
 	// ---- 1. sample
-	const int TS_SAMPLE_STEP = n > 448 ? 16 : 12;         // sample = all pairs whose distance is a multiple of this
+	const int TS_SAMPLE_STEP = 8;         // sample = all pairs whose distance is a multiple of this
 	int m = 0;
 	for (int d = TS_SAMPLE_STEP; d < n; d += TS_SAMPLE_STEP)
 		m += n - d;
-	if (m >= 512 && m <= TS_LIST_CAP) {
-		int base = 0;
-		for (int d = TS_SAMPLE_STEP; d < n; d += TS_SAMPLE_STEP) {
-			for (int i = tid; i < n - d; i += 256)
-				s.buf[base + i] = (s.y[i + d] - s.y[i]) / (float)d;
-			base += n - d;
-		}
-		__syncthreads();
-		auto sample = [&](auto emit) { for (int i = tid; i < m; i += 256) emit(s.buf[i]); };
-		int K = (int)(2.25f * sqrtf((float)m)) + 2;           // 4.5 sigma of Binomial(m, 1/2)
+	if (m >= 512) {
+		// the sample is never stored: its slopes are recomputed (cheap reciprocal form - a bracket needs
+		// no exactness) in each of the four histogram passes
+		auto sample = [&](auto emit) {
+			for (int d = TS_SAMPLE_STEP; d < n; d += TS_SAMPLE_STEP) {
+				const float rd = __builtin_amdgcn_rcpf((float)d);
+				for (int i = tid; i < n - d; i += 256)
+					emit((s.y[i + d] - s.y[i]) * rd);
+			}
+		};
+		int K = (int)(1.6f * sqrtf((float)m)) + 2;            // 3.2 sigma of Binomial(m, 1/2)
 		int rlo = m / 2 - K, rhi = m / 2 + K;
 		if (rlo < 0) rlo = 0;
 		if (rhi > m - 1) rhi = m - 1;
 #ifdef TS_PROBE_SKIP_SAMPLE_SELECT
 		const float T_lo = -1e-3f, T_hi = 1e-3f;
 #else
-		const float T_lo = select_rank(s, tid, rlo, sample);
-		const float T_hi = select_rank(s, tid, rhi, sample);
+		const float T_lo = select_rank<-1>(s, tid, rlo, sample);
+		const float T_hi = select_rank<+1>(s, tid, rhi, sample);
 #endif
-		// ---- 2. classify every pair.  Appends go to a per-wave segment of the list; the fill count of
-		// a segment lives in a wave-uniform register (ballot + popcount), so there is no LDS atomic.
+		// ---- 2. classify every pair.  Kept pairs go to a shared LDS list in chunks of 128 slots: a wave
+		// owns one chunk at a time (fill count in a wave-uniform register, ballot + mbcnt for the slot),
+		// and takes the next chunk with one LDS atomic when it runs out; the tail of the old chunk is
+		// padded with a sentinel that later sorts above every real slope.
+		if (tid == 0) s.list_n = 0;
 		__syncthreads();
 		const int lane = tid & 63, wave = tid >> 6;
-		constexpr int SEG = TS_LIST_CAP / 4;
-		int below = 0, fill = 0;
-		unsigned *seg = (unsigned *)s.buf + wave * SEG;
+		constexpr int CHUNK = 128, SENT = 0xffffffffu;
+		int below = 0, kept = 0, cbase = -1, cfill = CHUNK;
+		unsigned *list = (unsigned *)s.buf;
 		// q = a*rcp(d) is within 3*2^-24 relative of the correctly rounded quotient; thresholds moved
 		// outwards by 1e-6 relative (+ an absolute floor) make "q < T_lo_m" imply "exact < T_lo"
 		const float T_lo_m = T_lo - (1e-6f * fabsf(T_lo) + 1e-36f);
 		const float T_hi_m = T_hi + (1e-6f * fabsf(T_hi) + 1e-36f);
 #ifndef TS_PROBE_SKIP_MAIN
 		{
-			// folds q (distance q paired with n-q) are taken 4 at a time and both halves e = tid,
-			// tid+256 together, so 16 LDS reads are in flight before the first classification
-			const int folds = (n - 1) / 2, extra = (n & 1) == 0 ? 1 : 0;   // extra fold: d = n/2 alone
-			constexpr int QB = 4;
-			for (int q0 = 1; q0 <= folds + extra; q0 += QB) {
-				float a[2 * QB], rc[2 * QB];
-				unsigned pk[2 * QB];
-				bool vv[2 * QB];
-				#pragma unroll
-				for (int u = 0; u < QB; ++u) {
-					const int q = q0 + u;
-					#pragma unroll
-					for (int h = 0; h < 2; ++h) {
-						const int e = tid + 256 * h, x = 2 * u + h;
-						int i, d;
-						bool valid;
-						if (q <= folds) {
-							if (e < n - q) { i = e; d = q; } else { i = e - (n - q); d = n - q; }
-							valid = e < n;
-						} else {
-							i = e; d = n / 2;
-							valid = q == folds + 1 && extra && e < n - d;
+			// Lane = point i (kept in a register), loop = distance d (wave-uniform): one LDS read, one
+			// subtract, one multiply and two compares per pair; "below" is counted with a scalar popcount
+			// of the compare mask.  Blocks of 64 points are dealt to the 4 waves boustrophedon-wise so the
+			// triangular trip counts (n-1-64b) balance; no block-level sync inside.
+			const int nblk = (n + 63) >> 6;
+			for (int turn = 0; turn * 4 < nblk; ++turn) {
+				const int b = (turn & 1) ? (turn + 1) * 4 - 1 - wave : turn * 4 + wave;
+				if (b >= nblk)
+					continue;
+				const int i = b * 64 + lane;
+				const float yi = i < n ? s.y[i] : 0.f;
+				const int dmax = n - 1 - b * 64;              // largest distance with any valid lane
+				constexpr int U = 8;
+				for (int dblk = 0; dblk < dmax; dblk += 64) {
+					// reciprocals of the next 64 distances, one per lane; read back with v_readlane
+					const float rcl = __builtin_amdgcn_rcpf((float)(dblk + lane + 1));
+					const int dend = dmax - dblk < 64 ? dmax - dblk : 64;
+					for (int u0 = 0; u0 < dend; u0 += U) {
+						// phase A (branch-free, 8 independent chains): classify 8 distances
+						unsigned long long kb[U];
+						unsigned pk[U];
+						#pragma unroll
+						for (int u = 0; u < U; ++u) {
+							const int d = dblk + u0 + u + 1;
+							const int j = i + d;
+							const float ydv = s.y[j < n ? j : n - 1];
+							const float rc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcl), (u0 + u) & 63));
+							const bool valid = j < n && u0 + u < dend;
+							const float q = (ydv - yi) * rc;
+							const bool lo = valid & (q < T_lo_m);         // certainly below T_lo even after rounding
+							const bool keep = valid & !lo & !(q > T_hi_m);
+							below += __popcll(__builtin_amdgcn_ballot_w64(lo));   // wave-uniform scalar count
+							kb[u] = __builtin_amdgcn_ballot_w64(keep);
+							pk[u] = (unsigned)i | ((unsigned)d << 16);
 						}
-						if (!valid) { i = 0; d = 1; }
-						a[x] = s.y[i + d] - s.y[i];
-						rc[x] = __builtin_amdgcn_rcpf((float)d);   // 1 ulp reciprocal: inside the margin
-						pk[x] = (unsigned)i | ((unsigned)d << 16);
-						vv[x] = valid;
+						// phase B: append the kept pairs (their exact quotient is computed once, after the pass)
+						#pragma unroll
+						for (int u = 0; u < U; ++u) {
+							const unsigned long long bal = kb[u];
+							const int c = __popcll(bal);
+							if (cfill + c > CHUNK) {          // chunk exhausted: pad its tail, take a new one (rare)
+								if (cbase >= 0 && cbase + CHUNK <= TS_LIST_CAP && lane < CHUNK - cfill)
+									list[cbase + cfill + lane] = SENT;
+								int nb = 0;
+								if (lane == 0)
+									nb = atomicAdd(&s.list_n, CHUNK);
+								cbase = __builtin_amdgcn_readfirstlane(nb);
+								cfill = 0;
+							}
+							if (((bal >> lane) & 1) && cbase + CHUNK <= TS_LIST_CAP) {
+								int slot = cfill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+								list[cbase + slot] = pk[u];
+							}
+							cfill += c;
+							kept += c;
+						}
 					}
-				}
-				#pragma unroll
-				for (int x = 0; x < 2 * QB; ++x) {
-					const float q = a[x] * rc[x];
-					const bool lo = vv[x] && q < T_lo_m;      // certainly below T_lo even after rounding
-					const bool keep = vv[x] && !lo && !(q > T_hi_m);
-					below += lo;
-					const unsigned long long bal = __ballot(keep);
-					if (keep) {   // remember the pair; its exact quotient is computed once, after the pass
-						int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-						if (slot < SEG)
-							seg[slot] = pk[x];
-					}
-					fill += __popcll(bal);
 				}
 			}
+			if (cbase >= 0 && cbase + CHUNK <= TS_LIST_CAP && lane + cfill < CHUNK)   // pad the last chunk (<= 128 - cfill slots, 2 rounds)
+				list[cbase + cfill + lane] = SENT;
+			if (cbase >= 0 && cbase + CHUNK <= TS_LIST_CAP && lane + 64 + cfill < CHUNK)
+				list[cbase + cfill + lane + 64] = SENT;
 		}
 #endif
-		#pragma unroll
-		for (int mm = 32; mm; mm >>= 1)
-			below += __shfl_xor(below, mm);
 		if (lane == 0) {
 			s.red[wave] = below;
-			s.part[wave] = fill;
+			s.part[wave] = kept;
 		}
 		__syncthreads();
 		below = s.red[0] + s.red[1] + s.red[2] + s.red[3];
-		const int f0 = s.part[0], f1 = s.part[1], f2 = s.part[2], f3 = s.part[3];
-		const int ln = (f0 > SEG || f1 > SEG || f2 > SEG || f3 > SEG) ? TS_LIST_CAP + 1 : f0 + f1 + f2 + f3;
+		const int real = s.part[0] + s.part[1] + s.part[2] + s.part[3];
+		const int ln = s.list_n;                              // allocated slots (multiple of 128)
 		const int r = target - below;
-		{
-			const int fs[4] = { f0, f1, f2, f3 };
-			#pragma unroll
-			for (int w4 = 0; w4 < 4; ++w4)
-				for (int i = tid; i < fs[w4] && i < SEG; i += 256) {
-					unsigned pk = ((const unsigned *)s.buf)[w4 * SEG + i];
-					int pi = pk & 0xffff, pd = pk >> 16;
-					s.buf[w4 * SEG + i] = (s.y[pi + pd] - s.y[pi]) / (float)pd;
-				}
-		}
 		__syncthreads();
-		if (ln <= TS_LIST_CAP && r >= 0 && r < ln) {
-			auto list = [&](auto emit) {
-				for (int i = tid; i < f0; i += 256) emit(s.buf[i]);
-				for (int i = tid; i < f1; i += 256) emit(s.buf[SEG + i]);
-				for (int i = tid; i < f2; i += 256) emit(s.buf[2 * SEG + i]);
-				for (int i = tid; i < f3; i += 256) emit(s.buf[3 * SEG + i]);
-			};
-			float v = select_rank(s, tid, r, list);
+		if (ln <= TS_LIST_CAP && r >= 0 && r < real) {
+			for (int i = tid; i < ln; i += 256) {             // pair index -> exact slope, in place
+				unsigned pk = list[i];
+				int pi = pk & 0xffff, pd = pk >> 16;
+				s.buf[i] = pk == SENT ? __int_as_float(0x7f7fffff) : (s.y[pi + pd] - s.y[pi]) / (float)pd;
+			}
+			__syncthreads();
+			auto lst = [&](auto emit) { for (int i = tid; i < ln; i += 256) emit(s.buf[i]); };
+			float v = select_rank(s, tid, r, lst);
 			if (v >= T_lo && v <= T_hi) {
 				slope = v;
 				done = true;
