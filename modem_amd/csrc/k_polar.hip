@@ -136,7 +136,7 @@ __device__ __forceinline__ void fused_pass(const float *__restrict__ llr, float 
 	const uint8_t *__restrict__ hb_g, const uint8_t *hb_l, int m, int lane, int gl)
 {
 	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
-	constexpr int XB = D == 3 ? 2 : (D == 2 ? 4 : 8);   // columns batched: 16 loads in flight
+	constexpr int XB = D == 3 ? 3 : (D == 2 ? 4 : 8);   // columns batched: 24 loads in flight (4 -> 256 VGPRs)
 	const int S = 1 << (m - D + 1 - 3);       // local indices at the lowest produced level
 	const int half = 1 << (m - 3);            // partner distance (local) at level m+1
 	const int j = lane >> 3, k = lane & 7;
