@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="resident frames per pass (0 = library default)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="cpu_baseline sample size (-1 auto, 0 off)")
     ap.add_argument("--seed", type=int, default=2021)
+    ap.add_argument("--unique", type=int, default=-1,
+                    help="distinct payloads / clean frames made by the device transmitter (-1 = every frame distinct, "
+                         "0 = tile the 4 committed fixture frames instead)")
     ap.add_argument("--channels", type=int, default=2, choices=[1, 2],
                     help="2 = configs[2] (analytic + AWGN, the headline workload); 1 = configs[1] flavour: clean 16-bit mono frames "
                          "(exercises the D1 front end)")
@@ -78,25 +81,56 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    fx = np.load(os.path.join(ROOT, "tests", "golden", "base_frames_2ch.npz"))
-    base, base_pay = fx["pcm"], fx["payload"]
-    n_base, spf = base.shape[0], base.shape[1]
     B = args.frames
-    rx = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=torch.cuda.current_stream().cuda_stream)
-    d_base = torch.from_numpy(base).to(dev)
     ch = args.channels
+    # ONE explicit (non-default) HIP stream shared by torch and the library: the default stream's handle is 0,
+    # which the C ABI reads as "create your own stream", and two streams would race on the device buffers
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    rx = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=stream.cuda_stream)
+    spf = rx.tx_frame_samples(6)
     d_in = torch.empty((B, spf, ch), dtype=torch.int16, device=dev)
     d_out = torch.zeros((B, 5380), dtype=torch.uint8, device=dev)
     d_res = torch.zeros((B, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    # synthetic batch: frame f = base[f % n_base] + AWGN(noise level) keyed by the GLOBAL frame index
-    if ch == 2:
-        rx.awgn_tile(d_base.data_ptr(), n_base, d_in.data_ptr(), B, spf, args.noise_db, args.seed,
-                     shard.frame_seed_offset(B, rank))
-    else:   # a 1-channel WAV from encode is the real part of the same stream (encode.cc:127-128)
-        idx = torch.arange(B, device=dev) % n_base
-        for lo in range(0, B, 4096):
-            d_in[lo:lo + 4096, :, 0] = d_base[idx[lo:lo + 4096], :, 0]
+    t_gen = time.perf_counter()
+    if args.unique != 0:
+        # synthetic batch made entirely on the device: random payloads -> device transmitter (N2) -> AWGN (N3).
+        # Payload RNG and channel RNG are keyed by the GLOBAL frame index, so ranks never repeat each other.
+        U = B if args.unique < 0 else min(args.unique, B)
+        g = torch.Generator(device=dev)
+        g.manual_seed(args.seed * 1000003 + rank)
+        d_pay = torch.randint(0, 256, (U, 5380), dtype=torch.uint8, device=dev, generator=g)
+        n_base = U
+        if U == B:
+            d_clean = d_in                        # transmit straight into the batch, add the noise in place
+        else:
+            d_clean = torch.empty((U, spf, ch), dtype=torch.int16, device=dev)
+        rx.tx_encode(d_pay.data_ptr(), U, d_clean.data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=ch)
+        if ch == 2:
+            rx.awgn_tile(d_clean.data_ptr(), U, d_in.data_ptr(), B, spf, args.noise_db, args.seed,
+                         shard.frame_seed_offset(B, rank))
+        elif U != B:
+            idx = torch.arange(B, device=dev) % U
+            for lo in range(0, B, 4096):
+                d_in[lo:lo + 4096] = d_clean[idx[lo:lo + 4096]]
+        source = "device transmitter, %d distinct random payloads" % U
+    else:
+        fx = np.load(os.path.join(ROOT, "tests", "golden", "base_frames_2ch.npz"))
+        base = fx["pcm"]
+        n_base = base.shape[0]
+        d_pay = torch.from_numpy(fx["payload"]).to(dev)
+        d_base = torch.from_numpy(base).to(dev)
+        if ch == 2:
+            rx.awgn_tile(d_base.data_ptr(), n_base, d_in.data_ptr(), B, spf, args.noise_db, args.seed,
+                         shard.frame_seed_offset(B, rank))
+        else:   # a 1-channel WAV from encode is the real part of the same stream (encode.cc:127-128)
+            idx = torch.arange(B, device=dev) % n_base
+            for lo in range(0, B, 4096):
+                d_in[lo:lo + 4096, :, 0] = d_base[idx[lo:lo + 4096], :, 0]
+        source = "%d committed fixture frames (tests/golden/base_frames_2ch.npz) tiled" % n_base
+    rx.synchronize()
     torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t_gen
 
     def step():
         rx.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out.data_ptr(), d_res.data_ptr())
@@ -123,11 +157,14 @@ def main():
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
 
-    out = d_out.cpu().numpy()
     res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
-    ref = base_pay[np.arange(B) % n_base]
-    frame_err = int((out != ref).any(axis=1).sum())
-    bit_err = int(np.unpackbits(out ^ ref, axis=1).sum())
+    pop = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=dev)
+    frame_err = bit_err = 0
+    for lo in range(0, B, 8192):
+        ref = d_pay[torch.arange(lo, min(lo + 8192, B), device=dev) % n_base]
+        be = pop[(d_out[lo:lo + 8192] ^ ref).long()].sum(dim=1)
+        frame_err += int((be > 0).sum().item())
+        bit_err += int(be.sum().item())
     ok_status = int((res["status"] == 0).sum())
     secs, (frames_total, frame_err, bit_err, ok_status) = shard.reduce_counters(
         (secs, [B * args.steps, frame_err, bit_err, ok_status]), world, dist, dev)
@@ -143,10 +180,10 @@ def main():
             "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("configs[2]: batch %d analytic (2-ch int16) mode-6 8 kHz frames per GPU, AWGN noise "
-                                    "level %g dB, inputs resident in HBM; %d base frames x on-device noise keyed by frame index"
-                                    % (B, args.noise_db, n_base)) if ch == 2 else
+                                    "level %g dB, inputs resident in HBM; %s, on-device noise keyed by frame index"
+                                    % (B, args.noise_db, source)) if ch == 2 else
                                    ("configs[1] flavour: batch %d clean 16-bit mono mode-6 8 kHz frames per GPU, inputs resident "
-                                    "in HBM; %d base frames tiled" % (B, n_base)),
+                                    "in HBM; %s" % (B, source)),
                        "frames_per_gpu": B, "list_size": 8, "chunk_frames": rx.chunk_frames, "parallelism": "frames x%d" % n_gpus},
             "ber": bit_err / (43040.0 * B * n_gpus), "fer": frame_err / float(B * n_gpus),
             "frames_ok": ok_status, "frames": B * n_gpus,
@@ -155,6 +192,7 @@ def main():
                          "frames_per_launch": frames_per_launch, "avg_launch_ms": 1e3 * avg_launch_s,
                          "algorithmic_bytes_per_frame": B_FRAME_2CH if ch == 2 else 95200 * 2 + 5380},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+            "input_generation_s": gen_s,
         }
         ncpu = args.cpu_frames
         if n_gpus == 1 and ncpu != 0:
@@ -163,7 +201,8 @@ def main():
                 ncpu = 4 * threads
             ncpu = min(ncpu, B)
             sample = d_in[:ncpu].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(sample, ref[:ncpu], threads, ch)
+            ref_cpu = d_pay[torch.arange(ncpu, device=dev) % n_base].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(sample, ref_cpu, threads, ch)
         print(json.dumps(line), flush=True)
     rx.close()
     if dist:

@@ -177,6 +177,14 @@ typedef struct {
 int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_t *d_out, size_t n_frames,
 	size_t samples_per_frame, const ofdmrx_channel *ch);
 
+/* ---- N2: the transmitter on the device (replaces Encoder<value,cmplx,8000>(pcm, inp, count=1, freq_off,
+ * call_sign, oper_mode), encode.cc:271, for batches).  d_payload: n_frames x 5380 UNSCRAMBLED bytes (what main()
+ * reads from the input files, encode.cc:414); d_pcm: n_frames x ofdmrx_tx_frame_samples(mode) x channels int16,
+ * exactly the body of the WAV `encode OUT 8000 16 CHANNELS OFFSET MODE CALLSIGN file` writes. DEVICE pointers. */
+long ofdmrx_tx_frame_samples(int oper_mode);
+int ofdmrx_tx_encode_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_frames, int oper_mode,
+	int freq_off, const char *call_sign, int channels, int16_t *d_pcm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,12 +154,12 @@ template <> struct Bfly<5> {
 	}
 };
 
-template <int N, int R, int P, int NT>
+template <int N, int R, int P, int NT, int TWN = 1280>
 __device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
 {
 	constexpr int T = N / R;
 	constexpr int NB = (T + NT - 1) / NT;
-	constexpr int TWS = 1280 / (P * R);
+	constexpr int TWS = TWN / (P * R);   // tw = table of TWN roots e^{-j 2 pi m / TWN}
 	cf v[NB][R];
 	#pragma unroll
 	for (int q = 0; q < NB; ++q) {
@@ -210,6 +210,18 @@ __device__ __forceinline__ void fft640(cf *buf, const cf *tw, int tid)
 	fft_stage<640, 4, 20, NT>(buf, tw, tid);
 	fft_stage<640, 4, 80, NT>(buf, tw, tid);
 	fft_stage<640, 2, 320, NT>(buf, tw, tid);
+}
+
+// forward 5120 = 5*4*4*4*4*4 (transmitter PAPR step, encode.cc:43-44); tw = table of 5120 roots
+template <int NT>
+__device__ __forceinline__ void fft5120(cf *buf, const cf *tw5120, int tid)
+{
+	fft_stage<5120, 5, 1, NT, 5120>(buf, tw5120, tid);
+	fft_stage<5120, 4, 5, NT, 5120>(buf, tw5120, tid);
+	fft_stage<5120, 4, 20, NT, 5120>(buf, tw5120, tid);
+	fft_stage<5120, 4, 80, NT, 5120>(buf, tw5120, tid);
+	fft_stage<5120, 4, 320, NT, 5120>(buf, tw5120, tid);
+	fft_stage<5120, 4, 1280, NT, 5120>(buf, tw5120, tid);
 }
 
 // ---- wave helpers ----------------------------------------------------------

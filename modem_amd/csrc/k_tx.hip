@@ -1,0 +1,270 @@
+// k_tx.hip -- N2: the transmitter (Encoder<value,cmplx,8000>, encode.cc:27-318) on the device, so that
+// synthetic batches with DISTINCT payloads never cross PCIe.  Not on the receive hot path; built to the same
+// parity bar (waveform within +-1 LSB of the CPU restatement after the int16 quantiser, identical bits).
+//   k_tx_code     payload -> scramble -> CRC-32 -> systematic polar codeword (encode.cc:293-303,415-419)
+//   k_tx_symbol   one OFDM symbol: carriers (pilot / Schmidl-Cox / meta / differential 8PSK|QPSK rows) ->
+//                 PAPR clip via 4x oversampling (encode.cc:80-100) -> IFFT1280 -> scale (encode.cc:101-109)
+//   k_tx_assemble raised-cosine guard cross-fade with the previous symbol (encode.cc:110-114), quantise to
+//                 int16 like DSP::WriteWAV, silence before and after (encode.cc:423,441)
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace rx {
+
+struct TxParams {
+	int oper_mode, offset, channels, nsym;     // offset = freq_off*1280/8000 bins (encode.cc:283)
+	unsigned long long md;                     // (call_sign << 8) | mode  (encode.cc:291)
+	long frame_samples;
+};
+
+// ---------------------------------------------------------------- polar systematic encoder
+__global__ __launch_bounds__(256) void k_tx_code(const uint8_t *__restrict__ payload_all, Tables tb, TxParams tp,
+	uint32_t *__restrict__ code_all)
+{
+	const int f = blockIdx.x, tid = threadIdx.x;
+	const ModeDesc md = mode_desc(tp.oper_mode);
+	const uint32_t *frozen = tb.frozen + (md.table ? 2048 : 0);
+	__shared__ uint8_t msg[PAYLOAD_BYTES + 4];
+	__shared__ uint32_t cw[2048];
+	__shared__ uint32_t crctab[256];
+	__shared__ int rank[2048];                 // unfrozen positions before word w
+	crctab[tid] = tb.crc32_tab[tid];
+	for (int i = tid; i < PAYLOAD_BYTES; i += 256)
+		msg[i] = payload_all[(size_t)f * PAYLOAD_BYTES + i] ^ tb.scramble[i];   // encode.cc:417-419
+	__syncthreads();
+	if (tid == 0) {                            // CRC<uint32_t>(0xD419CC15) over the scrambled bytes, encode.cc:295-297
+		uint32_t crc = 0;
+		for (int i = 0; i < PAYLOAD_BYTES; ++i)
+			crc = (crc >> 8) ^ crctab[(crc ^ msg[i]) & 255];
+		for (int b = 0; b < 4; ++b)
+			msg[PAYLOAD_BYTES + b] = (uint8_t)(crc >> (8 * b));   // appended LSB first, encode.cc:298-299
+		int acc = 0;
+		for (int w = 0; w < 2048; ++w) {
+			rank[w] = acc;
+			acc += 32 - __popc(frozen[w]);
+		}
+	}
+	__syncthreads();
+	// u: message bit k at the k-th unfrozen position (bits >= 43072 are +1 = 0), frozen positions 0
+	for (int w = tid; w < 2048; w += 256) {
+		uint32_t fz = frozen[w], v = 0;
+		int k = rank[w];
+		for (int b = 0; b < 32; ++b)
+			if (!((fz >> b) & 1)) {
+				if (k < CRC_BITS)
+					v |= (uint32_t)((msg[k >> 3] >> (k & 7)) & 1) << b;
+				++k;
+			}
+		cw[w] = v;
+	}
+	__syncthreads();
+	// x = u F^{(x)16} twice with the frozen positions cleared in between (CODE::PolarSysEnc, encode.cc:302)
+	for (int pass = 0; pass < 2; ++pass) {
+		for (int w = tid; w < 2048; w += 256) {
+			uint32_t v = cw[w];
+			if (pass)
+				v &= ~frozen[w];
+			v ^= (v >> 1) & 0x55555555u;
+			v ^= (v >> 2) & 0x33333333u;
+			v ^= (v >> 4) & 0x0f0f0f0fu;
+			v ^= (v >> 8) & 0x00ff00ffu;
+			v ^= (v >> 16) & 0x0000ffffu;
+			cw[w] = v;
+		}
+		__syncthreads();
+		for (int h = 1; h < 2048; h <<= 1) {
+			for (int q = tid; q < 1024; q += 256) {
+				int a = ((q & ~(h - 1)) << 1) | (q & (h - 1));   // word index with bit h clear
+				cw[a] ^= cw[a + h];
+			}
+			__syncthreads();
+		}
+	}
+	for (int w = tid; w < 2048; w += 256)
+		code_all[(size_t)f * 2048 + w] = cw[w];
+}
+
+// ---------------------------------------------------------------- one OFDM symbol
+__device__ __forceinline__ int bin1280(int c) { return (c + SYMBOL_LEN) % SYMBOL_LEN; }
+__device__ __forceinline__ int bin5120(int c) { return (c + 4 * SYMBOL_LEN) % (4 * SYMBOL_LEN); }
+
+struct TxShared {
+	cf big[4 * SYMBOL_LEN];
+	cf fdom[SYMBOL_LEN];
+	float cum[256];
+	uint8_t bits[32];
+};
+
+// symbol kinds in transmission order (encode.cc:288-313): pilot | S&C | meta | pilot | rows x data | zero
+__global__ __launch_bounds__(256) void k_tx_symbol(const uint32_t *__restrict__ code_all, Tables tb, TxParams tp,
+	const cf *__restrict__ tw5120, cf *__restrict__ tdom_all)
+{
+	const int f = blockIdx.x / tp.nsym, sidx = blockIdx.x % tp.nsym, tid = threadIdx.x;
+	const ModeDesc md = mode_desc(tp.oper_mode);
+	__shared__ TxShared sh;
+	const int code_off = tp.offset - md.cols / 2;             // encode.cc:284
+	const int mls0_off = tp.offset - 127 + 1;                 // encode.cc:285
+	const int mls1_off = tp.offset - 255 / 2;                 // encode.cc:286
+	for (int i = tid; i < SYMBOL_LEN; i += 256)
+		sh.fdom[i] = mk(0.f, 0.f);
+	__syncthreads();
+	bool papr = true;
+	const int last = tp.nsym - 1;
+	if (sidx == 1) {                                          // schmidl_cox(): encode.cc:142-154
+		papr = false;
+		if (tid == 0) {
+			float c = sqrtf((float)(2 * SYMBOL_LEN) / 127.f);
+			sh.fdom[bin1280(mls0_off - 2)] = mk(c, 0.f);
+			for (int i = 0; i < 127; ++i) {
+				c *= tb.mls0_nrz[i];
+				sh.fdom[bin1280(2 * i + mls0_off)] = mk(c, 0.f);
+			}
+		}
+	} else if (sidx == 2) {                                   // meta_data(): encode.cc:155-179
+		if (tid == 0) {
+			uint32_t cwd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+			unsigned long long m = tp.md;
+			// 55 bits of md LSB first, then CRC-16(md << 9) LSB first; codeword = XOR of generator rows
+			unsigned crc = 0;
+			unsigned long long d9 = m << 9;
+			for (int i = 0; i < 64; ++i) {
+				unsigned t = crc ^ (unsigned)((d9 >> i) & 1);
+				crc = (crc >> 1) ^ ((t & 1) * 0xA8F4u);
+			}
+			crc &= 0xffffu;
+			for (int i = 0; i < 71; ++i) {
+				int bit = i < 55 ? (int)((m >> i) & 1) : (int)((crc >> (i - 55)) & 1);
+				if (bit)
+					for (int w = 0; w < 8; ++w)
+						cwd[w] ^= tb.genmat_bits[i * 8 + w];
+			}
+			float c = sqrtf((float)SYMBOL_LEN / 255.f);
+			sh.fdom[bin1280(mls1_off - 1)] = mk(c, 0.f);
+			for (int i = 0; i < 255; ++i) {
+				int bit = (cwd[i >> 5] >> (i & 31)) & 1;
+				c *= (float)(1 - 2 * bit);
+				sh.fdom[bin1280(i + mls1_off)] = mk(c * tb.mls1_nrz[i], 0.f);   // scrambled after the differential step
+			}
+		}
+	} else if (sidx != last) {
+		// pilot (sidx 0, 3) or data row j = sidx - 4: fdom = pilot * product of the rows' PSK symbols (encode.cc:304-309)
+		const int j = sidx - 4;
+		const float code_fac = sqrtf((float)SYMBOL_LEN / (float)md.cols);   // encode.cc:135
+		const uint32_t *code = code_all + (size_t)f * 2048;
+		const float cos_pi_8 = 0.92387953251128675613f, sin_pi_8 = 0.38268343236508977173f, r2 = 0.70710678118654752440f;
+		for (int i = tid; i < md.cols; i += 256) {
+			cf acc = mk(code_fac * tb.mls2_nrz[i], 0.f);
+			for (int r = 0; r <= j; ++r) {
+				const int p = md.mod_bits * (md.cols * r + i);
+				float b[3];
+				#pragma unroll
+				for (int t = 0; t < 3; ++t) {
+					int q = p + t;
+					b[t] = t < md.mod_bits ? (float)(1 - 2 * (int)((code[q >> 5] >> (q & 31)) & 1)) : 1.f;
+				}
+				cf m;
+				if (md.mod_bits == 3) {                       // psk.hh:132-139
+					float re = cos_pi_8, im = sin_pi_8;
+					if (b[0] < 0.f) { re = sin_pi_8; im = cos_pi_8; }
+					m = mk(re * b[1], im * b[2]);
+				} else {
+					m = mk(r2 * b[0], r2 * b[1]);             // psk.hh:82-85
+				}
+				acc = cmul(acc, m);
+			}
+			sh.fdom[bin1280(i + code_off)] = acc;
+		}
+	}
+	__syncthreads();
+	// symbol(): encode.cc:101-109
+	cf *temp = sh.big;                                        // reused after the PAPR step
+	if (papr && sidx != last) {
+		// improve_papr(): encode.cc:80-100
+		for (int i = tid; i < 4 * SYMBOL_LEN; i += 256)
+			sh.big[i] = mk(0.f, 0.f);
+		__syncthreads();
+		for (int i = tid; i < SYMBOL_LEN; i += 256) {
+			int c = i - SYMBOL_LEN / 2;
+			sh.big[bin5120(c)] = cconj(sh.fdom[bin1280(c)]);  // conj in, conj out = backward transform
+		}
+		__syncthreads();
+		fft5120<256>(sh.big, tw5120, tid);
+		const float s4 = sqrtf((float)(4 * SYMBOL_LEN));
+		for (int i = tid; i < 4 * SYMBOL_LEN; i += 256) {
+			cf v = cconj(sh.big[i]);
+			v = mk(v.re / s4, v.im / s4);
+			float amp = fmaxf(fabsf(v.re), fabsf(v.im));
+			if (amp > 1.f)
+				v = mk(v.re / amp, v.im / amp);
+			sh.big[i] = v;
+		}
+		__syncthreads();
+		fft5120<256>(sh.big, tw5120, tid);
+		cf keep[5];
+		#pragma unroll
+		for (int q = 0; q < 5; ++q) {
+			int i = tid + 256 * q, c = i - SYMBOL_LEN / 2;
+			cf o = sh.fdom[bin1280(c)], v = sh.big[bin5120(c)];
+			keep[q] = cnorm(o) != 0.f ? mk(v.re / s4, v.im / s4) : mk(0.f, 0.f);
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int q = 0; q < 5; ++q) {
+			int i = tid + 256 * q, c = i - SYMBOL_LEN / 2;
+			temp[bin1280(c)] = cconj(keep[q]);
+		}
+	} else {
+		for (int i = tid; i < SYMBOL_LEN; i += 256)
+			temp[i] = cconj(sh.fdom[i]);
+	}
+	__syncthreads();
+	fft1280<256>(temp, tb.tw1280, tid);
+	const float s8 = sqrtf((float)(8 * SYMBOL_LEN));
+	cf *out = tdom_all + ((size_t)f * tp.nsym + sidx) * SYMBOL_LEN;
+	for (int i = tid; i < SYMBOL_LEN; i += 256) {
+		cf v = cconj(temp[i]);
+		out[i] = mk(v.re / s8, v.im / s8);
+	}
+}
+
+// ---------------------------------------------------------------- guard cross-fade + int16
+__global__ __launch_bounds__(256) void k_tx_assemble(const cf *__restrict__ tdom_all, TxParams tp, int16_t *__restrict__ pcm_all)
+{
+	const int f = blockIdx.x / (tp.nsym + 2), part = blockIdx.x % (tp.nsym + 2), tid = threadIdx.x;
+	int16_t *pcm = pcm_all + (size_t)f * tp.frame_samples * tp.channels;
+	const int ch = tp.channels;
+	auto put = [&](long n, cf v) {
+		float re = fminf(fmaxf(v.re, -1.f), 1.f), im = fminf(fmaxf(v.im, -1.f), 1.f);
+		pcm[n * ch] = (int16_t)nearbyintf(32767.f * re);
+		if (ch == 2)
+			pcm[n * ch + 1] = (int16_t)nearbyintf(32767.f * im);
+	};
+	if (part >= tp.nsym) {                                    // silence(rate) before and after, encode.cc:423,441
+		long base = part == tp.nsym ? 0 : 8000 + (long)tp.nsym * SYM_STRIDE;
+		for (int i = tid; i < 8000; i += 256)
+			put(base + i, mk(0.f, 0.f));
+		return;
+	}
+	const cf *cur = tdom_all + ((size_t)f * tp.nsym + part) * SYMBOL_LEN;
+	const cf *prv = part ? cur - SYMBOL_LEN : nullptr;
+	const long base = 8000 + (long)part * SYM_STRIDE;
+	for (int i = tid; i < GUARD_LEN; i += 256) {              // encode.cc:110-114
+		float x = (float)i / (float)(GUARD_LEN - 1);
+		x = 0.5f * (1.f - cosf(PI_F * x));
+		cf a = prv ? prv[i] : mk(0.f, 0.f), b = cur[i + SYMBOL_LEN - GUARD_LEN];
+		put(base + i, mk((1.f - x) * a.re + x * b.re, (1.f - x) * a.im + x * b.im));
+	}
+	for (int i = tid; i < SYMBOL_LEN; i += 256)
+		put(base + GUARD_LEN + i, cur[i]);
+}
+
+void launch_tx(hipStream_t s, int n, const uint8_t *payload, Tables tb, const void *tp_, const cf *tw5120,
+	uint32_t *code, cf *tdom, int16_t *pcm)
+{
+	TxParams tp = *(const TxParams *)tp_;
+	hipLaunchKernelGGL(k_tx_code, dim3(n), dim3(256), 0, s, payload, tb, tp, code);
+	hipLaunchKernelGGL(k_tx_symbol, dim3(n * tp.nsym), dim3(256), 0, s, code, tb, tp, tw5120, tdom);
+	hipLaunchKernelGGL(k_tx_assemble, dim3(n * (tp.nsym + 2)), dim3(256), 0, s, tdom, tp, pcm);
+}
+
+}  // namespace rx

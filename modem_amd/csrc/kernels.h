@@ -40,6 +40,9 @@ struct Tables {                    // device-resident constants, built once per 
 	const cf *tw1280;              // e^{-j 2 pi m / 1280}
 	const cf *sc_kern;             // conj(FFT640(mls0))/640, decode.cc:80-82
 	const float *mls1_nrz;         // +-1 descrambler, decode.cc:407-409
+	const float *mls0_nrz;         // [127] MLS 0b10001001 (transmitter: Schmidl-Cox symbol, encode.cc:144)
+	const float *mls2_nrz;         // [512] MLS 0b100101010001 (transmitter: pilot block, encode.cc:134)
+	const cf *tw5120;              // e^{-j 2 pi m / 5120} (transmitter PAPR step)
 	const uint32_t *frozen;        // [2][2048] words, bit set = frozen: frozen_64800_43072, frozen_64512_43072 (regenerated)
 	const uint16_t *info_pos;      // [2][44096] ascending unfrozen positions per table
 	const uint32_t *genmat_bits;   // BCH(255,71) systematic generator, [71][8] words, bit i of row j
@@ -78,6 +81,8 @@ void launch_fft_debug(hipStream_t s, int n, int len, int sign, const cf *in, cf 
 void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t *out, size_t n_out,
 	size_t spf, float sigma, uint64_t seed, uint64_t first_frame);
 void launch_channel(hipStream_t s, const int16_t *in, int16_t *out, size_t n, size_t spf, const void *params);
+void launch_tx(hipStream_t s, int n, const uint8_t *payload, Tables tb, const void *tp, const cf *tw5120,
+	uint32_t *code, cf *tdom, int16_t *pcm);
 void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts);
 
 }  // namespace rx

@@ -142,6 +142,9 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.tw1280, &h->dev.tw1280);
 	r = r ? r : upload(h, h->host.sc_kern, &h->dev.sc_kern);
 	r = r ? r : upload(h, h->host.mls1_nrz, &h->dev.mls1_nrz);
+	r = r ? r : upload(h, h->host.mls0_nrz, &h->dev.mls0_nrz);
+	r = r ? r : upload(h, h->host.mls2_nrz, &h->dev.mls2_nrz);
+	r = r ? r : upload(h, h->host.tw5120, &h->dev.tw5120);
 	r = r ? r : upload(h, h->host.frozen, &h->dev.frozen);
 	r = r ? r : upload(h, h->host.info_pos, &h->dev.info_pos);
 	r = r ? r : upload(h, h->host.genmat_bits, &h->dev.genmat_bits);
@@ -553,5 +556,64 @@ extern "C" int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_
 	if (cp.ntaps == 0) { cp.ntaps = 1; cp.delays[0] = 0; cp.gre[0] = 1.f; cp.gim[0] = 0.f; }
 	launch_channel(h->stream, d_in, d_out, n_frames, spf, &cp);
 	HIP_OK(hipGetLastError());
+	return 0;
+}
+
+// ---- N2: transmitter on the device (Encoder<value,cmplx,8000>, encode.cc:271-317) -------------------
+static long long base37(const char *str)   // encode.cc:320-335
+{
+	long long acc = 0;
+	for (char c = *str++; c; c = *str++) {
+		acc *= 37;
+		if (c >= '0' && c <= '9') acc += c - '0' + 1;
+		else if (c >= 'a' && c <= 'z') acc += c - 'a' + 11;
+		else if (c >= 'A' && c <= 'Z') acc += c - 'A' + 11;
+		else if (c != ' ') return -1;
+	}
+	return acc;
+}
+
+extern "C" long ofdmrx_tx_frame_samples(int oper_mode)
+{
+	if (oper_mode < 6 || oper_mode > 13)
+		return OFDMRX_E_ARG;
+	ModeDesc md = mode_desc(oper_mode);
+	return 2 * 8000 + (long)(md.rows + 5) * SYM_STRIDE;   // silence + pilot|S&C|meta|pilot|rows|zero + silence
+}
+
+extern "C" int ofdmrx_tx_encode_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_frames, int oper_mode,
+	int freq_off, const char *call_sign, int channels, int16_t *d_pcm)
+{
+	if (!h || !d_payload || !d_pcm || !n_frames || !call_sign || channels < 1 || channels > 2)
+		return OFDMRX_E_ARG;
+	if (oper_mode < 6 || oper_mode > 13 || freq_off % 50)   // encode.cc:353,394
+		return OFDMRX_E_ARG;
+	long long cs = base37(call_sign);
+	if (cs <= 0 || cs >= 129961739795077LL)               // encode.cc:358
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	struct { int oper_mode, offset, channels, nsym; unsigned long long md; long frame_samples; } tp;
+	ModeDesc md = mode_desc(oper_mode);
+	tp.oper_mode = oper_mode;
+	tp.offset = (freq_off * SYMBOL_LEN) / 8000;           // encode.cc:283
+	tp.channels = channels;
+	tp.nsym = md.rows + 5;
+	tp.md = ((unsigned long long)cs << 8) | (unsigned)oper_mode;
+	tp.frame_samples = ofdmrx_tx_frame_samples(oper_mode);
+	const size_t chunk = 1024;
+	DevBuf code, tdom;
+	int r = code.ensure(std::min(chunk, n_frames) * 2048 * sizeof(uint32_t));
+	r = r ? r : tdom.ensure(std::min(chunk, n_frames) * (size_t)tp.nsym * SYMBOL_LEN * sizeof(cf));
+	if (r) { code.release(); tdom.release(); return r; }
+	for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
+		int n = (int)std::min(chunk, n_frames - f0);
+		launch_tx(h->stream, n, d_payload + f0 * PAYLOAD_BYTES, h->dev, &tp, h->dev.tw5120, code.as<uint32_t>(), tdom.as<cf>(),
+			d_pcm + f0 * (size_t)tp.frame_samples * channels);
+	}
+	hipError_t e = hipGetLastError();
+	e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;   // scratch is freed below
+	code.release();
+	tdom.release();
+	if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return OFDMRX_E_HIP; }
 	return 0;
 }

@@ -143,6 +143,21 @@ void build_tables(HostTables &t)
 		for (int i = 0; i < 255; ++i)
 			t.mls1_nrz[i] = (float)(1 - 2 * m1.next());
 	}
+	{
+		Mls m0(0x89), m2(0x951);
+		t.mls0_nrz.resize(128, 1.f);
+		for (int i = 0; i < 127; ++i)
+			t.mls0_nrz[i] = (float)(1 - 2 * m0.next());
+		t.mls2_nrz.resize(512);
+		for (int i = 0; i < 512; ++i)
+			t.mls2_nrz[i] = (float)(1 - 2 * m2.next());
+		t.tw5120.resize(5120);
+		for (int k = 0; k < 5120; ++k) {
+			double a = -2.0 * M_PI * k / 5120.0;
+			t.tw5120[k].re = (float)std::cos(a);
+			t.tw5120[k].im = (float)std::sin(a);
+		}
+	}
 	t.frozen.resize(2 * 2048);
 	frozen_mask(t.frozen.data(), 64800);
 	frozen_mask(t.frozen.data() + 2048, 64512);

@@ -7,8 +7,8 @@
 namespace rx {
 
 struct HostTables {
-	std::vector<cf> tw1280, sc_kern;
-	std::vector<float> mls1_nrz;
+	std::vector<cf> tw1280, sc_kern, tw5120;
+	std::vector<float> mls1_nrz, mls0_nrz, mls2_nrz;
 	std::vector<uint32_t> frozen, genmat_bits, crc32_tab;
 	std::vector<uint16_t> info_pos;
 	std::vector<uint8_t> osd_pairs, osd_triples, scramble;

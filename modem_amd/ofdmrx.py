@@ -22,7 +22,7 @@ EXPORTS = [
     "ofdmrx_abi_version", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
     "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames",
     "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
-    "ofdmrx_util_awgn_tile", "ofdmrx_util_channel",
+    "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_tx_frame_samples", "ofdmrx_tx_encode_device",
 ]
 
 
@@ -113,6 +113,9 @@ def load_library():
     L.ofdmrx_util_awgn_tile.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                         C.c_float, C.c_uint64, C.c_uint64]
     L.ofdmrx_util_channel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(Channel)]
+    L.ofdmrx_tx_frame_samples.restype = C.c_long
+    L.ofdmrx_tx_frame_samples.argtypes = [C.c_int]
+    L.ofdmrx_tx_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
     _LIB = L
     return L
 
@@ -123,6 +126,10 @@ def _ptr(a):
 
 class Receiver:
     """Batch counterpart of `new Decoder<float, Complex<float>, 8000>(out, pcm, skip)` (decode.cc:592).
+
+    stream: a hipStream_t handle (int) to run on.  None / 0 (note: torch's DEFAULT stream has handle 0) makes the
+    library create its own non-blocking stream - then synchronise explicitly before sharing device buffers with
+    other libraries, or pass a non-default stream (torch.cuda.Stream().cuda_stream) and use it on both sides.
 
     decode(pcm) takes raw PCM frames [n_frames, samples, channels] (int16 / uint8 / float32, what
     DSP::ReadWAV would deliver) and returns (payload[n_frames, 5380] uint8, results structured array).
@@ -244,3 +251,10 @@ class Receiver:
         for i, (d, g) in enumerate(multipath):
             ch.delays[i], ch.gains_re[i], ch.gains_im[i] = int(d), float(complex(g).real), float(complex(g).imag)
         self._check(self._lib.ofdmrx_util_channel(self._h, d_in, d_out, n, spf, C.byref(ch)))
+
+    def tx_frame_samples(self, mode=6):
+        return int(self._lib.ofdmrx_tx_frame_samples(mode))
+
+    def tx_encode(self, d_payload, n, d_pcm, mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=2):
+        """device transmitter: n x 5380 payload bytes -> n x tx_frame_samples(mode) x channels int16 (device pointers)"""
+        self._check(self._lib.ofdmrx_tx_encode_device(self._h, d_payload, n, mode, freq_off, call_sign.encode(), channels, d_pcm))

@@ -86,6 +86,8 @@ def lib():
         L.orc_crc16_u64.argtypes = [C.c_uint16, C.c_uint64]
         L.orc_crc32_bytes.restype = C.c_uint32
         L.orc_crc32_bytes.argtypes = [C.c_uint32, C.c_void_p, C.c_int]
+        L.orc_base37_encode.restype = C.c_longlong
+        L.orc_base37_encode.argtypes = [C.c_char_p]
         L.orc_scramble.argtypes = [C.c_void_p, C.c_int]
         L.orc_mode_lookup.restype = C.c_int
         L.orc_mode_lookup.argtypes = [C.c_int, C.POINTER(Mode)]

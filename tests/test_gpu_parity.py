@@ -410,3 +410,30 @@ def test_mixed_mode_batch(rx):
     out, res = rx.decode(batch)
     assert (res["status"] == 0).all() and list(res["oper_mode"]) == [m for m, _ in specs]
     assert (out == np.stack(pays)).all()
+
+
+@pytest.mark.parametrize("mode,channels,freq", [(6, 2, 2000), (6, 1, 2000), (8, 2, -500), (13, 2, 1000)])
+def test_device_transmitter_matches_oracle_encoder(rx, mode, channels, freq):
+    """N2: Encoder<value,cmplx,8000> (encode.cc:271-317) on the device: the int16 stream equals the CPU
+    restatement's within +-1 LSB (fp32 FFT rounding at the quantiser; PAPR clip decisions included), and
+    both receivers decode it to the payload"""
+    import torch
+    dev = torch.device("cuda:0")
+    pays = np.stack([O.payload_for(800 + mode + i) for i in range(3)])
+    spf = rx.tx_frame_samples(mode)
+    d_pay = torch.from_numpy(pays).to(dev)
+    d_pcm = torch.zeros((3, spf, channels), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    rx.tx_encode(d_pay.data_ptr(), 3, d_pcm.data_ptr(), mode=mode, freq_off=freq, call_sign="GPU TX", channels=channels)
+    rx.synchronize()
+    got = d_pcm.cpu().numpy()
+    for i in range(3):
+        ref = O.encode_pcm(pays[i], channels=channels, freq_off=freq, call_sign="GPU TX", mode=mode)
+        assert ref.shape == got[i].shape
+        diff = np.abs(got[i].astype(np.int32) - ref.astype(np.int32))
+        assert diff.max() <= 1, (i, diff.max(), np.argmax(diff.max(axis=1)))
+        assert (diff > 0).mean() < 0.05
+    out, res = rx.decode(got)
+    assert (res["status"] == 0).all() and (out == pays).all() and (res["oper_mode"] == mode).all()
+    o, r = O.decode(got[1])
+    assert r.status == 0 and (o == pays[1]).all() and r.call_sign == O.lib().orc_base37_encode(b"GPU TX")

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BER / FER sweep over the AWGN noise LEVEL (BASELINE.json configs[4]): Monte-Carlo throughput + BER curve.
 
-Every point decodes `--frames` frames: base frames (tests/golden/base_frames_2ch.npz, 4 payloads) with
-independent on-device noise (counter RNG keyed by the global frame index, never reused across points).
+Every point decodes `--frames` frames made entirely on the device: random payloads -> device transmitter (N2) ->
+independent AWGN (N3, counter RNG keyed by the global frame index, never reused across points).
 With torchrun the frames of every point are sharded over the ranks; the only reduction is the sum of four
 integer counters per point (no collective on the data path).  Prints one JSON line per point and a summary.
 
@@ -41,17 +41,18 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    fx = np.load(os.path.join(ROOT, "tests", "golden", "base_frames_2ch.npz"))
-    base, base_pay = fx["pcm"], fx["payload"]
-    n_base, spf = base.shape[0], base.shape[1]
-    rx = modem_amd.Receiver(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    d_base = torch.from_numpy(base).to(dev)
-    d_pay = torch.from_numpy(base_pay).to(dev)
+    # ONE explicit (non-default) HIP stream shared by torch and the library (the default stream's handle is 0,
+    # which the C ABI reads as "create your own stream": torch.randint and the transmitter would then race)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    rx = modem_amd.Receiver(device=local_rank, stream=stream.cuda_stream)
+    spf = rx.tx_frame_samples(6)
     nb = min(args.batch, args.frames)
     d_in = torch.empty((nb, spf, 2), dtype=torch.int16, device=dev)
     d_out = torch.zeros((nb, 5380), dtype=torch.uint8, device=dev)
     d_res = torch.zeros((nb, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     pop = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=dev)
+    gen = torch.Generator(device=dev)
 
     levels = np.arange(args.lo, args.hi + 1e-9, args.step)
     lo, hi = shard.block_range(args.frames, rank, world)
@@ -64,12 +65,15 @@ def main():
         while f < hi:
             n = min(nb, hi - f)
             gidx = li * args.frames + f          # global frame index: distinct noise everywhere
-            rx.awgn_tile(d_base.data_ptr(), n_base, d_in.data_ptr(), n, spf, float(db), args.seed, gidx)
+            gen.manual_seed(args.seed * 7919 + gidx)
+            d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=gen)
+            rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=2)
+            rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, float(db), args.seed, gidx)   # in place
             rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
             rx.synchronize()
-            ref = d_pay[torch.arange(n, device=dev) % n_base]
-            x = d_out[:n] ^ ref
-            biterr = pop[x.long()].sum(dim=1)
+            biterr = torch.zeros(n, dtype=torch.int64, device=dev)
+            for lo2 in range(0, n, 8192):
+                biterr[lo2:lo2 + 8192] = pop[(d_out[lo2:lo2 + 8192] ^ d_pay[lo2:lo2 + 8192]).long()].sum(dim=1)
             res = d_res[:n].cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
             counters[0] += n
             counters[1] += int((biterr > 0).sum().item())
