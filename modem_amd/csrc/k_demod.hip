@@ -210,14 +210,16 @@ constexpr int TS_GRID_ROWS = 50;
 
 // y[0..n) in s.y ; x[i] = i - n/2.  Returns slope and yint in all threads.
 // Exact median of the n(n-1)/2 pairwise slopes (decode.cc:488, rank count/2):
-//  1. a ~8% sample of the pairs (exact fp32 divisions) brackets the median: [T_lo, T_hi] =
-//     sample order statistics +-4.5 sigma around the sample median;
-//  2. ONE pass over all pairs with the cheap slope a*rcp(d) (relative error < 2^-22 of the
+//  1. a 1/8 sample of the pairs (every distance that is a multiple of 8, cheap a*rcp(d) slopes, never
+//     stored: recomputed by each radix pass) brackets the median: [T_lo, T_hi] = the sample order
+//     statistics 3.2 sigma of Binomial(m, 1/2) either side of the sample median;
+//  2. ONE pass over all pairs with the cheap slope a*rcp(d) (relative error < 3*2^-24 of the
 //     correctly rounded quotient): pairs certainly below T_lo are counted, pairs certainly
-//     above T_hi are dropped, the rest (~5%) get the exact division and go to an LDS list;
-//  3. the wanted order statistic is selected exactly inside the list.  The result is accepted only
-//     if it lies in [T_lo, T_hi] (then its rank is provably exact); otherwise, or when the list
-//     overflows (ties), the exact 3-digit radix select over all pairs runs instead.
+//     above T_hi are dropped, the rest (~2-3%) are appended to an LDS list as (i, d);
+//  3. the listed pairs get the exact fp32 division and the wanted order statistic is selected exactly
+//     inside the list.  The result is accepted only if it lies in [T_lo, T_hi] (then its rank is
+//     provably exact); otherwise, or when the list overflows (ties), the exact 3-digit radix select
+//     over all pairs with exact divisions runs instead.
 __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float &yint)
 {
 	const int count = n * (n - 1) / 2, target = count / 2;

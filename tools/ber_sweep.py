@@ -73,7 +73,8 @@ def main():
             rx.synchronize()
             biterr = torch.zeros(n, dtype=torch.int64, device=dev)
             for lo2 in range(0, n, 8192):
-                biterr[lo2:lo2 + 8192] = pop[(d_out[lo2:lo2 + 8192] ^ d_pay[lo2:lo2 + 8192]).long()].sum(dim=1)
+                hi2 = min(lo2 + 8192, n)
+                biterr[lo2:hi2] = pop[(d_out[lo2:hi2] ^ d_pay[lo2:hi2]).long()].sum(dim=1)
             res = d_res[:n].cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
             counters[0] += n
             counters[1] += int((biterr > 0).sum().item())
