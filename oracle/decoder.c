@@ -22,8 +22,16 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { SL = ORC_SYMBOL_LEN, GL = ORC_GUARD_LEN, HS = SL / 2 /* correlator symbol_len, decode.cc:196 */ };
-enum { MATCH_LEN = GL | 1, MATCH_DEL = (MATCH_LEN - 1) / 2 };   /* decode.cc:41-42 */
+/* constants of the Decoder<value,cmplx,rate> instantiation in use (decode.cc:171-173,188-189,590-602) */
+static _Thread_local orc_rate_cfg RC = { ORC_RATE, ORC_SYMBOL_LEN, ORC_GUARD_LEN, ORC_FILTER_LEN, 8640, 2880 };
+#define SL (RC.symbol_len)
+#define GL (RC.guard_len)
+#define HS (SL / 2)                      /* correlator symbol_len, decode.cc:196 */
+#define MATCH_LEN (GL | 1)               /* decode.cc:41 */
+#define MATCH_DEL ((MATCH_LEN - 1) / 2)  /* decode.cc:42 */
+#define BUFFER_LEN (RC.buffer_len)
+#define SEARCH_POS (RC.search_pos)
+enum { HS_MAX = 3840 };
 static const float TWO_PI = 6.28318530717958647692f, PI_F = 3.14159265358979323846f;
 
 static inline int bin(int carrier) { return (carrier + SL) % SL; }       /* decode.cc:219-222 */
@@ -70,7 +78,7 @@ static inline orc_cf phasor(float omega, long k)
 
 /* ---- SchmidlCox ---------------------------------------------------------- */
 typedef struct {
-	orc_cf kern[HS];     /* decode.cc:80-82 */
+	orc_cf kern[HS_MAX]; /* decode.cc:80-82 */
 	double *Sc_re, *Sc_im, *Sp, *Sm;   /* prefix sums, index shifted by 1 */
 	float *timing;
 	size_t n;
@@ -83,7 +91,7 @@ static void sc_init_kern(orc_cf *kern)
 	orc_cf seq[HS], tmp[HS];
 	orc_mls seq0;
 	orc_mls_init(&seq0, ORC_MLS0_POLY);
-	memset(seq, 0, sizeof(seq));
+	memset(seq, 0, sizeof(orc_cf) * (size_t)HS);
 	const int mls0_off = -ORC_MLS0_LEN + 1;   /* decode.cc:183 */
 	for (int i = 0; i < ORC_MLS0_LEN; ++i) {
 		seq[(i + mls0_off / 2 + HS) % HS].re = (float)nrz(orc_mls_next(&seq0));
@@ -117,8 +125,8 @@ static void sc_prepare(sc_t *s, const orc_cf *z, size_t n)
 	#define PFX(S, i) ((i) <= 0 ? 0.0 : (S)[(size_t)(i) > n ? n : (size_t)(i)])
 	for (size_t t = 0; t < n; ++t) {
 		/* P sums c[u] for u in (t-5119-640, t-5119]; R sums p[u] for u in (t-4479-1280, t-4479] */
-		long hc = (long)t - (ORC_BUFFER_LEN - 1 - (ORC_SEARCH_POS + HS)) + 1;   /* exclusive end */
-		long hp = (long)t - (ORC_BUFFER_LEN - 1 - (ORC_SEARCH_POS + 2 * HS)) + 1;
+		long hc = (long)t - (BUFFER_LEN - 1 - (SEARCH_POS + HS)) + 1;   /* exclusive end */
+		long hp = (long)t - (BUFFER_LEN - 1 - (SEARCH_POS + 2 * HS)) + 1;
 		float Pre = (float)(PFX(s->Sc_re, hc) - PFX(s->Sc_re, hc - HS));
 		float Pim = (float)(PFX(s->Sc_im, hc) - PFX(s->Sc_im, hc - HS));
 		float R = 0.5f * (float)(PFX(s->Sp, hp) - PFX(s->Sp, hp - 2 * HS));
@@ -135,7 +143,7 @@ static float sc_phase(const sc_t *s, long t)
 	size_t n = s->n;
 	if (t < 0)
 		return 0.f;
-	long hc = t - (ORC_BUFFER_LEN - 1 - (ORC_SEARCH_POS + HS)) + 1;
+	long hc = t - (BUFFER_LEN - 1 - (SEARCH_POS + HS)) + 1;
 	float Pre = (float)(PFX(s->Sc_re, hc) - PFX(s->Sc_re, hc - HS));
 	float Pim = (float)(PFX(s->Sc_im, hc) - PFX(s->Sc_im, hc - HS));
 	return atan2f(Pim, Pre);
@@ -153,8 +161,8 @@ static int sc_process(const sc_t *s, long t, int index_max, float phase_max,
 {
 	orc_cf tmp0[HS], tmp1[HS], tmp2[HS];
 	float frac_cfo = phase_max / (float)HS;                 /* decode.cc:110 */
-	int symbol_pos = ORC_SEARCH_POS - index_max;            /* decode.cc:114 */
-	long base = t - (ORC_BUFFER_LEN - 1);
+	int symbol_pos = SEARCH_POS - index_max;            /* decode.cc:114 */
+	long base = t - (BUFFER_LEN - 1);
 	for (int i = 0; i < HS; ++i)                            /* decode.cc:117-118 */
 		tmp1[i] = cmul(zat(s->z, s->n, base + i + symbol_pos + HS), phasor(frac_cfo, i));
 	orc_fft(tmp0, tmp1, HS, -1);
@@ -244,9 +252,21 @@ static void zero_result(orc_result *r)
 int orc_decode_cf(const orc_cf *z, size_t n, int skip_count, int list_size,
 	int descramble, uint8_t *payload, orc_result *res, orc_taps *taps)
 {
+	return orc_decode_cf_rate(ORC_RATE, z, n, skip_count, list_size, descramble, payload, res, taps);
+}
+
+int orc_decode_cf_rate(int rate, const orc_cf *z, size_t n, int skip_count, int list_size,
+	int descramble, uint8_t *payload, orc_result *res, orc_taps *taps)
+{
 	orc_result rr;
 	zero_result(&rr);
 	memset(payload, 0, ORC_DATA_BYTES);
+	if (!orc_rate_lookup(rate, &RC)) {                     /* decode.cc:603-605 */
+		orc_rate_lookup(ORC_RATE, &RC);
+		rr.status = ORC_NO_SYNC;
+		*res = rr;
+		return -1;
+	}
 	const int L = (list_size == 4) ? 4 : 8;
 	sc_t sc;
 	sc_init_kern(sc.kern);
@@ -275,8 +295,8 @@ int orc_decode_cf(const orc_cf *z, size_t n, int skip_count, int list_size,
 		t_hit = tr.t - 1;
 		rr.symbol_pos = symbol_pos;
 		rr.cfo_rad = cfo_rad;
-		rr.sc_start = t_hit - (ORC_BUFFER_LEN - 1) + symbol_pos;
-		long base = t_hit - (ORC_BUFFER_LEN - 1);
+		rr.sc_start = t_hit - (BUFFER_LEN - 1) + symbol_pos;
+		long base = t_hit - (BUFFER_LEN - 1);
 		/* the Phasor keeps its phase across omega() changes; only continuity
 		 * within one frame matters (differential demodulation), so the phase
 		 * origin is restarted at each header attempt */
@@ -485,15 +505,22 @@ int orc_decode_cf(const orc_cf *z, size_t n, int skip_count, int list_size,
 	return rr.status;
 }
 
-int orc_decode(const void *samples, int fmt, int channels, size_t n_frames,
+int orc_decode_rate(int rate, const void *samples, int fmt, int channels, size_t n_frames,
 	int skip_count, int list_size, int descramble,
 	uint8_t *payload, orc_result *res, orc_taps *taps)
 {
 	orc_cf *z = (orc_cf *)malloc(sizeof(orc_cf) * (n_frames ? n_frames : 1));
-	orc_front_end(samples, fmt, channels, n_frames, z);
-	int r = orc_decode_cf(z, n_frames, skip_count, list_size, descramble, payload, res, taps);
+	orc_front_end_rate(rate, samples, fmt, channels, n_frames, z);
+	int r = orc_decode_cf_rate(rate, z, n_frames, skip_count, list_size, descramble, payload, res, taps);
 	free(z);
 	return r;
+}
+
+int orc_decode(const void *samples, int fmt, int channels, size_t n_frames,
+	int skip_count, int list_size, int descramble,
+	uint8_t *payload, orc_result *res, orc_taps *taps)
+{
+	return orc_decode_rate(ORC_RATE, samples, fmt, channels, n_frames, skip_count, list_size, descramble, payload, res, taps);
 }
 
 int orc_decode_batch(const void *samples, int fmt, int channels, size_t frames_per,

@@ -126,7 +126,10 @@ static double kaiser(double a, int n, int N)
 }
 void orc_hilbert_coeffs(float *reco, float *imco)
 {
-	const int TAPS = ORC_FILTER_LEN;
+	orc_hilbert_coeffs_n(ORC_FILTER_LEN, reco, imco);
+}
+void orc_hilbert_coeffs_n(int TAPS, float *reco, float *imco)
+{
 	*reco = (float)kaiser(2.0, (TAPS - 1) / 2, TAPS);
 	for (int i = 0; i < (TAPS - 1) / 4; ++i)
 		imco[i] = (float)(kaiser(2.0, (2 * i + 1) + (TAPS - 1) / 2, TAPS) * 2.0 / ((2 * i + 1) * M_PI));
@@ -144,6 +147,14 @@ static inline float sample_at(const void *p, int fmt, size_t idx)
 
 void orc_front_end(const void *samples, int fmt, int channels, size_t n, orc_cf *z)
 {
+	orc_front_end_rate(ORC_RATE, samples, fmt, channels, n, z);
+}
+
+void orc_front_end_rate(int rate, const void *samples, int fmt, int channels, size_t n, orc_cf *z)
+{
+	orc_rate_cfg rc;
+	if (!orc_rate_lookup(rate, &rc))
+		orc_rate_lookup(ORC_RATE, &rc);
 	if (channels == 2) {
 		/* decode.cc:297-298: the two channels are taken as (re, im) */
 		for (size_t i = 0; i < n; ++i) {
@@ -153,10 +164,11 @@ void orc_front_end(const void *samples, int fmt, int channels, size_t n, orc_cf 
 		return;
 	}
 	/* decode.cc:299: tmp = hilbert(blockdc(tmp.real())) */
-	float reco, imco[5];
-	orc_hilbert_coeffs(&reco, imco);
+	float reco, imco[32];
+	const int NIM = (rc.filter_len - 1) / 4;
+	orc_hilbert_coeffs_n(rc.filter_len, &reco, imco);
 	/* BlockDC::samples(2*(symbol_len+guard_len)) decode.cc:386 */
-	const float s = 2 * (ORC_SYMBOL_LEN + ORC_GUARD_LEN);
+	const float s = 2 * (rc.symbol_len + rc.guard_len);
 	const float a = (s - 1.f) / s, b = (1.f + a) / 2.f;
 	float *dc = (float *)malloc(sizeof(float) * (n + 1));
 	float x1 = 0.f, y1 = 0.f;
@@ -167,14 +179,14 @@ void orc_front_end(const void *samples, int fmt, int channels, size_t n, orc_cf 
 		y1 = y0;
 		dc[i] = y0;
 	}
-	const int C = (ORC_FILTER_LEN - 1) / 2;
+	const int C = (rc.filter_len - 1) / 2;
 	for (size_t i = 0; i < n; ++i) {
 		/* delay line holds dc[i-20..i]; centre tap = dc[i-10] */
 		#define DC(k) (((long)(k) >= 0) ? dc[(k)] : 0.f)
 		long c = (long)i - C;
 		float re = reco * DC(c);
 		float im = imco[0] * (DC(c - 1) - DC(c + 1));
-		for (int k = 1; k < 5; ++k)
+		for (int k = 1; k < NIM; ++k)
 			im += imco[k] * (DC(c - (2 * k + 1)) - DC(c + (2 * k + 1)));
 		#undef DC
 		z[i].re = re;

@@ -9,14 +9,16 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { SL = ORC_SYMBOL_LEN, GL = ORC_GUARD_LEN };
+/* symbol_len / guard_len of the Encoder<value,cmplx,rate> instantiation in use (encode.cc:31-32) */
+static _Thread_local int SL = ORC_SYMBOL_LEN, GL = ORC_GUARD_LEN;
+enum { SL_MAX = 7680, GL_MAX = 960 };
 
 typedef struct {
 	orc_mode md;
 	const uint32_t *frozen;
 	int code_off, mls0_off, mls1_off;
-	orc_cf fdom[SL], tdom[SL], temp[SL], guard[GL];
-	orc_cf fdom4[4 * SL], tdom4[4 * SL];
+	orc_cf fdom[SL_MAX], tdom[SL_MAX], temp[SL_MAX], guard[GL_MAX];
+	orc_cf fdom4[4 * SL_MAX], tdom4[4 * SL_MAX];
 	orc_cf *out;
 	size_t pos;
 	int papr;
@@ -92,7 +94,7 @@ static void pilot_block(enc_t *e)
 	orc_mls seq2;
 	orc_mls_init(&seq2, ORC_MLS2_POLY);
 	float code_fac = sqrtf((float)SL / (float)e->md.cons_cols);
-	memset(e->fdom, 0, sizeof(e->fdom));
+	memset(e->fdom, 0, sizeof(orc_cf) * (size_t)SL);
 	for (int i = e->code_off; i < e->code_off + e->md.cons_cols; ++i) {
 		e->fdom[bin(i)].re = code_fac * (float)nrz(orc_mls_next(&seq2));
 		e->fdom[bin(i)].im = 0.f;
@@ -106,7 +108,7 @@ static void schmidl_cox(enc_t *e)
 	orc_mls seq0;
 	orc_mls_init(&seq0, ORC_MLS0_POLY);
 	float mls0_fac = sqrtf((float)(2 * SL) / (float)ORC_MLS0_LEN);
-	memset(e->fdom, 0, sizeof(e->fdom));
+	memset(e->fdom, 0, sizeof(orc_cf) * (size_t)SL);
 	e->fdom[bin(e->mls0_off - 2)].re = mls0_fac;
 	for (int i = 0; i < ORC_MLS0_LEN; ++i)
 		e->fdom[bin(2 * i + e->mls0_off)].re = (float)nrz(orc_mls_next(&seq0));
@@ -132,7 +134,7 @@ static void meta_data(enc_t *e, uint64_t md)
 	orc_mls seq4;
 	orc_mls_init(&seq4, ORC_MLS1_POLY);
 	float mls1_fac = sqrtf((float)SL / (float)ORC_MLS1_LEN);
-	memset(e->fdom, 0, sizeof(e->fdom));
+	memset(e->fdom, 0, sizeof(orc_cf) * (size_t)SL);
 	e->fdom[bin(e->mls1_off - 1)].re = mls1_fac;
 	for (int i = 0; i < 71; ++i)
 		e->fdom[bin(i + e->mls1_off)].re = (float)nrz(orc_get_be_bit(data, i));
@@ -152,9 +154,14 @@ static void meta_data(enc_t *e, uint64_t md)
 	symbol(e, 1);
 }
 
-size_t orc_encode(orc_cf *out, const uint8_t *inp, int count, int freq_off,
+size_t orc_encode_rate(int rate, orc_cf *out, const uint8_t *inp, int count, int freq_off,
 	uint64_t call_sign, int oper_mode, int papr)
 {
+	orc_rate_cfg rc;
+	if (!orc_rate_lookup(rate, &rc))                /* encode.cc:424-439 */
+		return 0;
+	SL = rc.symbol_len;
+	GL = rc.guard_len;
 	enc_t *e = (enc_t *)calloc(1, sizeof(enc_t));
 	if (!orc_mode_lookup(oper_mode, &e->md)) {   /* encode.cc:281-282 */
 		free(e);
@@ -163,7 +170,7 @@ size_t orc_encode(orc_cf *out, const uint8_t *inp, int count, int freq_off,
 	e->frozen = orc_frozen_get(e->md.table);
 	e->out = out;
 	e->papr = papr;
-	int offset = (freq_off * SL) / ORC_RATE;        /* encode.cc:283 */
+	int offset = (freq_off * SL) / rate;            /* encode.cc:283 */
 	e->code_off = offset - e->md.cons_cols / 2;     /* encode.cc:284 */
 	e->mls0_off = offset - ORC_MLS0_LEN + 1;        /* encode.cc:285 */
 	e->mls1_off = offset - ORC_MLS1_LEN / 2;        /* encode.cc:286 */
@@ -202,7 +209,7 @@ size_t orc_encode(orc_cf *out, const uint8_t *inp, int count, int freq_off,
 			symbol(e, 1);
 		}
 	}
-	memset(e->fdom, 0, sizeof(e->fdom));
+	memset(e->fdom, 0, sizeof(orc_cf) * (size_t)SL);
 	symbol(e, 1);                                    /* encode.cc:311-313 */
 	size_t n = e->pos;
 	free(code);
@@ -211,12 +218,19 @@ size_t orc_encode(orc_cf *out, const uint8_t *inp, int count, int freq_off,
 	return n;
 }
 
+size_t orc_encode(orc_cf *out, const uint8_t *inp, int count, int freq_off,
+	uint64_t call_sign, int oper_mode, int papr)
+{
+	return orc_encode_rate(ORC_RATE, out, inp, count, freq_off, call_sign, oper_mode, papr);
+}
+
 /* main(): encode.cc:399-441 */
-size_t orc_encode_pcm(void *pcm, int bits, int channels, const uint8_t *payload,
+size_t orc_encode_pcm_rate(int rate, void *pcm, int bits, int channels, const uint8_t *payload,
 	int count, int freq_off, const char *call_sign, int oper_mode)
 {
 	orc_mode md;
-	if (!orc_mode_lookup(oper_mode, &md))
+	orc_rate_cfg rc;
+	if (!orc_mode_lookup(oper_mode, &md) || !orc_rate_lookup(rate, &rc))
 		return 0;
 	long long cs = orc_base37_encode(call_sign);
 	if (cs <= 0 || cs >= 129961739795077LL)      /* encode.cc:358 */
@@ -226,12 +240,18 @@ size_t orc_encode_pcm(void *pcm, int bits, int channels, const uint8_t *payload,
 	for (int j = 0; j < count; ++j)
 		orc_scramble(inp + (size_t)j * ORC_DATA_BYTES, ORC_DATA_BYTES);   /* encode.cc:417-419 */
 	size_t syms = 2 + (size_t)count * (3 + (size_t)md.cons_rows);
-	size_t total = 2 * ORC_RATE + syms * (SL + GL);
+	size_t total = 2 * (size_t)rate + syms * (size_t)(rc.symbol_len + rc.guard_len);   /* encode.cc:423,441 */
 	orc_cf *z = (orc_cf *)calloc(total, sizeof(orc_cf));
-	size_t n = orc_encode(z + ORC_RATE, inp, count, freq_off, (uint64_t)cs, oper_mode, 1);
+	size_t n = orc_encode_rate(rate, z + rate, inp, count, freq_off, (uint64_t)cs, oper_mode, 1);
 	(void)n;
 	orc_quantise(pcm, bits, channels, z, total);
 	free(z);
 	free(inp);
 	return total;
+}
+
+size_t orc_encode_pcm(void *pcm, int bits, int channels, const uint8_t *payload,
+	int count, int freq_off, const char *call_sign, int oper_mode)
+{
+	return orc_encode_pcm_rate(ORC_RATE, pcm, bits, channels, payload, count, freq_off, call_sign, oper_mode);
 }

@@ -6,7 +6,7 @@
  * encode.cc:42-44,86-97,107-109): out-of-place, UNNORMALISED in both
  * directions (decode.cc:82 divides by N explicitly), natural order in/out,
  * SIGN=-1 forward e^{-j2pi kn/N}, SIGN=+1 backward.
- * Plain fp32 mixed-radix decimation-in-time (radix 4, 2, 5, 3, generic) with
+ * Plain fp32 mixed-radix decimation-in-time (radix 4, 2, 5, 3, 7, generic <= 16) with
  * twiddles computed in double and rounded once.
  */
 #include "modem_oracle.h"
@@ -14,7 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAX_PLANS 8
+#define MAX_PLANS 16
 typedef struct { int n; orc_cf *tw; } plan_t;
 static plan_t plans[MAX_PLANS];
 static int n_plans;
@@ -75,7 +75,7 @@ static void fft_rec(const ctx_t *c, orc_cf *out, const orc_cf *in, int n, int st
 		out[0] = in[0];
 		return;
 	}
-	int p = (n % 4 == 0) ? 4 : (n % 2 == 0) ? 2 : (n % 5 == 0) ? 5 : (n % 3 == 0) ? 3 : n;
+	int p = (n % 4 == 0) ? 4 : (n % 2 == 0) ? 2 : (n % 5 == 0) ? 5 : (n % 3 == 0) ? 3 : (n % 7 == 0) ? 7 : n;
 	int m = n / p;
 	for (int q = 0; q < p; ++q)
 		fft_rec(c, out + q * m, in + q * stride, m, stride * p);

@@ -30,18 +30,19 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	int skip_count = argc > 3 ? atoi(argv[3]) : 0;
-	if (w.rate != 8000) {
+	orc_rate_cfg rc;
+	if (!orc_rate_lookup(w.rate, &rc)) {                  /* decode.cc:590-605 */
 		fprintf(stderr, "Unsupported sample rate.\n");
 		return 1;
 	}
 	uint8_t out[ORC_DATA_BYTES];
 	orc_result r;
-	orc_decode(w.data, w.fmt, w.channels, w.frames, skip_count, 8, 1, out, &r, NULL);
+	orc_decode_rate(w.rate, w.data, w.fmt, w.channels, w.frames, skip_count, 8, 1, out, &r, NULL);
 	static const char *msg[] = { "", "", "OSD error.", "header CRC error.", "operation mode unsupported.",
 		"call sign unsupported.", "payload decoding error." };
 	if (r.sc_start >= 0) {
 		fprintf(stderr, "symbol pos: %d\n", r.symbol_pos);
-		fprintf(stderr, "coarse cfo: %g Hz \n", r.cfo_rad * (8000 / 6.28318530717958647692f));
+		fprintf(stderr, "coarse cfo: %g Hz \n", r.cfo_rad * ((float)w.rate / 6.28318530717958647692f));
 	}
 	if (r.status >= ORC_OSD_ERROR && r.status <= ORC_PAYLOAD_CRC)
 		fprintf(stderr, "%s\n", msg[r.status]);
@@ -50,7 +51,7 @@ int main(int argc, char **argv)
 		orc_base37_decode(cs, (long long)r.call_sign, 9);
 		cs[9] = 0;
 		fprintf(stderr, "oper mode: %d\ncall sign: %s\n", r.oper_mode, cs);
-		fprintf(stderr, "finer cfo: %g Hz \n", r.cfo_fine * (8000 / 6.28318530717958647692f));
+		fprintf(stderr, "finer cfo: %g Hz \n", r.cfo_fine * ((float)w.rate / 6.28318530717958647692f));
 		fprintf(stderr, "Es/N0 (dB): ... %g\n", r.esn0_db_last);
 	}
 	if (r.status == ORC_OK)

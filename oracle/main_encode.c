@@ -39,8 +39,9 @@ int main(int argc, char **argv)
 		fprintf(stderr, "Frequency offset must be divisible by 50.\n");
 		return 1;
 	}
-	if (output_rate != 8000) {
-		fprintf(stderr, "Unsupported sample rate.\n");   /* this restatement: 8 kHz only */
+	orc_rate_cfg rc;
+	if (!orc_rate_lookup(output_rate, &rc)) {             /* encode.cc:424-439 */
+		fprintf(stderr, "Unsupported sample rate.\n");
 		return 1;
 	}
 	int count = argc - 8;
@@ -58,10 +59,9 @@ int main(int argc, char **argv)
 			payload[(size_t)j * ORC_DATA_BYTES + i] = (uint8_t)fgetc(f);   /* encode.cc:414 */
 		fclose(f);
 	}
-	size_t syms = 2 + (size_t)count * (3 + (size_t)md.cons_rows);
-	size_t total = 2 * (size_t)output_rate + syms * 1440;
+	size_t total = orc_frame_samples(output_rate, oper_mode, count);
 	void *pcm = malloc(total * (size_t)output_chan * (size_t)(output_bits / 8));
-	size_t n = orc_encode_pcm(pcm, output_bits, output_chan, payload, count, freq_off, argv[7], oper_mode);
+	size_t n = orc_encode_pcm_rate(output_rate, pcm, output_bits, output_chan, payload, count, freq_off, argv[7], oper_mode);
 	/* write via the WAV writer from already-quantised data: re-expand to cf */
 	orc_cf *z = (orc_cf *)calloc(n, sizeof(orc_cf));
 	float factor = (float)((1u << (output_bits - 1)) - 1);

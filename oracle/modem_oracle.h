@@ -62,6 +62,13 @@ enum {
 	ORC_FRAME_SAMPLES = 95200       /* one-frame file from encode @8k */
 };
 
+/* the four sample rates main() instantiates (decode.cc:590-602, encode.cc:424-436) and
+ * their derived lengths (decode.cc:171-173,188-189).  The plain entry points
+ * below are the 8 kHz instantiation; the *_rate variants take the rate. */
+typedef struct { int rate, symbol_len, guard_len, filter_len, buffer_len, search_pos; } orc_rate_cfg;
+int orc_rate_lookup(int rate, orc_rate_cfg *c);   /* 1 = supported */
+size_t orc_frame_samples(int rate, int oper_mode, int count);   /* sample frames of encode's output file */
+
 /* sample formats of the in-memory stream handed to the decoder */
 enum { ORC_FMT_S16 = 0, ORC_FMT_U8 = 1, ORC_FMT_F32 = 2 };
 
@@ -151,8 +158,10 @@ int orc_osd_decode(uint8_t *hard /*32 B, BE bits*/, const int8_t *soft /*255*/, 
 void orc_theil_sen(const float *x, const float *y, int n, float *slope, float *yint);
 /* DSP::Hilbert<cmplx,21> coefficients: reco + 5 imco */
 void orc_hilbert_coeffs(float *reco, float *imco /*5*/);
+void orc_hilbert_coeffs_n(int taps, float *reco, float *imco /*(taps-1)/4*/);
 /* front end: D0/D1.  raw interleaved samples -> complex stream z[n_frames] */
 void orc_front_end(const void *samples, int fmt, int channels, size_t n, orc_cf *z);
+void orc_front_end_rate(int rate, const void *samples, int fmt, int channels, size_t n, orc_cf *z);
 
 /* ---- WAV ----------------------------------------------------------------- */
 typedef struct {
@@ -179,6 +188,10 @@ size_t orc_encode(orc_cf *out, const uint8_t *inp, int count, int freq_off,
  * WriteWAV to 'bits' and returned as raw PCM (u8 or s16), interleaved
  * channels.  payload = count*5380 UNSCRAMBLED bytes.  Returns sample frames. */
 size_t orc_encode_pcm(void *pcm, int bits, int channels, const uint8_t *payload,
+	int count, int freq_off, const char *call_sign, int oper_mode);
+size_t orc_encode_rate(int rate, orc_cf *out, const uint8_t *inp, int count, int freq_off,
+	uint64_t call_sign, int oper_mode, int papr);
+size_t orc_encode_pcm_rate(int rate, void *pcm, int bits, int channels, const uint8_t *payload,
 	int count, int freq_off, const char *call_sign, int oper_mode);
 
 /* ---- decoder (decode.cc:161-557) ----------------------------------------- */
@@ -218,6 +231,12 @@ int orc_decode(const void *samples, int fmt, int channels, size_t n_frames,
 
 /* same but from an already-conditioned complex stream (after D1) */
 int orc_decode_cf(const orc_cf *z, size_t n, int skip_count, int list_size,
+	int descramble, uint8_t *payload, orc_result *res, orc_taps *taps);
+
+int orc_decode_rate(int rate, const void *samples, int fmt, int channels, size_t n_frames,
+	int skip_count, int list_size, int descramble,
+	uint8_t *payload, orc_result *res, orc_taps *taps);
+int orc_decode_cf_rate(int rate, const orc_cf *z, size_t n, int skip_count, int list_size,
 	int descramble, uint8_t *payload, orc_result *res, orc_taps *taps);
 
 /* batch helper for the cpu_baseline: n frames at fixed stride, OpenMP over

@@ -36,6 +36,29 @@ int orc_mode_lookup(int oper_mode, orc_mode *m)
 	return 0;
 }
 
+/* ---- rates: decode.cc:590-602 / encode.cc:424-436 and decode.cc:171-173,188-189 */
+int orc_rate_lookup(int rate, orc_rate_cfg *c)
+{
+	if (rate != 8000 && rate != 16000 && rate != 44100 && rate != 48000)
+		return 0;
+	c->rate = rate;
+	c->symbol_len = (1280 * rate) / 8000;                       /* decode.cc:171 */
+	c->filter_len = (((21 * rate) / 8000) & ~3) | 1;            /* decode.cc:172 */
+	c->guard_len = c->symbol_len / 8;                           /* decode.cc:173 */
+	c->buffer_len = 6 * (c->symbol_len + c->guard_len);         /* decode.cc:188 */
+	c->search_pos = c->buffer_len - 4 * (c->symbol_len + c->guard_len);   /* decode.cc:189 */
+	return 1;
+}
+
+size_t orc_frame_samples(int rate, int oper_mode, int count)
+{
+	orc_rate_cfg rc;
+	orc_mode md;
+	if (!orc_rate_lookup(rate, &rc) || !orc_mode_lookup(oper_mode, &md))
+		return 0;
+	return 2 * (size_t)rate + (2 + (size_t)count * (3 + (size_t)md.cons_rows)) * (size_t)(rc.symbol_len + rc.guard_len);
+}
+
 /* ---- CODE::Xorshift32: Marsaglia xorshift32, default seed (decode.cc:613) */
 void orc_xorshift32_init(orc_xorshift32 *s) { s->y = 2463534242u; }
 uint32_t orc_xorshift32_next(orc_xorshift32 *s)
