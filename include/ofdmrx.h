@@ -61,11 +61,12 @@ typedef struct ofdmrx_handle ofdmrx_handle;
 
 typedef struct {
 	int32_t abi_version;       /* OFDMRX_ABI_VERSION */
-	int32_t sample_rate;       /* 8000 (decode.cc:590-593); other rates: OFDMRX_E_UNSUPPORTED */
+	int32_t sample_rate;       /* 8000, 16000, 44100 or 48000: which Decoder<value,cmplx,rate> this handle is
+	                            * (decode.cc:590-602); anything else: OFDMRX_E_UNSUPPORTED (decode.cc:603-605) */
 	int32_t list_size;         /* SCL list = SIMD width of the reference build (decode.cc:164-169): 8 */
 	int32_t device;            /* HIP device ordinal */
 	int32_t chunk_frames;      /* frames resident per pass (0 = default) */
-	int32_t max_samples;       /* max samples per frame (0 = OFDMRX_FRAME_SAMPLES) */
+	int32_t max_samples;       /* max samples per frame (0 = ofdmrx_frame_samples(sample_rate, 6)) */
 	int32_t descramble;        /* 1 = XOR payload with Xorshift32 like main(), decode.cc:613-615 */
 	int32_t flags;             /* bit 0: keep the pre-rotation constellation (OFDMRX_TAP_CONS_RAW) */
 	void *stream;              /* hipStream_t to run on, NULL = library-owned stream */
@@ -168,7 +169,7 @@ int ofdmrx_util_awgn_tile(ofdmrx_handle *h, const int16_t *d_base, size_t n_base
 /* deterministic part of the README.md:49 chain (multipath | cfo | sfo), applied to n 2-channel int16 frames on the
  * device (n <= 65535); ofdmrx_util_awgn_tile then adds the independent noise.  Definitions: DESIGN.md / oracle/channel.c */
 typedef struct {
-	float cfo_hz;              /* carrier frequency offset, Hz at 8 kHz */
+	float cfo_hz;              /* carrier frequency offset, Hz (at the handle's sample rate) */
 	float sfo_ppm;             /* sampling frequency offset, ppm */
 	int32_t ntaps;             /* multipath taps (0..8); 0 = pass-through */
 	int32_t delays[8];         /* samples */
@@ -177,10 +178,14 @@ typedef struct {
 int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_t *d_out, size_t n_frames,
 	size_t samples_per_frame, const ofdmrx_channel *ch);
 
-/* ---- N2: the transmitter on the device (replaces Encoder<value,cmplx,8000>(pcm, inp, count=1, freq_off,
- * call_sign, oper_mode), encode.cc:271, for batches).  d_payload: n_frames x 5380 UNSCRAMBLED bytes (what main()
- * reads from the input files, encode.cc:414); d_pcm: n_frames x ofdmrx_tx_frame_samples(mode) x channels int16,
- * exactly the body of the WAV `encode OUT 8000 16 CHANNELS OFFSET MODE CALLSIGN file` writes. DEVICE pointers. */
+/* ---- N2: the transmitter on the device (replaces Encoder<value,cmplx,rate>(pcm, inp, count=1, freq_off,
+ * call_sign, oper_mode), encode.cc:271,424-436, for batches; rate = the handle's sample_rate).  d_payload:
+ * n_frames x 5380 UNSCRAMBLED bytes (what main() reads from the input files, encode.cc:414); d_pcm: n_frames x
+ * ofdmrx_frame_samples(rate, mode) x channels int16, exactly the body of the WAV
+ * `encode OUT RATE 16 CHANNELS OFFSET MODE CALLSIGN file` writes.  DEVICE pointers.
+ * ofdmrx_frame_samples: sample frames of that one-payload file = 2 x rate of silence (encode.cc:423,441) +
+ * (rows + 5) symbols; ofdmrx_tx_frame_samples(mode) is the 8 kHz value. */
+long ofdmrx_frame_samples(int sample_rate, int oper_mode);
 long ofdmrx_tx_frame_samples(int oper_mode);
 int ofdmrx_tx_encode_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_frames, int oper_mode,
 	int freq_off, const char *call_sign, int channels, int16_t *d_pcm);

@@ -97,7 +97,7 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	int32_t skip_count = argc > 3 ? std::atoi(argv[3]) : 0;
-	if (w.rate != 8000) {   // this build: 8 kHz only (decode.cc:590-606 dispatches 8/16/44.1/48 kHz)
+	if (w.rate != 8000 && w.rate != 16000 && w.rate != 44100 && w.rate != 48000) {   // decode.cc:590-605
 		std::fprintf(stderr, "Unsupported sample rate.\n");
 		return 1;
 	}
@@ -125,7 +125,7 @@ int main(int argc, char **argv)
 		std::fprintf(stderr, "ofdmrx_decode_batch: %s\n", ofdmrx_strerror(r));
 		return 1;
 	}
-	const float hz = 8000.f / 6.28318530717958647692f;
+	const float hz = (float)w.rate / 6.28318530717958647692f;   // decode.cc:401,503
 	if (res.sc_start >= 0) {
 		std::fprintf(stderr, "symbol pos: %d\n", res.symbol_pos);
 		std::fprintf(stderr, "coarse cfo: %g Hz \n", res.cfo_rad * hz);

@@ -6,14 +6,30 @@
 
 namespace rx {
 
-constexpr int SYMBOL_LEN = 1280;    // decode.cc:171
-constexpr int GUARD_LEN = 160;      // decode.cc:173
-constexpr int SYM_STRIDE = 1440;    // symbol_len + guard_len
-constexpr int HALF_LEN = 640;       // correlator symbol_len, decode.cc:196
-constexpr int BUFFER_LEN = 8640;    // decode.cc:188
-constexpr int SEARCH_POS = 2880;    // decode.cc:189
-constexpr int MATCH_LEN = 161;      // decode.cc:41
-constexpr int MATCH_DEL = 80;       // decode.cc:42
+// the lengths that depend on the sample rate: one instantiation per rate like the reference's
+// Decoder<value, cmplx, rate> / Encoder<value, cmplx, rate> (decode.cc:590-602, encode.cc:424-436)
+template <int RATE> struct RateCfg {
+	static constexpr int SL = (int)((1280L * RATE) / 8000);       // symbol_len, decode.cc:171 (1280, 2560, 7056, 7680)
+	static constexpr int FILTER_LEN = (((21 * RATE) / 8000) & ~3) | 1;   // decode.cc:172 (21, 41, 113, 125)
+	static constexpr int GL = SL / 8;                              // guard_len, decode.cc:173
+	static constexpr int STRIDE = SL + GL;
+	static constexpr int HS = SL / 2;                              // correlator symbol_len, decode.cc:196
+	static constexpr int BUFFER_LEN = 6 * STRIDE;                  // decode.cc:188
+	static constexpr int SEARCH_POS = BUFFER_LEN - 4 * STRIDE;     // decode.cc:189
+	static constexpr int MATCH_LEN = GL | 1;                       // decode.cc:41
+	static constexpr int MATCH_DEL = (MATCH_LEN - 1) / 2;          // decode.cc:42
+};
+inline bool rate_supported(int rate) { return rate == 8000 || rate == 16000 || rate == 44100 || rate == 48000; }
+inline int rate_symbol_len(int rate) { return (int)((1280L * rate) / 8000); }
+inline int rate_filter_len(int rate) { return (((21 * rate) / 8000) & ~3) | 1; }
+// run `body` with the RateCfg of a run-time rate (launch wrappers)
+#define RX_RATE_SWITCH(rate, ...) \
+	switch (rate) { \
+	case 16000: { constexpr int RATE = 16000; __VA_ARGS__; } break; \
+	case 44100: { constexpr int RATE = 44100; __VA_ARGS__; } break; \
+	case 48000: { constexpr int RATE = 48000; __VA_ARGS__; } break; \
+	default: { constexpr int RATE = 8000; __VA_ARGS__; } break; \
+	}
 constexpr int CONS_COLS = 432;      // decode.cc:306 (mode 6; other modes via mode_desc)
 constexpr int CONS_ROWS = 50;       // decode.cc:453
 constexpr int CONS_CNT = 21600;     // decode.cc:372
@@ -154,6 +170,40 @@ template <> struct Bfly<5> {
 	}
 };
 
+template <> struct Bfly<3> {
+	static __device__ __forceinline__ void run(cf *v)
+	{
+		const float s = 0.86602540378443864676f;
+		cf a = cadd(v[1], v[2]), b = csub(v[1], v[2]);
+		cf m = mk(v[0].re - 0.5f * a.re, v[0].im - 0.5f * a.im);
+		cf jn = cmul_negj(mk(s * b.re, s * b.im));
+		v[0] = cadd(v[0], a);
+		v[1] = cadd(m, jn);
+		v[2] = csub(m, jn);
+	}
+};
+template <> struct Bfly<7> {
+	static __device__ __forceinline__ void run(cf *v)
+	{
+		const float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
+		const float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
+		cf a1 = cadd(v[1], v[6]), a2 = cadd(v[2], v[5]), a3 = cadd(v[3], v[4]);
+		cf b1 = csub(v[1], v[6]), b2 = csub(v[2], v[5]), b3 = csub(v[3], v[4]);
+		cf m1 = mk(v[0].re + c1 * a1.re + c2 * a2.re + c3 * a3.re, v[0].im + c1 * a1.im + c2 * a2.im + c3 * a3.im);
+		cf m2 = mk(v[0].re + c2 * a1.re + c3 * a2.re + c1 * a3.re, v[0].im + c2 * a1.im + c3 * a2.im + c1 * a3.im);
+		cf m3 = mk(v[0].re + c3 * a1.re + c1 * a2.re + c2 * a3.re, v[0].im + c3 * a1.im + c1 * a2.im + c2 * a3.im);
+		cf n1 = mk(s1 * b1.re + s2 * b2.re + s3 * b3.re, s1 * b1.im + s2 * b2.im + s3 * b3.im);
+		cf n2 = mk(s2 * b1.re - s3 * b2.re - s1 * b3.re, s2 * b1.im - s3 * b2.im - s1 * b3.im);
+		cf n3 = mk(s3 * b1.re - s1 * b2.re + s2 * b3.re, s3 * b1.im - s1 * b2.im + s2 * b3.im);
+		cf y0 = cadd(v[0], cadd(a1, cadd(a2, a3)));
+		cf j1 = cmul_negj(n1), j2 = cmul_negj(n2), j3 = cmul_negj(n3);
+		v[0] = y0;
+		v[1] = cadd(m1, j1); v[6] = csub(m1, j1);
+		v[2] = cadd(m2, j2); v[5] = csub(m2, j2);
+		v[3] = cadd(m3, j3); v[4] = csub(m3, j3);
+	}
+};
+
 template <int N, int R, int P, int NT, int TWN = 1280>
 __device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
 {
@@ -191,37 +241,26 @@ __device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
 	__syncthreads();
 }
 
-// forward 1280 = 5*4*4*4*4, in place in LDS, natural order in and out
-template <int NT>
-__device__ __forceinline__ void fft1280(cf *buf, const cf *tw, int tid)
+// Forward N-point transform in place (LDS or global scratch), natural order in and out, NT threads.
+// The radix plan is fixed at compile time: all 5s, then 7s, 3s, 4s and a final 2
+//   640 = 5.4.4.4.2   1280 = 5.4.4.4.4   2560 = 5.4.4.4.4.2   3528 = 7.7.3.3.4.2   3840 = 5.3.4.4.4.4
+//   5120 = 5.4^5   7056 = 7.7.3.3.4.4   7680 = 5.3.4.4.4.4.2
+// tw = table of TWN roots e^{-j 2 pi m / TWN}, N | TWN.
+template <int N, int REM, int P, int NT, int TWN> struct FftPlan {
+	static constexpr int R = REM % 5 == 0 ? 5 : REM % 7 == 0 ? 7 : REM % 3 == 0 ? 3 : REM % 4 == 0 ? 4 : 2;
+	static __device__ __forceinline__ void run(cf *buf, const cf *tw, int tid)
+	{
+		fft_stage<N, R, P, NT, TWN>(buf, tw, tid);
+		FftPlan<N, REM / R, P * R, NT, TWN>::run(buf, tw, tid);
+	}
+};
+template <int N, int P, int NT, int TWN> struct FftPlan<N, 1, P, NT, TWN> {
+	static __device__ __forceinline__ void run(cf *, const cf *, int) {}
+};
+template <int N, int NT, int TWN>
+__device__ __forceinline__ void fft_fwd(cf *buf, const cf *tw, int tid)
 {
-	fft_stage<1280, 5, 1, NT>(buf, tw, tid);
-	fft_stage<1280, 4, 5, NT>(buf, tw, tid);
-	fft_stage<1280, 4, 20, NT>(buf, tw, tid);
-	fft_stage<1280, 4, 80, NT>(buf, tw, tid);
-	fft_stage<1280, 4, 320, NT>(buf, tw, tid);
-}
-// forward 640 = 5*4*4*4*2
-template <int NT>
-__device__ __forceinline__ void fft640(cf *buf, const cf *tw, int tid)
-{
-	fft_stage<640, 5, 1, NT>(buf, tw, tid);
-	fft_stage<640, 4, 5, NT>(buf, tw, tid);
-	fft_stage<640, 4, 20, NT>(buf, tw, tid);
-	fft_stage<640, 4, 80, NT>(buf, tw, tid);
-	fft_stage<640, 2, 320, NT>(buf, tw, tid);
-}
-
-// forward 5120 = 5*4*4*4*4*4 (transmitter PAPR step, encode.cc:43-44); tw = table of 5120 roots
-template <int NT>
-__device__ __forceinline__ void fft5120(cf *buf, const cf *tw5120, int tid)
-{
-	fft_stage<5120, 5, 1, NT, 5120>(buf, tw5120, tid);
-	fft_stage<5120, 4, 5, NT, 5120>(buf, tw5120, tid);
-	fft_stage<5120, 4, 20, NT, 5120>(buf, tw5120, tid);
-	fft_stage<5120, 4, 80, NT, 5120>(buf, tw5120, tid);
-	fft_stage<5120, 4, 320, NT, 5120>(buf, tw5120, tid);
-	fft_stage<5120, 4, 1280, NT, 5120>(buf, tw5120, tid);
+	FftPlan<N, N, 1, NT, TWN>::run(buf, tw, tid);
 }
 
 // ---- wave helpers ----------------------------------------------------------

@@ -23,23 +23,30 @@ __device__ __forceinline__ cf psk8_hard_map(cf c)   // map(hard(c)): psk.hh:118-
 }
 
 // ---------------------------------------------------------------- D4
-struct DemodShared {
-	cf fft[4][SYMBOL_LEN];
+template <int RATE> struct DemodShared {                     // 8 kHz: one 1280-point buffer per wave
+	cf fft[4][RateCfg<RATE>::SL];
 	cf carr[8][COLS_MAX];
 };
+template <int RATE> struct DemodSharedBlock {                // other rates: one buffer, the whole block per symbol
+	cf fft[RateCfg<RATE>::SL];
+	cf carr[2][COLS_MAX];
+};
 
-// decode.cc:453-477.  One workgroup (4 waves) per frame; wave w transforms symbol 4g+w of
-// group g in its own LDS buffer (radix 5,4,4,4,4 Stockham stages); the 432 payload carriers
-// of each symbol are parked in an 8-slot LDS ring so that cons = X_j / X_{j-1} needs no
-// second pass over HBM.  Samples are read once, straight from the raw PCM (int16 pairs).
+// decode.cc:453-477.  One workgroup (4 waves) per frame.
+// 8 kHz: wave w transforms symbol 4g+w of group g in its own LDS buffer (radix 5,4,4,4,4 Stockham
+// stages); the payload carriers of each symbol are parked in an 8-slot LDS ring so that
+// cons = X_j / X_{j-1} needs no second pass over HBM.  Samples are read once, straight from the raw
+// PCM (int16 pairs).  16 / 44.1 / 48 kHz (2560 / 7056 / 7680 points, 20-61 KB): the four waves share
+// one buffer and walk the symbols in order, two carrier slots.
+template <int RATE>
 __global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
 	const SyncState *__restrict__ st_all, cf *__restrict__ cons_all)
 {
+	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, SYM_STRIDE = RateCfg<RATE>::STRIDE;
 	const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	const SyncState st = st_all[f];
 	if (!st.okay)
 		return;
-	__shared__ DemodShared sh;
 	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, fb.samples_per_frame,
 		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
 	const ModeDesc md = mode_desc(st.oper_mode);
@@ -47,29 +54,47 @@ __global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restri
 	const long body0 = st.sc_start + 2 * SYM_STRIDE;          // pilot body, decode.cc:456-459
 	const float omega = -st.cfo_rad;                          // decode.cc:403
 	const int code_off = -md.cols / 2;                        // decode.cc:454
-	const int groups = (md.rows + 1 + 3) / 4;
-	for (int g = 0; g < groups; ++g) {
-		const int s = 4 * g + wave;                           // 0 = pilot, 1..rows = data rows
-		const bool valid = s <= md.rows;
-		cf *buf = sh.fft[wave];
-		#pragma unroll 4
-		for (int q = 0; q < SYMBOL_LEN / 64; ++q) {
-			int i = lane + 64 * q;
-			cf v = mk(0.f, 0.f);
-			if (valid)   // osc() call count: 1280 (header) + s*1440 + i, decode.cc:459-470
-				v = cmul(src.at(body0 + (long)s * SYM_STRIDE + i), phasor(omega, 1280L + (long)s * SYM_STRIDE + i));
-			buf[i] = v;
+	if constexpr (RATE == 8000) {
+		__shared__ DemodShared<RATE> sh;
+		const int groups = (md.rows + 1 + 3) / 4;
+		for (int g = 0; g < groups; ++g) {
+			const int s = 4 * g + wave;                           // 0 = pilot, 1..rows = data rows
+			const bool valid = s <= md.rows;
+			cf *buf = sh.fft[wave];
+			#pragma unroll 4
+			for (int q = 0; q < SYMBOL_LEN / 64; ++q) {
+				int i = lane + 64 * q;
+				cf v = mk(0.f, 0.f);
+				if (valid)   // osc() call count: symbol_len (header) + s*stride + i, decode.cc:459-470
+					v = cmul(src.at(body0 + (long)s * SYM_STRIDE + i), phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + i));
+				buf[i] = v;
+			}
+			__syncthreads();
+			fft_fwd<SYMBOL_LEN, 64, SYMBOL_LEN>(buf, tb.tw_sym, lane);
+			if (valid)
+				for (int i = lane; i < md.cols; i += 64)
+					sh.carr[s & 7][i] = buf[(i + code_off + SYMBOL_LEN) % SYMBOL_LEN];
+			__syncthreads();
+			if (valid && s >= 1)
+				for (int i = lane; i < md.cols; i += 64)        // decode.cc:474-475
+					cons[(s - 1) * md.cols + i] = demod_or_erase(sh.carr[s & 7][i], sh.carr[(s - 1) & 7][i]);
+			__syncthreads();
 		}
-		__syncthreads();
-		fft1280<64>(buf, tb.tw1280, lane);
-		if (valid)
-			for (int i = lane; i < md.cols; i += 64)
-				sh.carr[s & 7][i] = buf[(i + code_off + SYMBOL_LEN) % SYMBOL_LEN];
-		__syncthreads();
-		if (valid && s >= 1)
-			for (int i = lane; i < md.cols; i += 64)        // decode.cc:474-475
-				cons[(s - 1) * md.cols + i] = demod_or_erase(sh.carr[s & 7][i], sh.carr[(s - 1) & 7][i]);
-		__syncthreads();
+	} else {
+		__shared__ DemodSharedBlock<RATE> sh;
+		for (int s = 0; s <= md.rows; ++s) {
+			for (int i = tid; i < SYMBOL_LEN; i += 256)
+				sh.fft[i] = cmul(src.at(body0 + (long)s * SYM_STRIDE + i), phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + i));
+			__syncthreads();
+			fft_fwd<SYMBOL_LEN, 256, SYMBOL_LEN>(sh.fft, tb.tw_sym, tid);
+			for (int i = tid; i < md.cols; i += 256) {
+				cf x = sh.fft[(i + code_off + SYMBOL_LEN) % SYMBOL_LEN];
+				sh.carr[s & 1][i] = x;
+				if (s >= 1)                                       // decode.cc:474-475 (same thread wrote slot (s-1)&1)
+					cons[(s - 1) * md.cols + i] = demod_or_erase(x, sh.carr[(s - 1) & 1][i]);
+			}
+			__syncthreads();
+		}
 	}
 }
 
@@ -433,7 +458,7 @@ __global__ __launch_bounds__(256) void k_theil_sen_raw(int cols, const float *__
 // decode.cc:505-529.  sp/np accumulate ACROSS rows (decode.cc:507 is outside the row loop):
 // per row the 432 terms are reduced in double and folded into the running fp32 sums once,
 // then the row's soft bits are emitted with that row's cumulative precision.
-__global__ __launch_bounds__(256) void k_llr(const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
+__global__ __launch_bounds__(256) void k_llr(int sym_stride, const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
 	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
 	float *__restrict__ llr_all, Result *__restrict__ res_all)
 {
@@ -503,14 +528,17 @@ __global__ __launch_bounds__(256) void k_llr(const SyncState *__restrict__ st_al
 		}
 		Result &r = res_all[f];
 		r.sfo_slope = sum_slope / (float)md.rows;
-		r.cfo_fine = st.cfo_rad + (sum_yint / (float)md.rows) / (float)SYM_STRIDE;   // decode.cc:501
+		r.cfo_fine = st.cfo_rad + (sum_yint / (float)md.rows) / (float)sym_stride;   // decode.cc:501
 		r.esn0_db_last = 10.f * log10f(precision);            // decode.cc:518
 	}
 }
 
 // ---------------------------------------------------------------- debug FFT entry
+// len = symbol_len or symbol_len/2 of the handle's rate, both directions (backward = conj . forward . conj)
+template <int RATE>
 __global__ __launch_bounds__(256) void k_fft_debug(int len, int sign, const cf *__restrict__ in, cf *__restrict__ out, const cf *__restrict__ tw)
 {
+	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL;
 	const int f = blockIdx.x, tid = threadIdx.x;
 	__shared__ cf buf[SYMBOL_LEN];
 	for (int i = tid; i < len; i += 256) {
@@ -518,15 +546,15 @@ __global__ __launch_bounds__(256) void k_fft_debug(int len, int sign, const cf *
 		buf[i] = sign > 0 ? cconj(v) : v;
 	}
 	__syncthreads();
-	if (len == SYMBOL_LEN) fft1280<256>(buf, tw, tid);
-	else fft640<256>(buf, tw, tid);
+	if (len == SYMBOL_LEN) fft_fwd<SYMBOL_LEN, 256, SYMBOL_LEN>(buf, tw, tid);
+	else fft_fwd<SYMBOL_LEN / 2, 256, SYMBOL_LEN>(buf, tw, tid);
 	for (int i = tid; i < len; i += 256)
 		out[(size_t)f * len + i] = sign > 0 ? cconj(buf[i]) : buf[i];
 }
 
-void launch_demod(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons)
+void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons)
 {
-	hipLaunchKernelGGL(k_demod, dim3(n), dim3(256), 0, s, fb, z, tb, st, cons);
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(256), 0, s, fb, z, tb, st, cons));
 }
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, float *slope, float *yint)
 {
@@ -536,14 +564,15 @@ void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, flo
 {
 	hipLaunchKernelGGL(k_theil_sen_raw, dim3(rows), dim3(256), 0, s, cols, y, slope, yint);
 }
-void launch_llr(hipStream_t s, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
+void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, float *llr, Result *res)
 {
-	hipLaunchKernelGGL(k_llr, dim3(n), dim3(256), 0, s, st, cons, slope, yint, precision, llr, res);
+	const int sym_stride = rate_symbol_len(rate) + rate_symbol_len(rate) / 8;
+	hipLaunchKernelGGL(k_llr, dim3(n), dim3(256), 0, s, sym_stride, st, cons, slope, yint, precision, llr, res);
 }
-void launch_fft_debug(hipStream_t s, int n, int len, int sign, const cf *in, cf *out, Tables tb)
+void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb)
 {
-	hipLaunchKernelGGL(k_fft_debug, dim3(n), dim3(256), 0, s, len, sign, in, out, tb.tw1280);
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_fft_debug<RATE>, dim3(n), dim3(256), 0, s, len, sign, in, out, tb.tw_sym));
 }
 
 }  // namespace rx

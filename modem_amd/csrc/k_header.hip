@@ -347,9 +347,11 @@ __device__ __forceinline__ unsigned crc16_u64(unsigned long long data)
 	return crc & 0xffffu;
 }
 
+template <int RATE>
 __global__ __launch_bounds__(256, 2) void k_header(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
 	SyncState *__restrict__ st_all, int8_t *__restrict__ hdr_soft)
 {
+	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, SYM_STRIDE = RateCfg<RATE>::STRIDE;
 	const int f = blockIdx.x, tid = threadIdx.x;
 	__shared__ OsdShared s;
 	__shared__ cf buf[SYMBOL_LEN];
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void k_header(FrameBatch fb, const cf *__re
 	for (int i = tid; i < SYMBOL_LEN; i += 256)
 		buf[i] = cmul(src.at(body + i), phasor(-st.cfo_rad, i));
 	__syncthreads();
-	fft1280<256>(buf, tb.tw1280, tid);
+	fft_fwd<SYMBOL_LEN, 256, SYMBOL_LEN>(buf, tb.tw_sym, tid);
 	if (tid < MLS1_LEN) {                                     // decode.cc:407-416
 		const int mls1_off = -MLS1_LEN / 2;
 		int b1 = (tid + mls1_off + SYMBOL_LEN) % SYMBOL_LEN, b0 = (tid - 1 + mls1_off + SYMBOL_LEN) % SYMBOL_LEN;
@@ -437,9 +439,9 @@ __global__ __launch_bounds__(256, 2) void k_osd_only(Tables tb, const int8_t *__
 		unique_out[f] = u ? 1 : 0;
 }
 
-void launch_header(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft)
+void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft)
 {
-	hipLaunchKernelGGL(k_header, dim3(n), dim3(256), 0, s, fb, z, tb, st, hdr_soft);
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_header<RATE>, dim3(n), dim3(256), 0, s, fb, z, tb, st, hdr_soft));
 }
 void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique)
 {

@@ -562,7 +562,7 @@ void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t
 // ---------------------------------------------------------------- build-owned channel chain (N3)
 // README.md:49 pipes encode through aicodix/disorders: multipath | cfo | sfo | awgn.  That repository is
 // absent; the definitions here are this build's own (same as oracle/channel.c, checked against it):
-//   multipath: FIR with integer delays and complex gains;   cfo: x[m] * e^{j 2 pi hz m / 8000};
+//   multipath: FIR with integer delays and complex gains;   cfo: x[m] * e^{j 2 pi hz m / rate};
 //   sfo: out[i] = resample at t = i (1 + ppm 1e-6), 32-tap Hann-windowed sinc;   awgn: k_awgn_tile.
 // 2-channel int16 in and out.  The chain is deterministic, so it is applied to the base frames once
 // and k_awgn_tile then adds independent noise per frame.
@@ -575,13 +575,13 @@ struct ChannelParams {
 	float gre[8], gim[8];
 };
 
-__global__ __launch_bounds__(256) void k_channel(const short2 *__restrict__ in, short2 *__restrict__ out, size_t spf, ChannelParams cp)
+__global__ __launch_bounds__(256) void k_channel(const short2 *__restrict__ in, short2 *__restrict__ out, size_t spf, ChannelParams cp, int rate)
 {
 	const size_t f = blockIdx.y;
 	const short2 *src = in + f * spf;
 	short2 *dst = out + f * spf;
 	const double step = 1.0 + (double)cp.sfo_ppm * 1e-6;
-	const double w0 = 2.0 * 3.14159265358979323846 * (double)cp.cfo_hz / 8000.0;
+	const double w0 = 2.0 * 3.14159265358979323846 * (double)cp.cfo_hz / (double)rate;
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < spf; i += (size_t)gridDim.x * 256) {
 		auto stage12 = [&](long m) -> cf {   // multipath then cfo at integer sample m
 			float re = 0.f, im = 0.f;
@@ -630,10 +630,10 @@ __global__ __launch_bounds__(256) void k_channel(const short2 *__restrict__ in, 
 	}
 }
 
-void launch_channel(hipStream_t s, const int16_t *in, int16_t *out, size_t n, size_t spf, const void *params)
+void launch_channel(hipStream_t s, int rate, const int16_t *in, int16_t *out, size_t n, size_t spf, const void *params)
 {
 	ChannelParams cp = *(const ChannelParams *)params;
-	hipLaunchKernelGGL(k_channel, dim3(128, (unsigned)n), dim3(256), 0, s, (const short2 *)in, (short2 *)out, spf, cp);
+	hipLaunchKernelGGL(k_channel, dim3(128, (unsigned)n), dim3(256), 0, s, (const short2 *)in, (short2 *)out, spf, cp, rate);
 }
 
 }  // namespace rx

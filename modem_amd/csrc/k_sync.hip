@@ -29,10 +29,14 @@ namespace rx {
 // weighted inclusive scan (v[t] += A^d v[t-d], A = a^16) inside each wave and across the 4 waves, and
 // every sample is corrected by a^(k+1) * carry.  The tile of y (plus a 20-sample history) sits in LDS
 // for the 21-tap Hilbert FIR; z is written as 128 contiguous bytes per lane.
-constexpr int FE_PER = 16, FE_TILE = 256 * FE_PER, FE_HIST = 32;
+// Other rates: Hilbert<cmplx, filter_len> with filter_len = 41 / 113 / 125 (decode.cc:172) - same kernel,
+// longer history and tap loop.
+constexpr int FE_PER = 16, FE_TILE = 256 * FE_PER;
 
+template <int RATE>
 __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, float *__restrict__ dc_all, cf *__restrict__ z_all)
 {
+	constexpr int FL = RateCfg<RATE>::FILTER_LEN, FE_HIST = (FL - 1 + 31) / 32 * 32, FE_C = (FL - 1) / 2, FE_NIM = (FL - 1) / 4;
 	const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const long n = fb.samples_per_frame;
 	const char *base = (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes;
@@ -120,18 +124,18 @@ __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, 
 		#pragma unroll 4
 		for (int i = 0; i < FE_PER; ++i) {
 			const int li = FE_HIST + tid * FE_PER + i;        // index of sample s0+i ; centre at li-10
-			const int c = li - 10;
+			const int c = li - FE_C;
 			float re = co.reco * ydc[c];
 			float im = co.imco[0] * (ydc[c - 1] - ydc[c + 1]);
 			#pragma unroll
-			for (int k = 1; k < 5; ++k)
+			for (int k = 1; k < FE_NIM; ++k)
 				im += co.imco[k] * (ydc[c - (2 * k + 1)] - ydc[c + (2 * k + 1)]);
 			if (s0 + i < n)
 				z[s0 + i] = mk(re, im);
 		}
 		__syncthreads();
 		if (tid < FE_HIST)
-			ydc[tid] = ydc[FE_TILE + tid];            // keep the last 32 samples as history
+			ydc[tid] = ydc[FE_TILE + tid];            // keep the last FE_HIST samples as history
 		__syncthreads();
 	}
 }
@@ -139,11 +143,13 @@ __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, 
 // ---------------------------------------------------------------- D2 + D3 sync
 constexpr int TILE = 1024, PER = 16, MRING = 2048;
 
-struct SyncShared {
+// 8 kHz: the two 640-point work arrays of the trigger part live in LDS.  Other rates (1280 / 3528 / 3840
+// points) keep them in a per-frame global scratch so the scanning loop's occupancy does not pay for them.
+template <int RATE> struct SyncShared {
 	double m[MRING];
 	float timing[TILE];
-	cf buf[HALF_LEN];
-	cf xr[HALF_LEN];
+	cf buf[RATE == 8000 ? RateCfg<RATE>::HS : 1];
+	cf xr[RATE == 8000 ? RateCfg<RATE>::HS : 1];
 };
 
 __device__ __forceinline__ int first_index(const float *timing, int T0, int lane, int lo_t, int hi_t, bool greater, float thr)
@@ -161,11 +167,15 @@ __device__ __forceinline__ int first_index(const float *timing, int T0, int lane
 }
 
 // P at time t by direct summation (decode.cc:86), double accumulate
+template <int RATE>
 __device__ __forceinline__ void direct_P(const SampleSrc &src, long t, int lane, double &re, double &im)
 {
+	constexpr int BUFFER_LEN = RateCfg<RATE>::BUFFER_LEN, SEARCH_POS = RateCfg<RATE>::SEARCH_POS, HALF_LEN = RateCfg<RATE>::HS;
 	double sr = 0.0, si = 0.0;
 	long a0 = t - (BUFFER_LEN - 1 - (SEARCH_POS + HALF_LEN));   // newest u
-	for (int q = 0; q < HALF_LEN / 64; ++q) {
+	for (int q = 0; q < (HALF_LEN + 63) / 64; ++q) {
+		if (q * 64 + lane >= HALF_LEN)
+			break;
 		long u = a0 - (q * 64 + lane);
 		cf x = src.at(u), y = src.at(u + HALF_LEN);
 		sr += (double)x.re * y.re + (double)x.im * y.im;
@@ -174,11 +184,15 @@ __device__ __forceinline__ void direct_P(const SampleSrc &src, long t, int lane,
 	re = wave_sum_d(sr);
 	im = wave_sum_d(si);
 }
+template <int RATE>
 __device__ __forceinline__ double direct_R(const SampleSrc &src, long t, int lane)
 {
+	constexpr int BUFFER_LEN = RateCfg<RATE>::BUFFER_LEN, SEARCH_POS = RateCfg<RATE>::SEARCH_POS, HALF_LEN = RateCfg<RATE>::HS;
 	double s = 0.0;
 	long a0 = t - (BUFFER_LEN - 1 - (SEARCH_POS + 2 * HALF_LEN));
-	for (int q = 0; q < 2 * HALF_LEN / 64; ++q) {
+	for (int q = 0; q < (2 * HALF_LEN + 63) / 64; ++q) {
+		if (q * 64 + lane >= 2 * HALF_LEN)
+			break;
 		cf x = src.at(a0 - (q * 64 + lane));
 		s += (double)x.re * x.re + (double)x.im * x.im;
 	}
@@ -186,34 +200,37 @@ __device__ __forceinline__ double direct_R(const SampleSrc &src, long t, int lan
 }
 
 // decode.cc:110-151 ; returns accept, fills symbol_pos (window coord) and cfo_rad
-__device__ bool sc_process(SyncShared &sh, const SampleSrc &src, const cf *tw, const cf *kern,
+template <int RATE>
+__device__ bool sc_process(cf *buf, cf *xr, const SampleSrc &src, const cf *tw, const cf *kern,
 	long t, int index_max, float phase_max, int lane, int &symbol_pos_out, float &cfo_out)
 {
+	typedef RateCfg<RATE> RC;
+	constexpr int BUFFER_LEN = RC::BUFFER_LEN, SEARCH_POS = RC::SEARCH_POS, HALF_LEN = RC::HS, GUARD_LEN = RC::GL;
 	const float frac_cfo = phase_max / (float)HALF_LEN;       // decode.cc:110
 	int symbol_pos = SEARCH_POS - index_max;                   // decode.cc:114
 	const long base = t - (BUFFER_LEN - 1);
 	__syncthreads();
 	for (int i = lane; i < HALF_LEN; i += 64)                  // decode.cc:117-118
-		sh.buf[i] = cmul(src.at(base + i + symbol_pos + HALF_LEN), phasor(frac_cfo, i));
+		buf[i] = cmul(src.at(base + i + symbol_pos + HALF_LEN), phasor(frac_cfo, i));
 	__syncthreads();
-	fft640<64>(sh.buf, tw, lane);
+	fft_fwd<HALF_LEN, 64, RC::SL>(buf, tw, lane);
 	for (int i = lane; i < HALF_LEN; i += 64)                  // decode.cc:120-121
-		sh.xr[i] = demod_or_erase(sh.buf[i], sh.buf[(i + HALF_LEN - 1) % HALF_LEN]);
+		xr[i] = demod_or_erase(buf[i], buf[(i + HALF_LEN - 1) % HALF_LEN]);
 	__syncthreads();
 	for (int i = lane; i < HALF_LEN; i += 64)
-		sh.buf[i] = sh.xr[i];
+		buf[i] = xr[i];
 	__syncthreads();
-	fft640<64>(sh.buf, tw, lane);
+	fft_fwd<HALF_LEN, 64, RC::SL>(buf, tw, lane);
 	// x kern, then backward transform as conj(FFT(conj(.)))
 	for (int i = lane; i < HALF_LEN; i += 64)
-		sh.buf[i] = cconj(cmul(sh.buf[i], kern[i]));
+		buf[i] = cconj(cmul(buf[i], kern[i]));
 	__syncthreads();
-	fft640<64>(sh.buf, tw, lane);
+	fft_fwd<HALF_LEN, 64, RC::SL>(buf, tw, lane);
 	// decode.cc:127-139: peak = max, shift = first index of it, next = runner-up
 	float pk = -1.f;
 	int sh_i = 0x7fffffff;
 	for (int i = lane; i < HALF_LEN; i += 64) {
-		float p = cnorm(sh.buf[i]);
+		float p = cnorm(buf[i]);
 		if (p > pk) { pk = p; sh_i = i; }
 	}
 	#pragma unroll
@@ -224,7 +241,7 @@ __device__ bool sc_process(SyncShared &sh, const SampleSrc &src, const cf *tw, c
 	}
 	float nx = 0.f;
 	for (int i = lane; i < HALF_LEN; i += 64) {
-		float p = cnorm(sh.buf[i]);
+		float p = cnorm(buf[i]);
 		if (i != sh_i && p > nx) nx = p;
 	}
 	#pragma unroll
@@ -234,7 +251,7 @@ __device__ bool sc_process(SyncShared &sh, const SampleSrc &src, const cf *tw, c
 	const int shift = peak > 0.f ? sh_i : 0;
 	if (peak <= nx * 4.f)                                      // decode.cc:140-141
 		return false;
-	cf v = cconj(sh.buf[shift]);
+	cf v = cconj(buf[shift]);
 	int pos_err = (int)nearbyintf(atan2f(v.im, v.re) * (float)HALF_LEN / TWO_PI_F);
 	if (abs(pos_err) > GUARD_LEN / 2)                          // decode.cc:144-145
 		return false;
@@ -247,9 +264,14 @@ __device__ bool sc_process(SyncShared &sh, const SampleSrc &src, const cf *tw, c
 	return true;
 }
 
+template <int RATE>
 __global__ __launch_bounds__(64) void k_sync(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
-	const cf *__restrict__ kern, SyncState *__restrict__ st_all)
+	const cf *__restrict__ kern, SyncState *__restrict__ st_all, cf *__restrict__ scratch)
 {
+	typedef RateCfg<RATE> RC;
+	constexpr int BUFFER_LEN = RC::BUFFER_LEN, SEARCH_POS = RC::SEARCH_POS, HALF_LEN = RC::HS, GUARD_LEN = RC::GL;
+	constexpr int MATCH_LEN = RC::MATCH_LEN, MATCH_DEL = RC::MATCH_DEL;
+	static_assert(TILE + MATCH_LEN <= MRING, "m ring too small");
 	const int f = blockIdx.x, lane = threadIdx.x;
 	SyncState st = st_all[f];
 	if (!st.active)
@@ -257,7 +279,9 @@ __global__ __launch_bounds__(64) void k_sync(FrameBatch fb, const cf *__restrict
 	const long n = fb.samples_per_frame;
 	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, n,
 		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
-	__shared__ SyncShared sh;
+	__shared__ SyncShared<RATE> sh;
+	cf *fbuf = RATE == 8000 ? sh.buf : scratch + (size_t)f * 2 * HALF_LEN;
+	cf *fxr = RATE == 8000 ? sh.xr : scratch + (size_t)f * 2 * HALF_LEN + HALF_LEN;
 	for (int i = lane; i < MRING; i += 64)
 		sh.m[i] = 0.0;
 	const float thr_lo = (float)(0.17 * MATCH_LEN), thr_hi = (float)(0.19 * MATCH_LEN);   // decode.cc:76
@@ -268,8 +292,8 @@ __global__ __launch_bounds__(64) void k_sync(FrameBatch fb, const cf *__restrict
 	// running window sums at time T0-1
 	double Wr = 0.0, Wi = 0.0, Wp = 0.0, Wm = 0.0;
 	if (T0 > 0) {
-		direct_P(src, T0 - 1, lane, Wr, Wi);
-		Wp = direct_R(src, T0 - 1, lane);
+		direct_P<RATE>(src, T0 - 1, lane, Wr, Wi);
+		Wp = direct_R<RATE>(src, T0 - 1, lane);
 	}
 	bool collecting = false, found = false;
 	float tmax = 0.f;
@@ -368,14 +392,14 @@ __global__ __launch_bounds__(64) void k_sync(FrameBatch fb, const cf *__restrict
 				long tp = nmax - MATCH_DEL;                    // decode.cc:91 delay(arg(P))
 				if (tp >= 0) {
 					double pr, pi;
-					direct_P(src, tp, lane, pr, pi);
+					direct_P<RATE>(src, tp, lane, pr, pi);
 					phase_max = atan2f((float)pi, (float)pr);
 				}
 			}
 			tmax = 0.f;                                        // decode.cc:115-116
 			int sp;
 			float cfo;
-			if (sc_process(sh, src, tw, kern, g, index_max, phase_max, lane, sp, cfo)) {
+			if (sc_process<RATE>(fbuf, fxr, src, tw, kern, g, index_max, phase_max, lane, sp, cfo)) {
 				found = true;
 				st.symbol_pos = sp;
 				st.cfo_rad = cfo;
@@ -426,13 +450,13 @@ void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_c
 {
 	hipLaunchKernelGGL(k_init_sync, dim3((n + 255) / 256), dim3(256), 0, s, n, st, skip_counts);
 }
-void launch_front_end(hipStream_t s, int n, FrameBatch fb, FrontCoef co, float *dc, cf *z)
+void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, float *dc, cf *z)
 {
-	hipLaunchKernelGGL(k_front_end, dim3(n), dim3(256), 0, s, fb, co, dc, z);
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_front_end<RATE>, dim3(n), dim3(256), 0, s, fb, co, dc, z));
 }
-void launch_sync(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st)
+void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, cf *scratch)
 {
-	hipLaunchKernelGGL(k_sync, dim3(n), dim3(64), 0, s, fb, z, tb.tw1280, tb.sc_kern, st);
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_sync<RATE>, dim3(n), dim3(64), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, scratch));
 }
 
 }  // namespace rx

@@ -12,7 +12,7 @@
 namespace rx {
 
 struct TxParams {
-	int oper_mode, offset, channels, nsym;     // offset = freq_off*1280/8000 bins (encode.cc:283)
+	int oper_mode, offset, channels, nsym;     // offset = freq_off*symbol_len/rate bins (encode.cc:283)
 	unsigned long long md;                     // (call_sign << 8) | mode  (encode.cc:291)
 	long frame_samples;
 };
@@ -85,27 +85,34 @@ __global__ __launch_bounds__(256) void k_tx_code(const uint8_t *__restrict__ pay
 }
 
 // ---------------------------------------------------------------- one OFDM symbol
-__device__ __forceinline__ int bin1280(int c) { return (c + SYMBOL_LEN) % SYMBOL_LEN; }
-__device__ __forceinline__ int bin5120(int c) { return (c + 4 * SYMBOL_LEN) % (4 * SYMBOL_LEN); }
-
-struct TxShared {
-	cf big[4 * SYMBOL_LEN];
-	cf fdom[SYMBOL_LEN];
-	float cum[256];
-	uint8_t bits[32];
+// The 4x oversampled PAPR buffer (encode.cc:50-51 fdom4/tdom4) is 5120 / 10240 points at 8 / 16 kHz and sits in
+// LDS (41 / 82 KB); at 44.1 / 48 kHz it is 28224 / 30720 points (226 / 246 KB > LDS) and lives in a per-workgroup
+// global scratch, worked on by 1024 threads so the in-place radix stages still fit the register file.
+template <int RATE> struct TxCfg {
+	static constexpr bool BIG_IN_LDS = RATE <= 16000;
+	static constexpr int NT = BIG_IN_LDS ? 256 : 1024;
+};
+template <int RATE> struct TxShared {
+	cf big[TxCfg<RATE>::BIG_IN_LDS ? 4 * RateCfg<RATE>::SL : 1];
+	cf fdom[RateCfg<RATE>::SL];
 };
 
 // symbol kinds in transmission order (encode.cc:288-313): pilot | S&C | meta | pilot | rows x data | zero
-__global__ __launch_bounds__(256) void k_tx_symbol(const uint32_t *__restrict__ code_all, Tables tb, TxParams tp,
-	const cf *__restrict__ tw5120, cf *__restrict__ tdom_all)
+template <int RATE>
+__global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const uint32_t *__restrict__ code_all, Tables tb, TxParams tp,
+	const cf *__restrict__ tw5120, cf *__restrict__ tdom_all, cf *__restrict__ big_scratch)
 {
+	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, NT = TxCfg<RATE>::NT;
+	auto bin1280 = [](int c) { return (c + SYMBOL_LEN) % SYMBOL_LEN; };               // encode.cc:68-71
+	auto bin5120 = [](int c) { return (c + 4 * SYMBOL_LEN) % (4 * SYMBOL_LEN); };     // encode.cc:72-75
 	const int f = blockIdx.x / tp.nsym, sidx = blockIdx.x % tp.nsym, tid = threadIdx.x;
 	const ModeDesc md = mode_desc(tp.oper_mode);
-	__shared__ TxShared sh;
+	__shared__ TxShared<RATE> sh;
+	cf *big = TxCfg<RATE>::BIG_IN_LDS ? sh.big : big_scratch + (size_t)blockIdx.x * (4 * SYMBOL_LEN);
 	const int code_off = tp.offset - md.cols / 2;             // encode.cc:284
 	const int mls0_off = tp.offset - 127 + 1;                 // encode.cc:285
 	const int mls1_off = tp.offset - 255 / 2;                 // encode.cc:286
-	for (int i = tid; i < SYMBOL_LEN; i += 256)
+	for (int i = tid; i < SYMBOL_LEN; i += NT)
 		sh.fdom[i] = mk(0.f, 0.f);
 	__syncthreads();
 	bool papr = true;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256) void k_tx_symbol(const uint32_t *__restrict__ 
 		const float code_fac = sqrtf((float)SYMBOL_LEN / (float)md.cols);   // encode.cc:135
 		const uint32_t *code = code_all + (size_t)f * 2048;
 		const float cos_pi_8 = 0.92387953251128675613f, sin_pi_8 = 0.38268343236508977173f, r2 = 0.70710678118654752440f;
-		for (int i = tid; i < md.cols; i += 256) {
+		for (int i = tid; i < md.cols; i += NT) {
 			cf acc = mk(code_fac * tb.mls2_nrz[i], 0.f);
 			for (int r = 0; r <= j; ++r) {
 				const int p = md.mod_bits * (md.cols * r + i);
@@ -177,59 +184,67 @@ __global__ __launch_bounds__(256) void k_tx_symbol(const uint32_t *__restrict__ 
 	}
 	__syncthreads();
 	// symbol(): encode.cc:101-109
-	cf *temp = sh.big;                                        // reused after the PAPR step
+	cf *temp = TxCfg<RATE>::BIG_IN_LDS ? big : sh.fdom;       // LDS: big reused after the PAPR step; else fdom itself
 	if (papr && sidx != last) {
 		// improve_papr(): encode.cc:80-100
-		for (int i = tid; i < 4 * SYMBOL_LEN; i += 256)
-			sh.big[i] = mk(0.f, 0.f);
+		for (int i = tid; i < 4 * SYMBOL_LEN; i += NT)
+			big[i] = mk(0.f, 0.f);
 		__syncthreads();
-		for (int i = tid; i < SYMBOL_LEN; i += 256) {
+		for (int i = tid; i < SYMBOL_LEN; i += NT) {
 			int c = i - SYMBOL_LEN / 2;
-			sh.big[bin5120(c)] = cconj(sh.fdom[bin1280(c)]);  // conj in, conj out = backward transform
+			big[bin5120(c)] = cconj(sh.fdom[bin1280(c)]);  // conj in, conj out = backward transform
 		}
 		__syncthreads();
-		fft5120<256>(sh.big, tw5120, tid);
+		fft_fwd<4 * SYMBOL_LEN, NT, 4 * SYMBOL_LEN>(big, tw5120, tid);
 		const float s4 = sqrtf((float)(4 * SYMBOL_LEN));
-		for (int i = tid; i < 4 * SYMBOL_LEN; i += 256) {
-			cf v = cconj(sh.big[i]);
+		for (int i = tid; i < 4 * SYMBOL_LEN; i += NT) {
+			cf v = cconj(big[i]);
 			v = mk(v.re / s4, v.im / s4);
 			float amp = fmaxf(fabsf(v.re), fabsf(v.im));
 			if (amp > 1.f)
 				v = mk(v.re / amp, v.im / amp);
-			sh.big[i] = v;
+			big[i] = v;
 		}
 		__syncthreads();
-		fft5120<256>(sh.big, tw5120, tid);
-		cf keep[5];
+		fft_fwd<4 * SYMBOL_LEN, NT, 4 * SYMBOL_LEN>(big, tw5120, tid);
+		constexpr int NK = (SYMBOL_LEN + NT - 1) / NT;
+		cf keep[NK];
 		#pragma unroll
-		for (int q = 0; q < 5; ++q) {
-			int i = tid + 256 * q, c = i - SYMBOL_LEN / 2;
-			cf o = sh.fdom[bin1280(c)], v = sh.big[bin5120(c)];
-			keep[q] = cnorm(o) != 0.f ? mk(v.re / s4, v.im / s4) : mk(0.f, 0.f);
+		for (int q = 0; q < NK; ++q) {
+			int i = tid + NT * q, c = i - SYMBOL_LEN / 2;
+			keep[q] = mk(0.f, 0.f);
+			if (i < SYMBOL_LEN) {
+				cf o = sh.fdom[bin1280(c)], v = big[bin5120(c)];
+				if (cnorm(o) != 0.f)
+					keep[q] = mk(v.re / s4, v.im / s4);
+			}
 		}
 		__syncthreads();
 		#pragma unroll
-		for (int q = 0; q < 5; ++q) {
-			int i = tid + 256 * q, c = i - SYMBOL_LEN / 2;
-			temp[bin1280(c)] = cconj(keep[q]);
+		for (int q = 0; q < NK; ++q) {
+			int i = tid + NT * q, c = i - SYMBOL_LEN / 2;
+			if (i < SYMBOL_LEN)
+				temp[bin1280(c)] = cconj(keep[q]);
 		}
 	} else {
-		for (int i = tid; i < SYMBOL_LEN; i += 256)
+		for (int i = tid; i < SYMBOL_LEN; i += NT)
 			temp[i] = cconj(sh.fdom[i]);
 	}
 	__syncthreads();
-	fft1280<256>(temp, tb.tw1280, tid);
+	fft_fwd<SYMBOL_LEN, NT, SYMBOL_LEN>(temp, tb.tw_sym, tid);
 	const float s8 = sqrtf((float)(8 * SYMBOL_LEN));
 	cf *out = tdom_all + ((size_t)f * tp.nsym + sidx) * SYMBOL_LEN;
-	for (int i = tid; i < SYMBOL_LEN; i += 256) {
+	for (int i = tid; i < SYMBOL_LEN; i += NT) {
 		cf v = cconj(temp[i]);
 		out[i] = mk(v.re / s8, v.im / s8);
 	}
 }
 
 // ---------------------------------------------------------------- guard cross-fade + int16
+template <int RATE>
 __global__ __launch_bounds__(256) void k_tx_assemble(const cf *__restrict__ tdom_all, TxParams tp, int16_t *__restrict__ pcm_all)
 {
+	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, GUARD_LEN = RateCfg<RATE>::GL, SYM_STRIDE = RateCfg<RATE>::STRIDE;
 	const int f = blockIdx.x / (tp.nsym + 2), part = blockIdx.x % (tp.nsym + 2), tid = threadIdx.x;
 	int16_t *pcm = pcm_all + (size_t)f * tp.frame_samples * tp.channels;
 	const int ch = tp.channels;
@@ -240,14 +255,14 @@ __global__ __launch_bounds__(256) void k_tx_assemble(const cf *__restrict__ tdom
 			pcm[n * ch + 1] = (int16_t)nearbyintf(32767.f * im);
 	};
 	if (part >= tp.nsym) {                                    // silence(rate) before and after, encode.cc:423,441
-		long base = part == tp.nsym ? 0 : 8000 + (long)tp.nsym * SYM_STRIDE;
-		for (int i = tid; i < 8000; i += 256)
+		long base = part == tp.nsym ? 0 : RATE + (long)tp.nsym * SYM_STRIDE;
+		for (int i = tid; i < RATE; i += 256)
 			put(base + i, mk(0.f, 0.f));
 		return;
 	}
 	const cf *cur = tdom_all + ((size_t)f * tp.nsym + part) * SYMBOL_LEN;
 	const cf *prv = part ? cur - SYMBOL_LEN : nullptr;
-	const long base = 8000 + (long)part * SYM_STRIDE;
+	const long base = RATE + (long)part * SYM_STRIDE;
 	for (int i = tid; i < GUARD_LEN; i += 256) {              // encode.cc:110-114
 		float x = (float)i / (float)(GUARD_LEN - 1);
 		x = 0.5f * (1.f - cosf(PI_F * x));
@@ -258,13 +273,19 @@ __global__ __launch_bounds__(256) void k_tx_assemble(const cf *__restrict__ tdom
 		put(base + GUARD_LEN + i, cur[i]);
 }
 
-void launch_tx(hipStream_t s, int n, const uint8_t *payload, Tables tb, const void *tp_, const cf *tw5120,
-	uint32_t *code, cf *tdom, int16_t *pcm)
+size_t tx_big_scratch_bytes(int rate, int n, int nsym)
+{
+	return rate <= 16000 ? 0 : (size_t)n * nsym * 4 * (size_t)rate_symbol_len(rate) * sizeof(cf);
+}
+
+void launch_tx(hipStream_t s, int rate, int n, const uint8_t *payload, Tables tb, const void *tp_, const cf *tw5120,
+	uint32_t *code, cf *tdom, cf *big_scratch, int16_t *pcm)
 {
 	TxParams tp = *(const TxParams *)tp_;
 	hipLaunchKernelGGL(k_tx_code, dim3(n), dim3(256), 0, s, payload, tb, tp, code);
-	hipLaunchKernelGGL(k_tx_symbol, dim3(n * tp.nsym), dim3(256), 0, s, code, tb, tp, tw5120, tdom);
-	hipLaunchKernelGGL(k_tx_assemble, dim3(n * (tp.nsym + 2)), dim3(256), 0, s, tdom, tp, pcm);
+	RX_RATE_SWITCH(rate,
+		hipLaunchKernelGGL(k_tx_symbol<RATE>, dim3(n * tp.nsym), dim3(TxCfg<RATE>::NT), 0, s, code, tb, tp, tw5120, tdom, big_scratch);
+		hipLaunchKernelGGL(k_tx_assemble<RATE>, dim3(n * (tp.nsym + 2)), dim3(256), 0, s, tdom, tp, pcm));
 }
 
 }  // namespace rx

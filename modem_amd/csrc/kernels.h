@@ -15,9 +15,9 @@ struct FrameBatch {
 	int channels;                  // 1 or 2
 };
 
-struct FrontCoef {                 // BlockDC::samples(2880) + Hilbert<cmplx,21> (decode.cc:386,193)
+struct FrontCoef {                 // BlockDC::samples(2*(symbol_len+guard_len)) + Hilbert<cmplx,filter_len> (decode.cc:386,193)
 	float dc_a, dc_b;
-	float reco, imco[5];
+	float reco, imco[32];          // (filter_len-1)/4 odd-tap pairs: 5 / 10 / 28 / 31 at 8 / 16 / 44.1 / 48 kHz
 };
 
 struct SyncState {                 // per frame, across sync rounds (decode.cc:390-448 loop)
@@ -37,12 +37,12 @@ struct SyncState {                 // per frame, across sync rounds (decode.cc:3
 };
 
 struct Tables {                    // device-resident constants, built once per handle
-	const cf *tw1280;              // e^{-j 2 pi m / 1280}
-	const cf *sc_kern;             // conj(FFT640(mls0))/640, decode.cc:80-82
+	const cf *tw_sym;              // e^{-j 2 pi m / symbol_len} (1280 at 8 kHz)
+	const cf *sc_kern;             // conj(FFT(mls0))/(symbol_len/2), decode.cc:80-82
 	const float *mls1_nrz;         // +-1 descrambler, decode.cc:407-409
 	const float *mls0_nrz;         // [127] MLS 0b10001001 (transmitter: Schmidl-Cox symbol, encode.cc:144)
 	const float *mls2_nrz;         // [512] MLS 0b100101010001 (transmitter: pilot block, encode.cc:134)
-	const cf *tw5120;              // e^{-j 2 pi m / 5120} (transmitter PAPR step)
+	const cf *tw_sym4;             // e^{-j 2 pi m / (4 symbol_len)} (transmitter PAPR step)
 	const uint32_t *frozen;        // [2][2048] words, bit set = frozen: frozen_64800_43072, frozen_64512_43072 (regenerated)
 	const uint16_t *info_pos;      // [2][44096] ascending unfrozen positions per table
 	const uint32_t *genmat_bits;   // BCH(255,71) systematic generator, [71][8] words, bit i of row j
@@ -65,24 +65,26 @@ struct Result {                    // device mirror of ofdmrx_frame_result (same
 };
 
 // ---- launch wrappers (defined next to their kernels) ------------------------
-void launch_front_end(hipStream_t s, int n, FrameBatch fb, FrontCoef co, float *dc, cf *z);
-void launch_sync(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st);
-void launch_header(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft);
+// `rate` selects the RateCfg instantiation (8000 / 16000 / 44100 / 48000)
+void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, float *dc, cf *z);
+void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, cf *scratch);
+void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft);
 void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique);
-void launch_demod(hipStream_t s, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons);
+void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons);
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, float *slope, float *yint);
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
-void launch_llr(hipStream_t s, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
+void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, float *llr, Result *res);
 void launch_polar(hipStream_t s, int n, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric);
 void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
 	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res);
-void launch_fft_debug(hipStream_t s, int n, int len, int sign, const cf *in, cf *out, Tables tb);
+void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb);
 void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t *out, size_t n_out,
 	size_t spf, float sigma, uint64_t seed, uint64_t first_frame);
-void launch_channel(hipStream_t s, const int16_t *in, int16_t *out, size_t n, size_t spf, const void *params);
-void launch_tx(hipStream_t s, int n, const uint8_t *payload, Tables tb, const void *tp, const cf *tw5120,
-	uint32_t *code, cf *tdom, int16_t *pcm);
+void launch_channel(hipStream_t s, int rate, const int16_t *in, int16_t *out, size_t n, size_t spf, const void *params);
+size_t tx_big_scratch_bytes(int rate, int n, int nsym);
+void launch_tx(hipStream_t s, int rate, int n, const uint8_t *payload, Tables tb, const void *tp, const cf *tw_sym4,
+	uint32_t *code, cf *tdom, cf *big_scratch, int16_t *pcm);
 void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts);
 
 }  // namespace rx

@@ -60,6 +60,7 @@ struct ofdmrx_handle {
 	bool own_stream = false;
 	int chunk = 0;
 	long max_samples = 0;
+	int rate = 8000;
 	HostTables host;
 	Tables dev{};
 	std::vector<void *> table_allocs;
@@ -71,6 +72,7 @@ struct ofdmrx_handle {
 	DevBuf cons_raw;          // only with cfg.flags & 1 (keep the pre-rotation constellation for taps)
 	long last_spf = 0;
 	DevBuf in_stage, skip_stage;
+	DevBuf sc_scratch;             // rates above 8 kHz: 2 x symbol_len/2 cf per frame for the S&C trigger part
 	int last_n = 0;           // frames in the last chunk (for taps)
 	bool last_mono = false;
 	// timing
@@ -105,7 +107,7 @@ extern "C" const char *ofdmrx_strerror(int err)
 	case OFDMRX_E_NOMEM: return g_last_error.empty() ? "out of device memory" : g_last_error.c_str();
 	case OFDMRX_E_HIP: return g_last_error.empty() ? "HIP error" : g_last_error.c_str();
 	case OFDMRX_E_NODEV: return "no usable HIP device (the receive path has no CPU fallback)";
-	case OFDMRX_E_UNSUPPORTED: return "unsupported configuration (8 kHz, list size 8 only)";
+	case OFDMRX_E_UNSUPPORTED: return "unsupported configuration (sample rate 8000/16000/44100/48000, list size 8)";
 	default: return "unknown error";
 	}
 }
@@ -114,7 +116,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 {
 	if (!cfg || !out || cfg->abi_version != OFDMRX_ABI_VERSION)
 		return OFDMRX_E_ARG;
-	if (cfg->sample_rate != 8000 || (cfg->list_size != 0 && cfg->list_size != 8))
+	if (!rate_supported(cfg->sample_rate) || (cfg->list_size != 0 && cfg->list_size != 8))   // decode.cc:590-605
 		return OFDMRX_E_UNSUPPORTED;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
@@ -124,8 +126,10 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	if (!h)
 		return OFDMRX_E_NOMEM;
 	h->cfg = *cfg;
-	h->chunk = cfg->chunk_frames > 0 ? cfg->chunk_frames : 8192;
-	h->max_samples = cfg->max_samples > 0 ? cfg->max_samples : OFDMRX_FRAME_SAMPLES;
+	h->rate = cfg->sample_rate;
+	// default chunk: 8192 frames at 8 kHz, scaled down with the samples per frame at the higher rates
+	h->chunk = cfg->chunk_frames > 0 ? cfg->chunk_frames : (int)(8192L * 8000 / cfg->sample_rate);
+	h->max_samples = cfg->max_samples > 0 ? cfg->max_samples : ofdmrx_frame_samples(cfg->sample_rate, 6);
 	if (cfg->stream) {
 		h->stream = (hipStream_t)cfg->stream;
 	} else {
@@ -137,14 +141,14 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		}
 		h->own_stream = true;
 	}
-	build_tables(h->host);
+	build_tables(h->host, h->rate);
 	int r = 0;
-	r = r ? r : upload(h, h->host.tw1280, &h->dev.tw1280);
+	r = r ? r : upload(h, h->host.tw_sym, &h->dev.tw_sym);
 	r = r ? r : upload(h, h->host.sc_kern, &h->dev.sc_kern);
 	r = r ? r : upload(h, h->host.mls1_nrz, &h->dev.mls1_nrz);
 	r = r ? r : upload(h, h->host.mls0_nrz, &h->dev.mls0_nrz);
 	r = r ? r : upload(h, h->host.mls2_nrz, &h->dev.mls2_nrz);
-	r = r ? r : upload(h, h->host.tw5120, &h->dev.tw5120);
+	r = r ? r : upload(h, h->host.tw_sym4, &h->dev.tw_sym4);
 	r = r ? r : upload(h, h->host.frozen, &h->dev.frozen);
 	r = r ? r : upload(h, h->host.info_pos, &h->dev.info_pos);
 	r = r ? r : upload(h, h->host.genmat_bits, &h->dev.genmat_bits);
@@ -168,7 +172,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->skip_stage })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->skip_stage, &h->sc_scratch })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -201,13 +205,14 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 		r = r ? r : h->payload.ensure(N * PAYLOAD_BYTES);
 		if (h->cfg.flags & 1)
 			r = r ? r : h->cons_raw.ensure(N * CONS_MAX * sizeof(cf));
+		if (h->rate != 8000)
+			r = r ? r : h->sc_scratch.ensure(N * (size_t)rate_symbol_len(h->rate) * sizeof(cf));
 		if (r)
 			return r;
 		h->cap = n;
 	}
 	if (mono) {
 		size_t need = (size_t)std::max(n, h->cap) * (size_t)samples;
-		r = r ? r : h->dc.ensure(need * sizeof(float));
 		r = r ? r : h->z.ensure(need * sizeof(cf));
 	}
 	return r;
@@ -239,15 +244,15 @@ static int run_chunk(ofdmrx_handle *h, FrameBatch fb, int n, const int32_t *d_sk
 	const cf *z = mono ? h->z.as<cf>() : nullptr;
 	size_t e0 = mark(h);
 	if (mono)
-		launch_front_end(s, n, fb, h->host.front, h->dc.as<float>(), h->z.as<cf>());
+		launch_front_end(s, h->rate, n, fb, h->host.front, nullptr, h->z.as<cf>());
 	size_t e1 = mark(h);
 	launch_init_sync(s, n, st, d_skip);
 	size_t e2 = e1, e3 = e1;
 	for (int round = 0; round <= max_skip; ++round) {      // decode.cc:390-448 do { } while (skip_count--)
 		size_t a = mark(h);
-		launch_sync(s, n, fb, z, h->dev, st);
+		launch_sync(s, h->rate, n, fb, z, h->dev, st, h->sc_scratch.as<cf>());
 		size_t b = mark(h);
-		launch_header(s, n, fb, z, h->dev, st, h->hdr_soft.as<int8_t>());
+		launch_header(s, h->rate, n, fb, z, h->dev, st, h->hdr_soft.as<int8_t>());
 		size_t c = mark(h);
 		h->spans.push_back({ OFDMRX_T_SYNC, a, b });
 		h->spans.push_back({ OFDMRX_T_HEADER, b, c });
@@ -255,13 +260,13 @@ static int run_chunk(ofdmrx_handle *h, FrameBatch fb, int n, const int32_t *d_sk
 		e3 = c;
 	}
 	(void)e2;
-	launch_demod(s, n, fb, z, h->dev, st, h->cons.as<cf>());
+	launch_demod(s, h->rate, n, fb, z, h->dev, st, h->cons.as<cf>());
 	if (h->cfg.flags & 1)
 		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
 	size_t e4 = mark(h);
 	launch_theil_sen(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>());
 	size_t e5 = mark(h);
-	launch_llr(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
+	launch_llr(s, h->rate, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
 		h->llr.as<float>(), d_res);
 	size_t e6 = mark(h);
 	launch_polar(s, n, st, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
@@ -509,7 +514,7 @@ extern "C" int ofdmrx_debug_osd(ofdmrx_handle *h, const int8_t *soft, size_t n, 
 
 extern "C" int ofdmrx_debug_fft(ofdmrx_handle *h, const float *in, size_t n, int len, int sign, float *out)
 {
-	if (!h || !in || !out || !n || (len != 1280 && len != 640) || (sign != 1 && sign != -1))
+	if (!h || !in || !out || !n || (len != rate_symbol_len(h->rate) && len != rate_symbol_len(h->rate) / 2) || (sign != 1 && sign != -1))
 		return OFDMRX_E_ARG;
 	HIP_OK(hipSetDevice(h->cfg.device));
 	DevBuf di, dout;
@@ -518,7 +523,7 @@ extern "C" int ofdmrx_debug_fft(ofdmrx_handle *h, const float *in, size_t n, int
 	r = r ? r : dout.ensure(bytes);
 	if (!r) {
 		hipError_t e = hipMemcpy(di.p, in, bytes, hipMemcpyHostToDevice);
-		launch_fft_debug(h->stream, (int)n, len, sign, di.as<cf>(), dout.as<cf>(), h->dev);
+		launch_fft_debug(h->stream, h->rate, (int)n, len, sign, di.as<cf>(), dout.as<cf>(), h->dev);
 		e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;
 		e = e == hipSuccess ? hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost) : e;
 		if (e != hipSuccess) {
@@ -554,12 +559,12 @@ extern "C" int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_
 	cp.ntaps = ch->ntaps;
 	for (int i = 0; i < 8; ++i) { cp.delays[i] = ch->delays[i]; cp.gre[i] = ch->gains_re[i]; cp.gim[i] = ch->gains_im[i]; }
 	if (cp.ntaps == 0) { cp.ntaps = 1; cp.delays[0] = 0; cp.gre[0] = 1.f; cp.gim[0] = 0.f; }
-	launch_channel(h->stream, d_in, d_out, n_frames, spf, &cp);
+	launch_channel(h->stream, h->rate, d_in, d_out, n_frames, spf, &cp);
 	HIP_OK(hipGetLastError());
 	return 0;
 }
 
-// ---- N2: transmitter on the device (Encoder<value,cmplx,8000>, encode.cc:271-317) -------------------
+// ---- N2: transmitter on the device (Encoder<value,cmplx,rate>, encode.cc:271-317) -------------------
 static long long base37(const char *str)   // encode.cc:320-335
 {
 	long long acc = 0;
@@ -573,13 +578,16 @@ static long long base37(const char *str)   // encode.cc:320-335
 	return acc;
 }
 
-extern "C" long ofdmrx_tx_frame_samples(int oper_mode)
+extern "C" long ofdmrx_frame_samples(int sample_rate, int oper_mode)
 {
-	if (oper_mode < 6 || oper_mode > 13)
+	if (oper_mode < 6 || oper_mode > 13 || !rate_supported(sample_rate))
 		return OFDMRX_E_ARG;
 	ModeDesc md = mode_desc(oper_mode);
-	return 2 * 8000 + (long)(md.rows + 5) * SYM_STRIDE;   // silence + pilot|S&C|meta|pilot|rows|zero + silence
+	const long stride = rate_symbol_len(sample_rate) + rate_symbol_len(sample_rate) / 8;
+	return 2L * sample_rate + (long)(md.rows + 5) * stride;   // silence + pilot|S&C|meta|pilot|rows|zero + silence
 }
+
+extern "C" long ofdmrx_tx_frame_samples(int oper_mode) { return ofdmrx_frame_samples(8000, oper_mode); }
 
 extern "C" int ofdmrx_tx_encode_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_frames, int oper_mode,
 	int freq_off, const char *call_sign, int channels, int16_t *d_pcm)
@@ -595,25 +603,30 @@ extern "C" int ofdmrx_tx_encode_device(ofdmrx_handle *h, const uint8_t *d_payloa
 	struct { int oper_mode, offset, channels, nsym; unsigned long long md; long frame_samples; } tp;
 	ModeDesc md = mode_desc(oper_mode);
 	tp.oper_mode = oper_mode;
-	tp.offset = (freq_off * SYMBOL_LEN) / 8000;           // encode.cc:283
+	const int SL = rate_symbol_len(h->rate);
+	tp.offset = (freq_off * SL) / h->rate;                // encode.cc:283
 	tp.channels = channels;
 	tp.nsym = md.rows + 5;
 	tp.md = ((unsigned long long)cs << 8) | (unsigned)oper_mode;
-	tp.frame_samples = ofdmrx_tx_frame_samples(oper_mode);
-	const size_t chunk = 1024;
-	DevBuf code, tdom;
-	int r = code.ensure(std::min(chunk, n_frames) * 2048 * sizeof(uint32_t));
-	r = r ? r : tdom.ensure(std::min(chunk, n_frames) * (size_t)tp.nsym * SYMBOL_LEN * sizeof(cf));
-	if (r) { code.release(); tdom.release(); return r; }
+	tp.frame_samples = ofdmrx_frame_samples(h->rate, oper_mode);
+	const size_t chunk = h->rate <= 16000 ? 1024 : 128;   // 44.1 / 48 kHz keep the 4x PAPR buffers in global scratch
+	DevBuf code, tdom, big;
+	const size_t nc = std::min(chunk, n_frames);
+	int r = code.ensure(nc * 2048 * sizeof(uint32_t));
+	r = r ? r : tdom.ensure(nc * (size_t)tp.nsym * SL * sizeof(cf));
+	if (tx_big_scratch_bytes(h->rate, (int)nc, tp.nsym))
+		r = r ? r : big.ensure(tx_big_scratch_bytes(h->rate, (int)nc, tp.nsym));
+	if (r) { code.release(); tdom.release(); big.release(); return r; }
 	for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
 		int n = (int)std::min(chunk, n_frames - f0);
-		launch_tx(h->stream, n, d_payload + f0 * PAYLOAD_BYTES, h->dev, &tp, h->dev.tw5120, code.as<uint32_t>(), tdom.as<cf>(),
-			d_pcm + f0 * (size_t)tp.frame_samples * channels);
+		launch_tx(h->stream, h->rate, n, d_payload + f0 * PAYLOAD_BYTES, h->dev, &tp, h->dev.tw_sym4, code.as<uint32_t>(), tdom.as<cf>(),
+			big.as<cf>(), d_pcm + f0 * (size_t)tp.frame_samples * channels);
 	}
 	hipError_t e = hipGetLastError();
 	e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;   // scratch is freed below
 	code.release();
 	tdom.release();
+	big.release();
 	if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return OFDMRX_E_HIP; }
 	return 0;
 }

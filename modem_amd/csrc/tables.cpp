@@ -110,31 +110,38 @@ static double kaiser(double a, int n, int N)
 	return bessel_i0(M_PI * a * std::sqrt(1.0 - t * t)) / bessel_i0(M_PI * a);
 }
 
-void build_tables(HostTables &t)
+void build_tables(HostTables &t, int rate)
 {
-	t.tw1280.resize(1280);
-	for (int k = 0; k < 1280; ++k) {
-		double a = -2.0 * M_PI * k / 1280.0;
-		t.tw1280[k].re = (float)std::cos(a);
-		t.tw1280[k].im = (float)std::sin(a);
-	}
-	// decode.cc:236-244 mls0_seq + decode.cc:80-82: kern = conj(FFT640(seq))/640
+	const int SL = rate_symbol_len(rate), HS = SL / 2;
+	auto roots = [](std::vector<cf> &v, int n) {
+		v.resize(n);
+		for (int k = 0; k < n; ++k) {
+			double a = -2.0 * M_PI * k / (double)n;
+			v[k].re = (float)std::cos(a);
+			v[k].im = (float)std::sin(a);
+		}
+	};
+	roots(t.tw_sym, SL);
+	roots(t.tw_sym4, 4 * SL);
+	// decode.cc:236-244 mls0_seq + decode.cc:80-82: kern = conj(FFT_{symbol_len/2}(seq)) / (symbol_len/2)
 	{
-		std::vector<double> seq(640, 0.0);
+		std::vector<double> seq(HS, 0.0);
 		Mls m0(0x89);
 		const int mls0_off = -127 + 1;
 		for (int i = 0; i < 127; ++i)
-			seq[(i + mls0_off / 2 + 640) % 640] = 1 - 2 * m0.next();
-		t.sc_kern.resize(640);
-		for (int k = 0; k < 640; ++k) {
+			seq[(i + mls0_off / 2 + HS) % HS] = 1 - 2 * m0.next();
+		t.sc_kern.resize(HS);
+		for (int k = 0; k < HS; ++k) {
 			double re = 0, im = 0;
-			for (int n = 0; n < 640; ++n) {
-				double a = -2.0 * M_PI * ((long)k * n % 640) / 640.0;
+			for (int n = 0; n < HS; ++n) {
+				if (seq[n] == 0.0)
+					continue;
+				double a = -2.0 * M_PI * ((long)k * n % HS) / (double)HS;
 				re += seq[n] * std::cos(a);
 				im += seq[n] * std::sin(a);
 			}
-			t.sc_kern[k].re = (float)(re / 640.0);
-			t.sc_kern[k].im = (float)(-im / 640.0);
+			t.sc_kern[k].re = (float)(re / (double)HS);
+			t.sc_kern[k].im = (float)(-im / (double)HS);
 		}
 	}
 	{
@@ -151,12 +158,6 @@ void build_tables(HostTables &t)
 		t.mls2_nrz.resize(512);
 		for (int i = 0; i < 512; ++i)
 			t.mls2_nrz[i] = (float)(1 - 2 * m2.next());
-		t.tw5120.resize(5120);
-		for (int k = 0; k < 5120; ++k) {
-			double a = -2.0 * M_PI * k / 5120.0;
-			t.tw5120[k].re = (float)std::cos(a);
-			t.tw5120[k].im = (float)std::sin(a);
-		}
 	}
 	t.frozen.resize(2 * 2048);
 	frozen_mask(t.frozen.data(), 64800);
@@ -199,13 +200,15 @@ void build_tables(HostTables &t)
 			t.scramble[i] = (uint8_t)y;
 		}
 	}
-	// BlockDC::samples(2*(1280+160)) decode.cc:386 ; Hilbert<cmplx,21> decode.cc:193
-	const float s = 2880.f;
+	// BlockDC::samples(2*(symbol_len+guard_len)) decode.cc:386 ; Hilbert<cmplx,filter_len> decode.cc:172,193
+	const float s = (float)(2 * (SL + SL / 8));
 	t.front.dc_a = (s - 1.f) / s;
 	t.front.dc_b = (1.f + t.front.dc_a) / 2.f;
-	const int TAPS = 21;
+	const int TAPS = rate_filter_len(rate);
 	t.front.reco = (float)kaiser(2.0, (TAPS - 1) / 2, TAPS);
-	for (int i = 0; i < 5; ++i)
+	for (int i = 0; i < 32; ++i)
+		t.front.imco[i] = 0.f;
+	for (int i = 0; i < (TAPS - 1) / 4; ++i)
 		t.front.imco[i] = (float)(kaiser(2.0, (2 * i + 1) + (TAPS - 1) / 2, TAPS) * 2.0 / ((2 * i + 1) * M_PI));
 }
 

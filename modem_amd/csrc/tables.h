@@ -7,7 +7,7 @@
 namespace rx {
 
 struct HostTables {
-	std::vector<cf> tw1280, sc_kern, tw5120;
+	std::vector<cf> tw_sym, sc_kern, tw_sym4;   // symbol_len roots, S&C kernel (symbol_len/2), 4*symbol_len roots
 	std::vector<float> mls1_nrz, mls0_nrz, mls2_nrz;
 	std::vector<uint32_t> frozen, genmat_bits, crc32_tab;
 	std::vector<uint16_t> info_pos;
@@ -15,6 +15,6 @@ struct HostTables {
 	FrontCoef front;
 };
 
-void build_tables(HostTables &t);
+void build_tables(HostTables &t, int rate);
 
 }  // namespace rx

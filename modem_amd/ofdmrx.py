@@ -22,7 +22,8 @@ EXPORTS = [
     "ofdmrx_abi_version", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
     "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames",
     "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
-    "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_tx_frame_samples", "ofdmrx_tx_encode_device",
+    "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
+    "ofdmrx_tx_encode_device",
 ]
 
 
@@ -115,6 +116,8 @@ def load_library():
     L.ofdmrx_util_channel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(Channel)]
     L.ofdmrx_tx_frame_samples.restype = C.c_long
     L.ofdmrx_tx_frame_samples.argtypes = [C.c_int]
+    L.ofdmrx_frame_samples.restype = C.c_long
+    L.ofdmrx_frame_samples.argtypes = [C.c_int, C.c_int]
     L.ofdmrx_tx_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
     _LIB = L
     return L
@@ -135,11 +138,13 @@ class Receiver:
     DSP::ReadWAV would deliver) and returns (payload[n_frames, 5380] uint8, results structured array).
     """
 
-    def __init__(self, device=0, chunk_frames=0, max_samples=0, descramble=True, keep_raw_cons=False, stream=None):
+    def __init__(self, device=0, chunk_frames=0, max_samples=0, descramble=True, keep_raw_cons=False, stream=None,
+                 sample_rate=8000):
         self._lib = load_library()
         if self._lib.ofdmrx_abi_version() != 1:
             raise OfdmRxError("ABI mismatch")
-        cfg = Config(1, 8000, 8, device, chunk_frames, max_samples, 1 if descramble else 0,
+        self.sample_rate = int(sample_rate)
+        cfg = Config(1, self.sample_rate, 8, device, chunk_frames, max_samples, 1 if descramble else 0,
                      1 if keep_raw_cons else 0, stream)
         self._h = C.c_void_p()
         self._check(self._lib.ofdmrx_create(C.byref(cfg), C.byref(self._h)))
@@ -253,7 +258,7 @@ class Receiver:
         self._check(self._lib.ofdmrx_util_channel(self._h, d_in, d_out, n, spf, C.byref(ch)))
 
     def tx_frame_samples(self, mode=6):
-        return int(self._lib.ofdmrx_tx_frame_samples(mode))
+        return int(self._lib.ofdmrx_frame_samples(self.sample_rate, mode))
 
     def tx_encode(self, d_payload, n, d_pcm, mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=2):
         """device transmitter: n x 5380 payload bytes -> n x tx_frame_samples(mode) x channels int16 (device pointers)"""

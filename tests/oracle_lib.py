@@ -60,6 +60,13 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.orc_encode_pcm.restype = C.c_size_t
         L.orc_encode_pcm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.orc_encode_pcm_rate.restype = C.c_size_t
+        L.orc_encode_pcm_rate.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.orc_frame_samples.restype = C.c_size_t
+        L.orc_frame_samples.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_decode_rate.restype = C.c_int
+        L.orc_decode_rate.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.POINTER(Result), C.POINTER(Taps)]
         L.orc_decode.restype = C.c_int
         L.orc_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.POINTER(Result), C.POINTER(Taps)]
@@ -119,16 +126,15 @@ def frame_len(count=1, rows=50):
     return 2 * 8000 + (2 + count * (3 + rows)) * 1440
 
 
-def encode_pcm(payload, bits=16, channels=1, freq_off=2000, call_sign="ANONYMOUS", mode=6):
-    """orc_encode_pcm -> numpy int16/uint8 array of shape [samples, channels]"""
+def encode_pcm(payload, bits=16, channels=1, freq_off=2000, call_sign="ANONYMOUS", mode=6, rate=8000):
+    """orc_encode_pcm_rate -> numpy int16/uint8 array of shape [samples, channels]"""
     payload = np.ascontiguousarray(payload, dtype=np.uint8)
     count = payload.size // DATA_BYTES
-    m = Mode()
-    assert lib().orc_mode_lookup(mode, C.byref(m))
-    n = frame_len(count, m.cons_rows)
+    n = int(lib().orc_frame_samples(rate, mode, count))
+    assert n > 0
     out = np.zeros((n, channels), dtype=np.int16 if bits == 16 else np.uint8)
-    got = lib().orc_encode_pcm(ptr(out), bits, channels, ptr(payload), count, freq_off,
-                               call_sign.encode(), mode)
+    got = lib().orc_encode_pcm_rate(rate, ptr(out), bits, channels, ptr(payload), count, freq_off,
+                                    call_sign.encode(), mode)
     assert got == n, (got, n)
     return out
 
@@ -166,16 +172,16 @@ class TapBuffers:
         self.c = Taps(*[ptr(getattr(self, n)) for n, _ in Taps._fields_])
 
 
-def decode(pcm, skip=0, list_size=8, descramble=1, taps=False):
-    """orc_decode on a [samples, channels] int16/uint8/float32 array"""
+def decode(pcm, skip=0, list_size=8, descramble=1, taps=False, rate=8000):
+    """orc_decode_rate on a [samples, channels] int16/uint8/float32 array"""
     pcm = np.ascontiguousarray(pcm)
     fmt = {np.dtype(np.int16): FMT_S16, np.dtype(np.uint8): FMT_U8, np.dtype(np.float32): FMT_F32}[pcm.dtype]
     channels = pcm.shape[1] if pcm.ndim == 2 else 1
     out = np.zeros(DATA_BYTES, np.uint8)
     res = Result()
     tb = TapBuffers() if taps else None
-    lib().orc_decode(ptr(pcm), fmt, channels, pcm.shape[0], skip, list_size, descramble, ptr(out),
-                     C.byref(res), C.byref(tb.c) if tb else None)
+    lib().orc_decode_rate(rate, ptr(pcm), fmt, channels, pcm.shape[0], skip, list_size, descramble, ptr(out),
+                          C.byref(res), C.byref(tb.c) if tb else None)
     return (out, res, tb) if taps else (out, res)
 
 
@@ -184,7 +190,7 @@ def frozen(table=0):
     return np.ctypeslib.as_array(p, shape=(2048,)).copy()
 
 
-def impair(pcm2, noise_db=None, cfo_hz=0.0, sfo_ppm=0.0, multipath=None, seed=1, frame=0, bits=16):
+def impair(pcm2, noise_db=None, cfo_hz=0.0, sfo_ppm=0.0, multipath=None, seed=1, frame=0, bits=16, rate=8000):
     """2-channel analytic stream -> impairment chain (build-owned models) -> re-quantised"""
     z = pcm_to_cf(pcm2)
     n = z.shape[0]
@@ -195,7 +201,7 @@ def impair(pcm2, noise_db=None, cfo_hz=0.0, sfo_ppm=0.0, multipath=None, seed=1,
         lib().orc_chan_multipath(ptr(o), ptr(z), n, ptr(delays), ptr(gains), len(multipath))
         z = o
     if cfo_hz:
-        lib().orc_chan_cfo(ptr(z), n, cfo_hz, 8000)
+        lib().orc_chan_cfo(ptr(z), n, cfo_hz, rate)
     if sfo_ppm:
         o = np.zeros_like(z)
         lib().orc_chan_sfo(ptr(o), ptr(z), n, sfo_ppm)

@@ -70,8 +70,15 @@ def test_argument_validation_without_device(lib):
     import modem_amd.ofdmrx as M
     cfg = M.Config(2, 8000, 8, 0, 0, 0, 1, 0, None)      # wrong ABI version
     assert lib.ofdmrx_create(C.byref(cfg), C.byref(h)) == -1
-    cfg = M.Config(1, 48000, 8, 0, 0, 0, 1, 0, None)     # decode.cc:599-601 rate this build does not cover
+    cfg = M.Config(1, 22050, 8, 0, 0, 0, 1, 0, None)     # decode.cc:603-605 "Unsupported sample rate."
     assert lib.ofdmrx_create(C.byref(cfg), C.byref(h)) == -5
+    cfg = M.Config(1, 48000, 4, 0, 0, 0, 1, 0, None)     # list size 4 (the non-AVX2 build, decode.cc:168) not covered
+    assert lib.ofdmrx_create(C.byref(cfg), C.byref(h)) == -5
+    # frame lengths: 2 x rate silence + (rows + 5) symbols of symbol_len + guard_len (encode.cc:423,441)
+    lib.ofdmrx_frame_samples.restype = C.c_long
+    assert lib.ofdmrx_frame_samples(8000, 6) == 95200 and lib.ofdmrx_tx_frame_samples(6) == 95200
+    assert lib.ofdmrx_frame_samples(48000, 6) == 571200 and lib.ofdmrx_frame_samples(44100, 13) == 1128078
+    assert lib.ofdmrx_frame_samples(22050, 6) == -1 and lib.ofdmrx_frame_samples(8000, 5) == -1
 
 
 def test_product_does_not_reference_the_oracle():
@@ -93,9 +100,10 @@ def test_host_tables_match_oracle_constants(lib):
     exe_src = r'''
 #include "tables.h"
 #include <cstdio>
-int main(){ rx::HostTables t; rx::build_tables(t);
+int main(){ rx::HostTables t; rx::build_tables(t, 48000);
   fwrite(t.frozen.data(),4,2048,stdout); fwrite(t.genmat_bits.data(),4,71*8,stdout);
-  fwrite(t.scramble.data(),1,5380,stdout); fwrite(t.crc32_tab.data(),4,256,stdout); return 0; }
+  fwrite(t.scramble.data(),1,5380,stdout); fwrite(t.crc32_tab.data(),4,256,stdout);
+  fwrite(&t.front.reco,4,1,stdout); fwrite(t.front.imco,4,32,stdout); return 0; }
 '''
     import tempfile
     d = tempfile.mkdtemp()
@@ -115,7 +123,12 @@ int main(){ rx::HostTables t; rx::build_tables(t);
     z = np.zeros(5380, np.uint8)
     O.lib().orc_scramble(O.ptr(z), 5380)
     assert (scr == z).all()
-    tab = np.frombuffer(raw[8192 + 71 * 32 + 5380:], np.uint32)
+    tab = np.frombuffer(raw[8192 + 71 * 32 + 5380:8192 + 71 * 32 + 5380 + 1024], np.uint32)
+    # Hilbert<cmplx, 125> taps of the 48 kHz instantiation (decode.cc:172,193)
+    hil = np.frombuffer(raw[8192 + 71 * 32 + 5380 + 1024:], np.float32)
+    reco, imco = np.zeros(1, np.float32), np.zeros(32, np.float32)
+    O.lib().orc_hilbert_coeffs_n(125, O.ptr(reco), O.ptr(imco))
+    assert hil[0] == reco[0] and (hil[1:33] == imco).all() and imco[30] != 0 and imco[31] == 0
     data = O.payload_for(1)
     crc = 0
     for b in data[:64]:

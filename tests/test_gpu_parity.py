@@ -437,3 +437,94 @@ def test_device_transmitter_matches_oracle_encoder(rx, mode, channels, freq):
     assert (res["status"] == 0).all() and (out == pays).all() and (res["oper_mode"] == mode).all()
     o, r = O.decode(got[1])
     assert r.status == 0 and (o == pays[1]).all() and r.call_sign == O.lib().orc_base37_encode(b"GPU TX")
+
+
+# ---------------------------------------------------------------- N4: the other three sample rates
+RATES = [16000, 44100, 48000]
+
+
+@pytest.fixture(scope="module", params=RATES)
+def rx_rate(request):
+    import modem_amd
+    r = modem_amd.Receiver(device=0, chunk_frames=8, keep_raw_cons=True, sample_rate=request.param)
+    yield r
+    r.close()
+
+
+def test_other_rates_fft(rx_rate):
+    """DSP::FastFourierTransform<symbol_len | symbol_len/2> at 16 / 44.1 / 48 kHz (decode.cc:171,191,196):
+    2560|1280, 7056|3528 (radix 7.7.3.3.4.4), 7680|3840 points, both directions, vs a double DFT and the oracle"""
+    sl = 1280 * rx_rate.sample_rate // 8000
+    for n in (sl, sl // 2):
+        rng = np.random.default_rng(n)
+        x = (rng.normal(size=(3, n)) + 1j * rng.normal(size=(3, n))).astype(np.complex64)
+        x[2] = 0
+        x[2, 5] = 1
+        for sign in (-1, 1):
+            y = rx_rate.fft(x, sign)
+            ref = np.fft.fft(x.astype(np.complex128), axis=1) if sign < 0 else np.fft.ifft(x.astype(np.complex128), axis=1) * n
+            for r in range(3):
+                assert np.abs(y[r] - ref[r]).max() <= REL * np.abs(ref[r]).max(), (n, sign, r)
+            o = np.zeros(n, np.complex64)
+            O.lib().orc_fft(O.ptr(o), O.ptr(x[0]), n, sign)
+            assert np.abs(y[0] - o).max() <= REL * np.abs(o).max()
+
+
+@pytest.mark.parametrize("mode,channels,freq,noise", [(6, 2, 2000, -30), (6, 1, 1500, None), (12, 2, -1000, -28), (10, 1, 1700, None)])
+def test_other_rates_decode_matches_oracle(rx_rate, mode, channels, freq, noise):
+    """N4: Decoder<value,cmplx,16000|44100|48000> (decode.cc:590-602): longer symbols / guards / Hilbert filters /
+    search windows, same carriers.  Bit-exact payload, sync decisions and header fields vs the oracle at that
+    rate; fp32 intermediates within 1e-5."""
+    import ctypes as C
+    rate = rx_rate.sample_rate
+    m = O.Mode()
+    assert O.lib().orc_mode_lookup(mode, C.byref(m))
+    p = O.payload_for(900 + mode + rate // 1000)
+    pcm = O.encode_pcm(p, channels=channels, freq_off=freq, call_sign="RATE%d" % (rate // 1000), mode=mode, rate=rate)
+    assert pcm.shape[0] == rx_rate.tx_frame_samples(mode)
+    if noise is not None:
+        pcm = O.impair(pcm, noise_db=noise, cfo_hz=12.5, seed=rate, frame=mode, rate=rate)
+    out, res = rx_rate.decode(pcm[None])
+    oout, ores, tb = O.decode(pcm, taps=True, rate=rate)
+    r = res[0]
+    assert ores.status == 0 and int(r["status"]) == 0 and int(r["oper_mode"]) == mode
+    assert (out[0] == p).all() and (out[0] == oout).all()
+    assert int(r["sc_start"]) == ores.sc_start and int(r["symbol_pos"]) == ores.symbol_pos
+    assert int(r["call_sign"]) == ores.call_sign and int(r["bit_flips"]) == ores.bit_flips
+    assert int(r["best_lane"]) == ores.best_lane
+    assert abs(float(r["cfo_rad"]) - ores.cfo_rad) <= 2e-7
+    _close(rx_rate.tap("CONS_RAW", 0, cons_cnt=m.cons_cnt), tb.cons_raw[:m.cons_cnt], what="cons_raw")
+    _close(rx_rate.tap("CONS_ROT", 0, cons_cnt=m.cons_cnt), tb.cons_rot[:m.cons_cnt], what="cons_rot")
+    _close(rx_rate.tap("PRECISION", 0, rows=m.cons_rows), tb.precision[:m.cons_rows], what="precision")
+    _close(rx_rate.tap("LLR", 0)[:m.cons_bits], tb.llr[:m.cons_bits], what="llr")
+
+
+def test_other_rates_device_transmitter(rx_rate):
+    """N2 at 16 / 44.1 / 48 kHz: Encoder<value,cmplx,rate> on the device (4x PAPR buffers of 10240 / 28224 / 30720
+    points) within +-1 LSB of the oracle encoder; decodes on both sides"""
+    import torch
+    dev = torch.device("cuda:0")
+    rate = rx_rate.sample_rate
+    for mode, channels, freq in ((6, 2, 2000), (9, 1, 1400)):
+        pays = np.stack([O.payload_for(950 + mode + i) for i in range(2)])
+        spf = rx_rate.tx_frame_samples(mode)
+        d_pay = torch.from_numpy(pays).to(dev)
+        d_pcm = torch.zeros((2, spf, channels), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        rx_rate.tx_encode(d_pay.data_ptr(), 2, d_pcm.data_ptr(), mode=mode, freq_off=freq, call_sign="TX RATE", channels=channels)
+        rx_rate.synchronize()
+        got = d_pcm.cpu().numpy()
+        ref = O.encode_pcm(pays[1], channels=channels, freq_off=freq, call_sign="TX RATE", mode=mode, rate=rate)
+        assert ref.shape == got[1].shape
+        diff = np.abs(got[1].astype(np.int32) - ref.astype(np.int32))
+        assert diff.max() <= 1, (rate, mode, diff.max(), np.argmax(diff.max(axis=1)))
+        assert (diff > 0).mean() < 0.05
+        out, res = rx_rate.decode(got)
+        assert (res["status"] == 0).all() and (out == pays).all()
+
+
+def test_unsupported_rate_is_refused():
+    """decode.cc:603-605 'Unsupported sample rate.'"""
+    import modem_amd
+    with pytest.raises(modem_amd.OfdmRxError):
+        modem_amd.Receiver(device=0, sample_rate=22050)

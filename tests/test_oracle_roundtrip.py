@@ -69,3 +69,18 @@ def test_failure_statuses():
     y[s + 10 * 1440: s + 40 * 1440] = 0
     out, res = O.decode(y)
     assert res.status == 6 and res.oper_mode == 6 and not out.any()
+
+
+@pytest.mark.parametrize("rate,mode,channels,bits", [(16000, 6, 1, 16), (16000, 13, 2, 16), (44100, 6, 2, 16),
+                                                      (44100, 9, 1, 8), (48000, 6, 1, 16), (48000, 10, 2, 16)])
+def test_round_trip_other_sample_rates(rate, mode, channels, bits):
+    """encode.cc:424-436 / decode.cc:590-602: the 16 / 44.1 / 48 kHz instantiations (symbol_len 2560 / 7056 / 7680,
+    Hilbert 41 / 113 / 125 taps) round-trip like README.md:4-40"""
+    p = O.payload_for(rate + mode)
+    pcm = O.encode_pcm(p, bits=bits, channels=channels, freq_off=1500, mode=mode, rate=rate)
+    sl = 1280 * rate // 8000
+    assert (pcm.shape[0] - 2 * rate) % (sl + sl // 8) == 0
+    out, res = O.decode(pcm, rate=rate)
+    assert res.status == 0 and res.oper_mode == mode and (out == p).all() and res.bit_flips == 0
+    # coarse CFO = the frequency offset in rad/sample at this rate (decode.cc:401)
+    assert abs(res.cfo_rad * rate / (2 * np.pi) - 1500) < 1.0
