@@ -319,6 +319,12 @@ def test_decode_cli_is_a_drop_in(tmp_path):
     subprocess.check_call([enc, str(wav), "8000", "8", "1", "2000", "6", "ANONYMOUS", str(a)])
     r = subprocess.run([exe, "-", "-"], stdin=open(wav, "rb"), capture_output=True)
     assert r.returncode == 0 and r.stdout == a.read_bytes()
+    # the other rates main() dispatches on (decode.cc:590-602), mono and analytic
+    for rate, ch, mode in ((16000, 1, 7), (44100, 2, 6), (48000, 1, 13)):
+        subprocess.check_call([enc, str(wav), str(rate), "16", str(ch), "1500", str(mode), "RATES", str(b)])
+        r = subprocess.run([exe, str(out), str(wav)], capture_output=True, text=True)
+        assert r.returncode == 0 and out.read_bytes() == b.read_bytes(), (rate, r.stderr)
+        assert "coarse cfo: 1500 Hz" in r.stderr and "oper mode: %d" % mode in r.stderr
 
 
 def test_config4_full_impairments_at_scale(rx):
