@@ -24,10 +24,13 @@
 
 namespace rx {
 
+// three VALU: v_xor, v_med3_f32 with |.| modifiers (median of (|a|, |b|, 0) = the smaller magnitude; unlike
+// fminf no canonicalising v_max is emitted), v_and_or.  A zero result may carry a minus sign; no consumer can tell.
 __device__ __forceinline__ float f_minsum(float a, float b)
 {
-	float m = fminf(fabsf(a), fabsf(b));
-	return ((a < 0.f) != (b < 0.f)) ? -m : m;
+	const uint32_t sgn = (__float_as_uint(a) ^ __float_as_uint(b)) & 0x80000000u;
+	const float m = __builtin_amdgcn_fmed3f(fabsf(a), fabsf(b), 0.f);
+	return __uint_as_float(sgn | __float_as_uint(m));
 }
 __device__ __forceinline__ float g_add(float a, float b, int u) { return u ? b - a : a + b; }
 
@@ -51,20 +54,24 @@ template <int ZZ> __device__ __forceinline__ float xj(float v, int lane)
 	i = ZZ == 0 ? xor8_i(i) : (ZZ == 1 ? xor16_i(i, lane) : xor32_i(i, lane));
 	return __int_as_float(i);
 }
-// min / max over the 8 paths (lanes k = 0..7 of a group); result in every lane
-__device__ __forceinline__ float group8_min(float v)
+// min / max over the 8 paths (lanes k = 0..7 of a group); result in every lane.  Path metrics are
+// non-negative floats, so their bit patterns order like unsigned integers: v_min_u32 / v_max_u32 fuse with the
+// DPP operand (one instruction per step) where the float forms need a canonicalising v_max each.
+__device__ __forceinline__ float group8_min(float vf)
 {
-	v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
-	v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
-	v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
-	return v;
+	uint32_t v = __float_as_uint(vf);
+	v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+	v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+	v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+	return __uint_as_float(v);
 }
-__device__ __forceinline__ float group8_max(float v)
+__device__ __forceinline__ float group8_max(float vf)
 {
-	v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));
-	v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));
-	v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));
-	return v;
+	uint32_t v = __float_as_uint(vf);
+	v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
+	v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
+	v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
+	return __uint_as_float(v);
 }
 
 constexpr uint32_t ID0 = 0x09249249u;   // 10 fields of 3 bits, each = 1
@@ -87,7 +94,10 @@ struct Maps {
 };
 
 constexpr int UB = 8;      // iterations batched per pass so that 2*UB loads are in flight per lane
-constexpr int LDS_TOP = 7; // tree levels 4..7 (sub-trees of <= 128 leaves) live in LDS
+#ifndef POLAR_LDS_TOP
+#define POLAR_LDS_TOP 7
+#endif
+constexpr int LDS_TOP = POLAR_LDS_TOP; // tree levels 4..7 (sub-trees of <= 128 leaves) live in LDS
 
 // One pass of the tree: level m (2^m positions x 8 paths) from level m+1.
 //   G = false: left child  f(a, b)
@@ -131,16 +141,36 @@ __device__ __forceinline__ void tree_pass(const float *src, float *dst, const ui
 // Address spaces are compile-time: the NG highest produced levels (and the source iff SRC_G) are
 // in global memory (gs = base of the codeword's soft array), the rest in LDS (ls); flat
 // addressing would serialise the two memory pipes.  Level L starts at element 8 << L in either.
+// Global accesses are raw buffer loads / stores: one per-lane byte offset in a VGPR (lane * 4, or the mapped
+// lane for the g step), everything else (level base, column, partner distance) in the scalar offset - so 24
+// loads in flight cost 24 data registers and no 64-bit address pairs.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, int bytes)
+{
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+__device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0); }
+__device__ __forceinline__ int bload_u8(rsrc_t r, int voff, int soff) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0); }
+
+struct PolarBufs {
+	rsrc_t soft, llr, hard;    // this codeword's 2 MiB level store, its 65536 channel LLRs, its 65536 partial-sum bytes
+};
+
 template <int D, int KIND, int NG, bool SRC_G>
-__device__ __forceinline__ void fused_pass(const float *__restrict__ llr, float *__restrict__ gs, float *ls,
-	const uint8_t *__restrict__ hb_g, const uint8_t *hb_l, int m, int lane, int gl)
+__device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int hb_g_off, const uint8_t *hb_l, int m, int lane, int gl)
 {
 	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
-	constexpr int XB = D == 3 ? 3 : (D == 2 ? 4 : 8);   // columns batched: 24 loads in flight (4 -> 256 VGPRs)
+#ifndef POLAR_XB3
+#define POLAR_XB3 3
+#endif
+	constexpr int XB = D == 3 ? POLAR_XB3 : (D == 2 ? 4 : 8);   // columns batched: XB * 2 * NT loads in flight
 	const int S = 1 << (m - D + 1 - 3);       // local indices at the lowest produced level
 	const int half = 1 << (m - 3);            // partner distance (local) at level m+1
 	const int j = lane >> 3, k = lane & 7;
-	const float *src = SRC_G ? gs + (8 << (m + 1)) : ls + (8 << (m + 1));
+	const float *src_l = ls + (8 << (m + 1));
+	const int src_off = (8 << (m + 1)) * 4;   // byte offset of level m+1 in the level store
+	const int vo_lane = lane * 4, vo_src = (KIND == 1 ? gl : lane) * 4, vo_j = j * 4;
 	#pragma unroll 1
 	for (int x0 = 0; x0 < S; x0 += XB) {
 		float a[XB][NT], b[XB][NT];
@@ -152,15 +182,18 @@ __device__ __forceinline__ void fused_pass(const float *__restrict__ llr, float 
 				if (x0 + xb < S) {
 					const int x = x0 + xb + s2 * S;
 					if (KIND >= 2) {
-						a[xb][s2] = llr[x * 8 + j];
-						b[xb][s2] = llr[(x + half) * 8 + j];
+						a[xb][s2] = bload(pb.llr, vo_j, x * 32);
+						b[xb][s2] = bload(pb.llr, vo_j, (x + half) * 32);
+					} else if (SRC_G) {
+						a[xb][s2] = bload(pb.soft, vo_src, src_off + x * 256);
+						b[xb][s2] = bload(pb.soft, vo_src, src_off + (x + half) * 256);
 					} else {
 						const int o = KIND == 1 ? gl : lane;
-						a[xb][s2] = src[x * 64 + o];
-						b[xb][s2] = src[(x + half) * 64 + o];
+						a[xb][s2] = src_l[x * 64 + o];
+						b[xb][s2] = src_l[(x + half) * 64 + o];
 					}
 					if (KIND & 1)
-						h[xb][s2] = (SRC_G || KIND == 3) ? hb_g[x * 8 + j] : hb_l[x * 8 + j];
+						h[xb][s2] = (SRC_G || KIND == 3) ? bload_u8(pb.hard, j, hb_g_off + x * 8) : hb_l[x * 8 + j];
 				}
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
@@ -169,8 +202,8 @@ __device__ __forceinline__ void fused_pass(const float *__restrict__ llr, float 
 				#pragma unroll
 				for (int s2 = 0; s2 < NT; ++s2) {
 					v[s2] = (KIND & 1) ? g_add(a[xb][s2], b[xb][s2], (h[xb][s2] >> k) & 1) : f_minsum(a[xb][s2], b[xb][s2]);
-					const int idx = (8 << m) + (x0 + xb + s2 * S) * 64 + lane;
-					if (NG > 0) gs[idx] = v[s2]; else ls[idx] = v[s2];
+					const int idx = (8 << m) + (x0 + xb + s2 * S) * 64;
+					if (NG > 0) bstore(pb.soft, vo_lane, idx * 4, v[s2]); else ls[idx + lane] = v[s2];
 				}
 				#pragma unroll
 				for (int d = 1; d < D; ++d) {
@@ -178,8 +211,8 @@ __device__ __forceinline__ void fused_pass(const float *__restrict__ llr, float 
 					#pragma unroll
 					for (int s2 = 0; s2 < n; ++s2) {
 						v[s2] = f_minsum(v[s2], v[s2 + n]);
-						const int idx = (8 << (m - d)) + (x0 + xb + s2 * S) * 64 + lane;
-						if (NG > d) gs[idx] = v[s2]; else ls[idx] = v[s2];
+						const int idx = (8 << (m - d)) + (x0 + xb + s2 * S) * 64;
+						if (NG > d) bstore(pb.soft, vo_lane, idx * 4, v[s2]); else ls[idx + lane] = v[s2];
 					}
 				}
 			}
@@ -198,27 +231,33 @@ __global__ __launch_bounds__(64) void k_polar(const SyncState *__restrict__ st_a
 	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;
 	__shared__ float ls[8 << (LDS_TOP + 1)];                  // level m <= 7 at ls + 8*2^m
 	__shared__ __attribute__((aligned(8))) uint8_t lh[1 << LDS_TOP];   // partial sums of the current 128-leaf sub-tree
+	PolarBufs pb;
+	pb.soft = make_rsrc(soft, 8 * CODE_LEN * 4);
+	pb.llr = make_rsrc(llr, CODE_LEN * 4);
+	pb.hard = make_rsrc(hard, CODE_LEN);
 	float M = k ? 1000.f : 0.f;                               // lane 0 carries the only real path
 	Maps A;
 	A.w0 = ID0 * (uint32_t)k;
 	A.w1 = ID1 * (uint32_t)k;
 	float r3 = 0.f, r2 = 0.f, r1 = 0.f, r0 = 0.f;
-	const int tmask = 0;
-	(void)tmask;
+#ifdef POLAR_STATS
+	int stat_r1 = 0, stat_r1_ok = 0;
+#endif
 
 	for (int t8 = 0; t8 < CODE_LEN / 8; ++t8) {
 		const int t = t8 * 8;
 		// ---------------- LLRs of this 8-leaf sub-tree into r3
 		{
 			int cur, kind;                                    // next level to produce and how its first step works
-			const uint8_t *ho_g = hard, *ho_l = lh;
+			int ho_g = 0;
+			const uint8_t *ho_l = lh;
 			int gl = lane;
 			if (t == 0) {
 				cur = 15; kind = 2;
 			} else {
 				const int z = __builtin_ctz(t);               // right child of the level-(z+1) node starts here
 				gl = (j << 3) | A.get(z + 1);
-				ho_g = hard + (t - (1 << z));                 // left child's partial sums: global for sub-trees >= 128 leaves,
+				ho_g = t - (1 << z);                          // left child's partial sums: global for sub-trees >= 128 leaves,
 				ho_l = lh + ((t - (1 << z)) & ((1 << LDS_TOP) - 1));   // else inside the current LDS block
 				cur = z; kind = z == 15 ? 3 : 1;
 			}
@@ -227,15 +266,16 @@ __global__ __launch_bounds__(64) void k_polar(const SyncState *__restrict__ st_a
 				r3 = g_add(a, b, (ho_l[j] >> k) & 1);
 			} else {
 				while (cur >= 4) {
-					#define FP(DD, KK, NGG, SG) fused_pass<DD, KK, NGG, SG>(llr, soft, ls, ho_g, ho_l, cur, lane, gl)
+					#define FP(DD, KK, NGG, SG) fused_pass<DD, KK, NGG, SG>(pb, ls, ho_g, ho_l, cur, lane, gl)
 					#define FPK(DD, NGG, SG) do { if (kind == 0) FP(DD, 0, NGG, SG); else FP(DD, 1, NGG, SG); } while (0)
 					int D = 3;
+					// NG = produced levels that are above LDS_TOP (global); SRC_G = the source level cur+1 is global
 					if (cur == 15) { if (kind == 2) FP(3, 2, 3, true); else FP(3, 3, 3, true); }
-					else if (cur >= 10) FPK(3, 3, true);
-					else if (cur == 9) FPK(3, 2, true);
-					else if (cur == 8) FPK(3, 1, true);
-					else if (cur == 7) FPK(3, 0, true);
-					else if (cur == 6) FPK(3, 0, false);
+					else if (cur >= LDS_TOP + 3) FPK(3, 3, true);
+					else if (cur == LDS_TOP + 2) FPK(3, 2, true);
+					else if (cur == LDS_TOP + 1) FPK(3, 1, true);
+					else if (cur == LDS_TOP) FPK(3, 0, true);
+					else if (cur >= 6) FPK(3, 0, false);
 					else if (cur == 5) { FPK(2, 0, false); D = 2; }
 					else { FPK(1, 0, false); D = 1; }
 					#undef FPK
@@ -250,6 +290,31 @@ __global__ __launch_bounds__(64) void k_polar(const SyncState *__restrict__ st_a
 		const uint32_t fz = (frozen[t >> 5] >> (t & 31)) & 0xffu;
 		// H: partial sums of the 8 leaves, one bit per position, for THIS lane's path (same in all j)
 		int H = 0;
+		// ---------------- rate-1 sub-tree (8 information leaves) in one step, when it is provably the same:
+		// if the list is sorted and max_k M_k < min_k (M_k + mu_k), mu_k = min_j |r3_j| of path k, then EVERY
+		// leaf of this sub-tree takes the stable-list fast path below (min-sum leaf magnitudes never drop
+		// under mu_k: f keeps the smaller input magnitude, and g adds two same-signed terms once the left
+		// decisions are the sign decisions), so no metric changes, no path is replaced, and the sub-tree's
+		// partial sums are the sign bits of r3 (u = hard decisions <=> x = hard(r3)).  Bit-identical to the
+		// leaf-by-leaf walk, just without walking.
+		bool whole = false;
+		if (fz == 0) {
+			uint32_t mu = __float_as_uint(r3) & 0x7fffffffu;
+			mu = min(mu, (uint32_t)xor8_i((int)mu));
+			mu = min(mu, (uint32_t)xor16_i((int)mu, lane));
+			mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
+			const float P = M + __uint_as_float(mu);
+			const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
+			const bool ok = (k == 0 || Mprev <= M) && group8_max(M) < group8_min(P);
+			whole = __ballot(!ok) == 0;
+		}
+#ifdef POLAR_STATS
+		if (fz == 0) { ++stat_r1; if (whole) ++stat_r1_ok; }
+#endif
+		if (whole) {
+			A.reset_upto(t ? __builtin_ctz(t) : 16, k);
+			H = r3 < 0.f ? 0xff : 0;                          // only bit j of lane (j, k) is read below
+		} else
 		// ---------------- the 8 leaves, all in registers
 		#pragma unroll
 		for (int p = 0; p < 8; ++p) {
@@ -401,7 +466,11 @@ __global__ __launch_bounds__(64) void k_polar(const SyncState *__restrict__ st_a
 		}
 		if ((tn & ((1 << LDS_TOP) - 1)) == 0) {               // a 128-leaf sub-tree is complete: publish its bytes
 			__syncthreads();
-			((unsigned short *)(hard + tn - (1 << LDS_TOP)))[lane] = ((const unsigned short *)lh)[lane];
+			if (LDS_TOP == 7)
+				((unsigned short *)(hard + tn - (1 << LDS_TOP)))[lane] = ((const unsigned short *)lh)[lane];
+			else
+				for (int q = lane; q < (1 << LDS_TOP) / 4; q += 64)
+					((uint32_t *)(hard + tn - (1 << LDS_TOP)))[q] = ((const uint32_t *)lh)[q];
 			for (int m = LDS_TOP + 1; m <= 16 && (tn & ((1 << m) - 1)) == 0; ++m) {
 				__syncthreads();
 				combine_wide(hard + tn - (1 << m), 1 << (m - 1), A.get(m - 1));
@@ -411,6 +480,9 @@ __global__ __launch_bounds__(64) void k_polar(const SyncState *__restrict__ st_a
 	}
 	if (j == 0)
 		metric_all[(size_t)cw * LIST + k] = M;
+#ifdef POLAR_STATS
+	if (lane == 0) { metric_all[(size_t)cw * LIST + 6] = (float)stat_r1; metric_all[(size_t)cw * LIST + 7] = (float)stat_r1_ok; }
+#endif
 }
 
 // ---------------------------------------------------------------- D10
