@@ -107,9 +107,15 @@ __global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restri
 #ifndef TS_LIST_CAP_V
 #define TS_LIST_CAP_V 4096   // 16 KB: with hist/part the block needs ~29 KB of LDS -> 5 workgroups per CU
 #endif
+// 1 / (k + 1), k = 0..639, correctly rounded at compile time (index d - 1 for distance d)
+struct TsRcpTab {
+	float v[640];
+	constexpr TsRcpTab() : v() { for (int k = 0; k < 640; ++k) v[k] = 1.0f / (float)(k + 1); }
+};
+__constant__ TsRcpTab TS_RCP;
+
 struct TsShared {
-	float y[512];
-	float rcp[512];            // correctly rounded 1/d
+	float y[640];              // [n, n + 128) = +3e38 (pairs that do not exist sort above everything)
 	float buf[TS_LIST_CAP_V];    // list of bracketed pairs -> their exact slopes; then the intercepts
 	int hist[2048];
 	int part[256];
@@ -118,6 +124,7 @@ struct TsShared {
 	int rank;
 	int list_n;
 	float pick;
+	int bin[2];                // linear-histogram bracket: bins holding the two wanted ranks
 };
 
 __device__ __forceinline__ unsigned fkey(float v)
@@ -200,6 +207,42 @@ __device__ void radix_digit(TsShared &s, int tid, int shift, int bits, unsigned 
 	}
 	__syncthreads();
 }
+// bins of s.hist[0..2048) that hold sorted positions r0 and r1 (s.bin[0], s.bin[1]; -1 if beyond the total)
+__device__ void hist_locate2(TsShared &s, int tid, int r0, int r1)
+{
+	int acc = 0;
+	#pragma unroll
+	for (int q = 0; q < 8; ++q)
+		acc += s.hist[tid * 8 + q];
+	const int lane = tid & 63, wave = tid >> 6;
+	int incl = acc;
+	#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		int o = __shfl_up(incl, d);
+		if (lane >= d)
+			incl += o;
+	}
+	if (lane == 63)
+		s.red[wave] = incl;
+	if (tid < 2)
+		s.bin[tid] = -1;
+	__syncthreads();
+	int off = 0;
+	for (int w = 0; w < wave; ++w)
+		off += s.red[w];
+	const int excl = incl - acc + off;
+	#pragma unroll
+	for (int which = 0; which < 2; ++which) {
+		const int r = which ? r1 : r0;
+		if (r >= excl && r < excl + acc) {
+			int rr = r - excl, b = tid * 8;
+			while (rr >= s.hist[b]) { rr -= s.hist[b]; ++b; }
+			s.bin[which] = b;
+		}
+	}
+	__syncthreads();
+}
+
 // value at sorted position `rank` of the multiset enumerated by `each` (exact, 3 digits 11+11+10).
 // EDGE = -1 / +1 stops after two digits and returns the lower / upper edge of the 22-bit key cell that
 // holds the rank (a value <= / >= the order statistic, within 2^-13 relative): enough for a bracket.
@@ -248,8 +291,8 @@ constexpr int TS_GRID_ROWS = 50;
 __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float &yint)
 {
 	const int count = n * (n - 1) / 2, target = count / 2;
-	for (int d = tid; d < 512; d += 256)
-		s.rcp[d] = d ? 1.f / (float)d : 0.f;
+	if (tid < 128)
+		s.y[n + tid] = 3.0e38f;                               // padding: see the classification pass
 	__syncthreads();
 	auto all_pairs_exact = [&](auto emit) {
 		for_each_pair(n, tid, [&](int i, int d, bool valid) { if (valid) emit((s.y[i + d] - s.y[i]) / (float)d); });
@@ -274,111 +317,145 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 		int rlo = m / 2 - K, rhi = m / 2 + K;
 		if (rlo < 0) rlo = 0;
 		if (rhi > m - 1) rhi = m - 1;
-#ifdef TS_PROBE_SKIP_SAMPLE_SELECT
-		const float T_lo = -1e-3f, T_hi = 1e-3f;
-#else
-		const float T_lo = select_rank<-1>(s, tid, rlo, sample);
-		const float T_hi = select_rank<+1>(s, tid, rhi, sample);
+		// The bracket comes from ONE pass over the sample: a 2048-bin histogram that is linear in the slope,
+		// centred on the mean of a small pre-sample (distances that are multiples of 64) and six mean absolute
+		// deviations wide, so the few per cent of the sample around its median spread over tens of bins and
+		// LDS atomics rarely collide.  T_lo / T_hi = outer edges of the bins holding the two ranks.  A bracket
+		// is only a hint - the result is validated below - so rounding in the binning is harmless; if a rank
+		// falls off the histogram the bracket comes from the radix select instead.
+		float T_lo, T_hi;
+		bool have = false;
+#ifndef TS_NO_LINEAR_HIST
+		{
+			const int lane = tid & 63, wave = tid >> 6;
+			auto block_sum = [&](float v) {
+				#pragma unroll
+				for (int mm = 32; mm; mm >>= 1)
+					v += __shfl_xor(v, mm);
+				if (lane == 0)
+					s.red[wave] = __float_as_int(v);
+				__syncthreads();
+				const float t = (__int_as_float(s.red[0]) + __int_as_float(s.red[1])) + (__int_as_float(s.red[2]) + __int_as_float(s.red[3]));
+				__syncthreads();
+				return t;
+			};
+			auto pre = [&](auto emit) {
+				for (int d = 64; d < n; d += 64) {
+					const float rd = __builtin_amdgcn_rcpf((float)d);
+					for (int i = tid; i < n - d; i += 256)
+						emit((s.y[i + d] - s.y[i]) * rd);
+				}
+			};
+			float a0 = 0.f, cntf = 0.f;
+			pre([&](float q) { a0 += q; cntf += 1.f; });
+			const float cnt = block_sum(cntf);
+			const float c = block_sum(a0) / cnt;
+			float a1 = 0.f;
+			pre([&](float q) { a1 += fabsf(q - c); });
+			const float dev = block_sum(a1) / cnt;
+			const float W = 6.f * dev, lo = c - W, inv = 1024.f / W, wbin = W * (1.f / 1024.f);
+			if (W > 0.f && inv < 3.0e38f) {
+				for (int i = tid; i < 2048; i += 256)
+					s.hist[i] = 0;
+				__syncthreads();
+				sample([&](float q) {
+					int b = (int)((q - lo) * inv);
+					b = b < 0 ? 0 : (b > 2047 ? 2047 : b);
+					atomicAdd(&s.hist[b], 1);
+				});
+				__syncthreads();
+				hist_locate2(s, tid, rlo, rhi);
+				const int b0 = s.bin[0], b1 = s.bin[1];
+				if (b0 > 0 && b1 >= b0 && b1 < 2047) {
+					T_lo = lo + (float)b0 * wbin;
+					T_hi = lo + (float)(b1 + 1) * wbin;
+					have = true;
+				}
+				__syncthreads();
+			}
+		}
 #endif
-		// ---- 2. classify every pair.  Kept pairs go to a shared LDS list in chunks of 128 slots: a wave
-		// owns one chunk at a time (fill count in a wave-uniform register, ballot + mbcnt for the slot),
-		// and takes the next chunk with one LDS atomic when it runs out; the tail of the old chunk is
-		// padded with a sentinel that later sorts above every real slope.
-		if (tid == 0) s.list_n = 0;
-		__syncthreads();
+		if (!have) {
+			T_lo = select_rank<-1>(s, tid, rlo, sample);
+			T_hi = select_rank<+1>(s, tid, rhi, sample);
+		}
+		// ---- 2. classify every pair: lane = point i (kept in a register), loop = distance d (wave-uniform),
+		// eight distances per step.  s.y is padded with +3e38 beyond n (and points i >= n read -3e38), so pairs
+		// that do not exist produce a huge positive slope and drop out as "above" - no index clamps, no
+		// validity masks; the eight phases are two ds_read2 pairs apart and the reciprocals of the distances
+		// come from a constant table through scalar loads.  Per pair: half a packed subtract, half a packed
+		// multiply, two compares straight into wave masks.  "below" is a scalar popcount.  Kept pairs go to a
+		// wave-private quarter of the LDS list (fill count in a scalar register, slot = fill + mbcnt), so the
+		// pass has no atomics and no block-level synchronisation.  Every wave walks all blocks of 64 points and
+		// takes every fourth group of eight distances: the trip counts balance, and so do the kept pairs (they
+		// come mostly from the long distances, whose slopes cluster around the median).
 		const int lane = tid & 63, wave = tid >> 6;
-		constexpr int CHUNK = 128, SENT = 0xffffffffu;
-		int below = 0, kept = 0, cbase = -1, cfill = CHUNK;
-		unsigned *list = (unsigned *)s.buf;
+		constexpr int WCAP = TS_LIST_CAP / 4;
+		int below = 0, cfill = 0;
+		unsigned *list = (unsigned *)s.buf + wave * WCAP;
 		// q = a*rcp(d) is within 3*2^-24 relative of the correctly rounded quotient; thresholds moved
 		// outwards by 1e-6 relative (+ an absolute floor) make "q < T_lo_m" imply "exact < T_lo"
 		const float T_lo_m = T_lo - (1e-6f * fabsf(T_lo) + 1e-36f);
 		const float T_hi_m = T_hi + (1e-6f * fabsf(T_hi) + 1e-36f);
 #ifndef TS_PROBE_SKIP_MAIN
 		{
-			// Lane = point i (kept in a register), loop = distance d (wave-uniform): one LDS read, one
-			// subtract, one multiply and two compares per pair; "below" is counted with a scalar popcount
-			// of the compare mask.  Blocks of 64 points are dealt to the 4 waves boustrophedon-wise so the
-			// triangular trip counts (n-1-64b) balance; no block-level sync inside.
 			const int nblk = (n + 63) >> 6;
-			for (int turn = 0; turn * 4 < nblk; ++turn) {
-				const int b = (turn & 1) ? (turn + 1) * 4 - 1 - wave : turn * 4 + wave;
-				if (b >= nblk)
-					continue;
+			for (int b = 0; b < nblk; ++b) {
 				const int i = b * 64 + lane;
-				const float yi = i < n ? s.y[i] : 0.f;
-				const int dmax = n - 1 - b * 64;              // largest distance with any valid lane
+				const float yi = i < n ? s.y[i] : -3.0e38f;
+				const int dmax = n - 1 - b * 64;              // largest distance with any existing pair
+				const float *yp = s.y + i + 1;
 				constexpr int U = 8;
-				for (int dblk = 0; dblk < dmax; dblk += 64) {
-					// reciprocals of the next 64 distances, one per lane; read back with v_readlane
-					const float rcl = __builtin_amdgcn_rcpf((float)(dblk + lane + 1));
-					const int dend = dmax - dblk < 64 ? dmax - dblk : 64;
-					for (int u0 = 0; u0 < dend; u0 += U) {
-						// phase A (branch-free, 8 independent chains): classify 8 distances
-						unsigned long long kb[U];
-						unsigned pk[U];
-						#pragma unroll
-						for (int u = 0; u < U; ++u) {
-							const int d = dblk + u0 + u + 1;
-							const int j = i + d;
-							const float ydv = s.y[j < n ? j : n - 1];
-							const float rc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcl), (u0 + u) & 63));
-							const bool valid = j < n && u0 + u < dend;
-							const float q = (ydv - yi) * rc;
-							const bool lo = valid & (q < T_lo_m);         // certainly below T_lo even after rounding
-							const bool keep = valid & !lo & !(q > T_hi_m);
-							below += __popcll(__builtin_amdgcn_ballot_w64(lo));   // wave-uniform scalar count
-							kb[u] = __builtin_amdgcn_ballot_w64(keep);
-							pk[u] = (unsigned)i | ((unsigned)d << 16);
+				for (int d0 = wave * U; d0 < dmax; d0 += 4 * U) {   // distances d0+1 .. d0+8; wave w takes every 4th group
+					bool lo[U], keep[U];
+					#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						const float q = (yp[d0 + u] - yi) * TS_RCP.v[d0 + u];
+						lo[u] = q < T_lo_m;                       // certainly below T_lo even after rounding
+						keep[u] = !(lo[u] | (q > T_hi_m));
+						below += __popcll(__builtin_amdgcn_ballot_w64(lo[u]));   // wave-uniform scalar count
+					}
+					#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep[u]);
+						if (keep[u]) {
+							int slot = cfill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+							slot = slot < WCAP ? slot : WCAP - 1;     // an overflowing wave is detected below
+							list[slot] = (unsigned)i | ((unsigned)(d0 + u + 1) << 16);
 						}
-						// phase B: append the kept pairs (their exact quotient is computed once, after the pass)
-						#pragma unroll
-						for (int u = 0; u < U; ++u) {
-							const unsigned long long bal = kb[u];
-							const int c = __popcll(bal);
-							if (cfill + c > CHUNK) {          // chunk exhausted: pad its tail, take a new one (rare)
-								if (cbase >= 0 && cbase + CHUNK <= TS_LIST_CAP && lane < CHUNK - cfill)
-									list[cbase + cfill + lane] = SENT;
-								int nb = 0;
-								if (lane == 0)
-									nb = atomicAdd(&s.list_n, CHUNK);
-								cbase = __builtin_amdgcn_readfirstlane(nb);
-								cfill = 0;
-							}
-							if (((bal >> lane) & 1) && cbase + CHUNK <= TS_LIST_CAP) {
-								int slot = cfill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-								list[cbase + slot] = pk[u];
-							}
-							cfill += c;
-							kept += c;
-						}
+						cfill += __popcll(bal);
 					}
 				}
 			}
-			if (cbase >= 0 && cbase + CHUNK <= TS_LIST_CAP && lane + cfill < CHUNK)   // pad the last chunk (<= 128 - cfill slots, 2 rounds)
-				list[cbase + cfill + lane] = SENT;
-			if (cbase >= 0 && cbase + CHUNK <= TS_LIST_CAP && lane + 64 + cfill < CHUNK)
-				list[cbase + cfill + lane + 64] = SENT;
 		}
 #endif
 		if (lane == 0) {
 			s.red[wave] = below;
-			s.part[wave] = kept;
+			s.part[wave] = cfill;
 		}
 		__syncthreads();
 		below = s.red[0] + s.red[1] + s.red[2] + s.red[3];
-		const int real = s.part[0] + s.part[1] + s.part[2] + s.part[3];
-		const int ln = s.list_n;                              // allocated slots (multiple of 128)
+		const int f0 = s.part[0], f1 = s.part[1], f2 = s.part[2], f3 = s.part[3];
+		const int real = f0 + f1 + f2 + f3;
 		const int r = target - below;
 		__syncthreads();
-		if (ln <= TS_LIST_CAP && r >= 0 && r < real) {
-			for (int i = tid; i < ln; i += 256) {             // pair index -> exact slope, in place
-				unsigned pk = list[i];
-				int pi = pk & 0xffff, pd = pk >> 16;
-				s.buf[i] = pk == SENT ? __int_as_float(0x7f7fffff) : (s.y[pi + pd] - s.y[pi]) / (float)pd;
-			}
+#ifdef TS_PROBE_DEBUG
+		if (tid == 0 && blockIdx.x < 3) printf("row %d: T_lo %g T_hi %g below %d fills %d %d %d %d target %d r %d\n", (int)blockIdx.x, T_lo, T_hi, below, f0, f1, f2, f3, target, r);
+#endif
+		if (f0 <= WCAP && f1 <= WCAP && f2 <= WCAP && f3 <= WCAP && r >= 0 && r < real) {
+			auto segs = [&](auto fn) {                        // every listed slot, segment by segment
+				for (int i = tid; i < f0; i += 256) fn(i);
+				for (int i = tid; i < f1; i += 256) fn(WCAP + i);
+				for (int i = tid; i < f2; i += 256) fn(2 * WCAP + i);
+				for (int i = tid; i < f3; i += 256) fn(3 * WCAP + i);
+			};
+			segs([&](int i) {                                 // pair index -> exact slope, in place
+				const unsigned pk = ((const unsigned *)s.buf)[i];
+				const int pi = pk & 0xffff, pd = pk >> 16;
+				s.buf[i] = (s.y[pi + pd] - s.y[pi]) / (float)pd;
+			});
 			__syncthreads();
-			auto lst = [&](auto emit) { for (int i = tid; i < ln; i += 256) emit(s.buf[i]); };
+			auto lst = [&](auto emit) { segs([&](int i) { emit(s.buf[i]); }); };
 			float v = select_rank(s, tid, r, lst);
 			if (v >= T_lo && v <= T_hi) {
 				slope = v;
