@@ -389,7 +389,7 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 		// pass has no atomics and no block-level synchronisation.  Every wave walks all blocks of 64 points and
 		// takes every fourth group of eight distances: the trip counts balance, and so do the kept pairs (they
 		// come mostly from the long distances, whose slopes cluster around the median).
-		const int lane = tid & 63, wave = tid >> 6;
+		const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: uniform loops, s_load of the table
 		constexpr int WCAP = TS_LIST_CAP / 4;
 		int below = 0, cfill = 0;
 		unsigned *list = (unsigned *)s.buf + wave * WCAP;
@@ -407,17 +407,21 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 				const float *yp = s.y + i + 1;
 				constexpr int U = 8;
 				for (int d0 = wave * U; d0 < dmax; d0 += 4 * U) {   // distances d0+1 .. d0+8; wave w takes every 4th group
-					bool lo[U], keep[U];
+					unsigned long long kb[U];
+					bool keep[U];
 					#pragma unroll
 					for (int u = 0; u < U; ++u) {
 						const float q = (yp[d0 + u] - yi) * TS_RCP.v[d0 + u];
-						lo[u] = q < T_lo_m;                       // certainly below T_lo even after rounding
-						keep[u] = !(lo[u] | (q > T_hi_m));
-						below += __popcll(__builtin_amdgcn_ballot_w64(lo[u]));   // wave-uniform scalar count
+						const bool lo = q < T_lo_m, hi = q > T_hi_m;  // certainly below T_lo / above T_hi even after rounding
+						const unsigned long long mlo = __builtin_amdgcn_ballot_w64(lo);
+						const unsigned long long mhi = __builtin_amdgcn_ballot_w64(hi);
+						below += __popcll(mlo);                   // wave-uniform scalar count
+						kb[u] = ~(mlo | mhi);                     // the same predicate as a wave mask (slots) ...
+						keep[u] = !(lo | hi);                     // ... and per lane (exec mask of the store)
 					}
 					#pragma unroll
 					for (int u = 0; u < U; ++u) {
-						const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep[u]);
+						const unsigned long long bal = kb[u];
 						if (keep[u]) {
 							int slot = cfill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
 							slot = slot < WCAP ? slot : WCAP - 1;     // an overflowing wave is detected below
@@ -441,6 +445,9 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 		__syncthreads();
 #ifdef TS_PROBE_DEBUG
 		if (tid == 0 && blockIdx.x < 3) printf("row %d: T_lo %g T_hi %g below %d fills %d %d %d %d target %d r %d\n", (int)blockIdx.x, T_lo, T_hi, below, f0, f1, f2, f3, target, r);
+#endif
+#ifdef TS_PROBE_SKIP_LIST
+		if (true) { slope = 0.f; done = true; } else
 #endif
 		if (f0 <= WCAP && f1 <= WCAP && f2 <= WCAP && f3 <= WCAP && r >= 0 && r < real) {
 			auto segs = [&](auto fn) {                        // every listed slot, segment by segment
@@ -477,7 +484,11 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 		s.buf[i] = sub_mul_nofma(s.y[i], slope, (float)(i - xoff));
 	__syncthreads();
 	auto icpt = [&](auto emit) { for (int i = tid; i < n; i += 256) emit(s.buf[i]); };
+#ifdef TS_PROBE_SKIP_YINT
+	yint = 0.f;
+#else
 	yint = select_rank(s, tid, n / 2, icpt);
+#endif
 	// the key order treats -0 < +0; nth_element would return whichever sits there: same value
 }
 

@@ -219,15 +219,20 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 	}
 }
 
-__global__ __launch_bounds__(64) void k_polar(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
+// Persistent grid: block b decodes codewords b, b + gridDim.x, ... and owns ONE 2 MiB level store
+// (soft_all + b * 2 MiB).  A grid smaller than the machine (launch_polar's `grid`) leaves LDS and registers on
+// every CU for the other stages' kernels of the next chunk, which run concurrently on a second stream: this
+// kernel is bound by memory latency / HBM traffic, those by VALU and LDS.
+__global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
 	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, float *__restrict__ metric_all)
 {
-	const int cw = blockIdx.x, lane = threadIdx.x, j = lane >> 3, k = lane & 7;
+	const int lane = threadIdx.x, j = lane >> 3, k = lane & 7;
+	for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
 	if (!st_all[cw].okay)
-		return;                                               // no header -> nothing to decode (decode.cc:450-451)
+		continue;                                             // no header -> nothing to decode (decode.cc:450-451)
 	const uint32_t *frozen = frozen2 + (st_all[cw].oper_mode >= 10 ? 2048 : 0);   // decode.cc:312,344
 	const float *llr = llr_all + (size_t)cw * CODE_LEN;
-	float *soft = soft_all + (size_t)cw * (8 * CODE_LEN);     // level m >= 8 at soft + 8*2^m
+	float *soft = soft_all + (size_t)blockIdx.x * (8 * CODE_LEN);   // level m >= 8 at soft + 8*2^m
 	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;
 	__shared__ float ls[8 << (LDS_TOP + 1)];                  // level m <= 7 at ls + 8*2^m
 	__shared__ __attribute__((aligned(8))) uint8_t lh[1 << LDS_TOP];   // partial sums of the current 128-leaf sub-tree
@@ -483,6 +488,8 @@ __global__ __launch_bounds__(64) void k_polar(const SyncState *__restrict__ st_a
 #ifdef POLAR_STATS
 	if (lane == 0) { metric_all[(size_t)cw * LIST + 6] = (float)stat_r1; metric_all[(size_t)cw * LIST + 7] = (float)stat_r1_ok; }
 #endif
+	__syncthreads();
+	}   // next codeword of this block
 }
 
 // ---------------------------------------------------------------- D10
@@ -499,6 +506,11 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 	__shared__ uint8_t mesg[LIST][MESG_BYTES_MAX];
 	__shared__ uint32_t crcs[LIST];
 	__shared__ int flips_red[4];
+	__shared__ uint32_t ctab[256], csh[1024], cpart[LIST][32];
+	ctab[tid] = tb.crc32_tab[tid];
+	#pragma unroll
+	for (int q = 0; q < 4; ++q)
+		csh[tid + 256 * q] = tb.crc32_shift168[tid + 256 * q];
 	Result r = res_all[f];
 	r.status = st.status;
 	r.symbol_pos = st.symbol_pos;
@@ -542,11 +554,29 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 	if (lane_mesg_all)
 		for (int i = tid; i < LIST * MESG_BYTES; i += 256)
 			lane_mesg_all[(size_t)f * LIST * MESG_BYTES + i] = mesg[i / MESG_BYTES][i % MESG_BYTES];
-	if (tid < LIST) {
+	// CRC<uint32_t>(0xD419CC15) over the first 43072 bits of each lane (decode.cc:533-541), 32 threads per lane:
+	// every thread runs the byte-table CRC over its own 168-byte segment from a zero state, then the 32 partial
+	// states are folded in order with the "advance by 168 zero bytes" operator (CRC is linear: state(A|B) =
+	// advance(state(A), |B|) ^ state(B)); that operator is four 256-entry tables built on the host.
+	{
+		constexpr int SEG = 168, NSEG = 32, TAIL = CRC_BITS / 8 - SEG * NSEG;   // 5384 = 32 * 168 + 8
+		const int lk = tid >> 5, seg = tid & 31;
+		const uint8_t *mp = mesg[lk] + seg * SEG;
 		uint32_t crc = 0;
-		for (int i = 0; i < CRC_BITS / 8; ++i)
-			crc = (crc >> 8) ^ tb.crc32_tab[(crc ^ mesg[tid][i]) & 255];
-		crcs[tid] = crc;
+		for (int i = 0; i < SEG; ++i)
+			crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
+		cpart[lk][seg] = crc;
+		__syncthreads();
+		if (tid < LIST) {
+			crc = 0;
+			for (int q = 0; q < NSEG; ++q) {
+				crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
+				crc ^= cpart[tid][q];
+			}
+			for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
+				crc = (crc >> 8) ^ ctab[(crc ^ mesg[tid][i]) & 255];
+			crcs[tid] = crc;
+		}
 	}
 	__syncthreads();
 	int best = -1;
@@ -613,9 +643,12 @@ __global__ __launch_bounds__(256) void k_awgn_tile(const short2 *__restrict__ ba
 	}
 }
 
-void launch_polar(hipStream_t s, int n, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric)
+// grid = number of resident decoders (each needs 2 MiB of `soft`); 0 or >= n: one per codeword
+void launch_polar(hipStream_t s, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric)
 {
-	hipLaunchKernelGGL(k_polar, dim3(n), dim3(64), 0, s, st, llr, soft, hard, tb.frozen, metric);
+	if (grid <= 0 || grid > n)
+		grid = n;
+	hipLaunchKernelGGL(k_polar, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, metric);
 }
 void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
 	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res)

@@ -49,6 +49,7 @@ struct Tables {                    // device-resident constants, built once per 
 	const uint8_t *osd_pairs;      // [2485][2] (a,b)
 	const uint8_t *osd_triples;    // [57155][3] (a,b,c) sorted by c (equal d-loop lengths are adjacent)
 	const uint32_t *crc32_tab;     // 256-entry byte table of CRC<uint32_t>(0xD419CC15)
+	const uint32_t *crc32_shift168; // [4][256]: the CRC state advanced by 168 zero bytes, per state byte (k_finish)
 	const uint8_t *scramble;       // 5380 bytes of the Xorshift32 stream (decode.cc:613-615)
 };
 
@@ -75,7 +76,7 @@ void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, float
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
 void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, float *llr, Result *res);
-void launch_polar(hipStream_t s, int n, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric);
+void launch_polar(hipStream_t s, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric);
 void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
 	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res);
 void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb);

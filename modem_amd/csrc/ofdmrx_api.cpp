@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include <cstring>
 #include <new>
 #include <string>
@@ -68,6 +70,12 @@ struct ofdmrx_handle {
 	int cap = 0;              // frames the buffers below are sized for
 	long cap_samples = 0;     // samples per frame the mono buffers are sized for
 	DevBuf st, hdr_soft, cons, slope, yint, precision, llr, soft, hard, metric, lane_mesg, res, payload;
+	DevBuf st2, llr2;         // second parity of the two buffers that cross from the front stages to the polar stage
+	hipStream_t stream_b = nullptr;   // polar + finish of chunk c run here while the front stages of chunk c+1 run on `stream`
+	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
+	int last_par = 0;         // parity used by the last chunk (taps)
+	SyncState *st_of(int par) { return (par ? st2 : st).as<SyncState>(); }
+	float *llr_of(int par) { return (par ? llr2 : llr).as<float>(); }
 	DevBuf dc, z;             // mono front end only
 	DevBuf cons_raw;          // only with cfg.flags & 1 (keep the pre-rotation constellation for taps)
 	long last_spf = 0;
@@ -141,6 +149,20 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		}
 		h->own_stream = true;
 	}
+	{
+		hipError_t e = hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+			ofdmrx_destroy(h);
+			return OFDMRX_E_HIP;
+		}
+		int cus = 0;
+		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
+		int wpc = 16;             // polar waves per CU while the next chunk's front stages share the machine
+		if (const char *e2 = std::getenv("OFDMRX_POLAR_WPC"))
+			wpc = std::atoi(e2);
+		h->polar_grid = wpc > 0 && cus > 0 ? wpc * cus : 0;
+	}
 	build_tables(h->host, h->rate);
 	int r = 0;
 	r = r ? r : upload(h, h->host.tw_sym, &h->dev.tw_sym);
@@ -155,6 +177,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.osd_pairs, &h->dev.osd_pairs);
 	r = r ? r : upload(h, h->host.osd_triples, &h->dev.osd_triples);
 	r = r ? r : upload(h, h->host.crc32_tab, &h->dev.crc32_tab);
+	r = r ? r : upload(h, h->host.crc32_shift168, &h->dev.crc32_shift168);
 	r = r ? r : upload(h, h->host.scramble, &h->dev.scramble);
 	if (r) {
 		ofdmrx_destroy(h);
@@ -171,8 +194,12 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 	(void)hipSetDevice(h->cfg.device);
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
+	if (h->stream_b) {
+		(void)hipStreamSynchronize(h->stream_b);
+		(void)hipStreamDestroy(h->stream_b);
+	}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->skip_stage, &h->sc_scratch })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2 })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -185,9 +212,16 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 
 extern "C" int ofdmrx_chunk_frames(ofdmrx_handle *h) { return h ? h->chunk : OFDMRX_E_ARG; }
 
-static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
+static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, bool two_parities = false)
 {
 	int r = 0;
+	if (two_parities) {
+		const size_t N2 = (size_t)std::max(n, h->cap);
+		r = r ? r : h->st2.ensure(N2 * sizeof(SyncState));
+		r = r ? r : h->llr2.ensure(N2 * CODE_LEN * sizeof(float));
+		if (r)
+			return r;
+	}
 	if (n > h->cap) {
 		const size_t N = (size_t)n;
 		r = r ? r : h->st.ensure(N * sizeof(SyncState));
@@ -218,7 +252,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 	return r;
 }
 
-static size_t mark(ofdmrx_handle *h)
+static size_t mark(ofdmrx_handle *h, hipStream_t on = nullptr)
 {
 	if (h->ev_used == h->ev_pool.size()) {
 		hipEvent_t e;
@@ -227,65 +261,86 @@ static size_t mark(ofdmrx_handle *h)
 		h->ev_pool.push_back(e);
 	}
 	size_t i = h->ev_used++;
-	(void)hipEventRecord(h->ev_pool[i], h->stream);
+	(void)hipEventRecord(h->ev_pool[i], on ? on : h->stream);
 	return i;
 }
 
-// one resident chunk: every stage of SURVEY 8(a) D1..D10 as kernels on the handle's stream
-static int run_chunk(ofdmrx_handle *h, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
-	uint8_t *d_payload, Result *d_res, bool want_lane_mesg)
+// One resident chunk = every stage of SURVEY 8(a) D1..D10 as kernels, in two halves:
+//   front (D1..D8: front end, sync/header rounds, demod, Theil-Sen, LLRs) -> st[par], llr[par]
+//   back  (D9, D10: polar list decoder, systematic bits / CRC / pack)     <- st[par], llr[par]
+// A one-chunk call runs both on the handle's stream.  A longer batch is pipelined: back(c) runs on the
+// second stream with a limited resident polar grid while front(c+1) runs on the handle's stream - the polar
+// stage is bound by memory latency and HBM traffic, the front stages by VALU and LDS, so they share CUs well.
+static int run_front(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
+	Result *d_res, size_t *t_begin)
 {
 	const bool mono = fb.channels == 1;
-	int r = ensure_capacity(h, n, mono, fb.samples_per_frame);
-	if (r)
-		return r;
-	hipStream_t s = h->stream;
-	SyncState *st = h->st.as<SyncState>();
+	SyncState *st = h->st_of(par);
 	const cf *z = mono ? h->z.as<cf>() : nullptr;
-	size_t e0 = mark(h);
+	size_t e0 = mark(h, s);
 	if (mono)
 		launch_front_end(s, h->rate, n, fb, h->host.front, nullptr, h->z.as<cf>());
-	size_t e1 = mark(h);
+	size_t e1 = mark(h, s);
 	launch_init_sync(s, n, st, d_skip);
-	size_t e2 = e1, e3 = e1;
+	size_t e3 = e1;
 	for (int round = 0; round <= max_skip; ++round) {      // decode.cc:390-448 do { } while (skip_count--)
-		size_t a = mark(h);
+		size_t a = mark(h, s);
 		launch_sync(s, h->rate, n, fb, z, h->dev, st, h->sc_scratch.as<cf>());
-		size_t b = mark(h);
+		size_t b = mark(h, s);
 		launch_header(s, h->rate, n, fb, z, h->dev, st, h->hdr_soft.as<int8_t>());
-		size_t c = mark(h);
+		size_t c = mark(h, s);
 		h->spans.push_back({ OFDMRX_T_SYNC, a, b });
 		h->spans.push_back({ OFDMRX_T_HEADER, b, c });
-		e2 = b;
 		e3 = c;
 	}
-	(void)e2;
 	launch_demod(s, h->rate, n, fb, z, h->dev, st, h->cons.as<cf>());
 	if (h->cfg.flags & 1)
 		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
-	size_t e4 = mark(h);
+	size_t e4 = mark(h, s);
 	launch_theil_sen(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>());
-	size_t e5 = mark(h);
+	size_t e5 = mark(h, s);
 	launch_llr(s, h->rate, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
-		h->llr.as<float>(), d_res);
-	size_t e6 = mark(h);
-	launch_polar(s, n, st, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
-	size_t e7 = mark(h);
-	launch_finish(s, n, st, h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
-		want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res);
-	size_t e8 = mark(h);
+		h->llr_of(par), d_res);
+	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_FRONT, e0, e1 });
 	h->spans.push_back({ OFDMRX_T_DEMOD, e3, e4 });
 	h->spans.push_back({ OFDMRX_T_THEILSEN, e4, e5 });
 	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
-	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
-	h->spans.push_back({ OFDMRX_T_FINISH, e7, e8 });
-	h->spans.push_back({ OFDMRX_T_TOTAL, e0, e8 });
+	*t_begin = e0;
 	HIP_OK(hipGetLastError());
 	h->last_n = n;
 	h->last_mono = mono;
 	h->last_spf = fb.samples_per_frame;
+	h->last_par = par;
 	return 0;
+}
+
+static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, int grid, uint8_t *d_payload, Result *d_res,
+	bool want_lane_mesg, size_t t_begin)
+{
+	SyncState *st = h->st_of(par);
+	size_t e6 = mark(h, s);
+	launch_polar(s, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	size_t e7 = mark(h, s);
+	launch_finish(s, n, st, h->llr_of(par), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
+		want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res);
+	size_t e8 = mark(h, s);
+	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
+	h->spans.push_back({ OFDMRX_T_FINISH, e7, e8 });
+	h->spans.push_back({ OFDMRX_T_TOTAL, t_begin, e8 });
+	HIP_OK(hipGetLastError());
+	return 0;
+}
+
+static int run_chunk(ofdmrx_handle *h, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
+	uint8_t *d_payload, Result *d_res, bool want_lane_mesg)
+{
+	int r = ensure_capacity(h, n, fb.channels == 1, fb.samples_per_frame);
+	if (r)
+		return r;
+	size_t t0 = 0;
+	r = run_front(h, h->stream, 0, fb, n, d_skip, max_skip, d_res, &t0);
+	return r ? r : run_back(h, h->stream, 0, n, 0, d_payload, d_res, want_lane_mesg, t0);
 }
 
 static int check_args(ofdmrx_handle *h, const void *samples, int fmt, int channels, size_t spf, size_t stride,
@@ -320,14 +375,47 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	}
 	h->ev_used = 0;
 	h->spans.clear();
-	for (size_t f0 = 0; f0 < n_frames; f0 += (size_t)h->chunk) {
-		int n = (int)std::min((size_t)h->chunk, n_frames - f0);
+	const size_t chunk = (size_t)h->chunk, n_chunks = (n_frames + chunk - 1) / chunk;
+	if (n_chunks == 1 || !h->stream_b || std::getenv("OFDMRX_NO_OVERLAP")) {
+		for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
+			int n = (int)std::min(chunk, n_frames - f0);
+			FrameBatch fb{ (const char *)d_samples + f0 * stride, stride, (long)spf, fmt, channels };
+			r = run_chunk(h, fb, n, d_skip ? d_skip + f0 : nullptr, max_skip, d_payload + f0 * PAYLOAD_BYTES,
+				(Result *)d_results + f0, true);
+			if (r)
+				return r;
+		}
+		return 0;
+	}
+	// pipeline: front(c) on the handle's stream, back(c) on the second stream, two parities of st / llr
+	r = ensure_capacity(h, (int)std::min(chunk, n_frames), channels == 1, (long)spf, true);
+	if (r)
+		return r;
+	std::vector<size_t> ev_back(n_chunks, (size_t)-1);
+	for (size_t c = 0; c < n_chunks; ++c) {
+		const size_t f0 = c * chunk;
+		const int n = (int)std::min(chunk, n_frames - f0), par = (int)(c & 1);
 		FrameBatch fb{ (const char *)d_samples + f0 * stride, stride, (long)spf, fmt, channels };
-		r = run_chunk(h, fb, n, d_skip ? d_skip + f0 : nullptr, max_skip, d_payload + f0 * PAYLOAD_BYTES,
-			(Result *)d_results + f0, true);
+		if (c >= 2 && ev_back[c - 2] != (size_t)-1)          // st[par] / llr[par] are free once back(c-2) is done
+			HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c - 2]], 0));
+		size_t t0 = 0;
+		r = run_front(h, h->stream, par, fb, n, d_skip ? d_skip + f0 : nullptr, max_skip, (Result *)d_results + f0, &t0);
 		if (r)
 			return r;
+		const size_t ev_front = mark(h, h->stream);
+		if (ev_front == (size_t)-1)
+			return OFDMRX_E_HIP;
+		HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_front], 0));
+		const bool last = c + 1 == n_chunks;                 // nothing left to share the machine with: all decoders resident
+		r = run_back(h, h->stream_b, par, n, last ? 0 : h->polar_grid, d_payload + f0 * PAYLOAD_BYTES,
+			(Result *)d_results + f0, true, t0);
+		if (r)
+			return r;
+		ev_back[c] = mark(h, h->stream_b);
 	}
+	for (size_t c = n_chunks >= 2 ? n_chunks - 2 : 0; c < n_chunks; ++c)   // the caller's stream sees the finished batch
+		if (ev_back[c] != (size_t)-1)
+			HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c]], 0));
 	return 0;
 }
 
@@ -419,7 +507,7 @@ extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *
 	case OFDMRX_TAP_SLOPE: src = h->slope.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
 	case OFDMRX_TAP_YINT: src = h->yint.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
 	case OFDMRX_TAP_PRECISION: src = h->precision.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
-	case OFDMRX_TAP_LLR: src = h->llr.as<float>() + frame * CODE_LEN; cap = CODE_LEN * 4; break;
+	case OFDMRX_TAP_LLR: src = h->llr_of(h->last_par) + frame * CODE_LEN; cap = CODE_LEN * 4; break;
 	case OFDMRX_TAP_METRIC: src = h->metric.as<float>() + frame * LIST; cap = LIST * 4; break;
 	case OFDMRX_TAP_LANE_MESG: src = h->lane_mesg.as<uint8_t>() + frame * LIST * MESG_BYTES; cap = LIST * MESG_BYTES; break;
 	case OFDMRX_TAP_ANALYTIC:
@@ -451,7 +539,7 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
-	launch_polar(h->stream, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	launch_polar(h->stream, (int)n, 0, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
 	launch_finish(h->stream, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, 0,
 		h->lane_mesg.as<uint8_t>(), h->payload.as<uint8_t>(), h->res.as<Result>());
 	HIP_OK(hipGetLastError());

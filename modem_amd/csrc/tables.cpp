@@ -192,6 +192,14 @@ void build_tables(HostTables &t, int rate)
 			c = (c >> 1) ^ ((c & 1) * 0xD419CC15u);   // CRC<uint32_t>(0xD419CC15), decode.cc:198
 		t.crc32_tab[j] = c;
 	}
+	t.crc32_shift168.resize(4 * 256);
+	for (int b = 0; b < 4; ++b)
+		for (uint32_t v = 0; v < 256; ++v) {
+			uint32_t c = v << (8 * b);
+			for (int i = 0; i < 168; ++i)
+				c = (c >> 8) ^ t.crc32_tab[c & 255];
+			t.crc32_shift168[b * 256 + v] = c;
+		}
 	t.scramble.resize(5380);
 	{
 		uint32_t y = 2463534242u;   // CODE::Xorshift32 default seed, decode.cc:613
