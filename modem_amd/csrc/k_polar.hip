@@ -223,6 +223,12 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 // (soft_all + b * 2 MiB).  A grid smaller than the machine (launch_polar's `grid`) leaves LDS and registers on
 // every CU for the other stages' kernels of the next chunk, which run concurrently on a second stream: this
 // kernel is bound by memory latency / HBM traffic, those by VALU and LDS.
+// The decoder is ONE wavefront per workgroup: LDS and vector-memory operations of a wave execute in program
+// order, so a value stored by one lane is visible to a later load by any lane of the same wave without a
+// workgroup barrier.  WAVE_ORDER only stops the compiler from moving memory operations across the point; a real
+// barrier would also drain every outstanding store (s_waitcnt vmcnt(0)) after each tree pass.
+#define WAVE_ORDER() __builtin_amdgcn_wave_barrier()
+
 __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
 	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, float *__restrict__ metric_all)
 {
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 					else { FPK(1, 0, false); D = 1; }
 					#undef FPK
 					#undef FP
-					__syncthreads();
+					WAVE_ORDER();
 					cur -= D;
 					kind = 0;
 				}
@@ -466,29 +472,29 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 		};
 		const int tn = t + 8;
 		for (int m = 4; m <= LDS_TOP && (tn & ((1 << m) - 1)) == 0; ++m) {
-			__syncthreads();
+			WAVE_ORDER();
 			combine((tn - (1 << m)) & ((1 << LDS_TOP) - 1), 1 << (m - 1), A.get(m - 1));
 		}
 		if ((tn & ((1 << LDS_TOP) - 1)) == 0) {               // a 128-leaf sub-tree is complete: publish its bytes
-			__syncthreads();
+			WAVE_ORDER();
 			if (LDS_TOP == 7)
 				((unsigned short *)(hard + tn - (1 << LDS_TOP)))[lane] = ((const unsigned short *)lh)[lane];
 			else
 				for (int q = lane; q < (1 << LDS_TOP) / 4; q += 64)
 					((uint32_t *)(hard + tn - (1 << LDS_TOP)))[q] = ((const uint32_t *)lh)[q];
 			for (int m = LDS_TOP + 1; m <= 16 && (tn & ((1 << m) - 1)) == 0; ++m) {
-				__syncthreads();
+				WAVE_ORDER();
 				combine_wide(hard + tn - (1 << m), 1 << (m - 1), A.get(m - 1));
 			}
 		}
-		__syncthreads();
+		WAVE_ORDER();
 	}
 	if (j == 0)
 		metric_all[(size_t)cw * LIST + k] = M;
 #ifdef POLAR_STATS
 	if (lane == 0) { metric_all[(size_t)cw * LIST + 6] = (float)stat_r1; metric_all[(size_t)cw * LIST + 7] = (float)stat_r1_ok; }
 #endif
-	__syncthreads();
+	WAVE_ORDER();
 	}   // next codeword of this block
 }
 
