@@ -158,7 +158,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		}
 		int cus = 0;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
-		int wpc = 16;             // polar waves per CU while the next chunk's front stages share the machine
+		int wpc = 12;             // polar waves per CU while the next chunk's Theil-Sen stage shares the machine
 		if (const char *e2 = std::getenv("OFDMRX_POLAR_WPC"))
 			wpc = std::atoi(e2);
 		h->polar_grid = wpc > 0 && cus > 0 ? wpc * cus : 0;
@@ -271,8 +271,8 @@ static size_t mark(ofdmrx_handle *h, hipStream_t on = nullptr)
 // A one-chunk call runs both on the handle's stream.  A longer batch is pipelined: back(c) runs on the
 // second stream with a limited resident polar grid while front(c+1) runs on the handle's stream - the polar
 // stage is bound by memory latency and HBM traffic, the front stages by VALU and LDS, so they share CUs well.
-static int run_front(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
-	Result *d_res, size_t *t_begin)
+static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
+	size_t *t_begin)
 {
 	const bool mono = fb.channels == 1;
 	SyncState *st = h->st_of(par);
@@ -297,21 +297,29 @@ static int run_front(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, in
 	if (h->cfg.flags & 1)
 		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
 	size_t e4 = mark(h, s);
-	launch_theil_sen(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>());
-	size_t e5 = mark(h, s);
-	launch_llr(s, h->rate, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
-		h->llr_of(par), d_res);
-	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_FRONT, e0, e1 });
 	h->spans.push_back({ OFDMRX_T_DEMOD, e3, e4 });
-	h->spans.push_back({ OFDMRX_T_THEILSEN, e4, e5 });
-	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
 	*t_begin = e0;
 	HIP_OK(hipGetLastError());
 	h->last_n = n;
 	h->last_mono = mono;
 	h->last_spf = fb.samples_per_frame;
 	h->last_par = par;
+	return 0;
+}
+
+static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_res)
+{
+	SyncState *st = h->st_of(par);
+	size_t e4 = mark(h, s);
+	launch_theil_sen(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>());
+	size_t e5 = mark(h, s);
+	launch_llr(s, h->rate, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
+		h->llr_of(par), d_res);
+	size_t e6 = mark(h, s);
+	h->spans.push_back({ OFDMRX_T_THEILSEN, e4, e5 });
+	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
+	HIP_OK(hipGetLastError());
 	return 0;
 }
 
@@ -339,7 +347,8 @@ static int run_chunk(ofdmrx_handle *h, FrameBatch fb, int n, const int32_t *d_sk
 	if (r)
 		return r;
 	size_t t0 = 0;
-	r = run_front(h, h->stream, 0, fb, n, d_skip, max_skip, d_res, &t0);
+	r = run_front1(h, h->stream, 0, fb, n, d_skip, max_skip, &t0);
+	r = r ? r : run_front2(h, h->stream, 0, n, d_res);
 	return r ? r : run_back(h, h->stream, 0, n, 0, d_payload, d_res, want_lane_mesg, t0);
 }
 
@@ -391,27 +400,45 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	r = ensure_capacity(h, (int)std::min(chunk, n_frames), channels == 1, (long)spf, true);
 	if (r)
 		return r;
-	std::vector<size_t> ev_back(n_chunks, (size_t)-1);
-	for (size_t c = 0; c < n_chunks; ++c) {
+	// Schedule per chunk c (A = the handle's stream, B = the second stream):
+	//   A: front1(c)   sync / header / demod          - LDS-heavy, runs while no polar grid is resident
+	//   B: back(c-1)   polar + finish, launched once front1(c) is through, limited resident grid
+	//   A: front2(c)   Theil-Sen + LLRs               - shares every CU with the polar grid of chunk c-1
+	std::vector<size_t> ev_back(n_chunks, (size_t)-1), ev_f2(n_chunks, (size_t)-1), t0s(n_chunks, 0);
+	for (size_t c = 0; c <= n_chunks; ++c) {
 		const size_t f0 = c * chunk;
-		const int n = (int)std::min(chunk, n_frames - f0), par = (int)(c & 1);
-		FrameBatch fb{ (const char *)d_samples + f0 * stride, stride, (long)spf, fmt, channels };
-		if (c >= 2 && ev_back[c - 2] != (size_t)-1)          // st[par] / llr[par] are free once back(c-2) is done
-			HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c - 2]], 0));
-		size_t t0 = 0;
-		r = run_front(h, h->stream, par, fb, n, d_skip ? d_skip + f0 : nullptr, max_skip, (Result *)d_results + f0, &t0);
-		if (r)
-			return r;
-		const size_t ev_front = mark(h, h->stream);
-		if (ev_front == (size_t)-1)
-			return OFDMRX_E_HIP;
-		HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_front], 0));
-		const bool last = c + 1 == n_chunks;                 // nothing left to share the machine with: all decoders resident
-		r = run_back(h, h->stream_b, par, n, last ? 0 : h->polar_grid, d_payload + f0 * PAYLOAD_BYTES,
-			(Result *)d_results + f0, true, t0);
-		if (r)
-			return r;
-		ev_back[c] = mark(h, h->stream_b);
+		const int par = (int)(c & 1);
+		size_t ev_f1 = (size_t)-1;
+		if (c < n_chunks) {
+			const int n = (int)std::min(chunk, n_frames - f0);
+			FrameBatch fb{ (const char *)d_samples + f0 * stride, stride, (long)spf, fmt, channels };
+			if (c >= 2 && ev_back[c - 2] != (size_t)-1)      // st[par] / llr[par] are free once back(c-2) is done
+				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c - 2]], 0));
+			r = run_front1(h, h->stream, par, fb, n, d_skip ? d_skip + f0 : nullptr, max_skip, &t0s[c]);
+			if (r)
+				return r;
+			ev_f1 = mark(h, h->stream);
+		}
+		if (c >= 1) {
+			const size_t p = c - 1, pf0 = p * chunk;
+			const int pn = (int)std::min(chunk, n_frames - pf0);
+			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f2[p]], 0));
+			if (ev_f1 != (size_t)-1)
+				HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
+			const bool last = c == n_chunks;                 // nothing left to share the machine with: all decoders resident
+			r = run_back(h, h->stream_b, (int)(p & 1), pn, last ? 0 : h->polar_grid, d_payload + pf0 * PAYLOAD_BYTES,
+				(Result *)d_results + pf0, true, t0s[p]);
+			if (r)
+				return r;
+			ev_back[p] = mark(h, h->stream_b);
+		}
+		if (c < n_chunks) {
+			const int n = (int)std::min(chunk, n_frames - f0);
+			r = run_front2(h, h->stream, par, n, (Result *)d_results + f0);
+			if (r)
+				return r;
+			ev_f2[c] = mark(h, h->stream);
+		}
 	}
 	for (size_t c = n_chunks >= 2 ? n_chunks - 2 : 0; c < n_chunks; ++c)   // the caller's stream sees the finished batch
 		if (ev_back[c] != (size_t)-1)
