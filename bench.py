@@ -174,6 +174,16 @@ def main():
         frames_per_launch = B * args.steps / max(polar_launches, 1)
         avg_launch_s = polar_ms / 1e3 / max(polar_launches, 1)
         achieved = (B_FRAME_2CH if ch == 2 else 95200 * 2 + 5380) * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # HBM bytes per k_polar launch from the committed PMC passes (bench.py cannot run the profiler on itself):
+        # scaled to this run's frames per launch; null when the file is absent
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_v3_traffic.json")) as fh:
+                tj = json.load(fh)
+            traffic = (tj["fetch_KiB"] + tj["write_KiB"]) * 1024.0 * frames_per_launch / tj["frames_per_launch"]
+            traffic_src = "profiles/r01_v3_traffic.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch"
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "decoded frames/sec + BER, mode-6 8kHz OFDM, batch 65536, 1/2/4/8 MI355X",
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -188,7 +198,7 @@ def main():
             "ber": bit_err / (43040.0 * B * n_gpus), "fer": frame_err / float(B * n_gpus),
             "frames_ok": ok_status, "frames": B * n_gpus,
             "roofline": {"bound": "hbm", "kernel": "k_polar (D9 SCL)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "frames_per_launch": frames_per_launch, "avg_launch_ms": 1e3 * avg_launch_s,
                          "algorithmic_bytes_per_frame": B_FRAME_2CH if ch == 2 else 95200 * 2 + 5380},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
