@@ -79,7 +79,9 @@ struct ofdmrx_handle {
 	DevBuf dc, z;             // mono front end only
 	DevBuf cons_raw;          // only with cfg.flags & 1 (keep the pre-rotation constellation for taps)
 	long last_spf = 0;
-	DevBuf in_stage, skip_stage;
+	DevBuf in_stage, in_stage2, skip_stage;
+	void *out_stage[2] = { nullptr, nullptr };   // pinned host staging of payloads + results (host-pointer entry)
+	size_t out_stage_cap[2] = { 0, 0 };
 	DevBuf sc_scratch;             // rates above 8 kHz: 2 x symbol_len/2 cf per frame for the S&C trigger part
 	int last_n = 0;           // frames in the last chunk (for taps)
 	bool last_mono = false;
@@ -199,10 +201,13 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 		(void)hipStreamDestroy(h->stream_b);
 	}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2 })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2 })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
+	for (void *p : h->out_stage)
+		if (p)
+			(void)hipHostFree(p);
 	for (hipEvent_t e : h->ev_pool)
 		(void)hipEventDestroy(e);
 	if (h->own_stream && h->stream)
@@ -454,6 +459,9 @@ extern "C" int ofdmrx_synchronize(ofdmrx_handle *h)
 	return 0;
 }
 
+// Host-pointer entry.  Chunks are double-buffered: while chunk c is decoded on the handle's stream, chunk c+1 is
+// copied in on a copy stream (from pageable memory that call blocks the host thread - which is exactly the time
+// the GPU needs for chunk c) and the payloads / results of chunk c-1 leave through pinned staging buffers.
 extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fmt, int channels,
 	size_t spf, size_t stride, size_t n_frames, const int32_t *skip, uint8_t *payload_out, ofdmrx_frame_result *results)
 {
@@ -468,33 +476,75 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 	max_skip = std::min(max_skip, 64);
 	h->ev_used = 0;
 	h->spans.clear();
-	for (size_t f0 = 0; f0 < n_frames; f0 += (size_t)h->chunk) {
-		int n = (int)std::min((size_t)h->chunk, n_frames - f0);
-		r = h->in_stage.ensure((size_t)n * stride);
+	const size_t chunk = (size_t)h->chunk, n_chunks = (n_frames + chunk - 1) / chunk, nc = std::min(chunk, n_frames);
+	r = ensure_capacity(h, (int)nc, channels == 1, (long)spf);
+	r = r ? r : h->in_stage.ensure(nc * stride);
+	if (n_chunks > 1)
+		r = r ? r : h->in_stage2.ensure(nc * stride);
+	if (skip)
+		r = r ? r : h->skip_stage.ensure(n_frames * sizeof(int32_t));
+	if (r)
+		return r;
+	const size_t out_bytes = nc * (PAYLOAD_BYTES + sizeof(Result));
+	for (int q = 0; q < (n_chunks > 1 ? 2 : 1); ++q)
+		if (h->out_stage_cap[q] < out_bytes) {
+			if (h->out_stage[q])
+				(void)hipHostFree(h->out_stage[q]);
+			h->out_stage[q] = nullptr;
+			h->out_stage_cap[q] = 0;
+			HIP_OK(hipHostMalloc(&h->out_stage[q], out_bytes, hipHostMallocDefault));
+			h->out_stage_cap[q] = out_bytes;
+		}
+	if (skip)
+		HIP_OK(hipMemcpy(h->skip_stage.p, skip, n_frames * sizeof(int32_t), hipMemcpyHostToDevice));
+	std::vector<size_t> ev_in(n_chunks, (size_t)-1), ev_done(n_chunks, (size_t)-1);
+	auto n_of = [&](size_t c) { return std::min(chunk, n_frames - c * chunk); };
+	auto copy_in = [&](size_t c) -> int {              // H2D of chunk c on the copy stream
+		hipStream_t cs = h->stream_b ? h->stream_b : h->stream;
+		if (c >= 2 && ev_done[c - 2] != (size_t)-1)      // in_stage[c & 1] was read by chunk c-2
+			HIP_OK(hipStreamWaitEvent(cs, h->ev_pool[ev_done[c - 2]], 0));
+		HIP_OK(hipMemcpyAsync((c & 1) ? h->in_stage2.p : h->in_stage.p, (const char *)samples + c * chunk * stride,
+			n_of(c) * stride, hipMemcpyHostToDevice, cs));
+		ev_in[c] = mark(h, cs);
+		return 0;
+	};
+	auto copy_out = [&](size_t c) -> int {             // pinned staging -> the caller's arrays, once chunk c is done
+		HIP_OK(hipEventSynchronize(h->ev_pool[ev_done[c]]));
+		const char *src = (const char *)h->out_stage[c & 1];
+		std::memcpy(payload_out + c * chunk * PAYLOAD_BYTES, src, n_of(c) * PAYLOAD_BYTES);
+		std::memcpy(results + c * chunk, src + nc * PAYLOAD_BYTES, n_of(c) * sizeof(Result));
+		return 0;
+	};
+	r = copy_in(0);
+	if (r)
+		return r;
+	for (size_t c = 0; c < n_chunks; ++c) {
+		const int n = (int)n_of(c);
+		HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_in[c]], 0));
+		FrameBatch fb{ (c & 1) ? h->in_stage2.p : h->in_stage.p, stride, (long)spf, fmt, channels };
+		r = run_chunk(h, fb, n, skip ? h->skip_stage.as<int32_t>() + c * chunk : nullptr, max_skip,
+			h->payload.as<uint8_t>(), h->res.as<Result>(), true);
 		if (r)
 			return r;
-		r = ensure_capacity(h, n, channels == 1, (long)spf);
-		if (r)
-			return r;
-		HIP_OK(hipMemcpyAsync(h->in_stage.p, (const char *)samples + f0 * stride, (size_t)n * stride,
-			hipMemcpyHostToDevice, h->stream));
-		int32_t *d_skip = nullptr;
-		if (skip) {
-			r = h->skip_stage.ensure((size_t)n * sizeof(int32_t));
+		char *dst = (char *)h->out_stage[c & 1];
+		HIP_OK(hipMemcpyAsync(dst, h->payload.p, (size_t)n * PAYLOAD_BYTES, hipMemcpyDeviceToHost, h->stream));
+		HIP_OK(hipMemcpyAsync(dst + nc * PAYLOAD_BYTES, h->res.p, (size_t)n * sizeof(Result), hipMemcpyDeviceToHost, h->stream));
+		ev_done[c] = mark(h, h->stream);
+		if (c + 1 < n_chunks) {
+			r = copy_in(c + 1);
 			if (r)
 				return r;
-			d_skip = h->skip_stage.as<int32_t>();
-			HIP_OK(hipMemcpyAsync(d_skip, skip + f0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
 		}
-		FrameBatch fb{ h->in_stage.p, stride, (long)spf, fmt, channels };
-		r = run_chunk(h, fb, n, d_skip, max_skip, h->payload.as<uint8_t>(), h->res.as<Result>(), true);
-		if (r)
-			return r;
-		HIP_OK(hipMemcpyAsync(payload_out + f0 * PAYLOAD_BYTES, h->payload.p, (size_t)n * PAYLOAD_BYTES,
-			hipMemcpyDeviceToHost, h->stream));
-		HIP_OK(hipMemcpyAsync(results + f0, h->res.p, (size_t)n * sizeof(Result), hipMemcpyDeviceToHost, h->stream));
-		HIP_OK(hipStreamSynchronize(h->stream));
+		if (c >= 1) {
+			r = copy_out(c - 1);
+			if (r)
+				return r;
+		}
 	}
+	r = copy_out(n_chunks - 1);
+	if (r)
+		return r;
+	HIP_OK(hipStreamSynchronize(h->stream));
 	return 0;
 }
 

@@ -534,3 +534,55 @@ def test_unsupported_rate_is_refused():
     import modem_amd
     with pytest.raises(modem_amd.OfdmRxError):
         modem_amd.Receiver(device=0, sample_rate=22050)
+
+
+def test_chunk_pipeline_matches_single_chunk():
+    """the two-stream chunk pipeline (front stages of chunk c+1 beside polar/finish of chunk c, two buffer parities)
+    must give exactly what one resident chunk gives: 23 frames of mixed kinds (good, noisy, silence, truncated,
+    different modes, SKIP) decoded with chunk_frames = 5 (five chunks, ragged tail) and with one chunk"""
+    import modem_amd
+    rng = np.random.default_rng(99)
+    pays = [O.payload_for(1200 + i) for i in range(6)]
+    base = [O.encode_pcm(pays[0], channels=2), O.encode_pcm(pays[1], channels=2, mode=9, freq_off=1500),
+            O.impair(O.encode_pcm(pays[2], channels=2), noise_db=-16, seed=5, frame=1),
+            O.impair(O.encode_pcm(pays[3], channels=2), noise_db=-12, seed=5, frame=2),      # below the waterfall
+            O.encode_pcm(np.concatenate([pays[4], pays[5]]), channels=2)]                    # two payloads: SKIP 1 takes the second
+    n = max(x.shape[0] for x in base)
+    frames, skips = [], []
+    for i in range(23):
+        kind = i % 7
+        f = np.zeros((n, 2), np.int16)
+        if kind < 5:
+            f[:base[kind].shape[0]] = base[kind]
+        elif kind == 5:
+            f[:] = rng.integers(-200, 200, size=(n, 2))                                      # noise only: NO_SYNC
+        else:
+            f[:40000] = base[0][:40000]                                                      # truncated before the payload ends
+        frames.append(f)
+        skips.append(1 if kind == 4 else 0)
+    batch, skips = np.stack(frames), np.asarray(skips, np.int32)
+    outs = []
+    for chunk in (5, 32):
+        rx = modem_amd.Receiver(device=0, chunk_frames=chunk, max_samples=n)
+        import torch
+        dev = torch.device("cuda:0")
+        d_in = torch.from_numpy(batch).to(dev)
+        d_skip = torch.from_numpy(skips).to(dev)
+        d_out = torch.zeros((23, 5380), dtype=torch.uint8, device=dev)
+        import modem_amd.ofdmrx as M
+        d_res = torch.zeros((23, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, n, n * 4, 23, d_out.data_ptr(), d_res.data_ptr(), d_skip=d_skip.data_ptr())
+        rx.synchronize()
+        outs.append((d_out.cpu().numpy(), d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)))
+        rx.close()
+    (o5, r5), (o32, r32) = outs
+    assert (o5 == o32).all()
+    for name in r5.dtype.names:
+        a, b = r5[name], r32[name]
+        assert ((a == b) | ((a != a) & (b != b))).all(), name
+    st = r5["status"]
+    assert (st[[0, 1, 2]] == 0).all() and st[3] != 0 and st[4] == 0 and st[5] == 1
+    assert (o5[0] == pays[0]).all() and (o5[1] == pays[1]).all() and (o5[2] == pays[2]).all() and (o5[4] == pays[5]).all()
+    o, r = O.decode(batch[3])
+    assert r.status == int(st[3]) and (o == o5[3]).all()
