@@ -1,0 +1,133 @@
+// k_finish.hip -- D10 (systematic message, CRC-32 lane selection, bit packing, descramble) for gfx950.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace rx {
+
+// ---------------------------------------------------------------- D10
+// decode.cc:254-261 (systematic message = codeword at the unfrozen positions),
+// decode.cc:532-541 (first lane whose CRC-32 over 43072 bits is 0), decode.cc:546-555
+// (LE bit packing + flip count), decode.cc:613-615 (descramble).
+__global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
+	const uint8_t *__restrict__ hard_all, Tables tb, int descramble, uint8_t *__restrict__ lane_mesg_all,
+	uint8_t *__restrict__ payload_all, Result *__restrict__ res_all)
+{
+	const int f = blockIdx.x, tid = threadIdx.x;
+	const SyncState st = st_all[f];
+	uint8_t *payload = payload_all + (size_t)f * PAYLOAD_BYTES;
+	__shared__ uint8_t mesg[LIST][MESG_BYTES_MAX];
+	__shared__ uint32_t crcs[LIST];
+	__shared__ int flips_red[4];
+	__shared__ uint32_t ctab[256], csh[1024], cpart[LIST][32];
+	ctab[tid] = tb.crc32_tab[tid];
+	#pragma unroll
+	for (int q = 0; q < 4; ++q)
+		csh[tid + 256 * q] = tb.crc32_shift168[tid + 256 * q];
+	Result r = res_all[f];
+	r.status = st.status;
+	r.symbol_pos = st.symbol_pos;
+	r.sc_start = st.sc_start;
+	r.cfo_rad = st.cfo_rad;
+	r.oper_mode = st.oper_mode;
+	r.call_sign = st.call_sign;
+	r.n_sync_rejects = st.rejects;
+	r.best_lane = -1;
+	r.bit_flips = 0;
+	if (!st.okay) {
+		r.cfo_fine = st.cfo_rad;
+		r.sfo_slope = 0.f;
+		r.esn0_db_last = 0.f;
+		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
+			payload[i] = 0;
+		if (tid == 0)
+			res_all[f] = r;
+		return;
+	}
+	const uint8_t *hard = hard_all + (size_t)f * CODE_LEN;
+	const float *llr = llr_all + (size_t)f * CODE_LEN;
+	const ModeDesc md = mode_desc(st.oper_mode);
+	const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
+	const int mesg_bytes = md.mesg_bits / 8;
+	// transpose: 8 code positions (one byte each, bit k = path k) -> one message byte per path
+	for (int bi = tid; bi < mesg_bytes; bi += 256) {
+		uint32_t o[LIST] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		#pragma unroll
+		for (int b = 0; b < 8; ++b) {
+			uint32_t x = hard[info_pos[8 * bi + b]];
+			#pragma unroll
+			for (int k = 0; k < LIST; ++k)
+				o[k] |= ((x >> k) & 1u) << b;
+		}
+		#pragma unroll
+		for (int k = 0; k < LIST; ++k)
+			mesg[k][bi] = (uint8_t)o[k];
+	}
+	__syncthreads();
+	if (lane_mesg_all)
+		for (int i = tid; i < LIST * MESG_BYTES; i += 256)
+			lane_mesg_all[(size_t)f * LIST * MESG_BYTES + i] = mesg[i / MESG_BYTES][i % MESG_BYTES];
+	// CRC<uint32_t>(0xD419CC15) over the first 43072 bits of each lane (decode.cc:533-541), 32 threads per lane:
+	// every thread runs the byte-table CRC over its own 168-byte segment from a zero state, then the 32 partial
+	// states are folded in order with the "advance by 168 zero bytes" operator (CRC is linear: state(A|B) =
+	// advance(state(A), |B|) ^ state(B)); that operator is four 256-entry tables built on the host.
+	{
+		constexpr int SEG = 168, NSEG = 32, TAIL = CRC_BITS / 8 - SEG * NSEG;   // 5384 = 32 * 168 + 8
+		const int lk = tid >> 5, seg = tid & 31;
+		const uint8_t *mp = mesg[lk] + seg * SEG;
+		uint32_t crc = 0;
+		for (int i = 0; i < SEG; ++i)
+			crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
+		cpart[lk][seg] = crc;
+		__syncthreads();
+		if (tid < LIST) {
+			crc = 0;
+			for (int q = 0; q < NSEG; ++q) {
+				crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
+				crc ^= cpart[tid][q];
+			}
+			for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
+				crc = (crc >> 8) ^ ctab[(crc ^ mesg[tid][i]) & 255];
+			crcs[tid] = crc;
+		}
+	}
+	__syncthreads();
+	int best = -1;
+	for (int k = LIST - 1; k >= 0; --k)
+		if (crcs[k] == 0)
+			best = k;
+	r.best_lane = best;
+	if (best < 0) {
+		r.status = 6;                                         // decode.cc:542-545
+		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
+			payload[i] = 0;
+		if (tid == 0)
+			res_all[f] = r;
+		return;
+	}
+	int flips = 0;
+	for (int i = tid; i < DATA_BITS; i += 256) {              // decode.cc:546-554
+		int received = llr[info_pos[i]] < 0.f;
+		int decoded = (mesg[best][i >> 3] >> (i & 7)) & 1;
+		flips += received != decoded;
+	}
+	#pragma unroll
+	for (int m = 32; m; m >>= 1)
+		flips += __shfl_xor(flips, m);
+	if ((tid & 63) == 0)
+		flips_red[tid >> 6] = flips;
+	for (int i = tid; i < PAYLOAD_BYTES; i += 256)
+		payload[i] = mesg[best][i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);
+	__syncthreads();
+	if (tid == 0) {
+		r.bit_flips = flips_red[0] + flips_red[1] + flips_red[2] + flips_red[3];
+		res_all[f] = r;
+	}
+}
+
+void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
+	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res)
+{
+	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, lane_mesg, payload, res);
+}
+
+}  // namespace rx

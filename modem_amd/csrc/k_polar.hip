@@ -1,5 +1,5 @@
-// k_polar.hip -- D9 (polar successive-cancellation list decoder, N = 65536, L = 8) and
-// D10 (systematic message, CRC-32 lane selection, bit packing) for gfx950.
+// k_polar.hip -- D9 (polar successive-cancellation list decoder, N = 65536, L = 8) for gfx950;
+// D10 lives in k_finish.hip.
 //
 // CODE::PolarListDecoder<SIMD<float,8>,16> (decode.cc:201,530): min-sum SCL.
 // One wavefront decodes one codeword.  Lane l = (j << 3) | k : k = list path (the
@@ -498,253 +498,11 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 	}   // next codeword of this block
 }
 
-// ---------------------------------------------------------------- D10
-// decode.cc:254-261 (systematic message = codeword at the unfrozen positions),
-// decode.cc:532-541 (first lane whose CRC-32 over 43072 bits is 0), decode.cc:546-555
-// (LE bit packing + flip count), decode.cc:613-615 (descramble).
-__global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
-	const uint8_t *__restrict__ hard_all, Tables tb, int descramble, uint8_t *__restrict__ lane_mesg_all,
-	uint8_t *__restrict__ payload_all, Result *__restrict__ res_all)
-{
-	const int f = blockIdx.x, tid = threadIdx.x;
-	const SyncState st = st_all[f];
-	uint8_t *payload = payload_all + (size_t)f * PAYLOAD_BYTES;
-	__shared__ uint8_t mesg[LIST][MESG_BYTES_MAX];
-	__shared__ uint32_t crcs[LIST];
-	__shared__ int flips_red[4];
-	__shared__ uint32_t ctab[256], csh[1024], cpart[LIST][32];
-	ctab[tid] = tb.crc32_tab[tid];
-	#pragma unroll
-	for (int q = 0; q < 4; ++q)
-		csh[tid + 256 * q] = tb.crc32_shift168[tid + 256 * q];
-	Result r = res_all[f];
-	r.status = st.status;
-	r.symbol_pos = st.symbol_pos;
-	r.sc_start = st.sc_start;
-	r.cfo_rad = st.cfo_rad;
-	r.oper_mode = st.oper_mode;
-	r.call_sign = st.call_sign;
-	r.n_sync_rejects = st.rejects;
-	r.best_lane = -1;
-	r.bit_flips = 0;
-	if (!st.okay) {
-		r.cfo_fine = st.cfo_rad;
-		r.sfo_slope = 0.f;
-		r.esn0_db_last = 0.f;
-		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
-			payload[i] = 0;
-		if (tid == 0)
-			res_all[f] = r;
-		return;
-	}
-	const uint8_t *hard = hard_all + (size_t)f * CODE_LEN;
-	const float *llr = llr_all + (size_t)f * CODE_LEN;
-	const ModeDesc md = mode_desc(st.oper_mode);
-	const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
-	const int mesg_bytes = md.mesg_bits / 8;
-	// transpose: 8 code positions (one byte each, bit k = path k) -> one message byte per path
-	for (int bi = tid; bi < mesg_bytes; bi += 256) {
-		uint32_t o[LIST] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-		#pragma unroll
-		for (int b = 0; b < 8; ++b) {
-			uint32_t x = hard[info_pos[8 * bi + b]];
-			#pragma unroll
-			for (int k = 0; k < LIST; ++k)
-				o[k] |= ((x >> k) & 1u) << b;
-		}
-		#pragma unroll
-		for (int k = 0; k < LIST; ++k)
-			mesg[k][bi] = (uint8_t)o[k];
-	}
-	__syncthreads();
-	if (lane_mesg_all)
-		for (int i = tid; i < LIST * MESG_BYTES; i += 256)
-			lane_mesg_all[(size_t)f * LIST * MESG_BYTES + i] = mesg[i / MESG_BYTES][i % MESG_BYTES];
-	// CRC<uint32_t>(0xD419CC15) over the first 43072 bits of each lane (decode.cc:533-541), 32 threads per lane:
-	// every thread runs the byte-table CRC over its own 168-byte segment from a zero state, then the 32 partial
-	// states are folded in order with the "advance by 168 zero bytes" operator (CRC is linear: state(A|B) =
-	// advance(state(A), |B|) ^ state(B)); that operator is four 256-entry tables built on the host.
-	{
-		constexpr int SEG = 168, NSEG = 32, TAIL = CRC_BITS / 8 - SEG * NSEG;   // 5384 = 32 * 168 + 8
-		const int lk = tid >> 5, seg = tid & 31;
-		const uint8_t *mp = mesg[lk] + seg * SEG;
-		uint32_t crc = 0;
-		for (int i = 0; i < SEG; ++i)
-			crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
-		cpart[lk][seg] = crc;
-		__syncthreads();
-		if (tid < LIST) {
-			crc = 0;
-			for (int q = 0; q < NSEG; ++q) {
-				crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
-				crc ^= cpart[tid][q];
-			}
-			for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
-				crc = (crc >> 8) ^ ctab[(crc ^ mesg[tid][i]) & 255];
-			crcs[tid] = crc;
-		}
-	}
-	__syncthreads();
-	int best = -1;
-	for (int k = LIST - 1; k >= 0; --k)
-		if (crcs[k] == 0)
-			best = k;
-	r.best_lane = best;
-	if (best < 0) {
-		r.status = 6;                                         // decode.cc:542-545
-		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
-			payload[i] = 0;
-		if (tid == 0)
-			res_all[f] = r;
-		return;
-	}
-	int flips = 0;
-	for (int i = tid; i < DATA_BITS; i += 256) {              // decode.cc:546-554
-		int received = llr[info_pos[i]] < 0.f;
-		int decoded = (mesg[best][i >> 3] >> (i & 7)) & 1;
-		flips += received != decoded;
-	}
-	#pragma unroll
-	for (int m = 32; m; m >>= 1)
-		flips += __shfl_xor(flips, m);
-	if ((tid & 63) == 0)
-		flips_red[tid >> 6] = flips;
-	for (int i = tid; i < PAYLOAD_BYTES; i += 256)
-		payload[i] = mesg[best][i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);
-	__syncthreads();
-	if (tid == 0) {
-		r.bit_flips = flips_red[0] + flips_red[1] + flips_red[2] + flips_red[3];
-		res_all[f] = r;
-	}
-}
-
-// ---------------------------------------------------------------- channel model utility
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
-{
-	x += 0x9e3779b97f4a7c15ull;
-	x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
-	x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
-	return x ^ (x >> 31);
-}
-// out frame f = base[f % n_base] + complex AWGN(sigma per component); counter-based RNG
-__global__ __launch_bounds__(256) void k_awgn_tile(const short2 *__restrict__ base, size_t n_base, short2 *__restrict__ out,
-	size_t spf, float sigma, unsigned long long seed, unsigned long long first_frame)
-{
-	const size_t f = blockIdx.x;
-	const unsigned long long key = splitmix64(seed ^ splitmix64(first_frame + f + 0x1234567ull));
-	const short2 *src = base + (f % n_base) * spf;
-	short2 *dst = out + f * spf;
-	for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < spf; i += (size_t)gridDim.y * 256) {
-		unsigned long long r = splitmix64(key + i);
-		float u1 = ((float)(unsigned)(r >> 40) + 0.5f) * (1.f / 16777216.f);
-		float u2 = ((float)(unsigned)((r >> 8) & 0xffffff) + 0.5f) * (1.f / 16777216.f);
-		float mag = sigma * sqrtf(-2.f * logf(u1));
-		float sn, cs;
-		sincosf(TWO_PI_F * u2, &sn, &cs);
-		short2 v = src[i];
-		float re = (float)v.x / 32767.f + mag * cs, im = (float)v.y / 32767.f + mag * sn;
-		re = fminf(fmaxf(re, -1.f), 1.f);
-		im = fminf(fmaxf(im, -1.f), 1.f);
-		dst[i] = make_short2((short)nearbyintf(32767.f * re), (short)nearbyintf(32767.f * im));
-	}
-}
-
-// grid = number of resident decoders (each needs 2 MiB of `soft`); 0 or >= n: one per codeword
 void launch_polar(hipStream_t s, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric)
 {
 	if (grid <= 0 || grid > n)
 		grid = n;
 	hipLaunchKernelGGL(k_polar, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, metric);
-}
-void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
-	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res)
-{
-	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, lane_mesg, payload, res);
-}
-void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t *out, size_t n_out,
-	size_t spf, float sigma, uint64_t seed, uint64_t first_frame)
-{
-	hipLaunchKernelGGL(k_awgn_tile, dim3((unsigned)n_out, 64), dim3(256), 0, s, (const short2 *)base, n_base, (short2 *)out,
-		spf, sigma, (unsigned long long)seed, (unsigned long long)first_frame);
-}
-
-}  // namespace rx
-
-// ---------------------------------------------------------------- build-owned channel chain (N3)
-// README.md:49 pipes encode through aicodix/disorders: multipath | cfo | sfo | awgn.  That repository is
-// absent; the definitions here are this build's own (same as oracle/channel.c, checked against it):
-//   multipath: FIR with integer delays and complex gains;   cfo: x[m] * e^{j 2 pi hz m / rate};
-//   sfo: out[i] = resample at t = i (1 + ppm 1e-6), 32-tap Hann-windowed sinc;   awgn: k_awgn_tile.
-// 2-channel int16 in and out.  The chain is deterministic, so it is applied to the base frames once
-// and k_awgn_tile then adds independent noise per frame.
-namespace rx {
-
-struct ChannelParams {
-	float cfo_hz, sfo_ppm;
-	int ntaps;
-	int delays[8];
-	float gre[8], gim[8];
-};
-
-__global__ __launch_bounds__(256) void k_channel(const short2 *__restrict__ in, short2 *__restrict__ out, size_t spf, ChannelParams cp, int rate)
-{
-	const size_t f = blockIdx.y;
-	const short2 *src = in + f * spf;
-	short2 *dst = out + f * spf;
-	const double step = 1.0 + (double)cp.sfo_ppm * 1e-6;
-	const double w0 = 2.0 * 3.14159265358979323846 * (double)cp.cfo_hz / (double)rate;
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < spf; i += (size_t)gridDim.x * 256) {
-		auto stage12 = [&](long m) -> cf {   // multipath then cfo at integer sample m
-			float re = 0.f, im = 0.f;
-			for (int t = 0; t < cp.ntaps; ++t) {
-				long idx = m - cp.delays[t];
-				if (idx < 0)
-					continue;
-				short2 v = src[idx];
-				float xr = (float)v.x / 32767.f, xi = (float)v.y / 32767.f;
-				re += xr * cp.gre[t] - xi * cp.gim[t];
-				im += xr * cp.gim[t] + xi * cp.gre[t];
-			}
-			if (cp.cfo_hz != 0.f) {
-				double a = w0 * (double)m;
-				float c = (float)cos(a), s = (float)sin(a);
-				float r2 = re * c - im * s, i2 = re * s + im * c;
-				re = r2; im = i2;
-			}
-			return mk(re, im);
-		};
-		float ore, oim;
-		if (cp.sfo_ppm == 0.f) {
-			cf v = stage12((long)i);
-			ore = v.re; oim = v.im;
-		} else {
-			const int HALF = 16;
-			double t = (double)i * step;
-			long t0 = (long)floor(t);
-			double fr = t - (double)t0, re = 0.0, im = 0.0;
-			for (int k = -HALF + 1; k <= HALF; ++k) {
-				long idx = t0 + k;
-				if (idx < 0 || (size_t)idx >= spf)
-					continue;
-				double x = (double)k - fr;
-				double sinc = fabs(x) < 1e-12 ? 1.0 : sin(3.14159265358979323846 * x) / (3.14159265358979323846 * x);
-				double w = 0.5 * (1.0 + cos(3.14159265358979323846 * x / (double)HALF));
-				cf v = stage12(idx);
-				re += sinc * w * v.re;
-				im += sinc * w * v.im;
-			}
-			ore = (float)re; oim = (float)im;
-		}
-		ore = fminf(fmaxf(ore, -1.f), 1.f);
-		oim = fminf(fmaxf(oim, -1.f), 1.f);
-		dst[i] = make_short2((short)nearbyintf(32767.f * ore), (short)nearbyintf(32767.f * oim));
-	}
-}
-
-void launch_channel(hipStream_t s, int rate, const int16_t *in, int16_t *out, size_t n, size_t spf, const void *params)
-{
-	ChannelParams cp = *(const ChannelParams *)params;
-	hipLaunchKernelGGL(k_channel, dim3(128, (unsigned)n), dim3(256), 0, s, (const short2 *)in, (short2 *)out, spf, cp, rate);
 }
 
 }  // namespace rx
