@@ -97,7 +97,10 @@ constexpr int UB = 8;      // iterations batched per pass so that 2*UB loads are
 #ifndef POLAR_LDS_TOP
 #define POLAR_LDS_TOP 7
 #endif
-constexpr int LDS_TOP = POLAR_LDS_TOP; // tree levels 4..7 (sub-trees of <= 128 leaves) live in LDS
+constexpr int LDS_TOP = POLAR_LDS_TOP;
+#ifndef POLAR_COMPACT
+#define POLAR_COMPACT (POLAR_LDS_TOP == 7)
+#endif // tree levels 4..7 (sub-trees of <= 128 leaves) live in LDS
 
 // One pass of the tree: level m (2^m positions x 8 paths) from level m+1.
 //   G = false: left child  f(a, b)
@@ -157,7 +160,13 @@ struct PolarBufs {
 	rsrc_t soft, llr, hard;    // this codeword's 2 MiB level store, its 65536 channel LLRs, its 65536 partial-sum bytes
 };
 
-template <int D, int KIND, int NG, bool SRC_G>
+// Compact arrays.  Until the first fork all eight paths hold the same LLRs, so the first left descent (t = 0)
+// computes eight identical copies of every level.  DST_C stores such a level ONCE (position-major, 2^L floats
+// at the start of the level's region, written by the k = 0 lanes as full 32-byte sectors) and SRC_C reads it
+// back with the channel-LLR indexing - at t = 0 for the next pass of the descent and at t = 2^z for the g step
+// of the right sibling on the left spine, the only other reader.  Values are unchanged; the level store sees
+// 1.75 MB fewer writes and ~2 MB fewer reads per codeword.
+template <int D, int KIND, int NG, bool SRC_G, bool SRC_C = false, bool DST_C = false>
 __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int hb_g_off, const uint8_t *hb_l, int m, int lane, int gl)
 {
 	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
@@ -184,6 +193,9 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 					if (KIND >= 2) {
 						a[xb][s2] = bload(pb.llr, vo_j, x * 32);
 						b[xb][s2] = bload(pb.llr, vo_j, (x + half) * 32);
+					} else if (SRC_C) {
+						a[xb][s2] = bload(pb.soft, vo_j, src_off + x * 32);
+						b[xb][s2] = bload(pb.soft, vo_j, src_off + (x + half) * 32);
 					} else if (SRC_G) {
 						a[xb][s2] = bload(pb.soft, vo_src, src_off + x * 256);
 						b[xb][s2] = bload(pb.soft, vo_src, src_off + (x + half) * 256);
@@ -203,7 +215,10 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 				for (int s2 = 0; s2 < NT; ++s2) {
 					v[s2] = (KIND & 1) ? g_add(a[xb][s2], b[xb][s2], (h[xb][s2] >> k) & 1) : f_minsum(a[xb][s2], b[xb][s2]);
 					const int idx = (8 << m) + (x0 + xb + s2 * S) * 64;
-					if (NG > 0) bstore(pb.soft, vo_lane, idx * 4, v[s2]); else ls[idx + lane] = v[s2];
+					if (NG > 0) {
+						if (!DST_C) bstore(pb.soft, vo_lane, idx * 4, v[s2]);
+						else if (k == 0) bstore(pb.soft, vo_j, ((8 << m) + (x0 + xb + s2 * S) * 8) * 4, v[s2]);
+					} else ls[idx + lane] = v[s2];
 				}
 				#pragma unroll
 				for (int d = 1; d < D; ++d) {
@@ -212,7 +227,10 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 					for (int s2 = 0; s2 < n; ++s2) {
 						v[s2] = f_minsum(v[s2], v[s2 + n]);
 						const int idx = (8 << (m - d)) + (x0 + xb + s2 * S) * 64;
-						if (NG > d) bstore(pb.soft, vo_lane, idx * 4, v[s2]); else ls[idx + lane] = v[s2];
+						if (NG > d) {
+							if (!DST_C) bstore(pb.soft, vo_lane, idx * 4, v[s2]);
+							else if (k == 0) bstore(pb.soft, vo_j, ((8 << (m - d)) + (x0 + xb + s2 * S) * 8) * 4, v[s2]);
+						} else ls[idx + lane] = v[s2];
 					}
 				}
 			}
@@ -278,10 +296,22 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 			} else {
 				while (cur >= 4) {
 					#define FP(DD, KK, NGG, SG) fused_pass<DD, KK, NGG, SG>(pb, ls, ho_g, ho_l, cur, lane, gl)
+					#define FPC(DD, KK, NGG, SC, DC) fused_pass<DD, KK, NGG, true, SC, DC>(pb, ls, ho_g, ho_l, cur, lane, gl)
 					#define FPK(DD, NGG, SG) do { if (kind == 0) FP(DD, 0, NGG, SG); else FP(DD, 1, NGG, SG); } while (0)
 					int D = 3;
 					// NG = produced levels that are above LDS_TOP (global); SRC_G = the source level cur+1 is global
-					if (cur == 15) { if (kind == 2) FP(3, 2, 3, true); else FP(3, 3, 3, true); }
+					static_assert(LDS_TOP == 7 || !POLAR_COMPACT, "the compact first descent is written for LDS_TOP = 7");
+					if (POLAR_COMPACT && t == 0 && cur >= LDS_TOP + 2) {          // first left descent: compact stores
+						if (cur == 15) FPC(3, 2, 3, false, true);
+						else if (cur >= LDS_TOP + 3) FPC(3, 0, 3, true, true);
+						else FPC(3, 0, 2, true, true);
+					} else if (POLAR_COMPACT && kind == 1 && (t & (t - 1)) == 0 && cur >= LDS_TOP && cur <= 14) {
+						if (cur >= LDS_TOP + 3) FPC(3, 1, 3, true, false);            // right sibling on the left spine:
+						else if (cur == LDS_TOP + 2) FPC(3, 1, 2, true, false);       // its source was stored compact at t = 0
+						else if (cur == LDS_TOP + 1) FPC(3, 1, 1, true, false);
+						else FPC(3, 1, 0, true, false);
+					}
+					else if (cur == 15) { if (kind == 2) FP(3, 2, 3, true); else FP(3, 3, 3, true); }
 					else if (cur >= LDS_TOP + 3) FPK(3, 3, true);
 					else if (cur == LDS_TOP + 2) FPK(3, 2, true);
 					else if (cur == LDS_TOP + 1) FPK(3, 1, true);
@@ -289,6 +319,7 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 					else if (cur >= 6) FPK(3, 0, false);
 					else if (cur == 5) { FPK(2, 0, false); D = 2; }
 					else { FPK(1, 0, false); D = 1; }
+					#undef FPC
 					#undef FPK
 					#undef FP
 					WAVE_ORDER();
