@@ -356,6 +356,18 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 		if (whole) {
 			A.reset_upto(t ? __builtin_ctz(t) : 16, k);
 			H = r3 < 0.f ? 0xff : 0;                          // only bit j of lane (j, k) is read below
+		} else if (fz == 0xffu) {
+			// ---------------- rate-0 sub-tree (8 frozen leaves) in one step: with min-sum the leaf penalties of the
+			// sub-tree add up to sum_j max(0, -r3_j) (max(0,-f(a,b)) + max(0,-(a+b)) = max(0,-a) + max(0,-b), by
+			// cases, then induction).  Summed in the butterfly order j^4, j^2, j^1 and added to the metric once -
+			// the order the oracle fixes for this node (the reference's -Ofast build leaves it open).
+			float pen = r3 < 0.f ? -r3 : 0.f;
+			pen = pen + xj<2>(pen, lane);
+			pen = pen + xj<1>(pen, lane);
+			pen = pen + xj<0>(pen, lane);
+			M += pen;
+			A.reset_upto(t ? __builtin_ctz(t) : 16, k);
+			H = 0;
 		} else
 		// ---------------- the 8 leaves, all in registers
 		#pragma unroll

@@ -354,7 +354,8 @@ static int run_chunk(ofdmrx_handle *h, FrameBatch fb, int n, const int32_t *d_sk
 	size_t t0 = 0;
 	r = run_front1(h, h->stream, 0, fb, n, d_skip, max_skip, &t0);
 	r = r ? r : run_front2(h, h->stream, 0, n, d_res);
-	return r ? r : run_back(h, h->stream, 0, n, 0, d_payload, d_res, want_lane_mesg, t0);
+	static const bool force_grid = std::getenv("OFDMRX_POLAR_FORCE_GRID") != nullptr;   // experiments: limited grid without overlap
+	return r ? r : run_back(h, h->stream, 0, n, force_grid ? h->polar_grid : 0, d_payload, d_res, want_lane_mesg, t0);
 }
 
 static int check_args(ofdmrx_handle *h, const void *samples, int fmt, int channels, size_t spf, size_t stride,

@@ -113,12 +113,15 @@ void orc_polar_sysenc(int8_t *code, const int8_t *mesg, const uint32_t *frozen, 
  *   f(a,b) = sign(a)sign(b)min(|a|,|b|);  g(a,b,u) = u*a + b
  *   left subtree = lower indices; each subtree returns the lane map it applied
  *   frozen leaf: metric += |llr| when llr < 0, hard = +1, identity map
+ *   (an aligned group of 8 frozen leaves is charged in one step, see scl_node)
  *   info leaf  : fork 2L candidates, keep the L smallest metrics.
  * Tie rule (std::nth_element is implementation-defined there): candidates are
  * ordered by (metric, candidate index 2k+u) and survivors are stored in that
  * sorted order, so the result is deterministic.  Initial metrics: lane 0 = 0,
  * others = 1000, so the list fills from one path.
  */
+enum { ORC_RATE0_LEVEL = 3 };
+
 typedef struct {
 	int L, count;
 	float *soft;       /* 2N*L */
@@ -180,11 +183,46 @@ static void scl_leaf(scl_t *s, int index, uint8_t *map)
 
 /* decode the size-n (n = 1<<m) node whose first leaf is 'index'; its input
  * LLRs are soft[(n+i)*L+k]; returns accumulated lane map in 'map' */
+/* all 1<<m leaves from 'index' frozen? */
+static int all_frozen(const uint32_t *frozen, int index, int m)
+{
+	for (int i = 0; i < (1 << m); ++i)
+		if (!is_frozen(frozen, index + i))
+			return 0;
+	return 1;
+}
+
 static void scl_node(scl_t *s, int m, int index, uint8_t *map)
 {
 	const int L = s->L;
 	if (m == 0) {
 		scl_leaf(s, index, map);
+		return;
+	}
+	if (m == ORC_RATE0_LEVEL && all_frozen(s->frozen, index, m)) {
+		/* Rate-0 node of 8 leaves in one step.  With min-sum, the frozen-leaf penalties of a sub-tree add up
+		 * to sum_i max(0, -llr_i) over the node's OWN input LLRs (f keeps the smaller magnitude with the
+		 * product sign, g with u = 0 is a + b: case by case max(0,-f(a,b)) + max(0,-(a+b)) =
+		 * max(0,-a) + max(0,-b), then induction over the levels), so the leaf walk is not needed.  The
+		 * reference is built -Ofast (Makefile:2) and may reassociate this sum anyway; the order fixed here
+		 * is the butterfly halving p[i] += p[i + h], h = 4, 2, 1 - the order a wave reduces it in - and the
+		 * total is added to the path metric once.  Partial sums are all +1, the lane map is the identity. */
+		const int n = 1 << m;
+		for (int k = 0; k < L; ++k) {
+			float p[1 << ORC_RATE0_LEVEL];
+			for (int i = 0; i < n; ++i) {
+				float v = s->soft[(size_t)(n + i) * L + k];
+				p[i] = v < 0.f ? -v : 0.f;
+			}
+			for (int h = n / 2; h >= 1; h /= 2)
+				for (int i = 0; i < h; ++i)
+					p[i] = p[i] + p[i + h];
+			s->metric[k] += p[0];
+			map[k] = (uint8_t)k;
+		}
+		for (int i = 0; i < n; ++i)
+			for (int k = 0; k < L; ++k)
+				s->hard[(size_t)(index + i) * L + k] = 1;
 		return;
 	}
 	const int n = 1 << m, h = n / 2;
