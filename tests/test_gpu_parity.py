@@ -586,3 +586,37 @@ def test_chunk_pipeline_matches_single_chunk():
     assert (o5[0] == pays[0]).all() and (o5[1] == pays[1]).all() and (o5[2] == pays[2]).all() and (o5[4] == pays[5]).all()
     o, r = O.decode(batch[3])
     assert r.status == int(st[3]) and (o == o5[3]).all()
+
+
+def test_config2_full_size_mono_round_trip():
+    """BASELINE configs[1] at its full size: 4096 clean 16-bit MONO frames (the D1 front end: DC blocker + Hilbert), made
+    by the device transmitter with 4096 distinct payloads; size-independent property: every payload comes back
+    bit-exact, no flips, one sync position for all frames; three frames are also checked against the oracle"""
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    n = 4096
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        rx = modem_amd.Receiver(device=0, chunk_frames=1024, stream=stream.cuda_stream)
+        spf = rx.tx_frame_samples(6)
+        g = torch.Generator(device=dev)
+        g.manual_seed(4096)
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+        d_in = torch.empty((n, spf, 1), dtype=torch.int16, device=dev)
+        rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=1)
+        d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 1, spf, spf * 2, n, d_out.data_ptr(), d_res.data_ptr())
+        rx.synchronize()
+        assert bool((d_out == d_pay).all())
+        res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+        assert (res["status"] == 0).all() and (res["bit_flips"] == 0).all() and (res["oper_mode"] == 6).all()
+        assert len(set(res["sc_start"].tolist())) == 1
+        frames = d_in[[0, 1777, 4095]].cpu().numpy()
+        pays = d_pay[[0, 1777, 4095]].cpu().numpy()
+    for f, p, r in zip(frames, pays, res[[0, 1777, 4095]]):
+        o, orr = O.decode(f)
+        assert orr.status == 0 and (o == p).all() and orr.sc_start == int(r["sc_start"]) and orr.symbol_pos == int(r["symbol_pos"])
+    rx.close()
