@@ -248,13 +248,15 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 #define WAVE_ORDER() __builtin_amdgcn_wave_barrier()
 
 __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
-	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, float *__restrict__ metric_all)
+	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev2,
+	float *__restrict__ metric_all)
 {
 	const int lane = threadIdx.x, j = lane >> 3, k = lane & 7;
 	for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
 	if (!st_all[cw].okay)
 		continue;                                             // no header -> nothing to decode (decode.cc:450-451)
 	const uint32_t *frozen = frozen2 + (st_all[cw].oper_mode >= 10 ? 2048 : 0);   // decode.cc:312,344
+	const uint8_t *node_lev = node_lev2 + (st_all[cw].oper_mode >= 10 ? 8192 : 0);
 	const float *llr = llr_all + (size_t)cw * CODE_LEN;
 	float *soft = soft_all + (size_t)blockIdx.x * (8 * CODE_LEN);   // level m >= 8 at soft + 8*2^m
 	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;
@@ -273,8 +275,14 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 	int stat_r1 = 0, stat_r1_ok = 0;
 #endif
 
-	for (int t8 = 0; t8 < CODE_LEN / 8; ++t8) {
+	for (int t8 = 0, adv = 1; t8 < CODE_LEN / 8; t8 += adv) {
 		const int t = t8 * 8;
+		// Uniform node that starts here (static, from the frozen pattern): level 4..7 = 16..128 leaves all frozen
+		// (nl0) or all information (nl1); such a node is decided in one step on its own LLR array (below), the
+		// 8-leaf case (level 3) in registers further down.  Ln = level of the node decided this way, 0 = none.
+		const int nl = node_lev[t8], nl0 = nl & 15, nl1 = nl >> 4, Lt = nl0 > nl1 ? nl0 : nl1;
+		int Ln = 0;
+		adv = 1;
 		// ---------------- LLRs of this 8-leaf sub-tree into r3
 		{
 			int cur, kind;                                    // next level to produce and how its first step works
@@ -294,7 +302,10 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 				float a = ls[(8 << 4) + gl], b = ls[(8 << 4) + gl + 64];
 				r3 = g_add(a, b, (ho_l[j] >> k) & 1);
 			} else {
-				while (cur >= 4) {
+				bool try_node = Lt >= 4, redo;
+				int stop = try_node ? Lt : 4;
+				do {
+				while (cur >= stop) {
 					#define FP(DD, KK, NGG, SG) fused_pass<DD, KK, NGG, SG>(pb, ls, ho_g, ho_l, cur, lane, gl)
 					#define FPC(DD, KK, NGG, SC, DC) fused_pass<DD, KK, NGG, true, SC, DC>(pb, ls, ho_g, ho_l, cur, lane, gl)
 					#define FPK(DD, NGG, SG) do { if (kind == 0) FP(DD, 0, NGG, SG); else FP(DD, 1, NGG, SG); } while (0)
@@ -326,9 +337,70 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 					cur -= D;
 					kind = 0;
 				}
-				r3 = f_minsum(ls[(8 << 4) + lane], ls[(8 << 4) + lane + 64]);
+				redo = false;
+				if (try_node) {
+					// level Lt (in LDS) now holds the node's LLRs: cnt = 2^(Lt-3) values per lane, position x*8 + j
+					try_node = false;
+					const int cnt = 1 << (Lt - 3);
+					const float *lv = ls + (8 << Lt) + lane;
+					uint8_t *lhn = lh + (t & ((1 << LDS_TOP) - 1));
+					if (nl0) {
+						// rate-0 node: sum of max(0, -llr) in the butterfly halving order the oracle fixes
+						// (positions i, i + n/2: lane-local while the distance is >= 8, then j^4, j^2, j^1)
+						float pz[16];
+						#pragma unroll
+						for (int x = 0; x < 16; ++x) {
+							const float v = x < cnt ? lv[x * 64] : 0.f;
+							pz[x] = v < 0.f ? -v : 0.f;
+						}
+						#pragma unroll
+						for (int hx = 8; hx >= 1; hx >>= 1)
+							#pragma unroll
+							for (int x = 0; x < hx; ++x)
+								pz[x] = pz[x] + pz[x + hx];           // + 0 beyond cnt: exact
+						float pen = pz[0];
+						pen = pen + xj<2>(pen, lane);
+						pen = pen + xj<1>(pen, lane);
+						pen = pen + xj<0>(pen, lane);
+						M += pen;
+						if (lane < cnt)
+							*(unsigned long long *)(lhn + lane * 8) = 0ull;
+						Ln = Lt;
+					} else {
+						// rate-1 node: same argument as for 8 leaves, mu_k = the smallest magnitude of the whole node
+						uint32_t mu = 0x7f800000u;
+						#pragma unroll
+						for (int x = 0; x < 16; ++x)
+							if (x < cnt)
+								mu = min(mu, __float_as_uint(lv[x * 64]) & 0x7fffffffu);
+						mu = min(mu, (uint32_t)xor8_i((int)mu));
+						mu = min(mu, (uint32_t)xor16_i((int)mu, lane));
+						mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
+						const float P = M + __uint_as_float(mu);
+						const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
+						const bool ok = (k == 0 || Mprev <= M) && group8_max(M) < group8_min(P);
+						if (__ballot(!ok) == 0) {
+							for (int x = 0; x < cnt; ++x) {           // partial sums = sign bits, one byte per position
+								const unsigned long long bal = __ballot(lv[x * 64] < 0.f);
+								if (lane == 0)
+									*(unsigned long long *)(lhn + x * 8) = bal;
+							}
+							Ln = Lt;
+						} else {
+							stop = 4;                                 // walk it after all: the 8-leaf groups get their own chance
+							redo = cur >= 4;
+						}
+					}
+				}
+				} while (redo);
+				if (Ln) {
+					A.reset_upto(t ? __builtin_ctz(t) : 16, k);
+					adv = 1 << (Ln - 3);
+				} else
+					r3 = f_minsum(ls[(8 << 4) + lane], ls[(8 << 4) + lane + 64]);
 			}
 		}
+		if (!Ln) {
 		const uint32_t fz = (frozen[t >> 5] >> (t & 31)) & 0xffu;
 		// H: partial sums of the 8 leaves, one bit per position, for THIS lane's path (same in all j)
 		int H = 0;
@@ -463,6 +535,7 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 			if (lane == 0)
 				*(unsigned long long *)(lh + (t & ((1 << LDS_TOP) - 1))) = bal;
 		}
+		}   // !Ln
 		auto combine = [&](int off, int hh, int rm) {        // LDS block: lh[i] = perm(lh[i], rm) ^ lh[i + hh]
 			uint8_t *hp = lh + off;
 			for (int it0 = 0; it0 < hh / 8; it0 += UB) {
@@ -513,8 +586,8 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 					}
 			}
 		};
-		const int tn = t + 8;
-		for (int m = 4; m <= LDS_TOP && (tn & ((1 << m) - 1)) == 0; ++m) {
+		const int tn = t + 8 * adv;
+		for (int m = Ln ? Ln + 1 : 4; m <= LDS_TOP && (tn & ((1 << m) - 1)) == 0; ++m) {
 			WAVE_ORDER();
 			combine((tn - (1 << m)) & ((1 << LDS_TOP) - 1), 1 << (m - 1), A.get(m - 1));
 		}
@@ -545,7 +618,7 @@ void launch_polar(hipStream_t s, int n, int grid, const SyncState *st, const flo
 {
 	if (grid <= 0 || grid > n)
 		grid = n;
-	hipLaunchKernelGGL(k_polar, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, metric);
+	hipLaunchKernelGGL(k_polar, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric);
 }
 
 }  // namespace rx

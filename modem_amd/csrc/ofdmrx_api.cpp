@@ -175,6 +175,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.tw_sym4, &h->dev.tw_sym4);
 	r = r ? r : upload(h, h->host.frozen, &h->dev.frozen);
 	r = r ? r : upload(h, h->host.info_pos, &h->dev.info_pos);
+	r = r ? r : upload(h, h->host.node_lev, &h->dev.node_lev);
 	r = r ? r : upload(h, h->host.genmat_bits, &h->dev.genmat_bits);
 	r = r ? r : upload(h, h->host.osd_pairs, &h->dev.osd_pairs);
 	r = r ? r : upload(h, h->host.osd_triples, &h->dev.osd_triples);

@@ -162,6 +162,28 @@ void build_tables(HostTables &t, int rate)
 	t.frozen.resize(2 * 2048);
 	frozen_mask(t.frozen.data(), 64800);
 	frozen_mask(t.frozen.data() + 2048, 64512);
+	// uniform sub-trees for the list decoder: for every aligned group of 8 leaves the level (3..7) of the largest
+	// aligned node that starts there and is all frozen (low nibble) or all information (high nibble); 0 = neither
+	t.node_lev.assign(2 * 8192, 0);
+	for (int tab = 0; tab < 2; ++tab)
+		for (int t8 = 0; t8 < 8192; ++t8) {
+			const int t0 = t8 * 8;
+			int lev[2] = { 0, 0 };
+			for (int kind = 0; kind < 2; ++kind)
+				for (int L = 3; L <= 7; ++L) {
+					if (t0 & ((1 << L) - 1))
+						break;
+					bool uniform = true;
+					for (int i = t0; i < t0 + (1 << L) && uniform; ++i) {
+						const int fr = (t.frozen[tab * 2048 + i / 32] >> (i % 32)) & 1;
+						uniform = kind == 0 ? fr == 1 : fr == 0;
+					}
+					if (!uniform)
+						break;
+					lev[kind] = L;
+				}
+			t.node_lev[tab * 8192 + t8] = (uint8_t)(lev[0] | (lev[1] << 4));
+		}
 	t.info_pos.assign(2 * 44096, 0);
 	for (int tab = 0; tab < 2; ++tab) {
 		int n = 0;
