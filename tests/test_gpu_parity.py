@@ -620,3 +620,45 @@ def test_config2_full_size_mono_round_trip():
         o, orr = O.decode(f)
         assert orr.status == 0 and (o == p).all() and orr.sc_start == int(r["sc_start"]) and orr.symbol_pos == int(r["symbol_pos"])
     rx.close()
+
+
+def test_waterfall_parity_at_scale():
+    """192 device-made frames at the edge of the waterfall (-14.6 dB: a mix of decoded and lost frames, every slow
+    path of the list decoder: failed node shortcuts, path replacement, CRC failures).  Everything decided - payload,
+    status, winning lane, sync position, header - must equal the oracle's frame by frame; the flip-count diagnostic
+    (sign of LLRs that may sit within the 1e-5 intermediate tolerance of zero) within 2."""
+    import os
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    n = 192
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        rx = modem_amd.Receiver(device=0, chunk_frames=80, stream=stream.cuda_stream)
+        spf = rx.tx_frame_samples(6)
+        g = torch.Generator(device=dev)
+        g.manual_seed(146)
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+        d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+        rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
+        rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, -14.6, 7, 0)
+        d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+        rx.synchronize()
+        out = d_out.cpu().numpy()
+        res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+        pcm = np.ascontiguousarray(d_in.cpu().numpy())
+        pays = d_pay.cpu().numpy()
+    rx.close()
+    oout = np.zeros((n, 5380), np.uint8)
+    ores = np.zeros(n * 56, np.uint8)
+    O.lib().orc_decode_batch(O.ptr(pcm), O.FMT_S16, 2, spf, spf * 4, n, 8, O.ptr(oout), O.ptr(ores), min(os.cpu_count() or 1, 32))
+    ores = ores.view(M.RESULT_DTYPE).reshape(-1)
+    ok = res["status"] == 0
+    assert 10 < ok.sum() < n - 10                               # really at the edge
+    assert (out == oout).all() and (out[ok] == pays[ok]).all()
+    for name in ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects"):
+        assert (res[name] == ores[name]).all(), name
+    assert (np.abs(res["bit_flips"].astype(np.int64) - ores["bit_flips"]) <= 2).all()

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""GPU path vs the CPU oracle frame by frame near the waterfall, where every slow path of the list decoder runs
+(failed node shortcuts, forks with path replacement, CRC failures): status, payload, winning lane, flips.
+usage: parity_sweep.py [frames per level] [levels dB ...]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import oracle_lib as O
+import modem_amd
+import modem_amd.ofdmrx as M
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+levels = [float(x) for x in sys.argv[2:]] or [-17.0, -15.5, -15.0, -14.5]
+dev = torch.device("cuda:0")
+stream = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(stream)
+rx = modem_amd.Receiver(device=0, chunk_frames=96, stream=stream.cuda_stream)
+spf = rx.tx_frame_samples(6)
+threads = min(os.cpu_count() or 1, 32)
+bad = 0
+for li, db in enumerate(levels):
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + li)
+    d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+    d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+    rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
+    rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, db, 99, li * n)
+    d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+    d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+    rx.synchronize()
+    out = d_out.cpu().numpy()
+    res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+    pcm = np.ascontiguousarray(d_in.cpu().numpy())
+    oout = np.zeros((n, 5380), np.uint8)
+    ores = np.zeros(n * 56, np.uint8)
+    t = time.perf_counter()
+    O.lib().orc_decode_batch(O.ptr(pcm), O.FMT_S16, 2, spf, spf * 4, n, 8, O.ptr(oout), O.ptr(ores), threads)
+    dt = time.perf_counter() - t
+    ores = ores.view(M.RESULT_DTYPE).reshape(-1)
+    # bit_flips (decode.cc:546-555) counts sign(llr) != decoded bit: an LLR within the 1e-5 intermediate tolerance
+    # of zero may carry either sign, so that diagnostic may differ by a count or two; everything decided must not
+    same = (out == oout).all(axis=1) & (res["status"] == ores["status"]) & (res["best_lane"] == ores["best_lane"]) \
+        & (np.abs(res["bit_flips"].astype(np.int64) - ores["bit_flips"]) <= 2) & (res["sc_start"] == ores["sc_start"]) \
+        & (res["symbol_pos"] == ores["symbol_pos"]) & (res["oper_mode"] == ores["oper_mode"]) & (res["call_sign"] == ores["call_sign"])
+    flips_equal = int((res["bit_flips"] == ores["bit_flips"]).sum())
+    nok = int((res["status"] == 0).sum())
+    bad += int((~same).sum())
+    print("%6.1f dB: %d frames, %d decoded, GPU == oracle (payload, status, lane, sync, header) on %d, flip count identical on %d "
+          "(oracle %.1f s on %d threads)" % (db, n, nok, int(same.sum()), flips_equal, dt, threads), flush=True)
+    if not same.all():
+        i = int(np.argmin(same))
+        print("   first mismatch frame %d: gpu status %d lane %d flips %d | oracle status %d lane %d flips %d" % (
+            i, res["status"][i], res["best_lane"][i], res["bit_flips"][i], ores["status"][i], ores["best_lane"][i], ores["bit_flips"][i]))
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
