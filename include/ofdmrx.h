@@ -63,7 +63,8 @@ typedef struct {
 	int32_t abi_version;       /* OFDMRX_ABI_VERSION */
 	int32_t sample_rate;       /* 8000, 16000, 44100 or 48000: which Decoder<value,cmplx,rate> this handle is
 	                            * (decode.cc:590-602); anything else: OFDMRX_E_UNSUPPORTED (decode.cc:603-605) */
-	int32_t list_size;         /* SCL list = SIMD width of the reference build (decode.cc:164-169): 8 */
+	int32_t list_size;         /* SCL list = SIMD width of the reference build (decode.cc:164-169): 8 (AVX2, the
+	                            * benchmarked configuration; 0 = 8) or 4 (the 128-bit build) */
 	int32_t device;            /* HIP device ordinal */
 	int32_t chunk_frames;      /* frames resident per pass (0 = default) */
 	int32_t max_samples;       /* max samples per frame (0 = ofdmrx_frame_samples(sample_rate, 6)) */

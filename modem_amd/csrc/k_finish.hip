@@ -9,7 +9,7 @@ namespace rx {
 // decode.cc:532-541 (first lane whose CRC-32 over 43072 bits is 0), decode.cc:546-555
 // (LE bit packing + flip count), decode.cc:613-615 (descramble).
 __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
-	const uint8_t *__restrict__ hard_all, Tables tb, int descramble, uint8_t *__restrict__ lane_mesg_all,
+	const uint8_t *__restrict__ hard_all, Tables tb, int descramble, int list, uint8_t *__restrict__ lane_mesg_all,
 	uint8_t *__restrict__ payload_all, Result *__restrict__ res_all)
 {
 	const int f = blockIdx.x, tid = threadIdx.x;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 	}
 	__syncthreads();
 	int best = -1;
-	for (int k = LIST - 1; k >= 0; --k)
+	for (int k = list - 1; k >= 0; --k)                       // decode.cc:532-541 over the list's lanes
 		if (crcs[k] == 0)
 			best = k;
 	r.best_lane = best;
@@ -124,10 +124,10 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 	}
 }
 
-void launch_finish(hipStream_t s, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
+void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
 	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res)
 {
-	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, lane_mesg, payload, res);
+	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, list == 4 ? 4 : 8, lane_mesg, payload, res);
 }
 
 }  // namespace rx

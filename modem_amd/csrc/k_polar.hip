@@ -57,20 +57,24 @@ template <int ZZ> __device__ __forceinline__ float xj(float v, int lane)
 // min / max over the 8 paths (lanes k = 0..7 of a group); result in every lane.  Path metrics are
 // non-negative floats, so their bit patterns order like unsigned integers: v_min_u32 / v_max_u32 fuse with the
 // DPP operand (one instruction per step) where the float forms need a canonicalising v_max each.
-__device__ __forceinline__ float group8_min(float vf)
+// LN = 4: the list of the reference's non-AVX2 build (SIMD<float,4>, decode.cc:168) runs on the same 8-lane layout
+// with paths 4..7 dead (metric +inf): the live paths are one quad, so the reduction stops after the quad steps.
+template <int LN> __device__ __forceinline__ float group8_min(float vf)
 {
 	uint32_t v = __float_as_uint(vf);
 	v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
 	v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-	v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+	if (LN == 8)
+		v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
 	return __uint_as_float(v);
 }
-__device__ __forceinline__ float group8_max(float vf)
+template <int LN> __device__ __forceinline__ float group8_max(float vf)
 {
 	uint32_t v = __float_as_uint(vf);
 	v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
 	v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
-	v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
+	if (LN == 8)
+		v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
 	return __uint_as_float(v);
 }
 
@@ -247,6 +251,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 // barrier would also drain every outstanding store (s_waitcnt vmcnt(0)) after each tree pass.
 #define WAVE_ORDER() __builtin_amdgcn_wave_barrier()
 
+template <int LN>
 __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
 	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev2,
 	float *__restrict__ metric_all)
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 	pb.soft = make_rsrc(soft, 8 * CODE_LEN * 4);
 	pb.llr = make_rsrc(llr, CODE_LEN * 4);
 	pb.hard = make_rsrc(hard, CODE_LEN);
-	float M = k ? 1000.f : 0.f;                               // lane 0 carries the only real path
+	float M = k == 0 ? 0.f : (k < LN ? 1000.f : __builtin_inff());   // lane 0 carries the only real path; k >= LN: dead
 	Maps A;
 	A.w0 = ID0 * (uint32_t)k;
 	A.w1 = ID1 * (uint32_t)k;
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 						mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
 						const float P = M + __uint_as_float(mu);
 						const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
-						const bool ok = (k == 0 || Mprev <= M) && group8_max(M) < group8_min(P);
+						const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
 						if (__ballot(!ok) == 0) {
 							for (int x = 0; x < cnt; ++x) {           // partial sums = sign bits, one byte per position
 								const unsigned long long bal = __ballot(lv[x * 64] < 0.f);
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 			mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
 			const float P = M + __uint_as_float(mu);
 			const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
-			const bool ok = (k == 0 || Mprev <= M) && group8_max(M) < group8_min(P);
+			const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
 			whole = __ballot(!ok) == 0;
 		}
 #ifdef POLAR_STATS
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 				// continuation is worse than every free one -> each path just takes its own sign bit
 				const float P = M + fabsf(r0);
 				const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
-				const bool ok = (k == 0 || Mprev <= M) && group8_max(M) < group8_min(P);
+				const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
 				if (__ballot(!ok) == 0) {
 					ubit = r0 < 0.f;
 				} else {
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 					int rv = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(val));
 					const int rcx = xor8_i(rc), rvx = xor8_i(rv);   // odd j sit at row position 8+k: take position k
 					if (j & 1) { rc = rcx; rv = rvx; }
-					M = __int_as_float(rv);
+					M = k < LN ? __int_as_float(rv) : __builtin_inff();   // list 4: ranks 4..7 do not survive
 					const int parent = rc >> 1;
 					ubit = rc & 1;
 					if (__ballot(parent != k)) {
@@ -614,11 +619,14 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 	}   // next codeword of this block
 }
 
-void launch_polar(hipStream_t s, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric)
+void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric)
 {
 	if (grid <= 0 || grid > n)
 		grid = n;
-	hipLaunchKernelGGL(k_polar, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric);
+	if (list == 4)
+		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric);
+	else
+		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric);
 }
 
 }  // namespace rx

@@ -63,6 +63,7 @@ struct ofdmrx_handle {
 	int chunk = 0;
 	long max_samples = 0;
 	int rate = 8000;
+	int list = 8;             // SCL list size: 8 (AVX2 build of the reference) or 4 (decode.cc:164-169)
 	HostTables host;
 	Tables dev{};
 	std::vector<void *> table_allocs;
@@ -117,7 +118,7 @@ extern "C" const char *ofdmrx_strerror(int err)
 	case OFDMRX_E_NOMEM: return g_last_error.empty() ? "out of device memory" : g_last_error.c_str();
 	case OFDMRX_E_HIP: return g_last_error.empty() ? "HIP error" : g_last_error.c_str();
 	case OFDMRX_E_NODEV: return "no usable HIP device (the receive path has no CPU fallback)";
-	case OFDMRX_E_UNSUPPORTED: return "unsupported configuration (sample rate 8000/16000/44100/48000, list size 8)";
+	case OFDMRX_E_UNSUPPORTED: return "unsupported configuration (sample rate 8000/16000/44100/48000, list size 4 or 8)";
 	default: return "unknown error";
 	}
 }
@@ -126,7 +127,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 {
 	if (!cfg || !out || cfg->abi_version != OFDMRX_ABI_VERSION)
 		return OFDMRX_E_ARG;
-	if (!rate_supported(cfg->sample_rate) || (cfg->list_size != 0 && cfg->list_size != 8))   // decode.cc:590-605
+	if (!rate_supported(cfg->sample_rate) || (cfg->list_size != 0 && cfg->list_size != 8 && cfg->list_size != 4))   // decode.cc:590-605,164-169
 		return OFDMRX_E_UNSUPPORTED;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
@@ -137,6 +138,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		return OFDMRX_E_NOMEM;
 	h->cfg = *cfg;
 	h->rate = cfg->sample_rate;
+	h->list = cfg->list_size == 4 ? 4 : 8;
 	// default chunk: 8192 frames at 8 kHz, scaled down with the samples per frame at the higher rates
 	h->chunk = cfg->chunk_frames > 0 ? cfg->chunk_frames : (int)(8192L * 8000 / cfg->sample_rate);
 	h->max_samples = cfg->max_samples > 0 ? cfg->max_samples : ofdmrx_frame_samples(cfg->sample_rate, 6);
@@ -334,9 +336,9 @@ static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, int grid, u
 {
 	SyncState *st = h->st_of(par);
 	size_t e6 = mark(h, s);
-	launch_polar(s, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	launch_polar(s, h->list, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
 	size_t e7 = mark(h, s);
-	launch_finish(s, n, st, h->llr_of(par), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
+	launch_finish(s, h->list, n, st, h->llr_of(par), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
 		want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res);
 	size_t e8 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
@@ -618,8 +620,8 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
-	launch_polar(h->stream, (int)n, 0, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
-	launch_finish(h->stream, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, 0,
+	launch_polar(h->stream, h->list, (int)n, 0, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	launch_finish(h->stream, h->list, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, 0,
 		h->lane_mesg.as<uint8_t>(), h->payload.as<uint8_t>(), h->res.as<Result>());
 	HIP_OK(hipGetLastError());
 	HIP_OK(hipStreamSynchronize(h->stream));

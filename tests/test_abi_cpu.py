@@ -72,7 +72,7 @@ def test_argument_validation_without_device(lib):
     assert lib.ofdmrx_create(C.byref(cfg), C.byref(h)) == -1
     cfg = M.Config(1, 22050, 8, 0, 0, 0, 1, 0, None)     # decode.cc:603-605 "Unsupported sample rate."
     assert lib.ofdmrx_create(C.byref(cfg), C.byref(h)) == -5
-    cfg = M.Config(1, 48000, 4, 0, 0, 0, 1, 0, None)     # list size 4 (the non-AVX2 build, decode.cc:168) not covered
+    cfg = M.Config(1, 48000, 16, 0, 0, 0, 1, 0, None)    # list sizes: 8 (AVX2 build) or 4 (decode.cc:164-169), nothing else
     assert lib.ofdmrx_create(C.byref(cfg), C.byref(h)) == -5
     # frame lengths: 2 x rate silence + (rows + 5) symbols of symbol_len + guard_len (encode.cc:423,441)
     lib.ofdmrx_frame_samples.restype = C.c_long

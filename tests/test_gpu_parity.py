@@ -662,3 +662,34 @@ def test_waterfall_parity_at_scale():
     for name in ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects"):
         assert (res[name] == ores[name]).all(), name
     assert (np.abs(res["bit_flips"].astype(np.int64) - ores["bit_flips"]) <= 2).all()
+
+
+def test_list_size_4():
+    """cfg.list_size = 4: the reference's 128-bit build (SIMD<float,4>, decode.cc:168).  The four lanes' messages and
+    metrics are bit-exact against the oracle's L = 4 decoder on identical LLRs, and whole frames near the L = 4
+    waterfall decode like the oracle with list_size 4 (status, payload, winning lane)."""
+    import modem_amd
+    rx4 = modem_amd.Receiver(device=0, chunk_frames=16, list_size=4)
+    llrs = []
+    frames, pays = [], []
+    for i, db in enumerate((None, -20, -16, -15.2, -14.8, -14.4)):
+        p = O.payload_for(1400 + i)
+        pcm = O.encode_pcm(p, channels=2)
+        if db is not None:
+            pcm = O.impair(pcm, noise_db=db, seed=31, frame=i)
+        _, res, tb = O.decode(pcm, taps=True, list_size=4)
+        llrs.append(tb.llr.copy())
+        frames.append(pcm)
+        pays.append(p)
+    llrs = np.stack(llrs)
+    mesg, metric = rx4.polar(llrs)
+    for i in range(llrs.shape[0]):
+        om, omet = O.polar_lane_mesg(llrs[i], L=4)
+        assert (metric[i][:4] == omet[:4]).all(), (i, metric[i], omet)
+        assert (mesg[i][:4] == om[:4]).all(), i
+    out, res = rx4.decode(np.stack(frames))
+    for i, f in enumerate(frames):
+        oo, orr = O.decode(f, list_size=4)
+        assert int(res[i]["status"]) == orr.status and int(res[i]["best_lane"]) == orr.best_lane and (out[i] == oo).all(), i
+    assert int(res[0]["status"]) == 0 and (out[0] == pays[0]).all()
+    rx4.close()
