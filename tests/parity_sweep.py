@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """GPU path vs the CPU oracle frame by frame near the waterfall, where every slow path of the list decoder runs
 (failed node shortcuts, forks with path replacement, CRC failures): status, payload, winning lane, flips.
-usage: parity_sweep.py [frames per level] [levels dB ...]"""
+(test infrastructure: the only place outside tests/*.py, smoke() and bench.py's cpu_baseline that runs the oracle)
+usage: python tests/parity_sweep.py [frames per level] [levels dB ...]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import torch
 import oracle_lib as O

@@ -2,7 +2,7 @@
 """debug: how often the rate-1 sub-tree shortcut of k_polar applies (library built with -DPOLAR_STATS)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import oracle_lib as O
 import modem_amd
