@@ -493,7 +493,7 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 }
 
 // decode.cc:479-504: one workgroup per (frame, row)
-__global__ __launch_bounds__(256) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
+__global__ __launch_bounds__(256, 5) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
 	float *__restrict__ slope_all, float *__restrict__ yint_all)
 {
 	// grid = frames x 50 (mode 6 has exactly 50 rows: one row per block); modes with more rows loop
