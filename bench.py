@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--channels", type=int, default=2, choices=[1, 2],
                     help="2 = configs[2] (analytic + AWGN, the headline workload); 1 = configs[1] flavour: clean 16-bit mono frames "
                          "(exercises the D1 front end)")
+    ap.add_argument("--impair", action="store_true",
+                    help="configs[3]: every frame also goes through the device channel chain multipath -> CFO +234.567 Hz "
+                         "-> SFO +147 ppm (README.md:49) before the AWGN")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,7 +109,17 @@ def main():
         else:
             d_clean = torch.empty((U, spf, ch), dtype=torch.int16, device=dev)
         rx.tx_encode(d_pay.data_ptr(), U, d_clean.data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=ch)
-        if ch == 2:
+        if ch == 2 and args.impair:
+            d_imp = torch.empty((U, spf, ch), dtype=torch.int16, device=dev)
+            taps = [(0, 1 + 0j), (5, 0.35 - 0.1j), (11, -0.2 + 0.2j), (23, 0.1 + 0.05j)]
+            for lo in range(0, U, 8192):
+                hi = min(lo + 8192, U)
+                rx.channel(d_clean[lo:hi].data_ptr(), d_imp[lo:hi].data_ptr(), hi - lo, spf, cfo_hz=234.567, sfo_ppm=147.0,
+                           multipath=taps)
+            rx.awgn_tile(d_imp.data_ptr(), U, d_in.data_ptr(), B, spf, args.noise_db, args.seed,
+                         shard.frame_seed_offset(B, rank))
+            del d_imp
+        elif ch == 2:
             rx.awgn_tile(d_clean.data_ptr(), U, d_in.data_ptr(), B, spf, args.noise_db, args.seed,
                          shard.frame_seed_offset(B, rank))
         elif U != B:
@@ -114,6 +127,8 @@ def main():
             for lo in range(0, B, 4096):
                 d_in[lo:lo + 4096] = d_clean[idx[lo:lo + 4096]]
         source = "device transmitter, %d distinct random payloads" % U
+        if ch == 2 and args.impair:
+            source += ", device channel chain multipath(4 taps) -> CFO +234.567 Hz -> SFO +147 ppm (configs[3])"
     else:
         fx = np.load(os.path.join(ROOT, "tests", "golden", "base_frames_2ch.npz"))
         base = fx["pcm"]
@@ -189,9 +204,9 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[2]: batch %d analytic (2-ch int16) mode-6 8 kHz frames per GPU, AWGN noise "
+            "config": {"workload": ("configs[%d]: batch %d analytic (2-ch int16) mode-6 8 kHz frames per GPU, AWGN noise "
                                     "level %g dB, inputs resident in HBM; %s, on-device noise keyed by frame index"
-                                    % (B, args.noise_db, source)) if ch == 2 else
+                                    % (3 if args.impair else 2, B, args.noise_db, source)) if ch == 2 else
                                    ("configs[1] flavour: batch %d clean 16-bit mono mode-6 8 kHz frames per GPU, inputs resident "
                                     "in HBM; %s" % (B, source)),
                        "frames_per_gpu": B, "list_size": 8, "chunk_frames": rx.chunk_frames, "parallelism": "frames x%d" % n_gpus},
