@@ -188,6 +188,16 @@ int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_t *d_out, s
  * (rows + 5) symbols; ofdmrx_tx_frame_samples(mode) is the 8 kHz value. */
 long ofdmrx_frame_samples(int sample_rate, int oper_mode);
 long ofdmrx_tx_frame_samples(int oper_mode);
+/* Streams of `count` payloads, as `encode OUT RATE BITS CHANNELS OFFSET MODE CALLSIGN file1 .. fileN` writes them
+ * (encode.cc:288-313: pilot | count x (S&C, meta, pilot, rows) | zero symbol, `rate` samples of silence either side),
+ * bits = 8 (unsigned, offset 128) or 16.  ofdmrx_stream_samples: sample frames of one such stream.
+ * _device: n_streams x count x 5380 payload bytes in, n_streams x samples x channels PCM out, DEVICE pointers.
+ * ofdmrx_tx_encode_stream: the same for ONE stream with HOST pointers (what the `encode` CLI calls). */
+long ofdmrx_stream_samples(int sample_rate, int oper_mode, int count);
+int ofdmrx_tx_encode_stream_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_streams, int count,
+	int oper_mode, int freq_off, const char *call_sign, int channels, int bits, void *d_pcm);
+int ofdmrx_tx_encode_stream(ofdmrx_handle *h, const uint8_t *payload, int count, int oper_mode, int freq_off,
+	const char *call_sign, int channels, int bits, void *pcm);
 int ofdmrx_tx_encode_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_frames, int oper_mode,
 	int freq_off, const char *call_sign, int channels, int16_t *d_pcm);
 

@@ -15,6 +15,7 @@ struct TxParams {
 	int oper_mode, offset, channels, nsym;     // offset = freq_off*symbol_len/rate bins (encode.cc:283)
 	unsigned long long md;                     // (call_sign << 8) | mode  (encode.cc:291)
 	long frame_samples;
+	int count, bits;                           // payloads per stream (encode.cc:289 loop), 8 or 16 bit samples
 };
 
 // ---------------------------------------------------------------- polar systematic encoder
@@ -117,7 +118,9 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const uint32_t *_
 	__syncthreads();
 	bool papr = true;
 	const int last = tp.nsym - 1;
-	if (sidx == 1) {                                          // schmidl_cox(): encode.cc:142-154
+	// stream layout (encode.cc:288-313): pilot | count x (S&C, meta, pilot, rows x data) | zero symbol
+	const int per = 3 + md.rows, q = sidx - 1, pay = (sidx > 0 && sidx < last) ? q / per : 0, w = (sidx > 0 && sidx < last) ? q % per : 2;
+	if (sidx != 0 && sidx != last && w == 0) {                // schmidl_cox(): encode.cc:142-154
 		papr = false;
 		if (tid == 0) {
 			float c = sqrtf((float)(2 * SYMBOL_LEN) / 127.f);
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const uint32_t *_
 				sh.fdom[bin1280(2 * i + mls0_off)] = mk(c, 0.f);
 			}
 		}
-	} else if (sidx == 2) {                                   // meta_data(): encode.cc:155-179
+	} else if (sidx != 0 && sidx != last && w == 1) {         // meta_data(): encode.cc:155-179
 		if (tid == 0) {
 			uint32_t cwd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 			unsigned long long m = tp.md;
@@ -154,10 +157,10 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const uint32_t *_
 			}
 		}
 	} else if (sidx != last) {
-		// pilot (sidx 0, 3) or data row j = sidx - 4: fdom = pilot * product of the rows' PSK symbols (encode.cc:304-309)
-		const int j = sidx - 4;
+		// pilot (w == 2, and the leading one) or data row j = w - 3: fdom = pilot * product of the rows' PSK symbols (encode.cc:304-309)
+		const int j = w - 3;
 		const float code_fac = sqrtf((float)SYMBOL_LEN / (float)md.cols);   // encode.cc:135
-		const uint32_t *code = code_all + (size_t)f * 2048;
+		const uint32_t *code = code_all + ((size_t)f * tp.count + pay) * 2048;
 		const float cos_pi_8 = 0.92387953251128675613f, sin_pi_8 = 0.38268343236508977173f, r2 = 0.70710678118654752440f;
 		for (int i = tid; i < md.cols; i += NT) {
 			cf acc = mk(code_fac * tb.mls2_nrz[i], 0.f);
@@ -242,17 +245,25 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const uint32_t *_
 
 // ---------------------------------------------------------------- guard cross-fade + int16
 template <int RATE>
-__global__ __launch_bounds__(256) void k_tx_assemble(const cf *__restrict__ tdom_all, TxParams tp, int16_t *__restrict__ pcm_all)
+__global__ __launch_bounds__(256) void k_tx_assemble(const cf *__restrict__ tdom_all, TxParams tp, void *__restrict__ pcm_all)
 {
 	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, GUARD_LEN = RateCfg<RATE>::GL, SYM_STRIDE = RateCfg<RATE>::STRIDE;
 	const int f = blockIdx.x / (tp.nsym + 2), part = blockIdx.x % (tp.nsym + 2), tid = threadIdx.x;
-	int16_t *pcm = pcm_all + (size_t)f * tp.frame_samples * tp.channels;
 	const int ch = tp.channels;
-	auto put = [&](long n, cf v) {
+	int16_t *pcm = (int16_t *)pcm_all + (size_t)f * tp.frame_samples * ch;
+	uint8_t *pcm8 = (uint8_t *)pcm_all + (size_t)f * tp.frame_samples * ch;
+	const bool b8 = tp.bits == 8;
+	auto put = [&](long n, cf v) {   // DSP::WriteWAV: clamp, scale by 2^(bits-1)-1, round; 8 bit = unsigned, offset 128
 		float re = fminf(fmaxf(v.re, -1.f), 1.f), im = fminf(fmaxf(v.im, -1.f), 1.f);
-		pcm[n * ch] = (int16_t)nearbyintf(32767.f * re);
-		if (ch == 2)
-			pcm[n * ch + 1] = (int16_t)nearbyintf(32767.f * im);
+		if (b8) {
+			pcm8[n * ch] = (uint8_t)((int)nearbyintf(127.f * re) + 128);
+			if (ch == 2)
+				pcm8[n * ch + 1] = (uint8_t)((int)nearbyintf(127.f * im) + 128);
+		} else {
+			pcm[n * ch] = (int16_t)nearbyintf(32767.f * re);
+			if (ch == 2)
+				pcm[n * ch + 1] = (int16_t)nearbyintf(32767.f * im);
+		}
 	};
 	if (part >= tp.nsym) {                                    // silence(rate) before and after, encode.cc:423,441
 		long base = part == tp.nsym ? 0 : RATE + (long)tp.nsym * SYM_STRIDE;
@@ -279,10 +290,10 @@ size_t tx_big_scratch_bytes(int rate, int n, int nsym)
 }
 
 void launch_tx(hipStream_t s, int rate, int n, const uint8_t *payload, Tables tb, const void *tp_, const cf *tw5120,
-	uint32_t *code, cf *tdom, cf *big_scratch, int16_t *pcm)
+	uint32_t *code, cf *tdom, cf *big_scratch, void *pcm)
 {
 	TxParams tp = *(const TxParams *)tp_;
-	hipLaunchKernelGGL(k_tx_code, dim3(n), dim3(256), 0, s, payload, tb, tp, code);
+	hipLaunchKernelGGL(k_tx_code, dim3(n * tp.count), dim3(256), 0, s, payload, tb, tp, code);
 	RX_RATE_SWITCH(rate,
 		hipLaunchKernelGGL(k_tx_symbol<RATE>, dim3(n * tp.nsym), dim3(TxCfg<RATE>::NT), 0, s, code, tb, tp, tw5120, tdom, big_scratch);
 		hipLaunchKernelGGL(k_tx_assemble<RATE>, dim3(n * (tp.nsym + 2)), dim3(256), 0, s, tdom, tp, pcm));

@@ -747,49 +747,57 @@ static long long base37(const char *str)   // encode.cc:320-335
 	return acc;
 }
 
-extern "C" long ofdmrx_frame_samples(int sample_rate, int oper_mode)
+extern "C" long ofdmrx_stream_samples(int sample_rate, int oper_mode, int count)
 {
-	if (oper_mode < 6 || oper_mode > 13 || !rate_supported(sample_rate))
+	if (oper_mode < 6 || oper_mode > 13 || !rate_supported(sample_rate) || count < 1 || count > 4096)
 		return OFDMRX_E_ARG;
 	ModeDesc md = mode_desc(oper_mode);
 	const long stride = rate_symbol_len(sample_rate) + rate_symbol_len(sample_rate) / 8;
-	return 2L * sample_rate + (long)(md.rows + 5) * stride;   // silence + pilot|S&C|meta|pilot|rows|zero + silence
+	// silence | pilot | count x (S&C, meta, pilot, rows) | zero symbol | silence  (encode.cc:288-313,423,441)
+	return 2L * sample_rate + (2 + (long)count * (3 + md.rows)) * stride;
 }
+
+extern "C" long ofdmrx_frame_samples(int sample_rate, int oper_mode) { return ofdmrx_stream_samples(sample_rate, oper_mode, 1); }
 
 extern "C" long ofdmrx_tx_frame_samples(int oper_mode) { return ofdmrx_frame_samples(8000, oper_mode); }
 
-extern "C" int ofdmrx_tx_encode_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_frames, int oper_mode,
-	int freq_off, const char *call_sign, int channels, int16_t *d_pcm)
+extern "C" int ofdmrx_tx_encode_stream_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_streams, int count,
+	int oper_mode, int freq_off, const char *call_sign, int channels, int bits, void *d_pcm)
 {
-	if (!h || !d_payload || !d_pcm || !n_frames || !call_sign || channels < 1 || channels > 2)
+	if (!h || !d_payload || !d_pcm || !n_streams || !call_sign || channels < 1 || channels > 2 || (bits != 8 && bits != 16))
 		return OFDMRX_E_ARG;
-	if (oper_mode < 6 || oper_mode > 13 || freq_off % 50)   // encode.cc:353,394
+	if (oper_mode < 6 || oper_mode > 13 || freq_off % 50 || count < 1 || count > 4096)   // encode.cc:353,394
 		return OFDMRX_E_ARG;
 	long long cs = base37(call_sign);
 	if (cs <= 0 || cs >= 129961739795077LL)               // encode.cc:358
 		return OFDMRX_E_ARG;
 	HIP_OK(hipSetDevice(h->cfg.device));
-	struct { int oper_mode, offset, channels, nsym; unsigned long long md; long frame_samples; } tp;
+	struct { int oper_mode, offset, channels, nsym; unsigned long long md; long frame_samples; int count, bits; } tp;
 	ModeDesc md = mode_desc(oper_mode);
-	tp.oper_mode = oper_mode;
 	const int SL = rate_symbol_len(h->rate);
+	tp.oper_mode = oper_mode;
 	tp.offset = (freq_off * SL) / h->rate;                // encode.cc:283
 	tp.channels = channels;
-	tp.nsym = md.rows + 5;
+	tp.nsym = 2 + count * (3 + md.rows);
 	tp.md = ((unsigned long long)cs << 8) | (unsigned)oper_mode;
-	tp.frame_samples = ofdmrx_frame_samples(h->rate, oper_mode);
-	const size_t chunk = h->rate <= 16000 ? 1024 : 128;   // 44.1 / 48 kHz keep the 4x PAPR buffers in global scratch
+	tp.frame_samples = ofdmrx_stream_samples(h->rate, oper_mode, count);
+	tp.count = count;
+	tp.bits = bits;
+	// streams per launch: bounded scratch (44.1 / 48 kHz keep the 4x PAPR buffers in global scratch)
+	const size_t budget = h->rate <= 16000 ? 1024 : 128;
+	const size_t chunk = std::max<size_t>(1, budget / (size_t)count);
 	DevBuf code, tdom, big;
-	const size_t nc = std::min(chunk, n_frames);
-	int r = code.ensure(nc * 2048 * sizeof(uint32_t));
+	const size_t nc = std::min(chunk, n_streams);
+	int r = code.ensure(nc * (size_t)count * 2048 * sizeof(uint32_t));
 	r = r ? r : tdom.ensure(nc * (size_t)tp.nsym * SL * sizeof(cf));
 	if (tx_big_scratch_bytes(h->rate, (int)nc, tp.nsym))
 		r = r ? r : big.ensure(tx_big_scratch_bytes(h->rate, (int)nc, tp.nsym));
 	if (r) { code.release(); tdom.release(); big.release(); return r; }
-	for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
-		int n = (int)std::min(chunk, n_frames - f0);
-		launch_tx(h->stream, h->rate, n, d_payload + f0 * PAYLOAD_BYTES, h->dev, &tp, h->dev.tw_sym4, code.as<uint32_t>(), tdom.as<cf>(),
-			big.as<cf>(), d_pcm + f0 * (size_t)tp.frame_samples * channels);
+	const size_t out_stride = (size_t)tp.frame_samples * channels * (bits / 8);
+	for (size_t f0 = 0; f0 < n_streams; f0 += chunk) {
+		int n = (int)std::min(chunk, n_streams - f0);
+		launch_tx(h->stream, h->rate, n, d_payload + f0 * (size_t)count * PAYLOAD_BYTES, h->dev, &tp, h->dev.tw_sym4,
+			code.as<uint32_t>(), tdom.as<cf>(), big.as<cf>(), (char *)d_pcm + f0 * out_stride);
 	}
 	hipError_t e = hipGetLastError();
 	e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;   // scratch is freed below
@@ -798,4 +806,38 @@ extern "C" int ofdmrx_tx_encode_device(ofdmrx_handle *h, const uint8_t *d_payloa
 	big.release();
 	if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return OFDMRX_E_HIP; }
 	return 0;
+}
+
+extern "C" int ofdmrx_tx_encode_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_frames, int oper_mode,
+	int freq_off, const char *call_sign, int channels, int16_t *d_pcm)
+{
+	return ofdmrx_tx_encode_stream_device(h, d_payload, n_frames, 1, oper_mode, freq_off, call_sign, channels, 16, d_pcm);
+}
+
+// host-pointer convenience for the `encode` CLI: payloads up, one stream down
+extern "C" int ofdmrx_tx_encode_stream(ofdmrx_handle *h, const uint8_t *payload, int count, int oper_mode, int freq_off,
+	const char *call_sign, int channels, int bits, void *pcm)
+{
+	if (!h || !payload || !pcm || count < 1)
+		return OFDMRX_E_ARG;
+	const long spf = ofdmrx_stream_samples(h->rate, oper_mode, count);
+	if (spf < 0 || channels < 1 || channels > 2 || (bits != 8 && bits != 16))
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	DevBuf dp, dx;
+	const size_t out_bytes = (size_t)spf * channels * (bits / 8);
+	int r = dp.ensure((size_t)count * PAYLOAD_BYTES);
+	r = r ? r : dx.ensure(out_bytes);
+	if (!r) {
+		hipError_t e = hipMemcpy(dp.p, payload, (size_t)count * PAYLOAD_BYTES, hipMemcpyHostToDevice);
+		if (e != hipSuccess) { g_last_error = hipGetErrorString(e); r = OFDMRX_E_HIP; }
+	}
+	r = r ? r : ofdmrx_tx_encode_stream_device(h, dp.as<uint8_t>(), 1, count, oper_mode, freq_off, call_sign, channels, bits, dx.p);
+	if (!r) {
+		hipError_t e = hipMemcpy(pcm, dx.p, out_bytes, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) { g_last_error = hipGetErrorString(e); r = OFDMRX_E_HIP; }
+	}
+	dp.release();
+	dx.release();
+	return r;
 }

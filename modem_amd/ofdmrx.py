@@ -23,7 +23,7 @@ EXPORTS = [
     "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames",
     "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
     "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
-    "ofdmrx_tx_encode_device",
+    "ofdmrx_tx_encode_device", "ofdmrx_stream_samples", "ofdmrx_tx_encode_stream_device", "ofdmrx_tx_encode_stream",
 ]
 
 
@@ -118,6 +118,14 @@ def load_library():
     L.ofdmrx_tx_frame_samples.argtypes = [C.c_int]
     L.ofdmrx_frame_samples.restype = C.c_long
     L.ofdmrx_frame_samples.argtypes = [C.c_int, C.c_int]
+    L.ofdmrx_stream_samples.restype = C.c_long
+    L.ofdmrx_stream_samples.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.ofdmrx_tx_encode_stream_device.restype = C.c_int
+    L.ofdmrx_tx_encode_stream_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                                 C.c_int, C.c_int, C.c_void_p]
+    L.ofdmrx_tx_encode_stream.restype = C.c_int
+    L.ofdmrx_tx_encode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                          C.c_void_p]
     L.ofdmrx_tx_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
     _LIB = L
     return L
@@ -259,6 +267,18 @@ class Receiver:
 
     def tx_frame_samples(self, mode=6):
         return int(self._lib.ofdmrx_frame_samples(self.sample_rate, mode))
+
+    def encode_stream(self, payloads, mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=1, bits=16):
+        """host convenience (the `encode` CLI's call): payloads [count, 5380] uint8 -> one PCM stream [samples, channels]"""
+        payloads = np.ascontiguousarray(payloads, dtype=np.uint8).reshape(-1, PAYLOAD_BYTES)
+        count = payloads.shape[0]
+        n = int(self._lib.ofdmrx_stream_samples(self.sample_rate, mode, count))
+        if n < 0:
+            raise OfdmRxError("bad mode / count")
+        pcm = np.zeros((n, channels), np.int16 if bits == 16 else np.uint8)
+        self._check(self._lib.ofdmrx_tx_encode_stream(self._h, _ptr(payloads), count, mode, freq_off, call_sign.encode(),
+                                                      channels, bits, _ptr(pcm)))
+        return pcm
 
     def tx_encode(self, d_payload, n, d_pcm, mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=2):
         """device transmitter: n x 5380 payload bytes -> n x tx_frame_samples(mode) x channels int16 (device pointers)"""

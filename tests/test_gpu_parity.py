@@ -693,3 +693,51 @@ def test_list_size_4():
         assert int(res[i]["status"]) == orr.status and int(res[i]["best_lane"]) == orr.best_lane and (out[i] == oo).all(), i
     assert int(res[0]["status"]) == 0 and (out[0] == pays[0]).all()
     rx4.close()
+
+
+def test_encode_cli_is_a_drop_in(tmp_path):
+    """`encode OUTPUT RATE BITS CHANNELS OFFSET MODE CALLSIGN INPUT..` (encode.cc:337-443) on the device transmitter:
+    same argv / checks / exit codes; the WAV equals the oracle encoder's file (header byte for byte, samples within
+    1 LSB: fp32 FFT rounding at the quantiser) for several input files, 8 and 16 bit, mono and analytic, two rates;
+    the `decode` CLI gets every payload back (SKIP selects the later ones)"""
+    import os
+    import subprocess
+    enc = os.path.join(O.ROOT, "modem_amd", "bin", "encode")
+    dec = os.path.join(O.ROOT, "modem_amd", "bin", "decode")
+    oenc = os.path.join(O.ORACLE_DIR, "encode")
+    files = []
+    for i in range(3):
+        f = tmp_path / ("p%d.dat" % i)
+        f.write_bytes(bytes(O.payload_for(1600 + i)))
+        files.append(f)
+    short = tmp_path / "short.dat"
+    short.write_bytes(b"hello")                                   # reads past the end give 0xff (encode.cc:414)
+    cases = [("8000", "8", "1", "2000", "6", "ANONYMOUS", files[:1]),          # `make test` format
+             ("8000", "16", "2", "1500", "6", "CALL 1", files),                # three payloads in one stream
+             ("48000", "16", "1", "1700", "9", "RATE48", files[:2]),
+             ("16000", "8", "2", "-1000", "13", "U8 IQ", [short])]
+    for rate, bits, ch, off, mode, cs, inputs in cases:
+        a, b = tmp_path / "gpu.wav", tmp_path / "cpu.wav"
+        args = [rate, bits, ch, off, mode, cs] + [str(x) for x in inputs]
+        subprocess.check_call([enc, str(a)] + args)
+        subprocess.check_call([oenc, str(b)] + args)
+        wa, wb = a.read_bytes(), b.read_bytes()
+        assert len(wa) == len(wb) and wa[:44] == wb[:44], (rate, bits, ch)
+        dt = np.uint8 if bits == "8" else np.int16
+        da, db = np.frombuffer(wa[44:], dt).astype(np.int32), np.frombuffer(wb[44:], dt).astype(np.int32)
+        assert np.abs(da - db).max() <= 1 and (da != db).mean() < 0.05, (rate, bits, ch, np.abs(da - db).max())
+        for k, inp in enumerate(inputs):
+            out = tmp_path / "d.dat"
+            r = subprocess.run([dec, str(out), str(a)] + ([str(k)] if k else []), capture_output=True, text=True)
+            want = inp.read_bytes()
+            want = want + b"\xff" * (5380 - len(want))
+            assert r.returncode == 0 and out.read_bytes() == want, (rate, mode, k, r.stderr)
+    # argument checks: exit code 1 with the reference's messages
+    for bad, msg in ((["8000", "16", "1", "2000", "5", "X", str(files[0])], "Unsupported operation mode."),
+                     (["8000", "16", "1", "2000", "6", "!!", str(files[0])], "Unsupported call sign."),
+                     (["8000", "16", "1", "1000", "6", "X", str(files[0])], "Unsupported frequency offset."),
+                     (["8000", "16", "2", "2025", "6", "X", str(files[0])], "Frequency offset must be divisible by 50."),
+                     (["22050", "16", "1", "2000", "6", "X", str(files[0])], "Unsupported sample rate.")):
+        r = subprocess.run([enc, str(tmp_path / "x.wav")] + bad, capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stderr, (bad, r.stderr)
+    assert subprocess.run([enc], capture_output=True).returncode == 1
