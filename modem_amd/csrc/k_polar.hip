@@ -241,6 +241,143 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 	}
 }
 
+
+// ---- the 8-leaf sub-tree in registers ------------------------------------------------------------------------
+// r[L] = this lane's LLR at level L of the node being decoded (position = the low L bits of j, duplicated over the
+// other bits of j); H = partial sums of the 8 leaves, one bit per position, for THIS lane's path - only the bit of
+// the lane's own position (mod the node size) is ever consumed, and the combines keep exactly that bit right.
+//
+// node<LV, P0>() decodes the 2^LV leaves from P0 top-down:
+//   all frozen      -> rate-0: with min-sum the leaf penalties of a sub-tree add up to sum max(0, -llr) over the node's
+//                      OWN inputs (max(0,-f(a,b)) + max(0,-(a+b)) = max(0,-a) + max(0,-b) by cases, then induction);
+//                      summed in the butterfly halving order the oracle fixes (the reference's -Ofast build leaves the
+//                      order open) and added to the metric once;
+//   all information -> rate-1: if the list is sorted and max_k M_k < min_k (M_k + mu_k), mu_k = the smallest magnitude
+//                      of path k's node LLRs, then EVERY leaf below takes the stable-list fast path (min-sum leaf
+//                      magnitudes never drop under mu_k: f keeps the smaller input magnitude, g adds two same-signed
+//                      terms once the left decisions are sign decisions), so no metric changes, no path is replaced and
+//                      the node's partial sums are the sign bits of its LLRs.  Bit-identical to the leaf walk.
+//                      If the condition fails the node is walked (its children get their own chance);
+//   otherwise       -> left child (f), right child (g with the left partial sums and the lane map), combine.
+template <int LN> struct Block8 {
+	float &M;
+	Maps &A;
+	int &H;
+	float r[4];
+	const uint32_t fz;
+	const int t, lane, j, k;
+
+	template <int B> __device__ __forceinline__ float xjb(float v) const { return xj<B>(v, lane); }
+	__device__ __forceinline__ void reset_at(int p0) { const int tt = t + p0; A.reset_upto(tt ? __builtin_ctz(tt) : 16, k); }
+	__device__ __forceinline__ bool list_is_stable(float mu) const
+	{
+		const float P = M + mu;
+		const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
+		const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
+		return __ballot(!ok) == 0;
+	}
+
+	template <int P0> __device__ __forceinline__ void leaf()
+	{
+		reset_at(P0);
+		const float r0 = r[0];
+		int ubit = 0;
+		if ((fz >> P0) & 1) {
+			if (r0 < 0.f)
+				M -= r0;
+		} else if (list_is_stable(fabsf(r0))) {
+			// stable-list fast path: paths already sorted by metric and every penalised continuation is worse
+			// than every free one -> each path just takes its own sign bit
+			ubit = r0 < 0.f;
+		} else {
+			float v0 = M, v1 = M;
+			if (r0 < 0.f) v0 = M - r0; else v1 = M + r0;
+			const int umine = j & 1;
+			const float val = umine ? v1 : v0;
+			const int cidx = 2 * k + umine;
+			int rank = 0;
+			#pragma unroll
+			for (int kk = 0; kk < 8; ++kk) {
+				const float o0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), kk));
+				const float o1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), kk));
+				rank += (o0 < val) | ((o0 == val) & (2 * kk < cidx));
+				rank += (o1 < val) | ((o1 == val) & (2 * kk + 1 < cidx));
+			}
+			// every row of 16 lanes holds the 16 candidates at position (u << 3) | k: scatter inside the row
+			const int dst = (lane & 48) | rank;
+			int rc = __builtin_amdgcn_ds_permute(dst << 2, cidx);
+			int rv = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(val));
+			const int rcx = xor8_i(rc), rvx = xor8_i(rv);   // odd j sit at row position 8+k: take position k
+			if (j & 1) { rc = rcx; rv = rvx; }
+			M = k < LN ? __int_as_float(rv) : __builtin_inff();   // list 4: ranks 4..7 do not survive
+			const int parent = rc >> 1;
+			ubit = rc & 1;
+			if (__ballot(parent != k)) {
+				A.w0 = __shfl((int)A.w0, (j << 3) | parent);
+				A.w1 = __shfl((int)A.w1, (j << 3) | parent);
+			}
+		}
+		H = (H & ~(1 << P0)) | (ubit << P0);
+	}
+
+	template <int LV, int P0> __device__ __forceinline__ void node()
+	{
+		if constexpr (LV == 0) {
+			leaf<P0>();
+		} else {
+			constexpr int N = 1 << LV, HALF = N / 2;
+			constexpr uint32_t MASK = ((1u << N) - 1u) << P0;
+			const uint32_t pat = fz & MASK;
+			if (pat == MASK) {                                    // rate-0
+				reset_at(P0);
+				float pen = r[LV] < 0.f ? -r[LV] : 0.f;
+				if constexpr (LV >= 3) pen = pen + xjb<2>(pen);
+				if constexpr (LV >= 2) pen = pen + xjb<1>(pen);
+				pen = pen + xjb<0>(pen);
+				M += pen;
+				H &= ~(int)MASK;
+				return;
+			}
+			if (pat == 0) {                                       // rate-1, if provably the same as the walk
+				uint32_t mu = __float_as_uint(r[LV]) & 0x7fffffffu;
+				if constexpr (LV >= 3) mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
+				if constexpr (LV >= 2) mu = min(mu, (uint32_t)xor16_i((int)mu, lane));
+				mu = min(mu, (uint32_t)xor8_i((int)mu));
+				if (list_is_stable(__uint_as_float(mu))) {
+					reset_at(P0);
+					H = (H & ~(int)MASK) | (r[LV] < 0.f ? (int)MASK : 0);   // own-position bit = sign bit
+					return;
+				}
+			}
+			// left child
+			r[LV - 1] = f_minsum(r[LV], xjb<LV - 1>(r[LV]));
+			node<LV - 1, P0>();
+			// right child: g at level LV with the left child's partial sums; the lane map since this node started
+			{
+				const int lk = A.get(LV);
+				float own = r[LV];
+				if (__ballot(lk != k))                            // not the identity: fetch the parent path's value
+					own = __shfl(r[LV], (j << 3) | lk);
+				const float oth = xjb<LV - 1>(own);
+				const bool hi = (j >> (LV - 1)) & 1;
+				const float a = hi ? oth : own, b = hi ? own : oth;
+				const int ub = (H >> (P0 + (j & (HALF - 1)))) & 1;
+				r[LV - 1] = g_add(a, b, ub);
+			}
+			node<LV - 1, P0 + HALF>();
+			// partial-sum combine of this node
+			{
+				constexpr int lmask = ((1 << HALF) - 1) << P0;
+				const int rm = A.get(LV - 1);
+				int L = H;
+				if (__ballot(rm != k))
+					L = __shfl(H, (j << 3) | rm);
+				H = (H & ~lmask) | ((L ^ (H >> HALF)) & lmask);
+			}
+		}
+	}
+};
+
 // Persistent grid: block b decodes codewords b, b + gridDim.x, ... and owns ONE 2 MiB level store
 // (soft_all + b * 2 MiB).  A grid smaller than the machine (launch_polar's `grid`) leaves LDS and registers on
 // every CU for the other stages' kernels of the next chunk, which run concurrently on a second stream: this
@@ -275,10 +412,7 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 	Maps A;
 	A.w0 = ID0 * (uint32_t)k;
 	A.w1 = ID1 * (uint32_t)k;
-	float r3 = 0.f, r2 = 0.f, r1 = 0.f, r0 = 0.f;
-#ifdef POLAR_STATS
-	int stat_r1 = 0, stat_r1_ok = 0;
-#endif
+	float r3 = 0.f;
 
 	for (int t8 = 0, adv = 1; t8 < CODE_LEN / 8; t8 += adv) {
 		const int t = t8 * 8;
@@ -407,132 +541,12 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 		}
 		if (!Ln) {
 		const uint32_t fz = (frozen[t >> 5] >> (t & 31)) & 0xffu;
-		// H: partial sums of the 8 leaves, one bit per position, for THIS lane's path (same in all j)
+		// ---------------- the 8 leaves, all in registers: a top-down walk of the 8-leaf sub-tree (Block8 above) that
+		// decides every uniform node it meets (8, 4 or 2 leaves all frozen / all information) in one step
 		int H = 0;
-		// ---------------- rate-1 sub-tree (8 information leaves) in one step, when it is provably the same:
-		// if the list is sorted and max_k M_k < min_k (M_k + mu_k), mu_k = min_j |r3_j| of path k, then EVERY
-		// leaf of this sub-tree takes the stable-list fast path below (min-sum leaf magnitudes never drop
-		// under mu_k: f keeps the smaller input magnitude, and g adds two same-signed terms once the left
-		// decisions are the sign decisions), so no metric changes, no path is replaced, and the sub-tree's
-		// partial sums are the sign bits of r3 (u = hard decisions <=> x = hard(r3)).  Bit-identical to the
-		// leaf-by-leaf walk, just without walking.
-		bool whole = false;
-		if (fz == 0) {
-			uint32_t mu = __float_as_uint(r3) & 0x7fffffffu;
-			mu = min(mu, (uint32_t)xor8_i((int)mu));
-			mu = min(mu, (uint32_t)xor16_i((int)mu, lane));
-			mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
-			const float P = M + __uint_as_float(mu);
-			const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
-			const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
-			whole = __ballot(!ok) == 0;
-		}
-#ifdef POLAR_STATS
-		if (fz == 0) { ++stat_r1; if (whole) ++stat_r1_ok; }
-#endif
-		if (whole) {
-			A.reset_upto(t ? __builtin_ctz(t) : 16, k);
-			H = r3 < 0.f ? 0xff : 0;                          // only bit j of lane (j, k) is read below
-		} else if (fz == 0xffu) {
-			// ---------------- rate-0 sub-tree (8 frozen leaves) in one step: with min-sum the leaf penalties of the
-			// sub-tree add up to sum_j max(0, -r3_j) (max(0,-f(a,b)) + max(0,-(a+b)) = max(0,-a) + max(0,-b), by
-			// cases, then induction).  Summed in the butterfly order j^4, j^2, j^1 and added to the metric once -
-			// the order the oracle fixes for this node (the reference's -Ofast build leaves it open).
-			float pen = r3 < 0.f ? -r3 : 0.f;
-			pen = pen + xj<2>(pen, lane);
-			pen = pen + xj<1>(pen, lane);
-			pen = pen + xj<0>(pen, lane);
-			M += pen;
-			A.reset_upto(t ? __builtin_ctz(t) : 16, k);
-			H = 0;
-		} else
-		// ---------------- the 8 leaves, all in registers
-		#pragma unroll
-		for (int p = 0; p < 8; ++p) {
-			const int tt = t + p;
-			A.reset_upto(tt ? __builtin_ctz(tt) : 16, k);
-			// LLRs down to the leaf
-			if (p == 0) {
-				r2 = f_minsum(r3, xj<2>(r3, lane));
-				r1 = f_minsum(r2, xj<1>(r2, lane));
-				r0 = f_minsum(r1, xj<0>(r1, lane));
-			} else {
-				constexpr int dummy = 0;
-				(void)dummy;
-				const int zz = __builtin_ctz(p);              // 0,1,2 : g at level zz+1
-				const int mg = zz + 1;
-				const int hbit = 1 << zz;                     // half size of the level-mg node
-				const int q = p - hbit;                       // first leaf of the left child
-				const int lk = A.get(mg);
-				const float rsrc = mg == 3 ? r3 : (mg == 2 ? r2 : r1);
-				float own = rsrc;
-				if (__ballot(lk != k))                        // lane map since the node started is not the identity
-					own = __shfl(rsrc, (j << 3) | lk);
-				const float oth = zz == 0 ? xj<0>(own, lane) : (zz == 1 ? xj<1>(own, lane) : xj<2>(own, lane));
-				const bool hi = (j >> zz) & 1;
-				const float a = hi ? oth : own, b = hi ? own : oth;
-				const int ub = (H >> (q + (j & (hbit - 1)))) & 1;
-				const float v = g_add(a, b, ub);
-				if (mg == 3) { r2 = v; r1 = f_minsum(r2, xj<1>(r2, lane)); r0 = f_minsum(r1, xj<0>(r1, lane)); }
-				else if (mg == 2) { r1 = v; r0 = f_minsum(r1, xj<0>(r1, lane)); }
-				else { r0 = v; }
-			}
-			// leaf decision
-			int ubit = 0;
-			if ((fz >> p) & 1) {
-				if (r0 < 0.f)
-					M -= r0;
-			} else {
-				// stable-list fast path: paths already sorted by metric and every penalised
-				// continuation is worse than every free one -> each path just takes its own sign bit
-				const float P = M + fabsf(r0);
-				const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
-				const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
-				if (__ballot(!ok) == 0) {
-					ubit = r0 < 0.f;
-				} else {
-					float v0 = M, v1 = M;
-					if (r0 < 0.f) v0 = M - r0; else v1 = M + r0;
-					const int umine = j & 1;
-					const float val = umine ? v1 : v0;
-					const int cidx = 2 * k + umine;
-					int rank = 0;
-					#pragma unroll
-					for (int kk = 0; kk < 8; ++kk) {
-						const float o0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), kk));
-						const float o1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), kk));
-						rank += (o0 < val) | ((o0 == val) & (2 * kk < cidx));
-						rank += (o1 < val) | ((o1 == val) & (2 * kk + 1 < cidx));
-					}
-					// every row of 16 lanes holds the 16 candidates at position (u << 3) | k: scatter inside the row
-					const int dst = (lane & 48) | rank;
-					int rc = __builtin_amdgcn_ds_permute(dst << 2, cidx);
-					int rv = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(val));
-					const int rcx = xor8_i(rc), rvx = xor8_i(rv);   // odd j sit at row position 8+k: take position k
-					if (j & 1) { rc = rcx; rv = rvx; }
-					M = k < LN ? __int_as_float(rv) : __builtin_inff();   // list 4: ranks 4..7 do not survive
-					const int parent = rc >> 1;
-					ubit = rc & 1;
-					if (__ballot(parent != k)) {
-						A.w0 = __shfl((int)A.w0, (j << 3) | parent);
-						A.w1 = __shfl((int)A.w1, (j << 3) | parent);
-					}
-				}
-			}
-			H = (H & ~(1 << p)) | (ubit << p);
-			// partial-sum combines that complete at this leaf (levels 1..3)
-			#pragma unroll
-			for (int m = 1; m <= 3; ++m) {
-				if (((p + 1) & ((1 << m) - 1)) == 0) {
-					const int hh = 1 << (m - 1), q = p + 1 - (1 << m);
-					const int lmask = ((1 << hh) - 1) << q;
-					const int rm = A.get(m - 1);
-					int L = H;
-					if (__ballot(rm != k))
-						L = __shfl(H, (j << 3) | rm);
-					H = (H & ~lmask) | ((L ^ (H >> hh)) & lmask);
-				}
-			}
+		{
+			Block8<LN> blk{ M, A, H, { 0.f, 0.f, 0.f, r3 }, fz, t, lane, j, k };
+			blk.template node<3, 0>();
 		}
 		// ---------------- partial sums of the sub-tree: bytes (bit k = path k) via ballot
 		{
@@ -612,9 +626,6 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 	}
 	if (j == 0)
 		metric_all[(size_t)cw * LIST + k] = M;
-#ifdef POLAR_STATS
-	if (lane == 0) { metric_all[(size_t)cw * LIST + 6] = (float)stat_r1; metric_all[(size_t)cw * LIST + 7] = (float)stat_r1_ok; }
-#endif
 	WAVE_ORDER();
 	}   // next codeword of this block
 }

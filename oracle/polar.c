@@ -113,14 +113,14 @@ void orc_polar_sysenc(int8_t *code, const int8_t *mesg, const uint32_t *frozen, 
  *   f(a,b) = sign(a)sign(b)min(|a|,|b|);  g(a,b,u) = u*a + b
  *   left subtree = lower indices; each subtree returns the lane map it applied
  *   frozen leaf: metric += |llr| when llr < 0, hard = +1, identity map
- *   (an aligned all-frozen node of 8..128 leaves is charged in one step, see scl_node)
+ *   (an aligned all-frozen node of 2..128 leaves is charged in one step, see scl_node)
  *   info leaf  : fork 2L candidates, keep the L smallest metrics.
  * Tie rule (std::nth_element is implementation-defined there): candidates are
  * ordered by (metric, candidate index 2k+u) and survivors are stored in that
  * sorted order, so the result is deterministic.  Initial metrics: lane 0 = 0,
  * others = 1000, so the list fills from one path.
  */
-enum { ORC_RATE0_MIN = 3, ORC_RATE0_MAX = 7 };   /* rate-0 nodes of 8..128 leaves are charged in one step */
+enum { ORC_RATE0_MIN = 1, ORC_RATE0_MAX = 7 };   /* rate-0 nodes of 2..128 leaves are charged in one step */
 
 typedef struct {
 	int L, count;
@@ -200,7 +200,7 @@ static void scl_node(scl_t *s, int m, int index, uint8_t *map)
 		return;
 	}
 	if (m >= ORC_RATE0_MIN && m <= ORC_RATE0_MAX && all_frozen(s->frozen, index, m)) {
-		/* Rate-0 node (8..128 leaves; the recursion is top-down, so this is the largest such node) in one step.  With min-sum, the frozen-leaf penalties of a sub-tree add up
+		/* Rate-0 node (2..128 leaves; the recursion is top-down, so this is the largest such node) in one step.  With min-sum, the frozen-leaf penalties of a sub-tree add up
 		 * to sum_i max(0, -llr_i) over the node's OWN input LLRs (f keeps the smaller magnitude with the
 		 * product sign, g with u = 0 is a + b: case by case max(0,-f(a,b)) + max(0,-(a+b)) =
 		 * max(0,-a) + max(0,-b), then induction over the levels), so the leaf walk is not needed.  The
