@@ -146,20 +146,30 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 		s.G[j][w] = v;
 	}
 	__syncthreads();
-	// Gauss-Jordan with the pivoting rule of row_echelon()
+	// Gauss-Jordan with the pivoting rule of row_echelon(): pivot = the first row >= k with a one in column k (found
+	// by all rows at once: LDS atomicMin), else the first later column that has a one in some row >= k (rare: serial)
+	if (tid == 0)
+		s.pivot_row = 255;
+	__syncthreads();
 	for (int k = 0; k < BCH_K; ++k) {
-		if (tid == 0) {
-			int pr = -1, pc = k;
-			for (int j = k; j < BCH_K; ++j)
-				if ((s.G[j][k >> 5] >> (k & 31)) & 1) { pr = j; break; }
-			for (int c = k + 1; pr < 0 && c < BCH_N; ++c)
-				for (int h = k; h < BCH_K; ++h)
-					if ((s.G[h][c >> 5] >> (c & 31)) & 1) { pr = h; pc = c; break; }
-			s.pivot_row = pr;
-			s.pivot_col = pc;
-		}
+		if (tid >= k && tid < BCH_K && ((s.G[tid][k >> 5] >> (k & 31)) & 1))
+			atomicMin(&s.pivot_row, tid);
 		__syncthreads();
-		const int pr = s.pivot_row, pc = s.pivot_col;
+		int pr = s.pivot_row, pc = k;
+		if (pr == 255) {                                      // same value in every thread
+			__syncthreads();
+			if (tid == 0) {
+				int r2 = -1, c2 = k;
+				for (int c = k + 1; r2 < 0 && c < BCH_N; ++c)
+					for (int h = k; h < BCH_K; ++h)
+						if ((s.G[h][c >> 5] >> (c & 31)) & 1) { r2 = h; c2 = c; break; }
+				s.pivot_row = r2;
+				s.pivot_col = c2;
+			}
+			__syncthreads();
+			pr = s.pivot_row;
+			pc = s.pivot_col;
+		}
 		if (pc != k) {   // column swap k <-> pc in every row, and in perm
 			if (tid < BCH_K) {
 				uint32_t bk = (s.G[tid][k >> 5] >> (k & 31)) & 1, bc = (s.G[tid][pc >> 5] >> (pc & 31)) & 1;
@@ -175,6 +185,8 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 			uint32_t t = s.G[k][tid]; s.G[k][tid] = s.G[pr][tid]; s.G[pr][tid] = t;
 		}
 		__syncthreads();
+		if (tid == 0)
+			s.pivot_row = 255;                                // for the next pivot search (read again only after two barriers)
 		{   // clear column k in every other row: read phase, barrier, write phase
 			uint32_t pv[3];
 			bool hit[3];
