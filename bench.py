@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--channels", type=int, default=2, choices=[1, 2],
                     help="2 = configs[2] (analytic + AWGN, the headline workload); 1 = configs[1] flavour: clean 16-bit mono frames "
                          "(exercises the D1 front end)")
+    ap.add_argument("--rate", type=int, default=8000, choices=[8000, 16000, 44100, 48000],
+                    help="sample rate of the frames (the headline metric is 8000; the others are the N4 instantiations)")
+    ap.add_argument("--mode", type=int, default=6, choices=range(6, 14), help="operation mode of the frames (headline: 6)")
     ap.add_argument("--impair", action="store_true",
                     help="configs[3]: every frame also goes through the device channel chain multipath -> CFO +234.567 Hz "
                          "-> SFO +147 ppm (README.md:49) before the AWGN")
@@ -90,8 +93,8 @@ def main():
     # which the C ABI reads as "create your own stream", and two streams would race on the device buffers
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    rx = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=stream.cuda_stream)
-    spf = rx.tx_frame_samples(6)
+    rx = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=stream.cuda_stream, sample_rate=args.rate)
+    spf = rx.tx_frame_samples(args.mode)
     d_in = torch.empty((B, spf, ch), dtype=torch.int16, device=dev)
     d_out = torch.zeros((B, 5380), dtype=torch.uint8, device=dev)
     d_res = torch.zeros((B, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
@@ -108,7 +111,7 @@ def main():
             d_clean = d_in                        # transmit straight into the batch, add the noise in place
         else:
             d_clean = torch.empty((U, spf, ch), dtype=torch.int16, device=dev)
-        rx.tx_encode(d_pay.data_ptr(), U, d_clean.data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=ch)
+        rx.tx_encode(d_pay.data_ptr(), U, d_clean.data_ptr(), mode=args.mode, freq_off=2000, call_sign="ANONYMOUS", channels=ch)
         if ch == 2 and args.impair:
             d_imp = torch.empty((U, spf, ch), dtype=torch.int16, device=dev)
             taps = [(0, 1 + 0j), (5, 0.35 - 0.1j), (11, -0.2 + 0.2j), (23, 0.1 + 0.05j)]
@@ -188,7 +191,8 @@ def main():
         value = frames_total / secs
         frames_per_launch = B * args.steps / max(polar_launches, 1)
         avg_launch_s = polar_ms / 1e3 / max(polar_launches, 1)
-        achieved = (B_FRAME_2CH if ch == 2 else 95200 * 2 + 5380) * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        b_frame = spf * 2 * ch + 5380          # compulsory input + output bytes per frame (386180 for the headline)
+        achieved = b_frame * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # HBM bytes per k_polar launch from the committed PMC passes (bench.py cannot run the profiler on itself):
         # scaled to this run's frames per launch; null when the file is absent
         traffic, traffic_src = None, None
@@ -204,9 +208,10 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[%d]: batch %d analytic (2-ch int16) mode-6 8 kHz frames per GPU, AWGN noise "
+            "config": {"workload": ("configs[%d]%s: batch %d analytic (2-ch int16) mode-%d %g kHz frames per GPU, AWGN noise "
                                     "level %g dB, inputs resident in HBM; %s, on-device noise keyed by frame index"
-                                    % (3 if args.impair else 2, B, args.noise_db, source)) if ch == 2 else
+                                    % (3 if args.impair else 2, "" if (args.rate == 8000 and args.mode == 6) else " variant (not the headline workload)",
+                                       B, args.mode, args.rate / 1000.0, args.noise_db, source)) if ch == 2 else
                                    ("configs[1] flavour: batch %d clean 16-bit mono mode-6 8 kHz frames per GPU, inputs resident "
                                     "in HBM; %s" % (B, source)),
                        "frames_per_gpu": B, "list_size": 8, "chunk_frames": rx.chunk_frames, "parallelism": "frames x%d" % n_gpus},
@@ -215,7 +220,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_polar (D9 SCL)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "frames_per_launch": frames_per_launch, "avg_launch_ms": 1e3 * avg_launch_s,
-                         "algorithmic_bytes_per_frame": B_FRAME_2CH if ch == 2 else 95200 * 2 + 5380},
+                         "algorithmic_bytes_per_frame": b_frame},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "input_generation_s": gen_s,
         }
