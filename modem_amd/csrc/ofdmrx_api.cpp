@@ -139,8 +139,9 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	h->cfg = *cfg;
 	h->rate = cfg->sample_rate;
 	h->list = cfg->list_size == 4 ? 4 : 8;
-	// default chunk: 8192 frames at 8 kHz, scaled down with the samples per frame at the higher rates
-	h->chunk = cfg->chunk_frames > 0 ? cfg->chunk_frames : (int)(8192L * 8000 / cfg->sample_rate);
+	// default chunk: 8192 frames (4096 at 44.1 / 48 kHz, whose frames are six times longer): the per-frame decoder
+	// state does not grow with the rate, and the polar stage needs a few thousand codewords per launch to fill the chip
+	h->chunk = cfg->chunk_frames > 0 ? cfg->chunk_frames : (cfg->sample_rate <= 16000 ? 8192 : 4096);
 	h->max_samples = cfg->max_samples > 0 ? cfg->max_samples : ofdmrx_frame_samples(cfg->sample_rate, 6);
 	if (cfg->stream) {
 		h->stream = (hipStream_t)cfg->stream;
