@@ -36,10 +36,12 @@ template <int RATE> struct DemodSharedBlock {                // other rates: one
 // 8 kHz: wave w transforms symbol 4g+w of group g in its own LDS buffer (radix 5,4,4,4,4 Stockham
 // stages); the payload carriers of each symbol are parked in an 8-slot LDS ring so that
 // cons = X_j / X_{j-1} needs no second pass over HBM.  Samples are read once, straight from the raw
-// PCM (int16 pairs).  16 / 44.1 / 48 kHz (2560 / 7056 / 7680 points, 20-61 KB): the four waves share
-// one buffer and walk the symbols in order, two carrier slots.
+// PCM (int16 pairs).  16 / 44.1 / 48 kHz (2560 / 7056 / 7680 points, 20-61 KB): 1024 threads share one buffer
+// (two to eight points per thread and radix stage) and walk the symbols in order, two carrier slots.
+template <int RATE> struct DemodCfg { static constexpr int NT = RATE == 8000 ? 256 : 1024; };   // threads per frame
+
 template <int RATE>
-__global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
+__global__ __launch_bounds__(DemodCfg<RATE>::NT) void k_demod(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
 	const SyncState *__restrict__ st_all, cf *__restrict__ cons_all)
 {
 	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, SYM_STRIDE = RateCfg<RATE>::STRIDE;
@@ -82,12 +84,25 @@ __global__ __launch_bounds__(256) void k_demod(FrameBatch fb, const cf *__restri
 		}
 	} else {
 		__shared__ DemodSharedBlock<RATE> sh;
+		// NCO: e^{j omega (k0 + tid + 256 q)} = (one closed-form phasor per thread and symbol) x (a table of
+		// e^{j omega 256 q}, q < symbol_len / 256, built once per frame): one complex multiply per sample instead
+		// of a double-precision range reduction and a sincos (2560..7680 samples per symbol at these rates)
+		constexpr int NT = DemodCfg<RATE>::NT, NQ = (SYMBOL_LEN + NT - 1) / NT;
+		__shared__ cf rot[NQ];
+		if (tid < NQ)
+			rot[tid] = phasor(omega, (long)NT * tid);
+		__syncthreads();
 		for (int s = 0; s <= md.rows; ++s) {
-			for (int i = tid; i < SYMBOL_LEN; i += 256)
-				sh.fft[i] = cmul(src.at(body0 + (long)s * SYM_STRIDE + i), phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + i));
+			const cf base = phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + tid);
+			#pragma unroll 2
+			for (int q = 0; q < NQ; ++q) {
+				const int i = tid + NT * q;
+				if (i < SYMBOL_LEN)
+					sh.fft[i] = cmul(src.at(body0 + (long)s * SYM_STRIDE + i), cmul(base, rot[q]));
+			}
 			__syncthreads();
-			fft_fwd<SYMBOL_LEN, 256, SYMBOL_LEN>(sh.fft, tb.tw_sym, tid);
-			for (int i = tid; i < md.cols; i += 256) {
+			fft_fwd<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fft, tb.tw_sym, tid);
+			for (int i = tid; i < md.cols; i += NT) {
 				cf x = sh.fft[(i + code_off + SYMBOL_LEN) % SYMBOL_LEN];
 				sh.carr[s & 1][i] = x;
 				if (s >= 1)                                       // decode.cc:474-475 (same thread wrote slot (s-1)&1)
@@ -642,7 +657,7 @@ __global__ __launch_bounds__(256) void k_fft_debug(int len, int sign, const cf *
 
 void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons)
 {
-	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(256), 0, s, fb, z, tb, st, cons));
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(DemodCfg<RATE>::NT), 0, s, fb, z, tb, st, cons));
 }
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, float *slope, float *yint)
 {
