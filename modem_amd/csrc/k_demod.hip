@@ -38,7 +38,10 @@ template <int RATE> struct DemodSharedBlock {                // other rates: one
 // cons = X_j / X_{j-1} needs no second pass over HBM.  Samples are read once, straight from the raw
 // PCM (int16 pairs).  16 / 44.1 / 48 kHz (2560 / 7056 / 7680 points, 20-61 KB): 1024 threads share one buffer
 // (two to eight points per thread and radix stage) and walk the symbols in order, two carrier slots.
-template <int RATE> struct DemodCfg { static constexpr int NT = RATE == 8000 ? 256 : 1024; };   // threads per frame
+#ifndef DEMOD_WAVE_PER_SYMBOL
+#define DEMOD_WAVE_PER_SYMBOL(R) ((R) == 8000)
+#endif
+template <int RATE> struct DemodCfg { static constexpr int NT = DEMOD_WAVE_PER_SYMBOL(RATE) ? 256 : 1024; };   // threads per frame
 
 template <int RATE>
 __global__ __launch_bounds__(DemodCfg<RATE>::NT) void k_demod(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT) void k_demod(FrameBatch fb, con
 	const long body0 = st.sc_start + 2 * SYM_STRIDE;          // pilot body, decode.cc:456-459
 	const float omega = -st.cfo_rad;                          // decode.cc:403
 	const int code_off = -md.cols / 2;                        // decode.cc:454
-	if constexpr (RATE == 8000) {
+	if constexpr (DEMOD_WAVE_PER_SYMBOL(RATE)) {
 		__shared__ DemodShared<RATE> sh;
 		const int groups = (md.rows + 1 + 3) / 4;
 		for (int g = 0; g < groups; ++g) {
