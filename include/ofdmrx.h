@@ -70,7 +70,10 @@ typedef struct {
 	int32_t max_samples;       /* max samples per frame (0 = ofdmrx_frame_samples(sample_rate, 6)) */
 	int32_t descramble;        /* 1 = XOR payload with Xorshift32 like main(), decode.cc:613-615 */
 	int32_t flags;             /* bit 0: keep the pre-rotation constellation (OFDMRX_TAP_CONS_RAW) */
-	void *stream;              /* hipStream_t to run on, NULL = library-owned stream */
+	void *stream;              /* hipStream_t to run on, NULL = library-owned stream.  Batches longer than one chunk
+	                            * also use a second, library-owned stream for the polar stage (two-stage chunk
+	                            * pipeline); the given stream waits for it, so work enqueued on `stream` after a
+	                            * decode call sees the finished batch */
 } ofdmrx_config;
 
 /* mirrors the reference's stderr diagnostics */
@@ -89,7 +92,9 @@ typedef struct {
 	int32_t n_sync_rejects;    /* falling edges rejected at decode.cc:140-145 */
 } ofdmrx_frame_result;
 
-/* hipEvent timings of the last decode call, milliseconds, summed over chunks */
+/* hipEvent timings of the last decode call, milliseconds, summed over chunks.  In a pipelined (multi-chunk) call the
+ * polar / finish spans run beside the Theil-Sen / LLR spans of the next chunk: the stage times then overlap and add up to
+ * more than the wall time; TOTAL sums the per-chunk latencies (first kernel to last kernel of each chunk). */
 enum {
 	OFDMRX_T_FRONT = 0, OFDMRX_T_SYNC, OFDMRX_T_HEADER, OFDMRX_T_DEMOD, OFDMRX_T_THEILSEN,
 	OFDMRX_T_LLR, OFDMRX_T_POLAR, OFDMRX_T_FINISH, OFDMRX_T_TOTAL, OFDMRX_T_COUNT
