@@ -13,13 +13,17 @@ import oracle_lib as O
 import modem_amd
 import modem_amd.ofdmrx as M
 
+mode = int(os.environ.get("SWEEP_MODE", "6"))
+rate = int(os.environ.get("SWEEP_RATE", "8000"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 levels = [float(x) for x in sys.argv[2:]] or [-17.0, -15.5, -15.0, -14.5]
 dev = torch.device("cuda:0")
 stream = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(stream)
-rx = modem_amd.Receiver(device=0, chunk_frames=96, stream=stream.cuda_stream)
-spf = rx.tx_frame_samples(6)
+rx = modem_amd.Receiver(device=0, chunk_frames=96, stream=stream.cuda_stream, sample_rate=rate)
+spf = rx.tx_frame_samples(mode)
+O.lib().orc_decode_rate   # (loads the library)
+print("mode %d, %d Hz" % (mode, rate), flush=True)
 threads = min(os.cpu_count() or 1, 32)
 bad = 0
 for li, db in enumerate(levels):
@@ -27,7 +31,7 @@ for li, db in enumerate(levels):
     g.manual_seed(1234 + li)
     d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
     d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
-    rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
+    rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr(), mode=mode)
     rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, db, 99, li * n)
     d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
     d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
@@ -39,7 +43,15 @@ for li, db in enumerate(levels):
     oout = np.zeros((n, 5380), np.uint8)
     ores = np.zeros(n * 56, np.uint8)
     t = time.perf_counter()
-    O.lib().orc_decode_batch(O.ptr(pcm), O.FMT_S16, 2, spf, spf * 4, n, 8, O.ptr(oout), O.ptr(ores), threads)
+    if rate == 8000:
+        O.lib().orc_decode_batch(O.ptr(pcm), O.FMT_S16, 2, spf, spf * 4, n, 8, O.ptr(oout), O.ptr(ores), threads)
+    else:   # the batch helper is the 8 kHz instantiation: other rates frame by frame
+        ov = ores.view(M.RESULT_DTYPE).reshape(-1)
+        for f in range(n):
+            o, r = O.decode(pcm[f], rate=rate)
+            oout[f] = o
+            for name in ov.dtype.names:
+                ov[name][f] = getattr(r, name)
     dt = time.perf_counter() - t
     ores = ores.view(M.RESULT_DTYPE).reshape(-1)
     # bit_flips (decode.cc:546-555) counts sign(llr) != decoded bit: an LLR within the 1e-5 intermediate tolerance
