@@ -398,14 +398,14 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 			T_hi = select_rank<+1>(s, tid, rhi, sample);
 		}
 		// ---- 2. classify every pair: lane = point i (kept in a register), loop = distance d (wave-uniform),
-		// eight distances per step.  s.y is padded with +3e38 beyond n (and points i >= n read -3e38), so pairs
+		// sixteen distances per step.  s.y is padded with +3e38 beyond n (and points i >= n read -3e38), so pairs
 		// that do not exist produce a huge positive slope and drop out as "above" - no index clamps, no
 		// validity masks; the eight phases are two ds_read2 pairs apart and the reciprocals of the distances
 		// come from a constant table through scalar loads.  Per pair: half a packed subtract, half a packed
 		// multiply, two compares straight into wave masks.  "below" is a scalar popcount.  Kept pairs go to a
 		// wave-private quarter of the LDS list (fill count in a scalar register, slot = fill + mbcnt), so the
 		// pass has no atomics and no block-level synchronisation.  Every wave walks all blocks of 64 points and
-		// takes every fourth group of eight distances: the trip counts balance, and so do the kept pairs (they
+		// takes every fourth group of sixteen distances: the trip counts balance, and so do the kept pairs (they
 		// come mostly from the long distances, whose slopes cluster around the median).
 		const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: uniform loops, s_load of the table
 		constexpr int WCAP = TS_LIST_CAP / 4;
@@ -423,7 +423,10 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 				const float yi = i < n ? s.y[i] : -3.0e38f;
 				const int dmax = n - 1 - b * 64;              // largest distance with any existing pair
 				const float *yp = s.y + i + 1;
-				constexpr int U = 8;
+#ifndef TS_U
+#define TS_U 16
+#endif
+				constexpr int U = TS_U;
 				for (int d0 = wave * U; d0 < dmax; d0 += 4 * U) {   // distances d0+1 .. d0+8; wave w takes every 4th group
 					unsigned long long kb[U];
 					bool keep[U];
