@@ -48,6 +48,7 @@ constexpr float TWO_PI_F = 6.28318530717958647692f;
 constexpr float PI_F = 3.14159265358979323846f;
 
 constexpr int CONS_MAX = 32400;     // decode.cc:178 cons_max
+constexpr int CARR_MAX = 32400 + 512;   // (rows + 1) x cols carriers per frame (pilot symbol + data rows)
 constexpr int ROWS_MAX = 126;       // decode.cc:181 rows_max
 constexpr int COLS_MAX = 512;       // decode.cc:180
 constexpr int MESG_BITS_MAX = 44096;
@@ -204,6 +205,16 @@ template <> struct Bfly<7> {
 	}
 };
 
+// NT = 64: the transform belongs to ONE wave (its LDS operations execute in order): no workgroup barrier, the other
+// waves of the block run their own transforms unsynchronised
+template <int NT> __device__ __forceinline__ void fft_sync()
+{
+	if (NT == 64)
+		__builtin_amdgcn_wave_barrier();
+	else
+		__syncthreads();
+}
+
 template <int N, int R, int P, int NT, int TWN = 1280>
 __device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
 {
@@ -226,7 +237,7 @@ __device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
 			Bfly<R>::run(v[q]);
 		}
 	}
-	__syncthreads();
+	fft_sync<NT>();
 	#pragma unroll
 	for (int q = 0; q < NB; ++q) {
 		int b = tid + q * NT;
@@ -238,7 +249,7 @@ __device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
 				buf[j + t * P] = v[q][t];
 		}
 	}
-	__syncthreads();
+	fft_sync<NT>();
 }
 
 // Forward N-point transform in place (LDS or global scratch), natural order in and out, NT threads.

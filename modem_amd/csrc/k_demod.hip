@@ -25,7 +25,6 @@ __device__ __forceinline__ cf psk8_hard_map(cf c)   // map(hard(c)): psk.hh:118-
 // ---------------------------------------------------------------- D4
 template <int RATE> struct DemodShared {                     // 8 kHz: one 1280-point buffer per wave
 	cf fft[4][RateCfg<RATE>::SL];
-	cf carr[8][COLS_MAX];
 };
 template <int RATE> struct DemodSharedBlock {                // other rates: one buffer, the whole block per symbol
 	cf fft[RateCfg<RATE>::SL];
@@ -41,11 +40,14 @@ template <int RATE> struct DemodSharedBlock {                // other rates: one
 #ifndef DEMOD_WAVE_PER_SYMBOL
 #define DEMOD_WAVE_PER_SYMBOL(R) ((R) == 8000)
 #endif
-template <int RATE> struct DemodCfg { static constexpr int NT = DEMOD_WAVE_PER_SYMBOL(RATE) ? 256 : 1024; };   // threads per frame
+template <int RATE> struct DemodCfg {
+	static constexpr int NT = DEMOD_WAVE_PER_SYMBOL(RATE) ? 256 : 1024;     // threads per frame
+	static constexpr int MINB = DEMOD_WAVE_PER_SYMBOL(RATE) ? 4 : 1;        // workgroups per CU the register budget is set for
+};
 
 template <int RATE>
-__global__ __launch_bounds__(DemodCfg<RATE>::NT) void k_demod(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
-	const SyncState *__restrict__ st_all, cf *__restrict__ cons_all)
+__global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_demod(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
+	const SyncState *__restrict__ st_all, cf *__restrict__ cons_all, cf *__restrict__ carr_all)
 {
 	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, SYM_STRIDE = RateCfg<RATE>::STRIDE;
 	const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT) void k_demod(FrameBatch fb, con
 			const int s = 4 * g + wave;                           // 0 = pilot, 1..rows = data rows
 			const bool valid = s <= md.rows;
 			cf *buf = sh.fft[wave];
-			#pragma unroll 4
+			#pragma unroll 2
 			for (int q = 0; q < SYMBOL_LEN / 64; ++q) {
 				int i = lane + 64 * q;
 				cf v = mk(0.f, 0.f);
@@ -74,16 +76,15 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT) void k_demod(FrameBatch fb, con
 					v = cmul(src.at(body0 + (long)s * SYM_STRIDE + i), phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + i));
 				buf[i] = v;
 			}
-			__syncthreads();
-			fft_fwd<SYMBOL_LEN, 64, SYMBOL_LEN>(buf, tb.tw_sym, lane);
-			if (valid)
+			fft_fwd<SYMBOL_LEN, 64, SYMBOL_LEN>(buf, tb.tw_sym, lane);   // one wave, its own buffer: no workgroup barriers
+			// the payload carriers of symbol s go to HBM (cols x 8 B); the time-differential step
+			// cons = X_j / X_{j-1} (decode.cc:474-475) happens where they are read (k_theil_sen): no carrier ring,
+			// no dependence between the waves, 40 KB of LDS per workgroup
+			if (valid) {
+				cf *carr = carr_all + (size_t)f * CARR_MAX + (size_t)s * md.cols;
 				for (int i = lane; i < md.cols; i += 64)
-					sh.carr[s & 7][i] = buf[(i + code_off + SYMBOL_LEN) % SYMBOL_LEN];
-			__syncthreads();
-			if (valid && s >= 1)
-				for (int i = lane; i < md.cols; i += 64)        // decode.cc:474-475
-					cons[(s - 1) * md.cols + i] = demod_or_erase(sh.carr[s & 7][i], sh.carr[(s - 1) & 7][i]);
-			__syncthreads();
+					carr[i] = buf[(i + code_off + SYMBOL_LEN) % SYMBOL_LEN];
+			}
 		}
 	} else {
 		__shared__ DemodSharedBlock<RATE> sh;
@@ -514,8 +515,10 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 }
 
 // decode.cc:479-504: one workgroup per (frame, row)
+// carr_all != nullptr (8 kHz): the row is formed here from the carriers of two consecutive symbols; cons_raw_all
+// (nullable) receives the unrotated row for the CONS_RAW tap
 __global__ __launch_bounds__(256, 5) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
-	float *__restrict__ slope_all, float *__restrict__ yint_all)
+	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all)
 {
 	// grid = frames x 50 (mode 6 has exactly 50 rows: one row per block); modes with more rows loop
 	const int f = blockIdx.x / TS_GRID_ROWS, tid = threadIdx.x;
@@ -525,10 +528,25 @@ __global__ __launch_bounds__(256, 5) void k_theil_sen(const SyncState *__restric
 	__shared__ TsShared s;
 	for (int j = blockIdx.x % TS_GRID_ROWS; j < md.rows; j += TS_GRID_ROWS) {
 		cf *row = cons_all + (size_t)f * CONS_MAX + (size_t)j * md.cols;
-		for (int i = tid; i < md.cols; i += 256) {            // decode.cc:482-487
-			cf c = row[i];
-			cf d = cmul(c, cconj(md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c)));
-			s.y[i] = atan2f(d.im, d.re);
+		cf cv[2];
+		#pragma unroll
+		for (int q = 0; q < 2; ++q) {                         // decode.cc:482-487
+			const int i = tid + 256 * q;
+			cv[q] = mk(0.f, 0.f);
+			if (i < md.cols) {
+				cf c;
+				if (carr_all) {                               // decode.cc:474-475
+					const cf *cr = carr_all + (size_t)f * CARR_MAX + (size_t)j * md.cols;
+					c = demod_or_erase(cr[md.cols + i], cr[i]);
+					if (cons_raw_all)
+						cons_raw_all[(size_t)f * CONS_MAX + (size_t)j * md.cols + i] = c;
+				} else {
+					c = row[i];
+				}
+				cv[q] = c;
+				cf d = cmul(c, cconj(md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c)));
+				s.y[i] = atan2f(d.im, d.re);
+			}
 		}
 		__syncthreads();
 		float slope, yint;
@@ -536,11 +554,15 @@ __global__ __launch_bounds__(256, 5) void k_theil_sen(const SyncState *__restric
 			theil_sen_block(s, CONS_COLS, tid, slope, yint);
 		else
 			theil_sen_block(s, md.cols, tid, slope, yint);
-		for (int i = tid; i < md.cols; i += 256) {            // decode.cc:493-494
-			float a = -(yint + slope * (float)(i - md.cols / 2));
-			float sn, cs;
-			sincosf(a, &sn, &cs);
-			row[i] = cmul(row[i], mk(cs, sn));
+		#pragma unroll
+		for (int q = 0; q < 2; ++q) {                         // decode.cc:493-494
+			const int i = tid + 256 * q;
+			if (i < md.cols) {
+				float a = -(yint + slope * (float)(i - md.cols / 2));
+				float sn, cs;
+				sincosf(a, &sn, &cs);
+				row[i] = cmul(cv[q], mk(cs, sn));
+			}
 		}
 		if (tid == 0) {
 			slope_all[(size_t)f * ROWS_MAX + j] = slope;
@@ -661,13 +683,14 @@ __global__ __launch_bounds__(256) void k_fft_debug(int len, int sign, const cf *
 		out[(size_t)f * len + i] = sign > 0 ? cconj(buf[i]) : buf[i];
 }
 
-void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons)
+bool demod_writes_carriers(int rate) { return DEMOD_WAVE_PER_SYMBOL(rate); }
+void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons, cf *carr)
 {
-	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(DemodCfg<RATE>::NT), 0, s, fb, z, tb, st, cons));
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(DemodCfg<RATE>::NT), 0, s, fb, z, tb, st, cons, carr));
 }
-void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, float *slope, float *yint)
+void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint)
 {
-	hipLaunchKernelGGL(k_theil_sen, dim3(n * TS_GRID_ROWS), dim3(256), 0, s, st, cons, slope, yint);
+	hipLaunchKernelGGL(k_theil_sen, dim3(n * TS_GRID_ROWS), dim3(256), 0, s, st, cons, carr, cons_raw, slope, yint);
 }
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint)
 {

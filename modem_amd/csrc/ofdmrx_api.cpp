@@ -83,6 +83,7 @@ struct ofdmrx_handle {
 	DevBuf in_stage, in_stage2, skip_stage;
 	void *out_stage[2] = { nullptr, nullptr };   // pinned host staging of payloads + results (host-pointer entry)
 	size_t out_stage_cap[2] = { 0, 0 };
+	DevBuf carr;                   // 8 kHz: payload carriers of every symbol (demod -> Theil-Sen)
 	DevBuf sc_scratch;             // rates above 8 kHz: 2 x symbol_len/2 cf per frame for the S&C trigger part
 	int last_n = 0;           // frames in the last chunk (for taps)
 	bool last_mono = false;
@@ -205,7 +206,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 		(void)hipStreamDestroy(h->stream_b);
 	}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2 })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -248,6 +249,8 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->payload.ensure(N * PAYLOAD_BYTES);
 		if (h->cfg.flags & 1)
 			r = r ? r : h->cons_raw.ensure(N * CONS_MAX * sizeof(cf));
+		if (demod_writes_carriers(h->rate))
+			r = r ? r : h->carr.ensure(N * CARR_MAX * sizeof(cf));
 		if (h->rate != 8000)
 			r = r ? r : h->sc_scratch.ensure(N * (size_t)rate_symbol_len(h->rate) * sizeof(cf));
 		if (r)
@@ -302,8 +305,8 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, i
 		h->spans.push_back({ OFDMRX_T_HEADER, b, c });
 		e3 = c;
 	}
-	launch_demod(s, h->rate, n, fb, z, h->dev, st, h->cons.as<cf>());
-	if (h->cfg.flags & 1)
+	launch_demod(s, h->rate, n, fb, z, h->dev, st, h->cons.as<cf>(), h->carr.as<cf>());
+	if ((h->cfg.flags & 1) && !demod_writes_carriers(h->rate))
 		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
 	size_t e4 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_FRONT, e0, e1 });
@@ -321,7 +324,9 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d
 {
 	SyncState *st = h->st_of(par);
 	size_t e4 = mark(h, s);
-	launch_theil_sen(s, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>());
+	const bool from_carr = demod_writes_carriers(h->rate);
+	launch_theil_sen(s, n, st, h->cons.as<cf>(), from_carr ? h->carr.as<cf>() : nullptr,
+		(from_carr && (h->cfg.flags & 1)) ? h->cons_raw.as<cf>() : nullptr, h->slope.as<float>(), h->yint.as<float>());
 	size_t e5 = mark(h, s);
 	launch_llr(s, h->rate, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
 		h->llr_of(par), d_res);
