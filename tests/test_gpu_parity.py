@@ -741,3 +741,32 @@ def test_encode_cli_is_a_drop_in(tmp_path):
         r = subprocess.run([enc, str(tmp_path / "x.wav")] + bad, capture_output=True, text=True)
         assert r.returncode == 1 and msg in r.stderr, (bad, r.stderr)
     assert subprocess.run([enc], capture_output=True).returncode == 1
+
+
+def test_chunk_pipeline_at_16k():
+    """the chunk pipeline at another sample rate (other kernels instantiations, other chunk default): 10 frames of
+    mode 12 at 16 kHz in chunks of 3 equal one chunk of 10 and the oracle"""
+    import modem_amd
+    rate = 16000
+    pays = [O.payload_for(1700 + i) for i in range(10)]
+    pcm = np.stack([O.impair(O.encode_pcm(p, channels=2, mode=12, freq_off=1500, rate=rate), noise_db=-24, seed=3, frame=i, rate=rate)
+                    for i, p in enumerate(pays)])
+    outs = []
+    for chunk in (3, 16):
+        rx = modem_amd.Receiver(device=0, chunk_frames=chunk, sample_rate=rate, max_samples=pcm.shape[1])
+        import torch
+        import modem_amd.ofdmrx as M
+        dev = torch.device("cuda:0")
+        d_in = torch.from_numpy(pcm).to(dev)
+        d_out = torch.zeros((10, 5380), dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((10, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, pcm.shape[1], pcm.shape[1] * 4, 10, d_out.data_ptr(), d_res.data_ptr())
+        rx.synchronize()
+        outs.append((d_out.cpu().numpy(), d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)))
+        rx.close()
+    (o3, r3), (o16, r16) = outs
+    assert (o3 == o16).all() and (r3["status"] == 0).all() and (r3["sc_start"] == r16["sc_start"]).all()
+    assert (o3 == np.stack(pays)).all()
+    o, r = O.decode(pcm[7], rate=rate)
+    assert r.status == 0 and (o == o3[7]).all() and r.sc_start == int(r3["sc_start"][7]) and r.bit_flips == int(r3["bit_flips"][7])
