@@ -42,7 +42,7 @@ template <int RATE> struct DemodSharedBlock {                // other rates: one
 #endif
 template <int RATE> struct DemodCfg {
 	static constexpr int NT = DEMOD_WAVE_PER_SYMBOL(RATE) ? 256 : 1024;     // threads per frame
-	static constexpr int MINB = DEMOD_WAVE_PER_SYMBOL(RATE) ? 4 : 1;        // workgroups per CU the register budget is set for
+	static constexpr int MINB = DEMOD_WAVE_PER_SYMBOL(RATE) ? 2 : 1;        // workgroups per CU the register budget is set for (4 would spill)
 };
 
 template <int RATE>
