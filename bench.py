@@ -197,10 +197,10 @@ def main():
         # scaled to this run's frames per launch; null when the file is absent
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_v7_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01_v8_traffic.json")) as fh:
                 tj = json.load(fh)
             traffic = (tj["fetch_KiB"] + tj["write_KiB"]) * 1024.0 * frames_per_launch / tj["frames_per_launch"]
-            traffic_src = "profiles/r01_v7_traffic.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch"
+            traffic_src = "profiles/r01_v8_traffic.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch"
         except (OSError, KeyError, ValueError):
             pass
         line = {
