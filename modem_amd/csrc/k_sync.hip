@@ -44,16 +44,19 @@ __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, 
 	cf *z = z_all + (size_t)f * fb.samples_per_frame;
 	(void)dc_all;
 	__shared__ float ydc[FE_HIST + FE_TILE];   // [0, FE_HIST) = tail of the previous tile
-	__shared__ float wave_end[4];
-	__shared__ float tile_carry;
-	const float a = co.dc_a, b = co.dc_b;
+	__shared__ double wave_end[4];
+	__shared__ double tile_carry;
+	// The recurrence is evaluated in double here (chunk-local states, scan weights, carries) and rounded once per
+	// sample: a parallel scan cannot reproduce the rounding sequence of the serial fp32 recurrence anyway, so the GPU
+	// side is made (nearly) exact and the difference to the CPU's serial fp32 filter is that filter's own rounding.
+	const double a = (double)co.dc_a, b = (double)co.dc_b;
 	// powers of a: a^1..a^16 in registers, A^(2^s) = a^(16*2^s) for the scan steps
-	float apow[FE_PER];
+	double apow[FE_PER];
 	apow[0] = a;
 	#pragma unroll
 	for (int i = 1; i < FE_PER; ++i)
 		apow[i] = apow[i - 1] * a;
-	float Apow[7];   // A^1, A^2, A^4, ... A^64
+	double Apow[7];   // A^1, A^2, A^4, ... A^64
 	Apow[0] = apow[FE_PER - 1];
 	#pragma unroll
 	for (int sft = 1; sft < 7; ++sft)
@@ -61,11 +64,12 @@ __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, 
 	if (tid < FE_HIST)
 		ydc[tid] = 0.f;
 	if (tid == 0)
-		tile_carry = 0.f;
+		tile_carry = 0.0;
 	__syncthreads();
 	for (long t0 = 0; t0 < n; t0 += FE_TILE) {
 		const long s0 = t0 + (long)tid * FE_PER;
-		float x[FE_PER + 1], y[FE_PER];
+		float x[FE_PER + 1];
+		double y[FE_PER];
 		x[0] = (s0 - 1 >= 0 && s0 - 1 < n) ? src.scalar(s0 - 1) : 0.f;
 		if (fb.fmt == 0 && s0 + FE_PER <= n && (((size_t)base + (size_t)s0 * 2) & 15) == 0) {
 			const int4 *p = (const int4 *)((const int16_t *)base + s0);
@@ -81,17 +85,17 @@ __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, 
 			for (int i = 0; i < FE_PER; ++i)
 				x[1 + i] = s0 + i < n ? src.scalar(s0 + i) : 0.f;
 		}
-		float yl = 0.f;
+		double yl = 0.0;
 		#pragma unroll
 		for (int i = 0; i < FE_PER; ++i) {
-			yl = b * (x[i + 1] - x[i]) + a * yl;
+			yl = b * (double)(x[i + 1] - x[i]) + a * yl;
 			y[i] = yl;
 		}
 		// weighted inclusive scan of the chunk end states over the 64 lanes of the wave
-		float v = yl;
+		double v = yl;
 		#pragma unroll
 		for (int sft = 0; sft < 6; ++sft) {
-			float o = __shfl_up(v, 1 << sft);
+			double o = shfl_up_d(v, 1 << sft);
 			if (lane >= (1 << sft))
 				v += Apow[sft] * o;
 		}
@@ -99,27 +103,27 @@ __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, 
 			wave_end[wave] = v;
 		__syncthreads();
 		// carry into this thread = state after the previous thread's last sample
-		float cin = tile_carry;                       // state at the end of the previous tile
+		double cin = tile_carry;                      // state at the end of the previous tile
 		{
 			// state at the end of the previous waves of this tile: fold them in order
-			float st = cin;
+			double st = cin;
 			for (int w2 = 0; w2 < wave; ++w2)
 				st = wave_end[w2] + Apow[6] * st;     // A^64 decays a whole wave (1024 samples)
 			// within the wave: exclusive value = inclusive of lane-1 (decayed state of lanes < lane)
-			float prev = __shfl_up(v, 1);
-			float decay = 1.f;                        // A^lane
+			double prev = shfl_up_d(v, 1);
+			double decay = 1.0;                       // A^lane
 			#pragma unroll
 			for (int sft = 0; sft < 6; ++sft)
 				if (lane & (1 << sft))
 					decay *= Apow[sft];
-			cin = (lane ? prev : 0.f) + decay * st;
+			cin = (lane ? prev : 0.0) + decay * st;
 		}
 		#pragma unroll
 		for (int i = 0; i < FE_PER; ++i)
-			ydc[FE_HIST + tid * FE_PER + i] = y[i] + apow[i] * cin;
+			ydc[FE_HIST + tid * FE_PER + i] = (float)(y[i] + apow[i] * cin);
 		__syncthreads();
 		if (tid == 255)
-			tile_carry = ydc[FE_HIST + FE_TILE - 1];
+			tile_carry = y[FE_PER - 1] + apow[FE_PER - 1] * cin;
 		// Hilbert<cmplx,21>: centre tap 10 back, odd taps +-1,3,5,7,9 around it
 		#pragma unroll 4
 		for (int i = 0; i < FE_PER; ++i) {
