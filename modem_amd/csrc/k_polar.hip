@@ -170,14 +170,21 @@ struct PolarBufs {
 // back with the channel-LLR indexing - at t = 0 for the next pass of the descent and at t = 2^z for the g step
 // of the right sibling on the left spine, the only other reader.  Values are unchanged; the level store sees
 // 1.75 MB fewer writes and ~2 MB fewer reads per codeword.
-template <int D, int KIND, int NG, bool SRC_G, bool SRC_C = false, bool DST_C = false>
+// Recomputed arrays.  The right sibling on the left spine (t = 2^z, level z) is g(C, partial sums) of a compact
+// array C (level z+1; the channel LLRs for z = 15): 4 bytes of C per position serve all eight paths.  Its own
+// level-z array is read exactly once more, by the g step of ITS right child at t = 3 * 2^(z-1).  SKIP0 does not
+// store it; SRC_R rebuilds both inputs of that g step from C and the level-(z+1) node's left partial sums (bit =
+// the path's ancestor at t = 2^z, the very lane map the stored array would have been read with) with the same
+// g_add, so every value is bit-identical: 2 MB fewer writes and ~1.5 MB fewer reads per codeword.
+//   SRC_R 1: C = compact level m+2      SRC_R 2: C = the channel LLRs (m = 14)
+template <int D, int KIND, int NG, bool SRC_G, bool SRC_C = false, bool DST_C = false, bool SKIP0 = false, int SRC_R = 0>
 __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int hb_g_off, const uint8_t *hb_l, int m, int lane, int gl)
 {
 	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
 #ifndef POLAR_XB3
 #define POLAR_XB3 3
 #endif
-	constexpr int XB = D == 3 ? POLAR_XB3 : (D == 2 ? 4 : 8);   // columns batched: XB * 2 * NT loads in flight
+	constexpr int XB = SRC_R ? 1 : (D == 3 ? POLAR_XB3 : (D == 2 ? 4 : 8));   // columns batched: XB * 2 * NT loads in flight
 	const int S = 1 << (m - D + 1 - 3);       // local indices at the lowest produced level
 	const int half = 1 << (m - 3);            // partner distance (local) at level m+1
 	const int j = lane >> 3, k = lane & 7;
@@ -194,7 +201,16 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 			for (int s2 = 0; s2 < NT; ++s2)
 				if (x0 + xb < S) {
 					const int x = x0 + xb + s2 * S;
-					if (KIND >= 2) {
+					if (SRC_R) {
+						const rsrc_t C = SRC_R == 2 ? pb.llr : pb.soft;
+						const int c_off = SRC_R == 2 ? 0 : (8 << (m + 2)) * 4, anc = gl & 7;
+						const float a1 = bload(C, vo_j, c_off + x * 32), a2 = bload(C, vo_j, c_off + (x + 2 * half) * 32);
+						const float b1 = bload(C, vo_j, c_off + (x + half) * 32), b2 = bload(C, vo_j, c_off + (x + 3 * half) * 32);
+						const int ha = bload_u8(pb.hard, j, hb_g_off - (2 << m) + x * 8);
+						const int hb = bload_u8(pb.hard, j, hb_g_off - (2 << m) + (x + half) * 8);
+						a[xb][s2] = g_add(a1, a2, (ha >> anc) & 1);
+						b[xb][s2] = g_add(b1, b2, (hb >> anc) & 1);
+					} else if (KIND >= 2) {
 						a[xb][s2] = bload(pb.llr, vo_j, x * 32);
 						b[xb][s2] = bload(pb.llr, vo_j, (x + half) * 32);
 					} else if (SRC_C) {
@@ -209,7 +225,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 						b[xb][s2] = src_l[(x + half) * 64 + o];
 					}
 					if (KIND & 1)
-						h[xb][s2] = (SRC_G || KIND == 3) ? bload_u8(pb.hard, j, hb_g_off + x * 8) : hb_l[x * 8 + j];
+						h[xb][s2] = (SRC_G || KIND == 3 || SRC_R) ? bload_u8(pb.hard, j, hb_g_off + x * 8) : hb_l[x * 8 + j];
 				}
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
@@ -219,7 +235,8 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 				for (int s2 = 0; s2 < NT; ++s2) {
 					v[s2] = (KIND & 1) ? g_add(a[xb][s2], b[xb][s2], (h[xb][s2] >> k) & 1) : f_minsum(a[xb][s2], b[xb][s2]);
 					const int idx = (8 << m) + (x0 + xb + s2 * S) * 64;
-					if (NG > 0) {
+					if (SKIP0) {
+					} else if (NG > 0) {
 						if (!DST_C) bstore(pb.soft, vo_lane, idx * 4, v[s2]);
 						else if (k == 0) bstore(pb.soft, vo_j, ((8 << m) + (x0 + xb + s2 * S) * 8) * 4, v[s2]);
 					} else ls[idx + lane] = v[s2];
@@ -456,12 +473,23 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 						else if (cur >= LDS_TOP + 3) FPC(3, 0, 3, true, true);
 						else FPC(3, 0, 2, true, true);
 					} else if (POLAR_COMPACT && kind == 1 && (t & (t - 1)) == 0 && cur >= LDS_TOP && cur <= 14) {
-						if (cur >= LDS_TOP + 3) FPC(3, 1, 3, true, false);            // right sibling on the left spine:
-						else if (cur == LDS_TOP + 2) FPC(3, 1, 2, true, false);       // its source was stored compact at t = 0
-						else if (cur == LDS_TOP + 1) FPC(3, 1, 1, true, false);
+						// right sibling on the left spine: its source was stored compact at t = 0; its own top level
+						// (if >= 8) is not stored, the one later reader recomputes it (SRC_R below)
+						if (cur >= LDS_TOP + 3) fused_pass<3, 1, 3, true, true, false, true>(pb, ls, ho_g, ho_l, cur, lane, gl);
+						else if (cur == LDS_TOP + 2) fused_pass<3, 1, 2, true, true, false, true>(pb, ls, ho_g, ho_l, cur, lane, gl);
+						else if (cur == LDS_TOP + 1) fused_pass<3, 1, 1, true, true, false, true>(pb, ls, ho_g, ho_l, cur, lane, gl);
 						else FPC(3, 1, 0, true, false);
+					} else if (POLAR_COMPACT && kind == 1 && (t >> cur) == 3 && cur >= LDS_TOP && cur <= 14) {
+						// t = 3 * 2^cur: right child of the right sibling on the left spine
+						#define FPR(NGG, RR) fused_pass<3, 1, NGG, true, false, false, false, RR>(pb, ls, ho_g, ho_l, cur, lane, gl)
+						if (cur == 14) FPR(3, 2);
+						else if (cur >= LDS_TOP + 3) FPR(3, 1);
+						else if (cur == LDS_TOP + 2) FPR(2, 1);
+						else if (cur == LDS_TOP + 1) FPR(1, 1);
+						else FPR(0, 1);
+						#undef FPR
 					}
-					else if (cur == 15) { if (kind == 2) FP(3, 2, 3, true); else FP(3, 3, 3, true); }
+					else if (cur == 15) { if (kind == 2) FP(3, 2, 3, true); else if (POLAR_COMPACT) fused_pass<3, 3, 3, true, false, false, true>(pb, ls, ho_g, ho_l, cur, lane, gl); else FP(3, 3, 3, true); }
 					else if (cur >= LDS_TOP + 3) FPK(3, 3, true);
 					else if (cur == LDS_TOP + 2) FPK(3, 2, true);
 					else if (cur == LDS_TOP + 1) FPK(3, 1, true);
