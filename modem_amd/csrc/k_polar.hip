@@ -191,8 +191,26 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 	const float *src_l = ls + (8 << (m + 1));
 	const int src_off = (8 << (m + 1)) * 4;   // byte offset of level m+1 in the level store
 	const int vo_lane = lane * 4, vo_src = (KIND == 1 ? gl : lane) * 4, vo_j = j * 4;
+	// Addressing of the global accesses: the per-lane offset register advances with x0, the column xb inside a batch is
+	// an immediate (xb * 256 < 4096) and everything that depends on s2 or the level is a loop-invariant scalar - no
+	// scalar arithmetic per access inside the loop.
+	constexpr int XS = (KIND >= 2 || SRC_C || SRC_R) ? 32 : 256;      // source bytes per local index
+	const rsrc_t C = (KIND >= 2 || SRC_R == 2) ? pb.llr : pb.soft;
+	const int c_off = (KIND >= 2 || SRC_R == 2) ? 0 : (SRC_R ? (8 << (m + 2)) * 4 : src_off);
+	int so_a[NT], so_h[NT], so_d[D][NT];
+	#pragma unroll
+	for (int s2 = 0; s2 < NT; ++s2) {
+		so_a[s2] = c_off + s2 * S * XS;
+		so_h[s2] = hb_g_off + s2 * S * 8;
+		#pragma unroll
+		for (int d = 0; d < D; ++d)
+			so_d[d][s2] = ((8 << (m - d)) + s2 * S * (DST_C ? 8 : 64)) * 4;
+	}
+	const int hx = half * XS;
+	int v_src = (KIND >= 2 || SRC_C || SRC_R) ? vo_j : vo_src, v_dst = DST_C ? vo_j : vo_lane, v_h = j;
+	const int anc = gl & 7;
 	#pragma unroll 1
-	for (int x0 = 0; x0 < S; x0 += XB) {
+	for (int x0 = 0; x0 < S; x0 += XB, v_src += XB * XS, v_dst += XB * (DST_C ? 32 : 256), v_h += XB * 8) {
 		float a[XB][NT], b[XB][NT];
 		int h[XB][NT];
 		#pragma unroll
@@ -202,30 +220,22 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 				if (x0 + xb < S) {
 					const int x = x0 + xb + s2 * S;
 					if (SRC_R) {
-						const rsrc_t C = SRC_R == 2 ? pb.llr : pb.soft;
-						const int c_off = SRC_R == 2 ? 0 : (8 << (m + 2)) * 4, anc = gl & 7;
-						const float a1 = bload(C, vo_j, c_off + x * 32), a2 = bload(C, vo_j, c_off + (x + 2 * half) * 32);
-						const float b1 = bload(C, vo_j, c_off + (x + half) * 32), b2 = bload(C, vo_j, c_off + (x + 3 * half) * 32);
-						const int ha = bload_u8(pb.hard, j, hb_g_off - (2 << m) + x * 8);
-						const int hb = bload_u8(pb.hard, j, hb_g_off - (2 << m) + (x + half) * 8);
+						const float a1 = bload(C, v_src + xb * XS, so_a[s2]), a2 = bload(C, v_src + xb * XS, so_a[s2] + 2 * hx);
+						const float b1 = bload(C, v_src + xb * XS, so_a[s2] + hx), b2 = bload(C, v_src + xb * XS, so_a[s2] + 3 * hx);
+						const int ha = bload_u8(pb.hard, v_h + xb * 8, so_h[s2] - (2 << m));
+						const int hb = bload_u8(pb.hard, v_h + xb * 8, so_h[s2] - (2 << m) + half * 8);
 						a[xb][s2] = g_add(a1, a2, (ha >> anc) & 1);
 						b[xb][s2] = g_add(b1, b2, (hb >> anc) & 1);
-					} else if (KIND >= 2) {
-						a[xb][s2] = bload(pb.llr, vo_j, x * 32);
-						b[xb][s2] = bload(pb.llr, vo_j, (x + half) * 32);
-					} else if (SRC_C) {
-						a[xb][s2] = bload(pb.soft, vo_j, src_off + x * 32);
-						b[xb][s2] = bload(pb.soft, vo_j, src_off + (x + half) * 32);
-					} else if (SRC_G) {
-						a[xb][s2] = bload(pb.soft, vo_src, src_off + x * 256);
-						b[xb][s2] = bload(pb.soft, vo_src, src_off + (x + half) * 256);
+					} else if (KIND >= 2 || SRC_C || SRC_G) {
+						a[xb][s2] = bload(C, v_src + xb * XS, so_a[s2]);
+						b[xb][s2] = bload(C, v_src + xb * XS, so_a[s2] + hx);
 					} else {
 						const int o = KIND == 1 ? gl : lane;
 						a[xb][s2] = src_l[x * 64 + o];
 						b[xb][s2] = src_l[(x + half) * 64 + o];
 					}
 					if (KIND & 1)
-						h[xb][s2] = (SRC_G || KIND == 3 || SRC_R) ? bload_u8(pb.hard, j, hb_g_off + x * 8) : hb_l[x * 8 + j];
+						h[xb][s2] = (SRC_G || KIND == 3 || SRC_R) ? bload_u8(pb.hard, v_h + xb * 8, so_h[s2]) : hb_l[x * 8 + j];
 				}
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
@@ -237,8 +247,8 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 					const int idx = (8 << m) + (x0 + xb + s2 * S) * 64;
 					if (SKIP0) {
 					} else if (NG > 0) {
-						if (!DST_C) bstore(pb.soft, vo_lane, idx * 4, v[s2]);
-						else if (k == 0) bstore(pb.soft, vo_j, ((8 << m) + (x0 + xb + s2 * S) * 8) * 4, v[s2]);
+						if (!DST_C) bstore(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]);
+						else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[0][s2], v[s2]);
 					} else ls[idx + lane] = v[s2];
 				}
 				#pragma unroll
@@ -249,8 +259,8 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 						v[s2] = f_minsum(v[s2], v[s2 + n]);
 						const int idx = (8 << (m - d)) + (x0 + xb + s2 * S) * 64;
 						if (NG > d) {
-							if (!DST_C) bstore(pb.soft, vo_lane, idx * 4, v[s2]);
-							else if (k == 0) bstore(pb.soft, vo_j, ((8 << (m - d)) + (x0 + xb + s2 * S) * 8) * 4, v[s2]);
+							if (!DST_C) bstore(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]);
+							else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[d][s2], v[s2]);
 						} else ls[idx + lane] = v[s2];
 					}
 				}
