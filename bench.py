@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 B_FRAME_2CH = 95200 * 2 * 2 + 5380      # algorithmic bytes per frame, SURVEY 8(d): 386180
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+TRAFFIC_FILE = "r01_v9_traffic.json"      # PMC bytes of k_polar, written by tools/profile_round.sh
 
 
 def cpu_baseline(pcm_sample, payload_ref, threads, ch=2):
@@ -197,10 +198,14 @@ def main():
         # scaled to this run's frames per launch; null when the file is absent
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_v8_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as fh:
                 tj = json.load(fh)
-            traffic = (tj["fetch_KiB"] + tj["write_KiB"]) * 1024.0 * frames_per_launch / tj["frames_per_launch"]
-            traffic_src = "profiles/r01_v8_traffic.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch"
+            # counted KiB -> bytes with the calibration of the same session (FETCH_SIZE counts half of this access
+            # pattern's bytes on gfx950, WRITE_SIZE all of them: tools/pmc_calib.hip)
+            traffic = ((tj["fetch_KiB"] * tj.get("fetch_scale", 1.0) + tj["write_KiB"] * tj.get("write_scale", 1.0))
+                       * 1024.0 * frames_per_launch / tj["frames_per_launch"])
+            traffic_src = ("profiles/%s (rocprofv3 PMC FETCH_SIZE x %.2f + WRITE_SIZE x %.2f, separate passes, calibrated on "
+                           "tools/pmc_calib.hip), bytes per launch" % (TRAFFIC_FILE, tj.get("fetch_scale", 1.0), tj.get("write_scale", 1.0)))
         except (OSError, KeyError, ValueError):
             pass
         line = {
@@ -219,6 +224,7 @@ def main():
             "frames_ok": ok_status, "frames": B * n_gpus,
             "roofline": {"bound": "hbm", "kernel": "k_polar (D9 SCL)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_GBps": (traffic / avg_launch_s / 1e9) if (traffic and avg_launch_s > 0) else None,
                          "frames_per_launch": frames_per_launch, "avg_launch_ms": 1e3 * avg_launch_s,
                          "algorithmic_bytes_per_frame": b_frame},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
