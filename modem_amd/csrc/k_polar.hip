@@ -6,9 +6,10 @@
 // reference's SIMD lane), j = one of 8 butterflies processed per wave instruction.
 //   f(a,b)   = sign(a) sign(b) min(|a|,|b|)              left child LLRs
 //   g(a,b,u) = u ? b - a : a + b                          right child LLRs
-// Tree levels 4..15 live in HBM/L2 as soft[level m][i][k] (fp32, 2 MiB per codeword, the
-// reference's own soft[N+i] layout); level 16 is the shared channel LLR vector; levels
-// 3..0 (8-leaf sub-trees) never leave registers: butterflies are cross-lane shuffles.
+// Tree levels 8..15 live in HBM as soft[level m][i][k] (fp32, 2 MiB per decoder, the
+// reference's own soft[N+i] layout), levels 4..7 in LDS with the same [i][k] layout; level
+// 16 is the shared channel LLR vector; levels 3..0 (8-leaf sub-trees) never leave
+// registers: butterflies are cross-lane shuffles.
 // Lane permutations after a fork are applied lazily exactly like the reference's vshuf at
 // the g step and at the partial-sum combine: per level the composition of all leaf maps
 // since that level's node started is kept as 3-bit fields packed in two registers per
@@ -105,39 +106,6 @@ constexpr int LDS_TOP = POLAR_LDS_TOP;
 #ifndef POLAR_COMPACT
 #define POLAR_COMPACT (POLAR_LDS_TOP == 7)
 #endif // tree levels 4..7 (sub-trees of <= 128 leaves) live in LDS
-
-// One pass of the tree: level m (2^m positions x 8 paths) from level m+1.
-//   G = false: left child  f(a, b)
-//   G = true : right child g(a, b, u) with partial sums hb[i] (bit k) and the lane map (gl = source lane)
-// SRC_TOP: level m+1 is the shared channel LLR vector (m = 15).  Pointers may be global or LDS.
-template <bool G, bool SRC_TOP>
-__device__ __forceinline__ void tree_pass(const float *src, float *dst, const uint8_t *hb, int m, int lane, int gl)
-{
-	const int half = 1 << m, iters = half >> 3, j = lane >> 3, k = lane & 7;
-	for (int it0 = 0; it0 < iters; it0 += UB) {
-		float a[UB], b[UB];
-		int h[UB];
-		#pragma unroll
-		for (int u = 0; u < UB; ++u)
-			if (it0 + u < iters) {
-				if (SRC_TOP) {
-					int i = (it0 + u) * 8 + j;
-					a[u] = src[i];
-					b[u] = src[i + half];
-				} else {
-					int base = (it0 + u) * 64 + (G ? gl : lane);
-					a[u] = src[base];
-					b[u] = src[base + half * 8];
-				}
-				if (G)
-					h[u] = hb[(it0 + u) * 8 + j];
-			}
-		#pragma unroll
-		for (int u = 0; u < UB; ++u)
-			if (it0 + u < iters)
-				dst[(it0 + u) * 64 + lane] = G ? g_add(a[u], b[u], (h[u] >> k) & 1) : f_minsum(a[u], b[u]);
-	}
-}
 
 // Fused pass: levels m, m-1, ..., m-D+1 from level m+1 in one sweep.  A lane owns butterfly column
 // (j, k) at EVERY level (position i = x*8 + j, local index x), and the partner of local index x at
