@@ -150,9 +150,15 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 {
 	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
 #ifndef POLAR_XB3
-#define POLAR_XB3 3
+#define POLAR_XB3 2
 #endif
-	constexpr int XB = SRC_R ? 1 : (D == 3 ? POLAR_XB3 : (D == 2 ? 4 : 8));   // columns batched: XB * 2 * NT loads in flight
+#ifndef POLAR_XB2
+#define POLAR_XB2 4
+#endif
+#ifndef POLAR_XB1
+#define POLAR_XB1 8
+#endif
+	constexpr int XB = SRC_R ? 1 : (D == 3 ? POLAR_XB3 : (D == 2 ? POLAR_XB2 : POLAR_XB1));   // columns batched: XB * 2 * NT loads in flight
 	const int S = 1 << (m - D + 1 - 3);       // local indices at the lowest produced level
 	const int half = 1 << (m - 3);            // partner distance (local) at level m+1
 	const int j = lane >> 3, k = lane & 7;
