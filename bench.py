@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 B_FRAME_2CH = 95200 * 2 * 2 + 5380      # algorithmic bytes per frame, SURVEY 8(d): 386180
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_FILE = "r01_v9_traffic.json"      # PMC bytes of k_polar, written by tools/profile_round.sh
+TRAFFIC_FILE = "r01_v10_traffic.json"      # PMC bytes of k_polar, written by tools/profile_round.sh
 
 
 def cpu_baseline(pcm_sample, payload_ref, threads, ch=2):
