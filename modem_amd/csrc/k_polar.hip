@@ -456,6 +456,12 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 						if (cur == 15) FPC(3, 2, 3, false, true);
 						else if (cur >= LDS_TOP + 3) FPC(3, 0, 3, true, true);
 						else FPC(3, 0, 2, true, true);
+					} else if (POLAR_COMPACT && kind == 1 && (t & (t - 1)) == 0 && cur >= LDS_TOP && cur <= 14 && cur == Lt) {
+						// ... unless this very level is a node decided on its own array (below): then it is stored
+						if (cur >= LDS_TOP + 3) FPC(3, 1, 3, true, false);
+						else if (cur == LDS_TOP + 2) FPC(3, 1, 2, true, false);
+						else if (cur == LDS_TOP + 1) FPC(3, 1, 1, true, false);
+						else FPC(3, 1, 0, true, false);
 					} else if (POLAR_COMPACT && kind == 1 && (t & (t - 1)) == 0 && cur >= LDS_TOP && cur <= 14) {
 						// right sibling on the left spine: its source was stored compact at t = 0; its own top level
 						// (if >= 8) is not stored, the one later reader recomputes it (SRC_R below)
@@ -495,7 +501,49 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 					const int cnt = 1 << (Lt - 3);
 					const float *lv = ls + (8 << Lt) + lane;
 					uint8_t *lhn = lh + (t & ((1 << LDS_TOP) - 1));
-					if (nl0) {
+					if (Lt > LDS_TOP) {
+						// rate-1 node of 256..2048 leaves: the same decision on its array in the level store (cnt = 32..256
+						// values per lane); the sign bytes go straight to the partial-sum array.  None of the levels
+						// below it is ever computed.
+						const int base = (8 << Lt) * 4;
+						uint32_t mu = 0x7f800000u;
+						for (int x0 = 0; x0 < cnt; x0 += 16) {
+							float v[16];
+							#pragma unroll
+							for (int u = 0; u < 16; ++u)
+								v[u] = bload(pb.soft, lane * 4, base + (x0 + u) * 256);
+							#pragma unroll
+							for (int u = 0; u < 16; ++u)
+								mu = min(mu, __float_as_uint(v[u]) & 0x7fffffffu);
+						}
+						mu = min(mu, (uint32_t)xor8_i((int)mu));
+						mu = min(mu, (uint32_t)xor16_i((int)mu, lane));
+						mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
+						const float P = M + __uint_as_float(mu);
+						const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
+						const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
+						if (__ballot(!ok) == 0) {
+							for (int x0 = 0; x0 < cnt; x0 += 16) {
+								float v[16];
+								#pragma unroll
+								for (int u = 0; u < 16; ++u)
+									v[u] = bload(pb.soft, lane * 4, base + (x0 + u) * 256);
+								unsigned long long mine = 0;
+								#pragma unroll
+								for (int u = 0; u < 16; ++u) {
+									const unsigned long long bal = __ballot(v[u] < 0.f);
+									if (lane == u)
+										mine = bal;
+								}
+								if (lane < 16)                        // 16 positions x 8 bytes: one 128-byte store
+									*(unsigned long long *)(hard + t + (x0 + lane) * 8) = mine;
+							}
+							Ln = Lt;
+						} else {
+							stop = 4;
+							redo = cur >= 4;
+						}
+					} else if (nl0) {
 						// rate-0 node: sum of max(0, -llr) in the butterfly halving order the oracle fixes
 						// (positions i, i + n/2: lane-local while the distance is >= 8, then j^4, j^2, j^1)
 						float pz[16];
@@ -624,12 +672,14 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 		}
 		if ((tn & ((1 << LDS_TOP) - 1)) == 0) {               // a 128-leaf sub-tree is complete: publish its bytes
 			WAVE_ORDER();
-			if (LDS_TOP == 7)
+			if (Ln > LDS_TOP) {
+				// a node of >= 256 leaves wrote its bytes itself
+			} else if (LDS_TOP == 7)
 				((unsigned short *)(hard + tn - (1 << LDS_TOP)))[lane] = ((const unsigned short *)lh)[lane];
 			else
 				for (int q = lane; q < (1 << LDS_TOP) / 4; q += 64)
 					((uint32_t *)(hard + tn - (1 << LDS_TOP)))[q] = ((const uint32_t *)lh)[q];
-			for (int m = LDS_TOP + 1; m <= 16 && (tn & ((1 << m) - 1)) == 0; ++m) {
+			for (int m = Ln > LDS_TOP ? Ln + 1 : LDS_TOP + 1; m <= 16 && (tn & ((1 << m) - 1)) == 0; ++m) {
 				WAVE_ORDER();
 				combine_wide(hard + tn - (1 << m), 1 << (m - 1), A.get(m - 1));
 			}

@@ -46,7 +46,7 @@ struct Tables {                    // device-resident constants, built once per 
 	const uint32_t *frozen;        // [2][2048] words, bit set = frozen: frozen_64800_43072, frozen_64512_43072 (regenerated)
 	const uint16_t *info_pos;      // [2][44096] ascending unfrozen positions per table
 	const uint8_t *node_lev;       // [2][8192] per 8-leaf group: level of the largest aligned all-frozen (low nibble) /
-	                               // all-information (high nibble) node of <= 128 leaves that starts there, 0 = none
+	                               // all-information (high nibble) node that starts there (frozen: <= 128 leaves, information: <= 2048), 0 = none
 	const uint32_t *genmat_bits;   // BCH(255,71) systematic generator, [71][8] words, bit i of row j
 	const uint8_t *osd_pairs;      // [2485][2] (a,b)
 	const uint8_t *osd_triples;    // [57155][3] (a,b,c) sorted by c (equal d-loop lengths are adjacent)

@@ -162,16 +162,16 @@ void build_tables(HostTables &t, int rate)
 	t.frozen.resize(2 * 2048);
 	frozen_mask(t.frozen.data(), 64800);
 	frozen_mask(t.frozen.data() + 2048, 64512);
-	// uniform sub-trees for the list decoder: for every aligned group of 8 leaves the level (3..7) of the largest
-	// aligned node that starts there and is all frozen (low nibble) or all information (high nibble); 0 = neither
+	// uniform sub-trees for the list decoder: for every aligned group of 8 leaves the level of the largest aligned
+	// node that starts there and is all frozen (low nibble, 3..7) or all information (high nibble, 3..11); 0 = neither
 	t.node_lev.assign(2 * 8192, 0);
 	for (int tab = 0; tab < 2; ++tab)
 		for (int t8 = 0; t8 < 8192; ++t8) {
 			const int t0 = t8 * 8;
 			int lev[2] = { 0, 0 };
 			for (int kind = 0; kind < 2; ++kind)
-				for (int L = 3; L <= 7; ++L) {
-					if (t0 & ((1 << L) - 1))
+				for (int L = 3; L <= (kind == 0 ? 7 : 11); ++L) {
+					if ((t0 & ((1 << L) - 1)) || (L > 7 && t0 == 0))
 						break;
 					bool uniform = true;
 					for (int i = t0; i < t0 + (1 << L) && uniform; ++i) {
