@@ -431,9 +431,16 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 				for (int d0 = wave * U; d0 < dmax; d0 += 4 * U) {   // distances d0+1 .. d0+8; wave w takes every 4th group
 					unsigned long long kb[U];
 					bool keep[U];
+					// all sixteen phases first: one LDS round trip per step instead of eight dependent ones (the wave
+					// shares its SIMD with few others when the polar decoders are resident)
+					float yv[U];
+					#pragma unroll
+					for (int u = 0; u < U; ++u)
+						yv[u] = yp[d0 + u];
+					__builtin_amdgcn_sched_barrier(0);
 					#pragma unroll
 					for (int u = 0; u < U; ++u) {
-						const float q = (yp[d0 + u] - yi) * TS_RCP.v[d0 + u];
+						const float q = (yv[u] - yi) * TS_RCP.v[d0 + u];
 						const bool lo = q < T_lo_m, hi = q > T_hi_m;  // certainly below T_lo / above T_hi even after rounding
 						const unsigned long long mlo = __builtin_amdgcn_ballot_w64(lo);
 						const unsigned long long mhi = __builtin_amdgcn_ballot_w64(hi);
