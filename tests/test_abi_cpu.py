@@ -103,7 +103,8 @@ def test_host_tables_match_oracle_constants(lib):
 int main(){ rx::HostTables t; rx::build_tables(t, 48000);
   fwrite(t.frozen.data(),4,2048,stdout); fwrite(t.genmat_bits.data(),4,71*8,stdout);
   fwrite(t.scramble.data(),1,5380,stdout); fwrite(t.crc32_tab.data(),4,256,stdout);
-  fwrite(&t.front.reco,4,1,stdout); fwrite(t.front.imco,4,32,stdout); return 0; }
+  fwrite(&t.front.reco,4,1,stdout); fwrite(t.front.imco,4,32,stdout);
+  fwrite(t.node_lev.data(),1,8192,stdout); return 0; }
 '''
     import tempfile
     d = tempfile.mkdtemp()
@@ -125,7 +126,21 @@ int main(){ rx::HostTables t; rx::build_tables(t, 48000);
     assert (scr == z).all()
     tab = np.frombuffer(raw[8192 + 71 * 32 + 5380:8192 + 71 * 32 + 5380 + 1024], np.uint32)
     # Hilbert<cmplx, 125> taps of the 48 kHz instantiation (decode.cc:172,193)
-    hil = np.frombuffer(raw[8192 + 71 * 32 + 5380 + 1024:], np.float32)
+    hil = np.frombuffer(raw[8192 + 71 * 32 + 5380 + 1024:8192 + 71 * 32 + 5380 + 1024 + 33 * 4], np.float32)
+    # uniform-node table of the list decoder: every entry names an aligned node that really is all frozen (low
+    # nibble, <= 128 leaves) / all information (high nibble, <= 2048 leaves), and it is the largest such node
+    nl = np.frombuffer(raw[8192 + 71 * 32 + 5380 + 1024 + 33 * 4:], np.uint8)
+    assert nl.size == 8192
+    fz = ((fr[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1).astype(np.int8)
+    for t8 in range(8192):
+        t0 = 8 * t8
+        for kind, lev, cap in ((1, int(nl[t8]) & 15, 7), (0, int(nl[t8]) >> 4, 11)):
+            if lev:
+                assert 3 <= lev <= cap and t0 % (1 << lev) == 0 and (fz[t0:t0 + (1 << lev)] == kind).all()
+            nxt = max(lev, 2) + 1
+            if nxt <= cap and t0 % (1 << nxt) == 0 and not (nxt > 7 and t0 == 0):
+                assert not (fz[t0:t0 + (1 << nxt)] == kind).all()
+    assert (nl >> 4).max() == 11 and (nl & 15).max() == 7
     reco, imco = np.zeros(1, np.float32), np.zeros(32, np.float32)
     O.lib().orc_hilbert_coeffs_n(125, O.ptr(reco), O.ptr(imco))
     assert hil[0] == reco[0] and (hil[1:33] == imco).all() and imco[30] != 0 and imco[31] == 0
