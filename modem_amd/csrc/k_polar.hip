@@ -22,6 +22,7 @@
 // candidate index 2k+u); survivors are stored in rank order (same rule as the CPU oracle).
 #include "dev_common.h"
 #include "kernels.h"
+#include <cstdio>
 
 namespace rx {
 
@@ -98,34 +99,42 @@ struct Maps {
 	}
 };
 
-constexpr int UB = 8;      // iterations batched per pass so that 2*UB loads are in flight per lane
-#ifndef POLAR_LDS_TOP
-#define POLAR_LDS_TOP 7
-#endif
-constexpr int LDS_TOP = POLAR_LDS_TOP;
-#ifndef POLAR_COMPACT
-#define POLAR_COMPACT (POLAR_LDS_TOP == 7)
-#endif // tree levels 4..7 (sub-trees of <= 128 leaves) live in LDS
+// Where the tree lives (v11):
+//   levels 9..15  HBM level store, soft[level m][i][k] (fp32, the reference's own soft[N+i] layout)
+//   level  8      LDS, 8 KB per decoder: the array of the current 256-leaf node, [x][lane]
+//   levels 4..7   registers: r7[16], r6[8], r5[4], r4[2] = the arrays of the CURRENT node of each level.  Position
+//                 i = x*8 + j of a level-L array is element x of lane (j, k), and the partner of x at level L+1 is
+//                 x + 2^(L-3): every f step below level 8 is lane-local with compile-time register indices, a g step
+//                 adds one cross-lane gather per element only when the lane map is not the identity
+//   levels 0..3   registers + DPP / permlane butterflies (Block8 below)
+// Partial sums of the current 256-leaf node are one register per lane (HR: bit x = position x*8 + j, own path); their
+// combines are shifts and masks; every finished 128-leaf block is published to the global byte array (bit k = path
+// k) with 16 ballots.
 
-// Fused pass: levels m, m-1, ..., m-D+1 from level m+1 in one sweep.  A lane owns butterfly column
+// Fused pass: levels m, m-1, ..., m-D+1 (all >= 8) from level m+1 in one sweep.  A lane owns butterfly column
 // (j, k) at EVERY level (position i = x*8 + j, local index x), and the partner of local index x at
 // level L is x + 2^(L-4): the whole f-chain below the first step is lane-local, so the intermediate
 // levels are produced in registers and each level is written exactly once, never re-read.
 //   KIND 0: first step f from level m+1      KIND 1: first step g (partial sums hb, lane map gl)
 //   KIND 2: first step f from the shared channel LLRs   KIND 3: first step g from the shared channel LLRs
-// Address spaces are compile-time: the NG highest produced levels (and the source iff SRC_G) are
-// in global memory (gs = base of the codeword's soft array), the rest in LDS (ls); flat
-// addressing would serialise the two memory pipes.  Level L starts at element 8 << L in either.
+// The NG highest produced levels are in global memory (gs = base of the codeword's soft array), a lower one can only
+// be level 8, in LDS (ls8).  Level L starts at element 8 << L of the level store.
 // Global accesses are raw buffer loads / stores: one per-lane byte offset in a VGPR (lane * 4, or the mapped
-// lane for the g step), everything else (level base, column, partner distance) in the scalar offset - so 24
-// loads in flight cost 24 data registers and no 64-bit address pairs.
+// lane for the g step), everything else (level base, column, partner distance) in the scalar offset - so 16
+// loads in flight cost 16 data registers and no 64-bit address pairs.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int bytes)
 {
 	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
-__device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0); }
+#ifndef POLAR_NT
+#define POLAR_NT 0     // experiment: 1 = the streaming levels (>= 11) are loaded / stored non-temporal
+#endif
+#ifndef POLAR_WAVES_PER_SIMD
+#define POLAR_WAVES_PER_SIMD 1     // register budget hint: 5 -> <= 96 VGPRs (spills a few), default: no limit beyond 128
+#endif
+template <int AUX = 0> __device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX)); }
+template <int AUX = 0> __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX); }
 __device__ __forceinline__ int bload_u8(rsrc_t r, int voff, int soff) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0); }
 
 struct PolarBufs {
@@ -145,8 +154,8 @@ struct PolarBufs {
 // the path's ancestor at t = 2^z, the very lane map the stored array would have been read with) with the same
 // g_add, so every value is bit-identical: 2 MB fewer writes and ~1.5 MB fewer reads per codeword.
 //   SRC_R 1: C = compact level m+2      SRC_R 2: C = the channel LLRs (m = 14)
-template <int D, int KIND, int NG, bool SRC_G, bool SRC_C = false, bool DST_C = false, bool SKIP0 = false, int SRC_R = 0>
-__device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int hb_g_off, const uint8_t *hb_l, int m, int lane, int gl)
+template <int D, int KIND, int NG, bool SRC_C = false, bool DST_C = false, bool SKIP0 = false, int SRC_R = 0>
+__device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int hb_g_off, int m, int lane, int gl)
 {
 	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
 #ifndef POLAR_XB3
@@ -158,11 +167,10 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 #ifndef POLAR_XB1
 #define POLAR_XB1 8
 #endif
-	constexpr int XB = SRC_R ? 1 : (D == 3 ? POLAR_XB3 : (D == 2 ? POLAR_XB2 : POLAR_XB1));   // columns batched: XB * 2 * NT loads in flight
+	constexpr int XB = SRC_R ? (D == 3 ? 1 : (D == 2 ? 2 : 4)) : (D == 3 ? POLAR_XB3 : (D == 2 ? POLAR_XB2 : POLAR_XB1));   // columns batched: XB * 2 * NT loads in flight
 	const int S = 1 << (m - D + 1 - 3);       // local indices at the lowest produced level
 	const int half = 1 << (m - 3);            // partner distance (local) at level m+1
 	const int j = lane >> 3, k = lane & 7;
-	const float *src_l = ls + (8 << (m + 1));
 	const int src_off = (8 << (m + 1)) * 4;   // byte offset of level m+1 in the level store
 	const int vo_lane = lane * 4, vo_src = (KIND == 1 ? gl : lane) * 4, vo_j = j * 4;
 	// Addressing of the global accesses: the per-lane offset register advances with x0, the column xb inside a batch is
@@ -192,7 +200,6 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 			#pragma unroll
 			for (int s2 = 0; s2 < NT; ++s2)
 				if (x0 + xb < S) {
-					const int x = x0 + xb + s2 * S;
 					if (SRC_R) {
 						const float a1 = bload(C, v_src + xb * XS, so_a[s2]), a2 = bload(C, v_src + xb * XS, so_a[s2] + 2 * hx);
 						const float b1 = bload(C, v_src + xb * XS, so_a[s2] + hx), b2 = bload(C, v_src + xb * XS, so_a[s2] + 3 * hx);
@@ -200,16 +207,13 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 						const int hb = bload_u8(pb.hard, v_h + xb * 8, so_h[s2] - (2 << m) + half * 8);
 						a[xb][s2] = g_add(a1, a2, (ha >> anc) & 1);
 						b[xb][s2] = g_add(b1, b2, (hb >> anc) & 1);
-					} else if (KIND >= 2 || SRC_C || SRC_G) {
-						a[xb][s2] = bload(C, v_src + xb * XS, so_a[s2]);
-						b[xb][s2] = bload(C, v_src + xb * XS, so_a[s2] + hx);
 					} else {
-						const int o = KIND == 1 ? gl : lane;
-						a[xb][s2] = src_l[x * 64 + o];
-						b[xb][s2] = src_l[(x + half) * 64 + o];
+						constexpr int AUXL = (POLAR_NT && NG == 3 && KIND < 2 && !SRC_C) ? 2 : 0;
+						a[xb][s2] = bload<AUXL>(C, v_src + xb * XS, so_a[s2]);
+						b[xb][s2] = bload<AUXL>(C, v_src + xb * XS, so_a[s2] + hx);
 					}
 					if (KIND & 1)
-						h[xb][s2] = (SRC_G || KIND == 3 || SRC_R) ? bload_u8(pb.hard, v_h + xb * 8, so_h[s2]) : hb_l[x * 8 + j];
+						h[xb][s2] = bload_u8(pb.hard, v_h + xb * 8, so_h[s2]);
 				}
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
@@ -218,12 +222,11 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 				#pragma unroll
 				for (int s2 = 0; s2 < NT; ++s2) {
 					v[s2] = (KIND & 1) ? g_add(a[xb][s2], b[xb][s2], (h[xb][s2] >> k) & 1) : f_minsum(a[xb][s2], b[xb][s2]);
-					const int idx = (8 << m) + (x0 + xb + s2 * S) * 64;
 					if (SKIP0) {
 					} else if (NG > 0) {
-						if (!DST_C) bstore(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]);
+						if (!DST_C) bstore<(POLAR_NT && NG == 3) ? 2 : 0>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]);
 						else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[0][s2], v[s2]);
-					} else ls[idx + lane] = v[s2];
+					} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
 				}
 				#pragma unroll
 				for (int d = 1; d < D; ++d) {
@@ -231,11 +234,10 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls, int h
 					#pragma unroll
 					for (int s2 = 0; s2 < n; ++s2) {
 						v[s2] = f_minsum(v[s2], v[s2 + n]);
-						const int idx = (8 << (m - d)) + (x0 + xb + s2 * S) * 64;
 						if (NG > d) {
 							if (!DST_C) bstore(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]);
 							else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[d][s2], v[s2]);
-						} else ls[idx + lane] = v[s2];
+						} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
 					}
 				}
 			}
@@ -389,22 +391,35 @@ template <int LN> struct Block8 {
 // barrier would also drain every outstanding store (s_waitcnt vmcnt(0)) after each tree pass.
 #define WAVE_ORDER() __builtin_amdgcn_wave_barrier()
 
+// -DPOLAR_PROF: shader-clock cycles per phase of the decoder loop, summed over all codewords (debug builds only;
+// printed by launch_polar).  0 passes with a global source, 1 LDS passes, 2 node decisions, 3 the 8-leaf walk,
+// 4 LDS combines, 5 publish + wide combines, 6 table look-ups / loop overhead, 7 codewords
+#ifdef POLAR_PROF
+__device__ unsigned long long g_polar_prof[8];
+#define PROF_DECL() unsigned long long pc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tl_ = __builtin_readcyclecounter()
+#define PROF(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pc_[i] += n_ - tl_; tl_ = n_; } while (0)
+#define PROF_FLUSH() do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 7; ++q_) atomicAdd(&g_polar_prof[q_], pc_[q_]); atomicAdd(&g_polar_prof[7], 1ull); } } while (0)
+#else
+#define PROF_DECL() do { } while (0)
+#define PROF(i) do { } while (0)
+#define PROF_FLUSH() do { } while (0)
+#endif
+
 template <int LN>
-__global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
+__global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
 	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev2,
 	float *__restrict__ metric_all)
 {
 	const int lane = threadIdx.x, j = lane >> 3, k = lane & 7;
+	__shared__ float ls8[32 * 64];                            // level 8 of the current 256-leaf node: [x][lane]
 	for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
 	if (!st_all[cw].okay)
 		continue;                                             // no header -> nothing to decode (decode.cc:450-451)
 	const uint32_t *frozen = frozen2 + (st_all[cw].oper_mode >= 10 ? 2048 : 0);   // decode.cc:312,344
 	const uint8_t *node_lev = node_lev2 + (st_all[cw].oper_mode >= 10 ? 8192 : 0);
 	const float *llr = llr_all + (size_t)cw * CODE_LEN;
-	float *soft = soft_all + (size_t)blockIdx.x * (8 * CODE_LEN);   // level m >= 8 at soft + 8*2^m
+	float *soft = soft_all + (size_t)blockIdx.x * (8 * CODE_LEN);   // level m >= 9 at soft + 8*2^m
 	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;
-	__shared__ float ls[8 << (LDS_TOP + 1)];                  // level m <= 7 at ls + 8*2^m
-	__shared__ __attribute__((aligned(8))) uint8_t lh[1 << LDS_TOP];   // partial sums of the current 128-leaf sub-tree
 	PolarBufs pb;
 	pb.soft = make_rsrc(soft, 8 * CODE_LEN * 4);
 	pb.llr = make_rsrc(llr, CODE_LEN * 4);
@@ -413,279 +428,388 @@ __global__ __launch_bounds__(64) void k_polar(int n_cw, const SyncState *__restr
 	Maps A;
 	A.w0 = ID0 * (uint32_t)k;
 	A.w1 = ID1 * (uint32_t)k;
-	float r3 = 0.f;
+	PROF_DECL();
 
-	for (int t8 = 0, adv = 1; t8 < CODE_LEN / 8; t8 += adv) {
-		const int t = t8 * 8;
-		// Uniform node that starts here (static, from the frozen pattern): level 4..7 = 16..128 leaves all frozen
-		// (nl0) or all information (nl1); such a node is decided in one step on its own LLR array (below), the
-		// 8-leaf case (level 3) in registers further down.  Ln = level of the node decided this way, 0 = none.
-		const int nl = node_lev[t8], nl0 = nl & 15, nl1 = nl >> 4, Lt = nl0 > nl1 ? nl0 : nl1;
+	// rate-1 test of a uniform node (the predicate of Block8::list_is_stable): mu = this lane's smallest |LLR| of the node
+	auto stable = [&](uint32_t mu) -> bool {
+		mu = min(mu, (uint32_t)xor8_i((int)mu));
+		mu = min(mu, (uint32_t)xor16_i((int)mu, lane));
+		mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
+		const float P = M + __uint_as_float(mu);
+		const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
+		const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
+		return __ballot(!ok) == 0;
+	};
+	// A uniform node of 16..128 leaves decided in one step on its register array r (CNT = 2^(level-3) elements per
+	// lane, blocks b .. b+CNT-1 of the current 256-leaf node).  Returns false if it has to be walked after all.
+	//   all frozen      -> the sum of max(0, -llr) in the butterfly halving order the oracle fixes (positions i, i + n/2:
+	//                      lane-local while the distance is >= 8 positions, then j^4, j^2, j^1), added to the metric once
+	//   all information -> if the list provably stays stable: partial sums = sign bits
+	auto try_node = [&](const auto &r, bool frozen_node, uint32_t &HR, int b) -> bool {
+		constexpr int CNT = (int)(sizeof(r) / sizeof(float));
+		const uint32_t nmask = ((1u << CNT) - 1u) << b;
+		if (frozen_node) {
+			float pz[CNT];
+			#pragma unroll
+			for (int x = 0; x < CNT; ++x)
+				pz[x] = r[x] < 0.f ? -r[x] : 0.f;
+			#pragma unroll
+			for (int hx = CNT / 2; hx >= 1; hx >>= 1)
+				#pragma unroll
+				for (int x = 0; x < hx; ++x)
+					pz[x] = pz[x] + pz[x + hx];
+			float pen = pz[0];
+			pen = pen + xj<2>(pen, lane);
+			pen = pen + xj<1>(pen, lane);
+			pen = pen + xj<0>(pen, lane);
+			M += pen;
+			HR &= ~nmask;
+			return true;
+		}
+		uint32_t mu = 0x7f800000u;
+		#pragma unroll
+		for (int x = 0; x < CNT; ++x)
+			mu = min(mu, __float_as_uint(r[x]) & 0x7fffffffu);
+		if (!stable(mu))
+			return false;
+		uint32_t bits = 0;
+		#pragma unroll
+		for (int x = 0; x < CNT; ++x)
+			bits |= (r[x] < 0.f ? 1u : 0u) << x;
+		HR = (HR & ~nmask) | (bits << b);
+		return true;
+	};
+	// partial-sum combine of a node of >= 512 leaves on the global byte array: one dword (4 positions) per lane
+	auto combine_wide = [&](uint8_t *hp, int hh, int rm) {
+		int rmk[8];
+		#pragma unroll
+		for (int kk = 0; kk < 8; ++kk)
+			rmk[kk] = __builtin_amdgcn_readlane(rm, kk);   // lanes 0..7 hold paths 0..7
+		const bool ident = __ballot(rm != k) == 0;
+		uint32_t *pl = (uint32_t *)hp, *pr = (uint32_t *)(hp + hh);
+		for (int i0 = 0; i0 < hh / 4; i0 += 64 * 4) {
+			uint32_t xl[4], xr[4];
+			#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				if (i0 + u * 64 + lane < hh / 4) {
+					xl[u] = pl[i0 + u * 64 + lane];
+					xr[u] = pr[i0 + u * 64 + lane];
+				}
+			#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				if (i0 + u * 64 + lane < hh / 4) {
+					uint32_t y = xl[u];
+					if (!ident) {                         // out bit k of every byte = in bit rm[k]
+						y = 0;
+						#pragma unroll
+						for (int kk = 0; kk < 8; ++kk)
+							y |= ((xl[u] >> rmk[kk]) & 0x01010101u) << kk;
+					}
+					pl[i0 + u * 64 + lane] = y ^ xr[u];
+				}
+		}
+	};
+
+	for (int t256 = 0, adv256 = 1; t256 < CODE_LEN / 256; t256 += adv256) {
+		const int t = t256 * 256;
+		adv256 = 1;
+		// all-information node of 256..2048 leaves that starts here (static, from the frozen pattern): decided on its own
+		// array - level 8 in LDS, levels 9..11 in the level store - before anything below it is computed
+		// this node's 32 table bytes and 8 frozen words, one per lane, fetched while the level passes run; the block loop
+		// reads them with v_readlane (no memory round trip per block)
+		const int nlv = node_lev[t256 * 32 + (lane & 31)];
+		const uint32_t fzv = frozen[t256 * 8 + (lane & 7)];
+		const int LtT = t ? __builtin_amdgcn_readfirstlane(nlv) >> 4 : 0;
 		int Ln = 0;
-		adv = 1;
-		// ---------------- LLRs of this 8-leaf sub-tree into r3
+		PROF(6);
+		// ---------------- level 8 of this 256-leaf node into LDS, through the level store
 		{
 			int cur, kind;                                    // next level to produce and how its first step works
-			int ho_g = 0;
-			const uint8_t *ho_l = lh;
-			int gl = lane;
+			int ho_g = 0, gl = lane;
 			if (t == 0) {
 				cur = 15; kind = 2;
 			} else {
 				const int z = __builtin_ctz(t);               // right child of the level-(z+1) node starts here
 				gl = (j << 3) | A.get(z + 1);
-				ho_g = t - (1 << z);                          // left child's partial sums: global for sub-trees >= 128 leaves,
-				ho_l = lh + ((t - (1 << z)) & ((1 << LDS_TOP) - 1));   // else inside the current LDS block
+				ho_g = t - (1 << z);                          // left child's partial sums (published bytes)
 				cur = z; kind = z == 15 ? 3 : 1;
 			}
-			if (cur == 3) {
-				float a = ls[(8 << 4) + gl], b = ls[(8 << 4) + gl + 64];
-				r3 = g_add(a, b, (ho_l[j] >> k) & 1);
-			} else {
-				bool try_node = Lt >= 4, redo;
-				int stop = try_node ? Lt : 4;
-				do {
+			bool try_big = LtT >= 9, redo;
+			int stop = try_big ? LtT : 8;
+			do {
 				while (cur >= stop) {
-					#define FP(DD, KK, NGG, SG) fused_pass<DD, KK, NGG, SG>(pb, ls, ho_g, ho_l, cur, lane, gl)
-					#define FPC(DD, KK, NGG, SC, DC) fused_pass<DD, KK, NGG, true, SC, DC>(pb, ls, ho_g, ho_l, cur, lane, gl)
-					#define FPK(DD, NGG, SG) do { if (kind == 0) FP(DD, 0, NGG, SG); else FP(DD, 1, NGG, SG); } while (0)
-					int D = 3;
-					// NG = produced levels that are above LDS_TOP (global); SRC_G = the source level cur+1 is global
-					static_assert(LDS_TOP == 7 || !POLAR_COMPACT, "the compact first descent is written for LDS_TOP = 7");
-					if (POLAR_COMPACT && t == 0 && cur >= LDS_TOP + 2) {          // first left descent: compact stores
-						if (cur == 15) FPC(3, 2, 3, false, true);
-						else if (cur >= LDS_TOP + 3) FPC(3, 0, 3, true, true);
-						else FPC(3, 0, 2, true, true);
-					} else if (POLAR_COMPACT && kind == 1 && (t & (t - 1)) == 0 && cur >= LDS_TOP && cur <= 14 && cur == Lt) {
-						// ... unless this very level is a node decided on its own array (below): then it is stored
-						if (cur >= LDS_TOP + 3) FPC(3, 1, 3, true, false);
-						else if (cur == LDS_TOP + 2) FPC(3, 1, 2, true, false);
-						else if (cur == LDS_TOP + 1) FPC(3, 1, 1, true, false);
-						else FPC(3, 1, 0, true, false);
-					} else if (POLAR_COMPACT && kind == 1 && (t & (t - 1)) == 0 && cur >= LDS_TOP && cur <= 14) {
+					// produced levels stay >= 8: three per pass down to 10, then (9, 8) and (8); NG = how many are above level 8
+					const int D = cur >= 10 ? 3 : (cur == 9 ? 2 : 1);
+					const bool spine = kind == 1 && (t & (t - 1)) == 0 && cur <= 14;
+					#define FP(...) fused_pass<__VA_ARGS__>(pb, ls8, ho_g, cur, lane, gl)
+					if (t == 0) {                                     // first left descent: compact stores
+						if (cur == 15) FP(3, 2, 3, false, true);      // levels 15, 14, 13
+						else if (cur == 12) FP(3, 0, 3, true, true);  // 12, 11, 10
+						else FP(2, 0, 1, true, true);                 // 9 and 8 (LDS)
+					} else if (spine && cur == LtT) {
+						// right sibling on the left spine that is a node decided on its own array (below): stored
+						if (cur >= 11) FP(3, 1, 3, true);
+						else if (cur == 10) FP(3, 1, 2, true);
+						else FP(2, 1, 1, true);
+					} else if (spine) {
 						// right sibling on the left spine: its source was stored compact at t = 0; its own top level
-						// (if >= 8) is not stored, the one later reader recomputes it (SRC_R below)
-						if (cur >= LDS_TOP + 3) fused_pass<3, 1, 3, true, true, false, true>(pb, ls, ho_g, ho_l, cur, lane, gl);
-						else if (cur == LDS_TOP + 2) fused_pass<3, 1, 2, true, true, false, true>(pb, ls, ho_g, ho_l, cur, lane, gl);
-						else if (cur == LDS_TOP + 1) fused_pass<3, 1, 1, true, true, false, true>(pb, ls, ho_g, ho_l, cur, lane, gl);
-						else FPC(3, 1, 0, true, false);
-					} else if (POLAR_COMPACT && kind == 1 && (t >> cur) == 3 && cur >= LDS_TOP && cur <= 14) {
+						// (if >= 9) is not stored, the one later reader recomputes it (SRC_R below)
+						if (cur >= 11) FP(3, 1, 3, true, false, true);
+						else if (cur == 10) FP(3, 1, 2, true, false, true);
+						else if (cur == 9) FP(2, 1, 1, true, false, true);
+						else FP(1, 1, 0, true);
+					} else if (kind == 1 && (t >> cur) == 3 && cur <= 14) {
 						// t = 3 * 2^cur: right child of the right sibling on the left spine
-						#define FPR(NGG, RR) fused_pass<3, 1, NGG, true, false, false, false, RR>(pb, ls, ho_g, ho_l, cur, lane, gl)
-						if (cur == 14) FPR(3, 2);
-						else if (cur >= LDS_TOP + 3) FPR(3, 1);
-						else if (cur == LDS_TOP + 2) FPR(2, 1);
-						else if (cur == LDS_TOP + 1) FPR(1, 1);
-						else FPR(0, 1);
-						#undef FPR
+						if (cur == 14) FP(3, 1, 3, false, false, false, 2);
+						else if (cur >= 11) FP(3, 1, 3, false, false, false, 1);
+						else if (cur == 10) FP(3, 1, 2, false, false, false, 1);
+						else if (cur == 9) FP(2, 1, 1, false, false, false, 1);
+						else FP(1, 1, 0, false, false, false, 1);
+					} else if (cur == 15) {
+						FP(3, 3, 3, false, false, true);              // t = 32768: g of the channel LLRs, level 15 itself is recomputed by its reader
+					} else if (kind == 0) {
+						if (cur >= 11) FP(3, 0, 3);
+						else if (cur == 10) FP(3, 0, 2);
+						else if (cur == 9) FP(2, 0, 1);
+						else FP(1, 0, 0);
+					} else {
+						if (cur >= 11) FP(3, 1, 3);
+						else if (cur == 10) FP(3, 1, 2);
+						else if (cur == 9) FP(2, 1, 1);
+						else FP(1, 1, 0);
 					}
-					else if (cur == 15) { if (kind == 2) FP(3, 2, 3, true); else if (POLAR_COMPACT) fused_pass<3, 3, 3, true, false, false, true>(pb, ls, ho_g, ho_l, cur, lane, gl); else FP(3, 3, 3, true); }
-					else if (cur >= LDS_TOP + 3) FPK(3, 3, true);
-					else if (cur == LDS_TOP + 2) FPK(3, 2, true);
-					else if (cur == LDS_TOP + 1) FPK(3, 1, true);
-					else if (cur == LDS_TOP) FPK(3, 0, true);
-					else if (cur >= 6) FPK(3, 0, false);
-					else if (cur == 5) { FPK(2, 0, false); D = 2; }
-					else { FPK(1, 0, false); D = 1; }
-					#undef FPC
-					#undef FPK
 					#undef FP
 					WAVE_ORDER();
 					cur -= D;
 					kind = 0;
+					PROF(0);
 				}
 				redo = false;
-				if (try_node) {
-					// level Lt (in LDS) now holds the node's LLRs: cnt = 2^(Lt-3) values per lane, position x*8 + j
-					try_node = false;
-					const int cnt = 1 << (Lt - 3);
-					const float *lv = ls + (8 << Lt) + lane;
-					uint8_t *lhn = lh + (t & ((1 << LDS_TOP) - 1));
-					if (Lt > LDS_TOP) {
-						// rate-1 node of 256..2048 leaves: the same decision on its array in the level store (cnt = 32..256
-						// values per lane); the sign bytes go straight to the partial-sum array.  None of the levels
-						// below it is ever computed.
-						const int base = (8 << Lt) * 4;
-						uint32_t mu = 0x7f800000u;
+				if (try_big) {
+					// rate-1 node of 512..2048 leaves on its array in the level store (cnt = 64..256 values per lane); the sign
+					// bytes go straight to the partial-sum array.  None of the levels below it is ever needed.
+					try_big = false;
+					const int cnt = 1 << (LtT - 3), base = (8 << LtT) * 4;
+					uint32_t mu = 0x7f800000u;
+					for (int x0 = 0; x0 < cnt; x0 += 16) {
+						float v[16];
+						#pragma unroll
+						for (int u = 0; u < 16; ++u)
+							v[u] = bload(pb.soft, lane * 4, base + (x0 + u) * 256);
+						#pragma unroll
+						for (int u = 0; u < 16; ++u)
+							mu = min(mu, __float_as_uint(v[u]) & 0x7fffffffu);
+					}
+					if (stable(mu)) {
 						for (int x0 = 0; x0 < cnt; x0 += 16) {
 							float v[16];
 							#pragma unroll
 							for (int u = 0; u < 16; ++u)
 								v[u] = bload(pb.soft, lane * 4, base + (x0 + u) * 256);
+							unsigned long long mine = 0;
 							#pragma unroll
-							for (int u = 0; u < 16; ++u)
-								mu = min(mu, __float_as_uint(v[u]) & 0x7fffffffu);
-						}
-						mu = min(mu, (uint32_t)xor8_i((int)mu));
-						mu = min(mu, (uint32_t)xor16_i((int)mu, lane));
-						mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
-						const float P = M + __uint_as_float(mu);
-						const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
-						const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
-						if (__ballot(!ok) == 0) {
-							for (int x0 = 0; x0 < cnt; x0 += 16) {
-								float v[16];
-								#pragma unroll
-								for (int u = 0; u < 16; ++u)
-									v[u] = bload(pb.soft, lane * 4, base + (x0 + u) * 256);
-								unsigned long long mine = 0;
-								#pragma unroll
-								for (int u = 0; u < 16; ++u) {
-									const unsigned long long bal = __ballot(v[u] < 0.f);
-									if (lane == u)
-										mine = bal;
-								}
-								if (lane < 16)                        // 16 positions x 8 bytes: one 128-byte store
-									*(unsigned long long *)(hard + t + (x0 + lane) * 8) = mine;
+							for (int u = 0; u < 16; ++u) {
+								const unsigned long long bal = __ballot(v[u] < 0.f);
+								if (lane == u)
+									mine = bal;
 							}
-							Ln = Lt;
-						} else {
-							stop = 4;
-							redo = cur >= 4;
+							if (lane < 16)                        // 16 positions x 8 bytes: one 128-byte store
+								*(unsigned long long *)(hard + t + (x0 + lane) * 8) = mine;
 						}
-					} else if (nl0) {
-						// rate-0 node: sum of max(0, -llr) in the butterfly halving order the oracle fixes
-						// (positions i, i + n/2: lane-local while the distance is >= 8, then j^4, j^2, j^1)
-						float pz[16];
-						#pragma unroll
-						for (int x = 0; x < 16; ++x) {
-							const float v = x < cnt ? lv[x * 64] : 0.f;
-							pz[x] = v < 0.f ? -v : 0.f;
-						}
-						#pragma unroll
-						for (int hx = 8; hx >= 1; hx >>= 1)
-							#pragma unroll
-							for (int x = 0; x < hx; ++x)
-								pz[x] = pz[x] + pz[x + hx];           // + 0 beyond cnt: exact
-						float pen = pz[0];
-						pen = pen + xj<2>(pen, lane);
-						pen = pen + xj<1>(pen, lane);
-						pen = pen + xj<0>(pen, lane);
-						M += pen;
-						if (lane < cnt)
-							*(unsigned long long *)(lhn + lane * 8) = 0ull;
-						Ln = Lt;
+						Ln = LtT;
 					} else {
-						// rate-1 node: same argument as for 8 leaves, mu_k = the smallest magnitude of the whole node
-						uint32_t mu = 0x7f800000u;
+						stop = 8;
+						redo = cur >= 8;
+					}
+					PROF(2);
+				}
+			} while (redo);
+		}
+		if (!Ln && LtT == 8) {
+			// rate-1 node of 256 leaves on the LDS array (32 values per lane)
+			uint32_t mu = 0x7f800000u;
+			#pragma unroll
+			for (int x = 0; x < 32; ++x)
+				mu = min(mu, __float_as_uint(ls8[x * 64 + lane]) & 0x7fffffffu);
+			if (stable(mu)) {
+				#pragma unroll
+				for (int x0 = 0; x0 < 32; x0 += 16) {
+					unsigned long long mine = 0;
+					#pragma unroll
+					for (int u = 0; u < 16; ++u) {
+						const unsigned long long bal = __ballot(ls8[(x0 + u) * 64 + lane] < 0.f);
+						if (lane == u)
+							mine = bal;
+					}
+					if (lane < 16)
+						*(unsigned long long *)(hard + t + (x0 + lane) * 8) = mine;
+				}
+				Ln = 8;
+			}
+			PROF(2);
+		}
+		if (Ln) {
+			A.reset_upto(t ? __builtin_ctz(t) : 16, k);
+			adv256 = 1 << (Ln - 8);
+		} else {
+			// ---------------- the 32 8-leaf blocks of this node; levels 7..4 in registers
+			float r7[16], r6[8], r5[4], r4[2];
+			uint32_t HR = 0;                                  // partial sums, own path: bit x = position x*8 + j of the node
+			for (int b = 0, adv = 1; b < 32; b += adv) {
+				const int t8 = t256 * 32 + b, tt = t8 * 8;
+				adv = 1;
+				const int zb = b ? __builtin_ctz(b) + 3 : 8;      // level of the largest node inside this one that starts here
+				// Uniform node that starts here: level 4..7 = 16..128 leaves all frozen (nl0) or all information (nl1),
+				// decided in one step on its register array; the 8-leaf case (level 3) is Block8's.
+				const int nl = __builtin_amdgcn_readlane(nlv, b), nl0 = nl & 15, nl1 = nl >> 4;
+				int Lt = nl0 > nl1 ? nl0 : nl1;
+				if (Lt > 7)
+					Lt = 0;                                       // b == 0: tried above
+				int L2 = 0;
+				// the one g step of this block is at level zb (right child of the level-(zb+1) node): lane map since that node
+				// started, partial sums of its left child = the 2^(zb-3) HR bits before b
+				const int glb = zb < 8 ? ((j << 3) | A.get(zb + 1)) : lane;
+				const bool mapped = __ballot(glb != lane) != 0;
+				const uint32_t hb = zb < 8 ? HR >> (b - (1 << (zb - 3))) : 0u;
+				PROF(6);
+				if (zb >= 7) {
+					if (zb == 7) {
 						#pragma unroll
 						for (int x = 0; x < 16; ++x)
-							if (x < cnt)
-								mu = min(mu, __float_as_uint(lv[x * 64]) & 0x7fffffffu);
-						mu = min(mu, (uint32_t)xor8_i((int)mu));
-						mu = min(mu, (uint32_t)xor16_i((int)mu, lane));
-						mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
-						const float P = M + __uint_as_float(mu);
-						const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
-						const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
-						if (__ballot(!ok) == 0) {
-							for (int x = 0; x < cnt; ++x) {           // partial sums = sign bits, one byte per position
-								const unsigned long long bal = __ballot(lv[x * 64] < 0.f);
-								if (lane == 0)
-									*(unsigned long long *)(lhn + x * 8) = bal;
-							}
-							Ln = Lt;
-						} else {
-							stop = 4;                                 // walk it after all: the 8-leaf groups get their own chance
-							redo = cur >= 4;
-						}
+							r7[x] = g_add(ls8[x * 64 + glb], ls8[(x + 16) * 64 + glb], (hb >> x) & 1);
+					} else {
+						#pragma unroll
+						for (int x = 0; x < 16; ++x)
+							r7[x] = f_minsum(ls8[x * 64 + lane], ls8[(x + 16) * 64 + lane]);
 					}
+					if (Lt == 7 && try_node(r7, nl0 == 7, HR, b))
+						L2 = 7;
 				}
-				} while (redo);
-				if (Ln) {
-					A.reset_upto(t ? __builtin_ctz(t) : 16, k);
-					adv = 1 << (Ln - 3);
-				} else
-					r3 = f_minsum(ls[(8 << 4) + lane], ls[(8 << 4) + lane + 64]);
-			}
-		}
-		if (!Ln) {
-		const uint32_t fz = (frozen[t >> 5] >> (t & 31)) & 0xffu;
-		// ---------------- the 8 leaves, all in registers: a top-down walk of the 8-leaf sub-tree (Block8 above) that
-		// decides every uniform node it meets (8, 4 or 2 leaves all frozen / all information) in one step
-		int H = 0;
-		{
-			Block8<LN> blk{ M, A, H, { 0.f, 0.f, 0.f, r3 }, fz, t, lane, j, k };
-			blk.template node<3, 0>();
-		}
-		// ---------------- partial sums of the sub-tree: bytes (bit k = path k) via ballot
-		{
-			const unsigned long long bal = __ballot((H >> j) & 1);
-			if (lane == 0)
-				*(unsigned long long *)(lh + (t & ((1 << LDS_TOP) - 1))) = bal;
-		}
-		}   // !Ln
-		auto combine = [&](int off, int hh, int rm) {        // LDS block: lh[i] = perm(lh[i], rm) ^ lh[i + hh]
-			uint8_t *hp = lh + off;
-			for (int it0 = 0; it0 < hh / 8; it0 += UB) {
-				int xl[UB], xr[UB];
-				#pragma unroll
-				for (int u = 0; u < UB; ++u)
-					if (it0 + u < hh / 8) {
-						xl[u] = hp[(it0 + u) * 8 + j];
-						xr[u] = hp[hh + (it0 + u) * 8 + j];
-					}
-				#pragma unroll
-				for (int u = 0; u < UB; ++u)
-					if (it0 + u < hh / 8) {
-						const int bit = ((xl[u] >> rm) ^ (xr[u] >> k)) & 1;
-						const unsigned long long bal = __ballot(bit != 0);
-						if (lane == 0)
-							*(unsigned long long *)(hp + (it0 + u) * 8) = bal;
-					}
-			}
-		};
-		// same for sub-trees of >= 256 leaves (hh >= 128): one dword (4 positions) per lane, 256 B per sweep
-		auto combine_wide = [&](uint8_t *hp, int hh, int rm) {
-			int rmk[8];
-			#pragma unroll
-			for (int kk = 0; kk < 8; ++kk)
-				rmk[kk] = __builtin_amdgcn_readlane(rm, kk);   // lanes 0..7 hold paths 0..7
-			const bool ident = __ballot(rm != k) == 0;
-			uint32_t *pl = (uint32_t *)hp, *pr = (uint32_t *)(hp + hh);
-			for (int i0 = 0; i0 < hh / 4; i0 += 64 * 4) {
-				uint32_t xl[4], xr[4];
-				#pragma unroll
-				for (int u = 0; u < 4; ++u)
-					if (i0 + u * 64 + lane < hh / 4) {
-						xl[u] = pl[i0 + u * 64 + lane];
-						xr[u] = pr[i0 + u * 64 + lane];
-					}
-				#pragma unroll
-				for (int u = 0; u < 4; ++u)
-					if (i0 + u * 64 + lane < hh / 4) {
-						uint32_t y = xl[u];
-						if (!ident) {                         // out bit k of every byte = in bit rm[k]
-							y = 0;
+				if (zb >= 6 && !L2) {
+					if (zb == 6) {
+						float p[16];
+						#pragma unroll
+						for (int x = 0; x < 16; ++x)
+							p[x] = r7[x];
+						if (mapped) {
 							#pragma unroll
-							for (int kk = 0; kk < 8; ++kk)
-								y |= ((xl[u] >> rmk[kk]) & 0x01010101u) << kk;
+							for (int x = 0; x < 16; ++x)
+								p[x] = __shfl(p[x], glb);
 						}
-						pl[i0 + u * 64 + lane] = y ^ xr[u];
+						#pragma unroll
+						for (int x = 0; x < 8; ++x)
+							r6[x] = g_add(p[x], p[x + 8], (hb >> x) & 1);
+					} else {
+						#pragma unroll
+						for (int x = 0; x < 8; ++x)
+							r6[x] = f_minsum(r7[x], r7[x + 8]);
 					}
+					if (Lt == 6 && try_node(r6, nl0 == 6, HR, b))
+						L2 = 6;
+				}
+				if (zb >= 5 && !L2) {
+					if (zb == 5) {
+						float p[8];
+						#pragma unroll
+						for (int x = 0; x < 8; ++x)
+							p[x] = r6[x];
+						if (mapped) {
+							#pragma unroll
+							for (int x = 0; x < 8; ++x)
+								p[x] = __shfl(p[x], glb);
+						}
+						#pragma unroll
+						for (int x = 0; x < 4; ++x)
+							r5[x] = g_add(p[x], p[x + 4], (hb >> x) & 1);
+					} else {
+						#pragma unroll
+						for (int x = 0; x < 4; ++x)
+							r5[x] = f_minsum(r6[x], r6[x + 4]);
+					}
+					if (Lt == 5 && try_node(r5, nl0 == 5, HR, b))
+						L2 = 5;
+				}
+				if (zb >= 4 && !L2) {
+					if (zb == 4) {
+						float p[4];
+						#pragma unroll
+						for (int x = 0; x < 4; ++x)
+							p[x] = r5[x];
+						if (mapped) {
+							#pragma unroll
+							for (int x = 0; x < 4; ++x)
+								p[x] = __shfl(p[x], glb);
+						}
+						r4[0] = g_add(p[0], p[2], hb & 1);
+						r4[1] = g_add(p[1], p[3], (hb >> 1) & 1);
+					} else {
+						r4[0] = f_minsum(r5[0], r5[2]);
+						r4[1] = f_minsum(r5[1], r5[3]);
+					}
+					if (Lt == 4 && try_node(r4, nl0 == 4, HR, b))
+						L2 = 4;
+				}
+				PROF(1);
+				if (L2) {
+					A.reset_upto(tt ? __builtin_ctz(tt) : 16, k);
+					adv = 1 << (L2 - 3);
+				} else {
+					float r3;
+					if (zb == 3) {
+						float p0 = r4[0], p1 = r4[1];
+						if (mapped) {
+							p0 = __shfl(p0, glb);
+							p1 = __shfl(p1, glb);
+						}
+						r3 = g_add(p0, p1, hb & 1);
+					} else
+						r3 = f_minsum(r4[0], r4[1]);
+					const uint32_t fz = ((uint32_t)__builtin_amdgcn_readlane((int)fzv, b >> 2) >> ((b & 3) * 8)) & 0xffu;
+					// the 8 leaves, all in registers: a top-down walk of the 8-leaf sub-tree (Block8 above) that decides every
+					// uniform node it meets (8, 4 or 2 leaves all frozen / all information) in one step
+					int H = 0;
+					{
+						Block8<LN> blk{ M, A, H, { 0.f, 0.f, 0.f, r3 }, fz, tt, lane, j, k };
+						blk.template node<3, 0>();
+					}
+					HR = (HR & ~(1u << b)) | ((uint32_t)((H >> j) & 1) << b);   // this lane's own position, own path
+					PROF(3);
+				}
+				// partial-sum combines of the nodes of 16..256 leaves that end here: hard[i] = perm(hard[i]) ^ hard[i + half]
+				const int bn = b + adv;
+				for (int m = L2 ? L2 + 1 : 4; m <= 8 && (bn & ((1 << (m - 3)) - 1)) == 0; ++m) {
+					const int half = 1 << (m - 4), b0 = bn - 2 * half;
+					const int rm = A.get(m - 1);
+					uint32_t Lp = HR;
+					if (__ballot(rm != k))
+						Lp = (uint32_t)__shfl((int)HR, (j << 3) | rm);
+					const uint32_t lmask = ((1u << half) - 1u) << b0;
+					HR = (HR & ~lmask) | ((Lp ^ (HR >> half)) & lmask);
+				}
+				PROF(4);
 			}
-		};
-		const int tn = t + 8 * adv;
-		for (int m = Ln ? Ln + 1 : 4; m <= LDS_TOP && (tn & ((1 << m) - 1)) == 0; ++m) {
-			WAVE_ORDER();
-			combine((tn - (1 << m)) & ((1 << LDS_TOP) - 1), 1 << (m - 1), A.get(m - 1));
+			// publish the node's 256 partial-sum bytes (bit k = path k): 32 ballots, lanes 0..31 store 8 bytes each
+			{
+				unsigned long long mine = 0;
+				#pragma unroll
+				for (int u = 0; u < 32; ++u) {
+					const unsigned long long bal = __ballot((HR >> u) & 1);
+					if (lane == u)
+						mine = bal;
+				}
+				if (lane < 32)
+					*(unsigned long long *)(hard + t + lane * 8) = mine;
+			}
 		}
-		if ((tn & ((1 << LDS_TOP) - 1)) == 0) {               // a 128-leaf sub-tree is complete: publish its bytes
+		const int tn = t + 256 * adv256;
+		for (int m = Ln ? Ln + 1 : 9; m <= 16 && (tn & ((1 << m) - 1)) == 0; ++m) {
 			WAVE_ORDER();
-			if (Ln > LDS_TOP) {
-				// a node of >= 256 leaves wrote its bytes itself
-			} else if (LDS_TOP == 7)
-				((unsigned short *)(hard + tn - (1 << LDS_TOP)))[lane] = ((const unsigned short *)lh)[lane];
-			else
-				for (int q = lane; q < (1 << LDS_TOP) / 4; q += 64)
-					((uint32_t *)(hard + tn - (1 << LDS_TOP)))[q] = ((const uint32_t *)lh)[q];
-			for (int m = Ln > LDS_TOP ? Ln + 1 : LDS_TOP + 1; m <= 16 && (tn & ((1 << m) - 1)) == 0; ++m) {
-				WAVE_ORDER();
-				combine_wide(hard + tn - (1 << m), 1 << (m - 1), A.get(m - 1));
-			}
+			combine_wide(hard + tn - (1 << m), 1 << (m - 1), A.get(m - 1));
 		}
 		WAVE_ORDER();
+		PROF(5);
 	}
+	PROF_FLUSH();
 	if (j == 0)
 		metric_all[(size_t)cw * LIST + k] = M;
 	WAVE_ORDER();
@@ -696,10 +820,24 @@ void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st,
 {
 	if (grid <= 0 || grid > n)
 		grid = n;
+#ifdef POLAR_PROF
+	unsigned long long z8[8] = { 0 };
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_polar_prof), z8, sizeof(z8));
+#endif
 	if (list == 4)
 		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric);
 	else
 		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric);
+#ifdef POLAR_PROF
+	(void)hipStreamSynchronize(s);
+	(void)hipMemcpyFromSymbol(z8, HIP_SYMBOL(g_polar_prof), sizeof(z8));
+	static const char *nm[7] = { "hbm_pass", "lds_pass", "node", "leaf8", "combine", "publish", "lookup" };
+	double tot = 0;
+	for (int q = 0; q < 7; ++q) tot += (double)z8[q];
+	fprintf(stderr, "POLAR_PROF grid %d cw %llu: cycles/cw %.0f |", grid, z8[7], tot / (double)(z8[7] ? z8[7] : 1));
+	for (int q = 0; q < 7; ++q) fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * (double)z8[q] / tot);
+	fprintf(stderr, "\n");
+#endif
 }
 
 }  // namespace rx

@@ -76,11 +76,61 @@ static inline orc_cf phasor(float omega, long k)
 	return r;
 }
 
+/* DSP::Phasor (phasor.hh ABSENT): osc() returns the current unit phasor and advances it by omega.  Default: closed
+ * form e^{j omega n} with the phase in double.  ORC_NUM_PHASOR_RECURSIVE: the recursive NCO in fp32,
+ * prev *= delta; prev /= |prev| after every call. */
+typedef struct { float omega; long n; orc_cf prev, delta; int recursive; } osc_t;
+static void osc_init(osc_t *o, float omega)
+{
+	o->omega = omega;
+	o->n = 0;
+	o->prev.re = 1.f; o->prev.im = 0.f;
+	o->delta.re = cosf(omega); o->delta.im = sinf(omega);
+	o->recursive = (orc_get_numerics() & ORC_NUM_PHASOR_RECURSIVE) != 0;
+}
+static inline orc_cf osc_next(osc_t *o)
+{
+	if (!o->recursive)
+		return phasor(o->omega, o->n++);
+	orc_cf tmp = o->prev;
+	orc_cf p = cmul(o->prev, o->delta);
+	float a = sqrtf(cnorm(p));
+	o->prev.re = p.re / a;
+	o->prev.im = p.im / a;
+	return tmp;
+}
+static inline void osc_skip(osc_t *o, int count)
+{
+	if (!o->recursive) { o->n += count; return; }
+	for (int i = 0; i < count; ++i)
+		(void)osc_next(o);
+}
+
+/* DSP::SMA4 (sma.hh / swa.hh ABSENT) in its plain fp32 form: a ring of NUM leaves under a binary add tree stored
+ * heap-style in tree[1 .. 2 NUM), parent = left + right; the window sum is tree[1] (ORC_NUM_SMA_TREE) */
+typedef struct { float *tree; int num, leaf; } swa_t;
+static void swa_init(swa_t *w, int num)
+{
+	w->tree = (float *)calloc((size_t)2 * num, sizeof(float));
+	w->num = num;
+	w->leaf = num;
+}
+static inline float swa_push(swa_t *w, float v)
+{
+	w->tree[w->leaf] = v;
+	for (int child = w->leaf, parent = child / 2; parent; child = parent, parent /= 2)
+		w->tree[parent] = w->tree[child & ~1] + w->tree[child | 1];
+	if (++w->leaf >= 2 * w->num)
+		w->leaf = w->num;
+	return w->tree[1];
+}
+
 /* ---- SchmidlCox ---------------------------------------------------------- */
 typedef struct {
 	orc_cf kern[HS_MAX]; /* decode.cc:80-82 */
 	double *Sc_re, *Sc_im, *Sp, *Sm;   /* prefix sums, index shifted by 1 */
 	float *timing;
+	float *argP;         /* ORC_NUM_SMA_TREE: arg(P) for every t (the tree form is streamed once), else NULL */
 	size_t n;
 	const orc_cf *z;
 } sc_t;
@@ -114,6 +164,26 @@ static void sc_prepare(sc_t *s, const orc_cf *z, size_t n)
 	s->Sp = s->Sc_im + (n + 1);
 	s->Sm = s->Sp + (n + 1);
 	s->timing = (float *)malloc(sizeof(float) * (n + 1));
+	s->argP = NULL;
+	if (orc_get_numerics() & ORC_NUM_SMA_TREE) {
+		/* decode.cc:86-91 sample by sample: cor / pwr / match are fp32 tree sums over rings of HS, 2 HS, MATCH_LEN inputs */
+		swa_t cre, cim, pw, mt;
+		swa_init(&cre, HS); swa_init(&cim, HS); swa_init(&pw, 2 * HS); swa_init(&mt, MATCH_LEN);
+		s->argP = (float *)malloc(sizeof(float) * (n + 1));
+		for (size_t t = 0; t < n; ++t) {
+			long u = (long)t - (BUFFER_LEN - 1) + SEARCH_POS + HS;   /* samples[search_pos+symbol_len] */
+			orc_cf a = zat(z, n, u), b = zat(z, n, u + HS);
+			orc_cf c = cmul(a, cconj(b));
+			float Pre = swa_push(&cre, c.re), Pim = swa_push(&cim, c.im);
+			float R = 0.5f * swa_push(&pw, cnorm(b));
+			float min_R = 0.0001f * HS;
+			R = fmaxf(R, min_R);
+			s->timing[t] = swa_push(&mt, (Pre * Pre + Pim * Pim) / (R * R));
+			s->argP[t] = atan2f(Pim, Pre);
+		}
+		free(cre.tree); free(cim.tree); free(pw.tree); free(mt.tree);
+		return;
+	}
 	s->Sc_re[0] = s->Sc_im[0] = s->Sp[0] = s->Sm[0] = 0.0;
 	for (size_t u = 0; u < n; ++u) {
 		double ar = z[u].re, ai = z[u].im, br = 0.0, bi = 0.0;
@@ -143,6 +213,8 @@ static float sc_phase(const sc_t *s, long t)
 	size_t n = s->n;
 	if (t < 0)
 		return 0.f;
+	if (s->argP)
+		return s->argP[t];
 	long hc = t - (BUFFER_LEN - 1 - (SEARCH_POS + HS)) + 1;
 	float Pre = (float)(PFX(s->Sc_re, hc) - PFX(s->Sc_re, hc - HS));
 	float Pim = (float)(PFX(s->Sc_im, hc) - PFX(s->Sc_im, hc - HS));
@@ -152,6 +224,7 @@ static void sc_free(sc_t *s)
 {
 	free(s->Sc_re);
 	free(s->timing);
+	free(s->argP);
 }
 
 /* decode.cc:110-151: the work done on the falling edge at time t.
@@ -163,8 +236,10 @@ static int sc_process(const sc_t *s, long t, int index_max, float phase_max,
 	float frac_cfo = phase_max / (float)HS;                 /* decode.cc:110 */
 	int symbol_pos = SEARCH_POS - index_max;            /* decode.cc:114 */
 	long base = t - (BUFFER_LEN - 1);
+	osc_t osc;                                              /* decode.cc:112-113 */
+	osc_init(&osc, frac_cfo);
 	for (int i = 0; i < HS; ++i)                            /* decode.cc:117-118 */
-		tmp1[i] = cmul(zat(s->z, s->n, base + i + symbol_pos + HS), phasor(frac_cfo, i));
+		tmp1[i] = cmul(zat(s->z, s->n, base + i + symbol_pos + HS), osc_next(&osc));
 	orc_fft(tmp0, tmp1, HS, -1);
 	for (int i = 0; i < HS; ++i)                            /* decode.cc:120-121 */
 		tmp1[i] = demod_or_erase(tmp0[i], tmp0[binh(i - 1)]);
@@ -282,7 +357,9 @@ int orc_decode_cf_rate(int rate, const orc_cf *z, size_t n, int skip_count, int 
 	memset(&md, 0, sizeof(md));
 	int okay, symbol_pos = 0;
 	float cfo_rad = 0.f;
-	long t_hit = 0, osc_n = 0;   /* osc_n: number of osc() calls so far (phase continuity) */
+	long t_hit = 0;
+	osc_t osc;                   /* decode.cc:403: keeps its phase from the header symbol through the payload symbols */
+	osc_init(&osc, 0.f);
 	orc_cf fdom[SL], tdom[SL];
 	do {                                                   /* decode.cc:390-448 */
 		okay = 0;
@@ -300,9 +377,9 @@ int orc_decode_cf_rate(int rate, const orc_cf *z, size_t n, int skip_count, int 
 		/* the Phasor keeps its phase across omega() changes; only continuity
 		 * within one frame matters (differential demodulation), so the phase
 		 * origin is restarted at each header attempt */
-		osc_n = 0;
+		osc_init(&osc, -cfo_rad);
 		for (int i = 0; i < SL; ++i)                       /* decode.cc:403-405 */
-			tdom[i] = cmul(zat(z, n, base + i + symbol_pos + (SL + GL)), phasor(-cfo_rad, osc_n++));
+			tdom[i] = cmul(zat(z, n, base + i + symbol_pos + (SL + GL)), osc_next(&osc));
 		orc_fft(fdom, tdom, SL, -1);
 		orc_mls seq1;
 		orc_mls_init(&seq1, ORC_MLS1_POLY);
@@ -364,14 +441,14 @@ int orc_decode_cf_rate(int rate, const orc_cf *z, size_t n, int skip_count, int 
 	/* decode.cc:456-462: pilot symbol body sits at sc_start + 2*1440 */
 	long body = rr.sc_start + 2 * (SL + GL);
 	for (int i = 0; i < SL; ++i)
-		tdom[i] = cmul(zat(z, n, body + i), phasor(-cfo_rad, osc_n++));
-	osc_n += GL;
+		tdom[i] = cmul(zat(z, n, body + i), osc_next(&osc));
+	osc_skip(&osc, GL);
 	orc_fft(fdom, tdom, SL, -1);
 	for (int j = 0; j < cons_rows; ++j) {                  /* decode.cc:464-477 */
 		body += SL + GL;
 		for (int i = 0; i < SL; ++i)
-			tdom[i] = cmul(zat(z, n, body + i), phasor(-cfo_rad, osc_n++));
-		osc_n += GL;
+			tdom[i] = cmul(zat(z, n, body + i), osc_next(&osc));
+		osc_skip(&osc, GL);
 		for (int i = 0; i < cons_cols; ++i)
 			prev[i] = fdom[bin(i + code_off)];
 		orc_fft(fdom, tdom, SL, -1);
@@ -414,6 +491,7 @@ int orc_decode_cf_rate(int rate, const orc_cf *z, size_t n, int skip_count, int 
 		memcpy(taps->cons_rot, cons, sizeof(orc_cf) * (size_t)md.cons_cnt);
 	{                                                      /* decode.cc:505-523 */
 		float sp = 0.f, np = 0.f;
+		const int snr_fp32 = (orc_get_numerics() & ORC_NUM_SNR_FP32) != 0;
 		for (int j = 0; j < cons_rows; ++j) {
 			double dsp = 0.0, dnp = 0.0;
 			for (int i = 0; i < cons_cols; ++i) {
@@ -421,12 +499,20 @@ int orc_decode_cf_rate(int rate, const orc_cf *z, size_t n, int skip_count, int 
 				orc_cf c = cons[cons_cols * j + i], h;
 				if (mod_bits == 3) { orc_psk8_hard(tmp, c); h = orc_psk8_map(tmp); }
 				else { orc_psk4_hard(tmp, c); h = orc_psk4_map(tmp); }
+				if (snr_fp32) {                            /* decode.cc:512-515 as written */
+					orc_cf e = { c.re - h.re, c.im - h.im };
+					sp += cnorm(h);
+					np += cnorm(e);
+					continue;
+				}
 				double er = (double)c.re - h.re, ei = (double)c.im - h.im;
 				dsp += (double)h.re * h.re + (double)h.im * h.im;
 				dnp += er * er + ei * ei;
 			}
-			sp = (float)((double)sp + dsp);
-			np = (float)((double)np + dnp);
+			if (!snr_fp32) {
+				sp = (float)((double)sp + dsp);
+				np = (float)((double)np + dnp);
+			}
 			float precision = sp / np;
 			if (taps && taps->precision) taps->precision[j] = precision;
 			rr.esn0_db_last = 10.f * log10f(precision);    /* DSP::decibel */

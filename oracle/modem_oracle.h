@@ -239,6 +239,25 @@ int orc_decode_rate(int rate, const void *samples, int fmt, int channels, size_t
 int orc_decode_cf_rate(int rate, const orc_cf *z, size_t n, int skip_count, int list_size,
 	int descramble, uint8_t *payload, orc_result *res, orc_taps *taps);
 
+/* ---- numerics the reference leaves open (-Ofast, absent headers): switches to the PLAIN forms ----------------
+ * The default restatement fixes a few fp32 evaluation orders so that the GPU kernels can reproduce them bit for
+ * bit.  Each flag below switches one of them back to the plain form a scalar build of the
+ * reference would most likely use; tests/test_oracle_numerics.py shows that payload, status, sync position and
+ * header fields do not depend on any of them (the winning lane index may, with ORC_NUM_SURVIVORS_UNSORTED).
+ * Process-wide, not thread-safe against concurrent decodes: set it before a batch. */
+enum {
+	ORC_NUM_RATE0_LEAFWALK = 1,      /* all-frozen nodes are walked leaf by leaf: each frozen leaf adds max(0,-llr) to the
+	                                  * metric when it is reached (default: nodes of 2..128 leaves charged once, butterfly order) */
+	ORC_NUM_SURVIVORS_UNSORTED = 2,  /* the L survivors of a fork stay in candidate order 2k+u (what a partition such as
+	                                  * std::nth_element may leave) instead of rank order */
+	ORC_NUM_SMA_TREE = 4,            /* sliding sums of decode.cc:86-90 as a fp32 ring of leaves under a binary add tree
+	                                  * (default: differences of double prefix sums) */
+	ORC_NUM_PHASOR_RECURSIVE = 8,    /* NCO as prev *= delta; prev /= |prev| in fp32 (default: closed form, phase in double) */
+	ORC_NUM_SNR_FP32 = 16            /* sp/np of decode.cc:507-517 accumulated term by term in fp32 (default: per-row double) */
+};
+void orc_set_numerics(unsigned flags);
+unsigned orc_get_numerics(void);
+
 /* batch helper for the cpu_baseline: n frames at fixed stride, OpenMP over
  * frames when built with -fopenmp. Returns threads used. */
 int orc_decode_batch(const void *samples, int fmt, int channels, size_t frames_per,

@@ -120,7 +120,10 @@ void orc_polar_sysenc(int8_t *code, const int8_t *mesg, const uint32_t *frozen, 
  * sorted order, so the result is deterministic.  Initial metrics: lane 0 = 0,
  * others = 1000, so the list fills from one path.
  */
-enum { ORC_RATE0_MIN = 1, ORC_RATE0_MAX = 7 };   /* rate-0 nodes of 2..128 leaves are charged in one step */
+enum { ORC_RATE0_MIN = 1, ORC_RATE0_MAX = 7 };
+static unsigned g_numerics;      /* ORC_NUM_* flags, see modem_oracle.h */
+void orc_set_numerics(unsigned flags) { g_numerics = flags; }
+unsigned orc_get_numerics(void) { return g_numerics; }   /* rate-0 nodes of 2..128 leaves are charged in one step */
 
 typedef struct {
 	int L, count;
@@ -171,6 +174,17 @@ static void scl_leaf(scl_t *s, int index, uint8_t *map)
 		}
 		perm[j] = c;
 	}
+	if (g_numerics & ORC_NUM_SURVIVORS_UNSORTED) {
+		/* same survivor SET (the L best by (metric, index)), left in candidate order */
+		for (int a = 1; a < L; ++a) {
+			int v = perm[a], j = a;
+			while (j > 0 && perm[j - 1] > v) {
+				perm[j] = perm[j - 1];
+				--j;
+			}
+			perm[j] = v;
+		}
+	}
 	for (int k = 0; k < L; ++k) {
 		s->metric[k] = fork[perm[k]];
 		map[k] = (uint8_t)(perm[k] >> 1);
@@ -199,7 +213,7 @@ static void scl_node(scl_t *s, int m, int index, uint8_t *map)
 		scl_leaf(s, index, map);
 		return;
 	}
-	if (m >= ORC_RATE0_MIN && m <= ORC_RATE0_MAX && all_frozen(s->frozen, index, m)) {
+	if (m >= ORC_RATE0_MIN && m <= ORC_RATE0_MAX && !(g_numerics & ORC_NUM_RATE0_LEAFWALK) && all_frozen(s->frozen, index, m)) {
 		/* Rate-0 node (2..128 leaves; the recursion is top-down, so this is the largest such node) in one step.  With min-sum, the frozen-leaf penalties of a sub-tree add up
 		 * to sum_i max(0, -llr_i) over the node's OWN input LLRs (f keeps the smaller magnitude with the
 		 * product sign, g with u = 0 is a + b: case by case max(0,-f(a,b)) + max(0,-(a+b)) =
