@@ -37,6 +37,7 @@ extern "C" {
 #define OFDMRX_CODE_LEN 65536         /* decode.cc:309  code_order 16 */
 #define OFDMRX_FRAME_SAMPLES 95200    /* one-frame file written by encode @ 8 kHz */
 #define OFDMRX_MAX_LIST 8
+#define OFDMRX_MAX_SKIP 64            /* largest SKIP count per frame (decode.cc:583-585,448); beyond it: OFDMRX_E_ARG */
 
 /* sample formats of the PCM body (what DSP::ReadWAV accepts, decode.cc:576) */
 enum { OFDMRX_FMT_S16 = 0, OFDMRX_FMT_U8 = 1, OFDMRX_FMT_F32 = 2 };
@@ -87,7 +88,10 @@ typedef struct {
 	int32_t oper_mode;         /* decode.cc:438 */
 	uint64_t call_sign;        /* decode.cc:439-446, base-37 integer */
 	int32_t best_lane;         /* decode.cc:532-541, -1 if no lane passed CRC-32 */
-	int32_t bit_flips;         /* decode.cc:555 */
+	int32_t bit_flips;         /* decode.cc:555: sign(LLR) != decoded bit over the payload positions.  LLRs are fp32 values
+	                            * within the 1e-5 intermediate tolerance of a scalar build's; one that sits that close to
+	                            * zero may carry either sign, so this diagnostic can differ by a count or two (observed:
+	                            * +-2 in 0.3 % of the frames near the waterfall, never above it) */
 	float esn0_db_last;        /* decode.cc:517-519, cumulative Es/N0 after the last row */
 	int32_t n_sync_rejects;    /* falling edges rejected at decode.cc:140-145 */
 } ofdmrx_frame_result;
@@ -116,7 +120,8 @@ void ofdmrx_destroy(ofdmrx_handle *h);
  * Decode n_frames independent frames.  Frame f occupies
  * samples + f*frame_stride_bytes, samples_per_frame sample frames of
  * `channels` interleaved values (1 = real, 2 = analytic I/Q; decode.cc:578,298).
- * skip_counts[f] (nullable) is decode.cc's SKIP argument (decode.cc:583-585,448).
+ * skip_counts[f] (nullable) is decode.cc's SKIP argument (decode.cc:583-585,448): 0..OFDMRX_MAX_SKIP preambles to
+ * pass over; a negative or larger count is OFDMRX_E_ARG (the reference would loop to the end of the stream).
  * payload_out: n_frames*5380 bytes, zeroed for failed frames (the reference
  * leaves them uninitialised, decode.cc:588).
  * HOST pointers; blocks until done.
@@ -126,7 +131,9 @@ int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int sample_format
 	const int32_t *skip_counts, uint8_t *payload_out, ofdmrx_frame_result *results);
 
 /* same with DEVICE pointers (inputs already resident in HBM); asynchronous on
- * the handle's stream.  d_payload_out / d_results are device buffers. */
+ * the handle's stream.  d_payload_out / d_results are device buffers.  d_skip_counts (nullable) is read back once on
+ * the handle's stream before anything is enqueued (the counts steer the host loop), so it is ordered after earlier
+ * work on that stream; that read-back is the call's only host synchronisation. */
 int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int sample_format, int channels,
 	size_t samples_per_frame, size_t frame_stride_bytes, size_t n_frames,
 	const int32_t *d_skip_counts, uint8_t *d_payload_out, ofdmrx_frame_result *d_results);
@@ -181,6 +188,7 @@ typedef struct {
 	int32_t delays[8];         /* samples */
 	float gains_re[8], gains_im[8];
 } ofdmrx_channel;
+/* delays must lie in [0, samples_per_frame); d_in and d_out must not overlap (else OFDMRX_E_ARG) */
 int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_t *d_out, size_t n_frames,
 	size_t samples_per_frame, const ofdmrx_channel *ch);
 
@@ -199,6 +207,10 @@ long ofdmrx_tx_frame_samples(int oper_mode);
  * _device: n_streams x count x 5380 payload bytes in, n_streams x samples x channels PCM out, DEVICE pointers.
  * ofdmrx_tx_encode_stream: the same for ONE stream with HOST pointers (what the `encode` CLI calls). */
 long ofdmrx_stream_samples(int sample_rate, int oper_mode, int count);
+/* call sign -> the base-37 integer of the header (encode.cc:320-335: ' ' = 0, digits 1..10, letters of either case
+ * 11..36), -1 if the string holds any other character.  Valid call signs are 0 < value < 129961739795077
+ * (encode.cc:358, decode.cc:439). */
+long long ofdmrx_callsign_value(const char *call_sign);
 int ofdmrx_tx_encode_stream_device(ofdmrx_handle *h, const uint8_t *d_payload, size_t n_streams, int count,
 	int oper_mode, int freq_off, const char *call_sign, int channels, int bits, void *d_pcm);
 int ofdmrx_tx_encode_stream(ofdmrx_handle *h, const uint8_t *payload, int count, int oper_mode, int freq_off,

@@ -139,8 +139,28 @@ int main(int argc, char **argv)
 			cs[i] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ"[v % 37];
 		cs[9] = 0;
 		std::fprintf(stderr, "oper mode: %d\ncall sign: %s\n", res.oper_mode, cs);
+		// rows of the mode (decode.cc:302-374, 453): cons_bits / mod_bits / cols
+		static const int cols[14] = { 0, 0, 0, 0, 0, 0, 432, 400, 400, 360, 512, 384, 384, 256 };
+		static const int bits[14] = { 0, 0, 0, 0, 0, 0, 3, 3, 2, 2, 3, 3, 2, 2 };
+		const int rows = ((res.oper_mode >= 10 ? 64512 : 64800) / bits[res.oper_mode]) / cols[res.oper_mode];
+		std::fprintf(stderr, "demod ");                     // decode.cc:463,476-478: one dot per payload symbol
+		for (int j = 0; j < rows; ++j)
+			std::fprintf(stderr, ".");
+		std::fprintf(stderr, " done\n");
+		// decode.cc:500,502: sfo_rad -= avg_slope * symbol_len / (symbol_len + guard_len).  The reference never initialises
+		// sfo_rad; this prints the value for a start from zero
+		const float sfo_rad = -res.sfo_slope * 8.f / 9.f;
+		std::fprintf(stderr, "coarse sfo: %g ppm\n", 1000000.f * sfo_rad / 6.28318530717958647692f);
 		std::fprintf(stderr, "finer cfo: %g Hz \n", res.cfo_fine * hz);
-		std::fprintf(stderr, "Es/N0 (dB): %g\n", res.esn0_db_last);
+		// decode.cc:506-523: the cumulative Es/N0 after every row = 10 log10 of the precision the soft demapper used
+		std::vector<float> prec((size_t)rows, 0.f);
+		std::fprintf(stderr, "Es/N0 (dB):");
+		if (ofdmrx_debug_dump(h, OFDMRX_TAP_PRECISION, 0, prec.data(), prec.size() * sizeof(float)) == 0)
+			for (int j = 0; j < rows; ++j)
+				std::fprintf(stderr, " %g", 10.f * std::log10(prec[j]));
+		else
+			std::fprintf(stderr, " %g", res.esn0_db_last);
+		std::fprintf(stderr, "\n");
 	}
 	if (res.status >= OFDMRX_OSD_ERROR && res.status <= OFDMRX_PAYLOAD_CRC)
 		std::fprintf(stderr, "%s\n", msg[res.status]);

@@ -9,19 +9,6 @@
 #include <cstring>
 #include <vector>
 
-static long long base37_encoder(const char *str)   // encode.cc:320-335
-{
-	long long acc = 0;
-	for (char c = *str++; c; c = *str++) {
-		acc *= 37;
-		if (c >= '0' && c <= '9') acc += c - '0' + 1;
-		else if (c >= 'a' && c <= 'z') acc += c - 'a' + 11;
-		else if (c >= 'A' && c <= 'Z') acc += c - 'A' + 11;
-		else if (c != ' ') return -1;
-	}
-	return acc;
-}
-
 static void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 static void put16(uint8_t *p, uint16_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
 
@@ -40,7 +27,7 @@ int main(int argc, char **argv)
 		std::fprintf(stderr, "Unsupported operation mode.\n");
 		return 1;
 	}
-	const long long call_sign = base37_encoder(argv[7]);
+	const long long call_sign = ofdmrx_callsign_value(argv[7]);   // encode.cc:357
 	if (call_sign <= 0 || call_sign >= 129961739795077LL) {
 		std::fprintf(stderr, "Unsupported call sign.\n");
 		return 1;

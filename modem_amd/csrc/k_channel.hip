@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_channel(const short2 *__restrict__ in, 
 			float re = 0.f, im = 0.f;
 			for (int t = 0; t < cp.ntaps; ++t) {
 				long idx = m - cp.delays[t];
-				if (idx < 0)
+				if (idx < 0 || (size_t)idx >= spf)
 					continue;
 				short2 v = src[idx];
 				float xr = (float)v.x / 32767.f, xi = (float)v.y / 32767.f;

@@ -128,10 +128,12 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int bytes)
 	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
 #ifndef POLAR_NT
-#define POLAR_NT 0     // experiment: 1 = the streaming levels (>= 11) are loaded / stored non-temporal
+#define POLAR_NT 1     // 1 = the top level of every three-level pass (levels >= 11, written once and read once ~ms later) is stored
+                       // and loaded non-temporal: -5 % kernel time (r02 sweep: 0 off, 2 everything, 3 stores only, 4 loads only)
 #endif
 #ifndef POLAR_WAVES_PER_SIMD
-#define POLAR_WAVES_PER_SIMD 1     // register budget hint: 5 -> <= 96 VGPRs (spills a few), default: no limit beyond 128
+#define POLAR_WAVES_PER_SIMD 5     // register budget: 5 waves per SIMD = 96 VGPRs (13 dwords of scratch) so that Theil-Sen workgroups of the next
+                                   // chunk fit beside 12 resident decoders per CU; 1 = unconstrained (125 VGPRs): 2 % faster alone, 12 % slower overlapped
 #endif
 template <int AUX = 0> __device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX)); }
 template <int AUX = 0> __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX); }
@@ -208,7 +210,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 						a[xb][s2] = g_add(a1, a2, (ha >> anc) & 1);
 						b[xb][s2] = g_add(b1, b2, (hb >> anc) & 1);
 					} else {
-						constexpr int AUXL = (POLAR_NT && NG == 3 && KIND < 2 && !SRC_C) ? 2 : 0;
+						constexpr int AUXL = (((POLAR_NT == 1 || POLAR_NT == 4) && NG == 3) || POLAR_NT == 2) && KIND < 2 && !SRC_C ? 2 : 0;
 						a[xb][s2] = bload<AUXL>(C, v_src + xb * XS, so_a[s2]);
 						b[xb][s2] = bload<AUXL>(C, v_src + xb * XS, so_a[s2] + hx);
 					}
@@ -224,7 +226,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 					v[s2] = (KIND & 1) ? g_add(a[xb][s2], b[xb][s2], (h[xb][s2] >> k) & 1) : f_minsum(a[xb][s2], b[xb][s2]);
 					if (SKIP0) {
 					} else if (NG > 0) {
-						if (!DST_C) bstore<(POLAR_NT && NG == 3) ? 2 : 0>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]);
+						if (!DST_C) bstore<(((POLAR_NT == 1 || POLAR_NT == 3) && NG == 3) || POLAR_NT == 2) ? 2 : 0>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]);
 						else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[0][s2], v[s2]);
 					} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
 				}
@@ -235,7 +237,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 					for (int s2 = 0; s2 < n; ++s2) {
 						v[s2] = f_minsum(v[s2], v[s2 + n]);
 						if (NG > d) {
-							if (!DST_C) bstore(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]);
+							if (!DST_C) bstore<POLAR_NT == 2 ? 2 : 0>(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]);
 							else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[d][s2], v[s2]);
 						} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
 					}

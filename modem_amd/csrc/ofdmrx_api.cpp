@@ -7,7 +7,9 @@
 #include "kernels.h"
 #include "tables.h"
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +56,57 @@ struct DevBuf {
 	template <typename T> T *as() const { return (T *)p; }
 };
 
+// ---- optional roctx ranges around the stage launches (OFDMRX_ROCTX=1): markers for rocprofv3 --marker-trace.
+// The library is looked up at run time, so libofdmrx.so keeps its single dependency (libamdhip64).
+struct Roctx {
+	int (*push)(const char *) = nullptr;
+	int (*pop)() = nullptr;
+	Roctx()
+	{
+		if (!std::getenv("OFDMRX_ROCTX"))
+			return;
+		for (const char *name : { "librocprofiler-sdk-roctx.so", "libroctx64.so" }) {
+			if (void *lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+				push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+				pop = (int (*)())dlsym(lib, "roctxRangePop");
+				if (push && pop)
+					return;
+			}
+		}
+		push = nullptr;
+		pop = nullptr;
+	}
+};
+struct Range {                     // RAII: one named range per stage of a chunk
+	static Roctx &api() { static Roctx r; return r; }
+	explicit Range(const char *name) { if (api().push) api().push(name); }
+	~Range() { if (api().pop) api().pop(); }
+};
+
+// call sign -> base-37 integer (the encoding of encode.cc:320-335: ' ' = 0, '0'..'9' = 1..10, letters of either case
+// = 11..36); -1 for any other character
+long long callsign_value(const char *str)
+{
+	static const std::array<int8_t, 256> digit = [] {
+		std::array<int8_t, 256> t{};
+		t.fill(-1);
+		t[(unsigned char)' '] = 0;
+		for (int i = 0; i < 10; ++i)
+			t[(unsigned char)('0' + i)] = (int8_t)(1 + i);
+		for (int i = 0; i < 26; ++i)
+			t[(unsigned char)('A' + i)] = t[(unsigned char)('a' + i)] = (int8_t)(11 + i);
+		return t;
+	}();
+	long long acc = 0;
+	for (; *str; ++str) {
+		const int d = digit[(unsigned char)*str];
+		if (d < 0)
+			return -1;
+		acc = acc * 37 + d;
+	}
+	return acc;
+}
+
 }  // namespace
 
 struct ofdmrx_handle {
@@ -72,7 +125,10 @@ struct ofdmrx_handle {
 	long cap_samples = 0;     // samples per frame the mono buffers are sized for
 	DevBuf st, hdr_soft, cons, slope, yint, precision, llr, soft, hard, metric, lane_mesg, res, payload;
 	DevBuf st2, llr2;         // second parity of the two buffers that cross from the front stages to the polar stage
+	DevBuf payload2, res2;    // second parity of the device-side output staging (host-pointer entry)
 	hipStream_t stream_b = nullptr;   // polar + finish of chunk c run here while the front stages of chunk c+1 run on `stream`
+	hipStream_t stream_c = nullptr;   // host-pointer entry: host-to-device copies of the next chunk
+	hipError_t sticky = hipSuccess;   // first failed hipEventRecord of the running call
 	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
 	int last_par = 0;         // parity used by the last chunk (taps)
 	SyncState *st_of(int par) { return (par ? st2 : st).as<SyncState>(); }
@@ -162,9 +218,15 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 			ofdmrx_destroy(h);
 			return OFDMRX_E_HIP;
 		}
+		e = hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+			ofdmrx_destroy(h);
+			return OFDMRX_E_HIP;
+		}
 		int cus = 0;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
-		int wpc = 13;             // polar waves per CU while the next chunk's Theil-Sen stage shares the machine
+		int wpc = 12;             // polar waves per CU while the next chunk's Theil-Sen stage shares the machine
 		if (const char *e2 = std::getenv("OFDMRX_POLAR_WPC"))
 			wpc = std::atoi(e2);
 		h->polar_grid = wpc > 0 && cus > 0 ? wpc * cus : 0;
@@ -201,12 +263,13 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 	(void)hipSetDevice(h->cfg.device);
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
-	if (h->stream_b) {
-		(void)hipStreamSynchronize(h->stream_b);
-		(void)hipStreamDestroy(h->stream_b);
-	}
+	for (hipStream_t sx : { h->stream_b, h->stream_c })
+		if (sx) {
+			(void)hipStreamSynchronize(sx);
+			(void)hipStreamDestroy(sx);
+		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2 })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -264,25 +327,36 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 	return r;
 }
 
-static size_t mark(ofdmrx_handle *h, hipStream_t on = nullptr)
+// Events come from a pool that is sized BEFORE a call enqueues anything (ensure_events), so recording one can never
+// allocate and an index is always valid; a failed hipEventRecord is remembered and fails the call at its end.
+static int ensure_events(ofdmrx_handle *h, size_t need)
 {
-	if (h->ev_used == h->ev_pool.size()) {
+	while (h->ev_pool.size() < need) {
 		hipEvent_t e;
-		if (hipEventCreate(&e) != hipSuccess)
-			return (size_t)-1;
+		HIP_OK(hipEventCreate(&e));
 		h->ev_pool.push_back(e);
 	}
+	return 0;
+}
+static size_t mark(ofdmrx_handle *h, hipStream_t on = nullptr)
+{
+	if (h->ev_used >= h->ev_pool.size()) {                // cannot happen: the pool was sized for the whole call
+		h->sticky = hipErrorOutOfMemory;
+		return 0;
+	}
 	size_t i = h->ev_used++;
-	(void)hipEventRecord(h->ev_pool[i], on ? on : h->stream);
+	hipError_t e = hipEventRecord(h->ev_pool[i], on ? on : h->stream);
+	if (e != hipSuccess && h->sticky == hipSuccess)
+		h->sticky = e;
 	return i;
 }
+static size_t events_per_chunk(int max_skip) { return 20 + 3 * (size_t)(max_skip + 1); }
 
 // One resident chunk = every stage of SURVEY 8(a) D1..D10 as kernels, in two halves:
 //   front (D1..D8: front end, sync/header rounds, demod, Theil-Sen, LLRs) -> st[par], llr[par]
 //   back  (D9, D10: polar list decoder, systematic bits / CRC / pack)     <- st[par], llr[par]
 // A one-chunk call runs both on the handle's stream.  A longer batch is pipelined: back(c) runs on the
-// second stream with a limited resident polar grid while front(c+1) runs on the handle's stream - the polar
-// stage is bound by memory latency and HBM traffic, the front stages by VALU and LDS, so they share CUs well.
+// second stream while front(c+1) runs on the handle's stream.
 static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
 	size_t *t_begin)
 {
@@ -290,22 +364,33 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, i
 	SyncState *st = h->st_of(par);
 	const cf *z = mono ? h->z.as<cf>() : nullptr;
 	size_t e0 = mark(h, s);
-	if (mono)
+	if (mono) {
+		Range r("ofdmrx:front_end");
 		launch_front_end(s, h->rate, n, fb, h->host.front, nullptr, h->z.as<cf>());
+	}
 	size_t e1 = mark(h, s);
 	launch_init_sync(s, n, st, d_skip);
 	size_t e3 = e1;
 	for (int round = 0; round <= max_skip; ++round) {      // decode.cc:390-448 do { } while (skip_count--)
 		size_t a = mark(h, s);
-		launch_sync(s, h->rate, n, fb, z, h->dev, st, h->sc_scratch.as<cf>());
+		{
+			Range r("ofdmrx:sync");
+			launch_sync(s, h->rate, n, fb, z, h->dev, st, h->sc_scratch.as<cf>());
+		}
 		size_t b = mark(h, s);
-		launch_header(s, h->rate, n, fb, z, h->dev, st, h->hdr_soft.as<int8_t>());
+		{
+			Range r("ofdmrx:header_osd");
+			launch_header(s, h->rate, n, fb, z, h->dev, st, h->hdr_soft.as<int8_t>());
+		}
 		size_t c = mark(h, s);
 		h->spans.push_back({ OFDMRX_T_SYNC, a, b });
 		h->spans.push_back({ OFDMRX_T_HEADER, b, c });
 		e3 = c;
 	}
-	launch_demod(s, h->rate, n, fb, z, h->dev, st, h->cons.as<cf>(), h->carr.as<cf>());
+	{
+		Range r("ofdmrx:demod");
+		launch_demod(s, h->rate, n, fb, z, h->dev, st, h->cons.as<cf>(), h->carr.as<cf>());
+	}
 	if ((h->cfg.flags & 1) && !demod_writes_carriers(h->rate))
 		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
 	size_t e4 = mark(h, s);
@@ -325,11 +410,17 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d
 	SyncState *st = h->st_of(par);
 	size_t e4 = mark(h, s);
 	const bool from_carr = demod_writes_carriers(h->rate);
-	launch_theil_sen(s, n, st, h->cons.as<cf>(), from_carr ? h->carr.as<cf>() : nullptr,
-		(from_carr && (h->cfg.flags & 1)) ? h->cons_raw.as<cf>() : nullptr, h->slope.as<float>(), h->yint.as<float>());
+	{
+		Range r("ofdmrx:theil_sen");
+		launch_theil_sen(s, n, st, h->cons.as<cf>(), from_carr ? h->carr.as<cf>() : nullptr,
+			(from_carr && (h->cfg.flags & 1)) ? h->cons_raw.as<cf>() : nullptr, h->slope.as<float>(), h->yint.as<float>());
+	}
 	size_t e5 = mark(h, s);
-	launch_llr(s, h->rate, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
-		h->llr_of(par), d_res);
+	{
+		Range r("ofdmrx:llr");
+		launch_llr(s, h->rate, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
+			h->llr_of(par), d_res);
+	}
 	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_THEILSEN, e4, e5 });
 	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
@@ -342,29 +433,22 @@ static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, int grid, u
 {
 	SyncState *st = h->st_of(par);
 	size_t e6 = mark(h, s);
-	launch_polar(s, h->list, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	{
+		Range r("ofdmrx:polar_scl");
+		launch_polar(s, h->list, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	}
 	size_t e7 = mark(h, s);
-	launch_finish(s, h->list, n, st, h->llr_of(par), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
-		want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res);
+	{
+		Range r("ofdmrx:finish");
+		launch_finish(s, h->list, n, st, h->llr_of(par), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
+			want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res);
+	}
 	size_t e8 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
 	h->spans.push_back({ OFDMRX_T_FINISH, e7, e8 });
 	h->spans.push_back({ OFDMRX_T_TOTAL, t_begin, e8 });
 	HIP_OK(hipGetLastError());
 	return 0;
-}
-
-static int run_chunk(ofdmrx_handle *h, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
-	uint8_t *d_payload, Result *d_res, bool want_lane_mesg)
-{
-	int r = ensure_capacity(h, n, fb.channels == 1, fb.samples_per_frame);
-	if (r)
-		return r;
-	size_t t0 = 0;
-	r = run_front1(h, h->stream, 0, fb, n, d_skip, max_skip, &t0);
-	r = r ? r : run_front2(h, h->stream, 0, n, d_res);
-	static const bool force_grid = std::getenv("OFDMRX_POLAR_FORCE_GRID") != nullptr;   // experiments: limited grid without overlap
-	return r ? r : run_back(h, h->stream, 0, n, force_grid ? h->polar_grid : 0, d_payload, d_res, want_lane_mesg, t0);
 }
 
 static int check_args(ofdmrx_handle *h, const void *samples, int fmt, int channels, size_t spf, size_t stride,
@@ -382,6 +466,143 @@ static int check_args(ofdmrx_handle *h, const void *samples, int fmt, int channe
 	return 0;
 }
 
+// decode.cc:583-585,448: SKIP = number of preambles to pass over.  0..OFDMRX_MAX_SKIP per frame; anything else is an
+// argument error (the reference would loop until the stream ends).  Returns the largest count or a negative error.
+static int max_skip_of(const int32_t *skip, size_t n)
+{
+	int m = 0;
+	for (size_t i = 0; i < n; ++i) {
+		if (skip[i] < 0 || skip[i] > OFDMRX_MAX_SKIP)
+			return OFDMRX_E_ARG;
+		m = std::max(m, (int)skip[i]);
+	}
+	return m;
+}
+
+// Frames per pipeline stage of a call: the handle's chunk, but a batch that would fit ONE chunk is split in two (rounded
+// up to whole waves of 64 codewords) when it is large enough for the two-stream overlap to pay - e.g. 8192 frames per
+// GPU under strong scaling of a 65536-frame batch over 8 GPUs.
+static size_t pipeline_chunk(const ofdmrx_handle *h, size_t n_frames)
+{
+	const size_t chunk = (size_t)h->chunk;
+	if (n_frames > chunk || n_frames < 2048 || std::getenv("OFDMRX_NO_OVERLAP"))
+		return chunk;
+	return std::min(chunk, ((n_frames + 1) / 2 + 63) & ~(size_t)63);
+}
+
+// The chunk pipeline behind both entry points.  Chunk c's samples are at src(c) on the device when front1(c) runs
+// (`ready` = event to wait for, or -1) and its payloads / results go to dst(c) (device buffers).
+//   A (the handle's stream):  front1(c)  sync | header+OSD | demod
+//   B (second stream):                 back(c-1)  polar | finish      beside
+//   A:                                 front2(c)  Theil-Sen | LLRs
+// after_front1(c) / after_back(c) let the host-pointer entry hang its copies on the same events.
+struct PipeHooks {
+	virtual ~PipeHooks() {}
+	virtual int before_front1(size_t c, FrameBatch *fb, size_t *ready) = 0;   // fill fb.samples; ready = event index or -1
+	virtual void dst(size_t c, uint8_t **payload, Result **res) = 0;
+	virtual int after_front1(size_t, size_t /*event*/) { return 0; }
+	virtual int after_back(size_t, size_t /*event*/, hipStream_t /*stream the back half ran on*/) { return 0; }
+};
+
+static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, int fmt, int channels, size_t spf, size_t stride, size_t n_frames,
+	const int32_t *d_skip, int max_skip)
+{
+	const size_t chunk = pipeline_chunk(h, n_frames), n_chunks = (n_frames + chunk - 1) / chunk;
+	int r = ensure_events(h, h->ev_used + n_chunks * events_per_chunk(max_skip) + 8);
+	if (r)
+		return r;
+	auto n_of = [&](size_t c) { return (int)std::min(chunk, n_frames - c * chunk); };
+	static const bool force_grid = std::getenv("OFDMRX_POLAR_FORCE_GRID") != nullptr;   // experiments: limited grid without overlap
+	if (n_chunks == 1 || !h->stream_b || std::getenv("OFDMRX_NO_OVERLAP")) {
+		r = ensure_capacity(h, (int)std::min(chunk, n_frames), channels == 1, (long)spf);
+		for (size_t c = 0; c < n_chunks && !r; ++c) {
+			FrameBatch fb{ nullptr, stride, (long)spf, fmt, channels };
+			size_t ready = (size_t)-1, t0 = 0;
+			uint8_t *pay;
+			Result *res;
+			r = hooks.before_front1(c, &fb, &ready);
+			if (r)
+				break;
+			if (ready != (size_t)-1)
+				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ready], 0));
+			hooks.dst(c, &pay, &res);
+			r = run_front1(h, h->stream, 0, fb, n_of(c), d_skip ? d_skip + c * chunk : nullptr, max_skip, &t0);
+			r = r ? r : hooks.after_front1(c, mark(h, h->stream));
+			r = r ? r : run_front2(h, h->stream, 0, n_of(c), res);
+			r = r ? r : run_back(h, h->stream, 0, n_of(c), force_grid ? h->polar_grid : 0, pay, res, true, t0);
+			r = r ? r : hooks.after_back(c, mark(h, h->stream), h->stream);
+		}
+		return r;
+	}
+	r = ensure_capacity(h, (int)std::min(chunk, n_frames), channels == 1, (long)spf, true);
+	if (r)
+		return r;
+	const size_t NONE = (size_t)-1;
+	std::vector<size_t> ev_back(n_chunks, NONE), ev_f2(n_chunks, NONE), t0s(n_chunks, 0);
+	for (size_t c = 0; c <= n_chunks; ++c) {
+		const int par = (int)(c & 1);
+		size_t ev_f1 = NONE;
+		if (c < n_chunks) {
+			FrameBatch fb{ nullptr, stride, (long)spf, fmt, channels };
+			size_t ready = NONE;
+			r = hooks.before_front1(c, &fb, &ready);
+			if (r)
+				return r;
+			if (ready != NONE)
+				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ready], 0));
+			if (c >= 2 && ev_back[c - 2] != NONE)        // st[par] / llr[par] are free once back(c-2) is done
+				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c - 2]], 0));
+			r = run_front1(h, h->stream, par, fb, n_of(c), d_skip ? d_skip + c * chunk : nullptr, max_skip, &t0s[c]);
+			if (r)
+				return r;
+			ev_f1 = mark(h, h->stream);
+			r = hooks.after_front1(c, ev_f1);
+			if (r)
+				return r;
+		}
+		if (c >= 1) {
+			const size_t p = c - 1;
+			uint8_t *pay;
+			Result *res;
+			hooks.dst(p, &pay, &res);
+			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f2[p]], 0));
+			if (ev_f1 != NONE)
+				HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
+			const bool last = c == n_chunks;                 // nothing left to share the machine with: all decoders resident
+			r = run_back(h, h->stream_b, (int)(p & 1), n_of(p), last ? 0 : h->polar_grid, pay, res, true, t0s[p]);
+			if (r)
+				return r;
+			ev_back[p] = mark(h, h->stream_b);
+			r = hooks.after_back(p, ev_back[p], h->stream_b);
+			if (r)
+				return r;
+		}
+		if (c < n_chunks) {
+			uint8_t *pay;
+			Result *res;
+			hooks.dst(c, &pay, &res);
+			r = run_front2(h, h->stream, par, n_of(c), res);
+			if (r)
+				return r;
+			ev_f2[c] = mark(h, h->stream);
+		}
+	}
+	for (size_t c = n_chunks >= 2 ? n_chunks - 2 : 0; c < n_chunks; ++c)   // the caller's stream sees the finished batch
+		if (ev_back[c] != NONE)
+			HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c]], 0));
+	return 0;
+}
+
+static int finish_call(ofdmrx_handle *h, int r)
+{
+	if (!r && h->sticky != hipSuccess) {
+		g_last_error = std::string("hipEventRecord: ") + hipGetErrorString(h->sticky);
+		r = OFDMRX_E_HIP;
+	}
+	h->sticky = hipSuccess;
+	return r;
+}
+
 extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int fmt, int channels,
 	size_t spf, size_t stride, size_t n_frames, const int32_t *d_skip, uint8_t *d_payload, ofdmrx_frame_result *d_results)
 {
@@ -391,74 +612,28 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	HIP_OK(hipSetDevice(h->cfg.device));
 	int max_skip = 0;
 	if (d_skip) {
+		// the counts steer the host loop (rounds of sync + header): fetched on the handle's stream, so they are ordered
+		// after whatever produced them there
 		std::vector<int32_t> hs(n_frames);
-		HIP_OK(hipMemcpy(hs.data(), d_skip, n_frames * sizeof(int32_t), hipMemcpyDeviceToHost));
-		for (int32_t v : hs)
-			max_skip = std::max(max_skip, (int)v);
-		max_skip = std::min(max_skip, 64);
+		HIP_OK(hipMemcpyAsync(hs.data(), d_skip, n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+		HIP_OK(hipStreamSynchronize(h->stream));
+		max_skip = max_skip_of(hs.data(), n_frames);
+		if (max_skip < 0)
+			return max_skip;
 	}
 	h->ev_used = 0;
 	h->spans.clear();
-	const size_t chunk = (size_t)h->chunk, n_chunks = (n_frames + chunk - 1) / chunk;
-	if (n_chunks == 1 || !h->stream_b || std::getenv("OFDMRX_NO_OVERLAP")) {
-		for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
-			int n = (int)std::min(chunk, n_frames - f0);
-			FrameBatch fb{ (const char *)d_samples + f0 * stride, stride, (long)spf, fmt, channels };
-			r = run_chunk(h, fb, n, d_skip ? d_skip + f0 : nullptr, max_skip, d_payload + f0 * PAYLOAD_BYTES,
-				(Result *)d_results + f0, true);
-			if (r)
-				return r;
-		}
-		return 0;
-	}
-	// pipeline: front(c) on the handle's stream, back(c) on the second stream, two parities of st / llr
-	r = ensure_capacity(h, (int)std::min(chunk, n_frames), channels == 1, (long)spf, true);
-	if (r)
-		return r;
-	// Schedule per chunk c (A = the handle's stream, B = the second stream):
-	//   A: front1(c)   sync / header / demod          - LDS-heavy, runs while no polar grid is resident
-	//   B: back(c-1)   polar + finish, launched once front1(c) is through, limited resident grid
-	//   A: front2(c)   Theil-Sen + LLRs               - shares every CU with the polar grid of chunk c-1
-	std::vector<size_t> ev_back(n_chunks, (size_t)-1), ev_f2(n_chunks, (size_t)-1), t0s(n_chunks, 0);
-	for (size_t c = 0; c <= n_chunks; ++c) {
-		const size_t f0 = c * chunk;
-		const int par = (int)(c & 1);
-		size_t ev_f1 = (size_t)-1;
-		if (c < n_chunks) {
-			const int n = (int)std::min(chunk, n_frames - f0);
-			FrameBatch fb{ (const char *)d_samples + f0 * stride, stride, (long)spf, fmt, channels };
-			if (c >= 2 && ev_back[c - 2] != (size_t)-1)      // st[par] / llr[par] are free once back(c-2) is done
-				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c - 2]], 0));
-			r = run_front1(h, h->stream, par, fb, n, d_skip ? d_skip + f0 : nullptr, max_skip, &t0s[c]);
-			if (r)
-				return r;
-			ev_f1 = mark(h, h->stream);
-		}
-		if (c >= 1) {
-			const size_t p = c - 1, pf0 = p * chunk;
-			const int pn = (int)std::min(chunk, n_frames - pf0);
-			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f2[p]], 0));
-			if (ev_f1 != (size_t)-1)
-				HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
-			const bool last = c == n_chunks;                 // nothing left to share the machine with: all decoders resident
-			r = run_back(h, h->stream_b, (int)(p & 1), pn, last ? 0 : h->polar_grid, d_payload + pf0 * PAYLOAD_BYTES,
-				(Result *)d_results + pf0, true, t0s[p]);
-			if (r)
-				return r;
-			ev_back[p] = mark(h, h->stream_b);
-		}
-		if (c < n_chunks) {
-			const int n = (int)std::min(chunk, n_frames - f0);
-			r = run_front2(h, h->stream, par, n, (Result *)d_results + f0);
-			if (r)
-				return r;
-			ev_f2[c] = mark(h, h->stream);
-		}
-	}
-	for (size_t c = n_chunks >= 2 ? n_chunks - 2 : 0; c < n_chunks; ++c)   // the caller's stream sees the finished batch
-		if (ev_back[c] != (size_t)-1)
-			HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c]], 0));
-	return 0;
+	struct Dev : PipeHooks {
+		const char *samples; size_t stride, chunk; uint8_t *pay; Result *res;
+		int before_front1(size_t c, FrameBatch *fb, size_t *) override { fb->samples = samples + c * chunk * stride; return 0; }
+		void dst(size_t c, uint8_t **p, Result **r) override { *p = pay + c * chunk * PAYLOAD_BYTES; *r = res + c * chunk; }
+	} hooks;
+	hooks.samples = (const char *)d_samples;
+	hooks.stride = stride;
+	hooks.chunk = pipeline_chunk(h, n_frames);
+	hooks.pay = d_payload;
+	hooks.res = (Result *)d_results;
+	return finish_call(h, run_pipeline(h, hooks, fmt, channels, spf, stride, n_frames, d_skip, max_skip));
 }
 
 extern "C" int ofdmrx_synchronize(ofdmrx_handle *h)
@@ -469,9 +644,11 @@ extern "C" int ofdmrx_synchronize(ofdmrx_handle *h)
 	return 0;
 }
 
-// Host-pointer entry.  Chunks are double-buffered: while chunk c is decoded on the handle's stream, chunk c+1 is
-// copied in on a copy stream (from pageable memory that call blocks the host thread - which is exactly the time
-// the GPU needs for chunk c) and the payloads / results of chunk c-1 leave through pinned staging buffers.
+// Host-pointer entry: the same chunk pipeline with three copies hung on its events.  Chunk c+1 is copied in on a copy
+// stream while chunk c runs (from pageable memory that call blocks the host thread - which is exactly the time the GPU
+// needs for chunk c; from pinned memory it is asynchronous); the staging buffer of chunk c is free once front1(c) has
+// read it (Theil-Sen, LLRs, polar work on the carriers).  Payloads and results leave through pinned staging buffers
+// right behind the back half of their chunk.
 extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fmt, int channels,
 	size_t spf, size_t stride, size_t n_frames, const int32_t *skip, uint8_t *payload_out, ofdmrx_frame_result *results)
 {
@@ -480,17 +657,23 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 		return r;
 	HIP_OK(hipSetDevice(h->cfg.device));
 	int max_skip = 0;
-	if (skip)
-		for (size_t i = 0; i < n_frames; ++i)
-			max_skip = std::max(max_skip, (int)skip[i]);
-	max_skip = std::min(max_skip, 64);
+	if (skip) {
+		max_skip = max_skip_of(skip, n_frames);
+		if (max_skip < 0)
+			return max_skip;
+	}
 	h->ev_used = 0;
 	h->spans.clear();
-	const size_t chunk = (size_t)h->chunk, n_chunks = (n_frames + chunk - 1) / chunk, nc = std::min(chunk, n_frames);
-	r = ensure_capacity(h, (int)nc, channels == 1, (long)spf);
+	const size_t chunk = pipeline_chunk(h, n_frames), n_chunks = (n_frames + chunk - 1) / chunk, nc = std::min(chunk, n_frames);
+	r = ensure_events(h, n_chunks * (events_per_chunk(max_skip) + 4) + 8);
 	r = r ? r : h->in_stage.ensure(nc * stride);
-	if (n_chunks > 1)
+	if (n_chunks > 1) {
 		r = r ? r : h->in_stage2.ensure(nc * stride);
+		r = r ? r : h->payload2.ensure(nc * PAYLOAD_BYTES);
+		r = r ? r : h->res2.ensure(nc * sizeof(Result));
+	}
+	r = r ? r : h->payload.ensure(nc * PAYLOAD_BYTES);
+	r = r ? r : h->res.ensure(nc * sizeof(Result));
 	if (skip)
 		r = r ? r : h->skip_stage.ensure(n_frames * sizeof(int32_t));
 	if (r)
@@ -505,57 +688,90 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 			HIP_OK(hipHostMalloc(&h->out_stage[q], out_bytes, hipHostMallocDefault));
 			h->out_stage_cap[q] = out_bytes;
 		}
-	if (skip)
-		HIP_OK(hipMemcpy(h->skip_stage.p, skip, n_frames * sizeof(int32_t), hipMemcpyHostToDevice));
-	std::vector<size_t> ev_in(n_chunks, (size_t)-1), ev_done(n_chunks, (size_t)-1);
-	auto n_of = [&](size_t c) { return std::min(chunk, n_frames - c * chunk); };
-	auto copy_in = [&](size_t c) -> int {              // H2D of chunk c on the copy stream
-		hipStream_t cs = h->stream_b ? h->stream_b : h->stream;
-		if (c >= 2 && ev_done[c - 2] != (size_t)-1)      // in_stage[c & 1] was read by chunk c-2
-			HIP_OK(hipStreamWaitEvent(cs, h->ev_pool[ev_done[c - 2]], 0));
-		HIP_OK(hipMemcpyAsync((c & 1) ? h->in_stage2.p : h->in_stage.p, (const char *)samples + c * chunk * stride,
-			n_of(c) * stride, hipMemcpyHostToDevice, cs));
-		ev_in[c] = mark(h, cs);
-		return 0;
-	};
-	auto copy_out = [&](size_t c) -> int {             // pinned staging -> the caller's arrays, once chunk c is done
-		HIP_OK(hipEventSynchronize(h->ev_pool[ev_done[c]]));
-		const char *src = (const char *)h->out_stage[c & 1];
-		std::memcpy(payload_out + c * chunk * PAYLOAD_BYTES, src, n_of(c) * PAYLOAD_BYTES);
-		std::memcpy(results + c * chunk, src + nc * PAYLOAD_BYTES, n_of(c) * sizeof(Result));
-		return 0;
-	};
-	r = copy_in(0);
-	if (r)
-		return r;
-	for (size_t c = 0; c < n_chunks; ++c) {
-		const int n = (int)n_of(c);
-		HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_in[c]], 0));
-		FrameBatch fb{ (c & 1) ? h->in_stage2.p : h->in_stage.p, stride, (long)spf, fmt, channels };
-		r = run_chunk(h, fb, n, skip ? h->skip_stage.as<int32_t>() + c * chunk : nullptr, max_skip,
-			h->payload.as<uint8_t>(), h->res.as<Result>(), true);
-		if (r)
-			return r;
-		char *dst = (char *)h->out_stage[c & 1];
-		HIP_OK(hipMemcpyAsync(dst, h->payload.p, (size_t)n * PAYLOAD_BYTES, hipMemcpyDeviceToHost, h->stream));
-		HIP_OK(hipMemcpyAsync(dst + nc * PAYLOAD_BYTES, h->res.p, (size_t)n * sizeof(Result), hipMemcpyDeviceToHost, h->stream));
-		ev_done[c] = mark(h, h->stream);
-		if (c + 1 < n_chunks) {
-			r = copy_in(c + 1);
-			if (r)
-				return r;
-		}
-		if (c >= 1) {
-			r = copy_out(c - 1);
-			if (r)
-				return r;
-		}
+	if (skip) {
+		HIP_OK(hipMemcpyAsync(h->skip_stage.p, skip, n_frames * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+		HIP_OK(hipStreamSynchronize(h->stream));         // `skip` may be pageable and go out of scope
 	}
-	r = copy_out(n_chunks - 1);
-	if (r)
-		return r;
-	HIP_OK(hipStreamSynchronize(h->stream));
-	return 0;
+	struct Host : PipeHooks {
+		ofdmrx_handle *h; const char *samples; size_t stride, chunk, n_frames, n_chunks, nc;
+		uint8_t *payload_out; ofdmrx_frame_result *results;
+		std::vector<size_t> ev_in, ev_f1, ev_out;
+		size_t copied_out = 0;
+		size_t n_of(size_t c) const { return std::min(chunk, n_frames - c * chunk); }
+		void *stage(size_t c) const { return (c & 1) ? h->in_stage2.p : h->in_stage.p; }
+		int copy_in(size_t c)
+		{
+			if (c >= 2 && ev_f1[c - 2] != (size_t)-1)    // the staging buffer was last read by front1(c-2)
+				HIP_OK(hipStreamWaitEvent(h->stream_c, h->ev_pool[ev_f1[c - 2]], 0));
+			HIP_OK(hipMemcpyAsync(stage(c), samples + c * chunk * stride, n_of(c) * stride, hipMemcpyHostToDevice, h->stream_c));
+			ev_in[c] = mark(h, h->stream_c);
+			return 0;
+		}
+		int copy_out(size_t c)                             // pinned staging -> the caller's arrays, once chunk c has left the device
+		{
+			HIP_OK(hipEventSynchronize(h->ev_pool[ev_out[c]]));
+			const char *src = (const char *)h->out_stage[c & 1];
+			std::memcpy(payload_out + c * chunk * PAYLOAD_BYTES, src, n_of(c) * PAYLOAD_BYTES);
+			std::memcpy(results + c * chunk, src + nc * PAYLOAD_BYTES, n_of(c) * sizeof(Result));
+			return 0;
+		}
+		int before_front1(size_t c, FrameBatch *fb, size_t *ready) override
+		{
+			if (c == 0) {
+				int r = copy_in(0);
+				if (r)
+					return r;
+			}
+			fb->samples = stage(c);
+			*ready = ev_in[c];
+			return 0;
+		}
+		int after_front1(size_t c, size_t ev) override
+		{
+			ev_f1[c] = ev;
+			return c + 1 < n_chunks ? copy_in(c + 1) : 0;    // chunk c+1 travels while chunk c is decoded
+		}
+		void dst(size_t c, uint8_t **p, Result **r) override
+		{
+			*p = ((c & 1) ? h->payload2 : h->payload).as<uint8_t>();
+			*r = ((c & 1) ? h->res2 : h->res).as<Result>();
+		}
+		int after_back(size_t c, size_t, hipStream_t s) override
+		{
+			// out_stage[c & 1] still holds chunk c-2 until the host has copied it out
+			while (copied_out + 2 <= c) {
+				int r = copy_out(copied_out++);
+				if (r)
+					return r;
+			}
+			uint8_t *p;
+			Result *rs;
+			dst(c, &p, &rs);
+			char *d = (char *)h->out_stage[c & 1];
+			HIP_OK(hipMemcpyAsync(d, p, n_of(c) * PAYLOAD_BYTES, hipMemcpyDeviceToHost, s));
+			HIP_OK(hipMemcpyAsync(d + nc * PAYLOAD_BYTES, rs, n_of(c) * sizeof(Result), hipMemcpyDeviceToHost, s));
+			ev_out[c] = mark(h, s);
+			return 0;
+		}
+	} hooks;
+	hooks.h = h;
+	hooks.samples = (const char *)samples;
+	hooks.stride = stride;
+	hooks.chunk = chunk;
+	hooks.n_frames = n_frames;
+	hooks.n_chunks = n_chunks;
+	hooks.nc = nc;
+	hooks.payload_out = payload_out;
+	hooks.results = results;
+	hooks.ev_in.assign(n_chunks, (size_t)-1);
+	hooks.ev_f1.assign(n_chunks, (size_t)-1);
+	hooks.ev_out.assign(n_chunks, (size_t)-1);
+	r = run_pipeline(h, hooks, fmt, channels, spf, stride, n_frames, skip ? h->skip_stage.as<int32_t>() : nullptr, max_skip);
+	while (!r && hooks.copied_out < n_chunks)
+		r = hooks.copy_out(hooks.copied_out++);
+	if (!r)
+		HIP_OK(hipStreamSynchronize(h->stream));
+	return finish_call(h, r);
 }
 
 extern "C" int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t)
@@ -725,8 +941,17 @@ extern "C" int ofdmrx_util_awgn_tile(ofdmrx_handle *h, const int16_t *d_base, si
 extern "C" int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_t *d_out, size_t n_frames, size_t spf,
 	const ofdmrx_channel *ch)
 {
-	if (!h || !d_in || !d_out || !n_frames || n_frames > 65535 || !spf || !ch || ch->ntaps < 0 || ch->ntaps > 8 || d_in == d_out)
+	if (!h || !d_in || !d_out || !n_frames || n_frames > 65535 || !spf || !ch || ch->ntaps < 0 || ch->ntaps > 8)
 		return OFDMRX_E_ARG;
+	for (int i = 0; i < ch->ntaps; ++i)
+		if (ch->delays[i] < 0 || (size_t)ch->delays[i] >= spf)
+			return OFDMRX_E_ARG;
+	{
+		const char *a = (const char *)d_in, *b = (const char *)d_out;
+		const size_t bytes = n_frames * spf * 2 * sizeof(int16_t);
+		if (a < b + bytes && b < a + bytes)                   // the resampler reads neighbours of what other blocks write
+			return OFDMRX_E_ARG;
+	}
 	HIP_OK(hipSetDevice(h->cfg.device));
 	struct { float cfo_hz, sfo_ppm; int ntaps; int delays[8]; float gre[8], gim[8]; } cp;
 	cp.cfo_hz = ch->cfo_hz;
@@ -740,18 +965,7 @@ extern "C" int ofdmrx_util_channel(ofdmrx_handle *h, const int16_t *d_in, int16_
 }
 
 // ---- N2: transmitter on the device (Encoder<value,cmplx,rate>, encode.cc:271-317) -------------------
-static long long base37(const char *str)   // encode.cc:320-335
-{
-	long long acc = 0;
-	for (char c = *str++; c; c = *str++) {
-		acc *= 37;
-		if (c >= '0' && c <= '9') acc += c - '0' + 1;
-		else if (c >= 'a' && c <= 'z') acc += c - 'a' + 11;
-		else if (c >= 'A' && c <= 'Z') acc += c - 'A' + 11;
-		else if (c != ' ') return -1;
-	}
-	return acc;
-}
+extern "C" long long ofdmrx_callsign_value(const char *call_sign) { return call_sign ? callsign_value(call_sign) : -1; }
 
 extern "C" long ofdmrx_stream_samples(int sample_rate, int oper_mode, int count)
 {
@@ -774,7 +988,7 @@ extern "C" int ofdmrx_tx_encode_stream_device(ofdmrx_handle *h, const uint8_t *d
 		return OFDMRX_E_ARG;
 	if (oper_mode < 6 || oper_mode > 13 || freq_off % 50 || count < 1 || count > 4096)   // encode.cc:353,394
 		return OFDMRX_E_ARG;
-	long long cs = base37(call_sign);
+	long long cs = callsign_value(call_sign);
 	if (cs <= 0 || cs >= 129961739795077LL)               // encode.cc:358
 		return OFDMRX_E_ARG;
 	HIP_OK(hipSetDevice(h->cfg.device));

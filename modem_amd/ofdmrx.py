@@ -24,6 +24,7 @@ EXPORTS = [
     "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
     "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
     "ofdmrx_tx_encode_device", "ofdmrx_stream_samples", "ofdmrx_tx_encode_stream_device", "ofdmrx_tx_encode_stream",
+    "ofdmrx_callsign_value",
 ]
 
 
@@ -126,6 +127,8 @@ def load_library():
     L.ofdmrx_tx_encode_stream.restype = C.c_int
     L.ofdmrx_tx_encode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                           C.c_void_p]
+    L.ofdmrx_callsign_value.restype = C.c_longlong
+    L.ofdmrx_callsign_value.argtypes = [C.c_char_p]
     L.ofdmrx_tx_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
     _LIB = L
     return L

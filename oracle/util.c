@@ -142,17 +142,15 @@ void orc_set_le_bit(uint8_t *buf, int i, int v)
 /* ---- base37: encode.cc:320-335, decode.cc:155-159 ------------------------ */
 long long orc_base37_encode(const char *str)
 {
+	/* ' ' = 0, '0'..'9' = 1..10, 'A'..'Z' / 'a'..'z' = 11..36; anything else is rejected */
+	static const char alphabet[] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ";
 	long long acc = 0;
-	for (char c = *str++; c; c = *str++) {
-		acc *= 37;
-		if (c >= '0' && c <= '9')
-			acc += c - '0' + 1;
-		else if (c >= 'a' && c <= 'z')
-			acc += c - 'a' + 11;
-		else if (c >= 'A' && c <= 'Z')
-			acc += c - 'A' + 11;
-		else if (c != ' ')
+	for (; *str; ++str) {
+		int c = (*str >= 'a' && *str <= 'z') ? *str - 'a' + 'A' : *str;
+		const char *hit = c ? strchr(alphabet, c) : NULL;
+		if (!hit)
 			return -1;
+		acc = acc * 37 + (hit - alphabet);
 	}
 	return acc;
 }

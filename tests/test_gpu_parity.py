@@ -11,6 +11,10 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 REL = 1e-5   # north_star tolerance on fp32 intermediates
+# bit_flips (decode.cc:546-555) counts payload positions whose LLR SIGN disagrees with the decoded bit.  LLRs are fp32
+# intermediates (tolerance REL); one that lies within that tolerance of zero may carry either sign, so the count is
+# compared with this slack (documented in include/ofdmrx.h; 0 on clean input, where no LLR is near zero)
+FLIPS_SLACK = 2
 
 
 @pytest.fixture(scope="module")
@@ -168,7 +172,7 @@ def _check_against_oracle(rx, pcm, payload, expect_ok=True):
         assert (rx.tap("LLR", 0)[64800:] == 9000).all()
         assert abs(float(r["cfo_fine"]) - ores.cfo_fine) <= REL and abs(float(r["esn0_db_last"]) - ores.esn0_db_last) < 1e-3
     if ores.status == 0:
-        assert int(r["bit_flips"]) == ores.bit_flips
+        assert abs(int(r["bit_flips"]) - ores.bit_flips) <= FLIPS_SLACK
         best = int(r["best_lane"])
         assert (rx.tap("LANE_MESG", 0)[best][:5380] ^ 0 == tb.lane_mesg[ores.best_lane][:5380]).all()
     return r, ores
@@ -312,6 +316,10 @@ def test_decode_cli_is_a_drop_in(tmp_path):
         assert r.returncode == 0, r.stderr
         assert out.read_bytes() == want.read_bytes()
         assert "call sign:  CALLSIGN" in r.stderr and "bit flips: 0" in r.stderr and "oper mode: 6" in r.stderr
+        # the remaining stderr lines of decode.cc:463-478,502,506-523: progress dots, coarse sfo, one Es/N0 value per row
+        assert "demod " + "." * 50 + " done" in r.stderr and "coarse sfo: " in r.stderr
+        esn0 = [ln for ln in r.stderr.splitlines() if ln.startswith("Es/N0 (dB):")]
+        assert len(esn0) == 1 and len(esn0[0].split()[2:]) == 50
     assert subprocess.run([exe], capture_output=True).returncode == 1            # usage
     r = subprocess.run([exe, str(out), str(tmp_path / "missing.wav")], capture_output=True)
     assert r.returncode == 1
@@ -396,7 +404,7 @@ def test_all_modes_of_the_mode_table(rx, mode, channels, freq):
     r = res[0]
     assert ores.status == 0 and int(r["status"]) == 0 and int(r["oper_mode"]) == mode
     assert (out[0] == p).all() and (out[0] == oout).all()
-    assert int(r["sc_start"]) == ores.sc_start and int(r["call_sign"]) == ores.call_sign and int(r["bit_flips"]) == ores.bit_flips
+    assert int(r["sc_start"]) == ores.sc_start and int(r["call_sign"]) == ores.call_sign and abs(int(r["bit_flips"]) - ores.bit_flips) <= FLIPS_SLACK
     _close(rx.tap("CONS_ROT", 0, cons_cnt=m.cons_cnt), tb.cons_rot[:m.cons_cnt], what="cons_rot")
     _close(rx.tap("PRECISION", 0, rows=m.cons_rows), tb.precision[:m.cons_rows], what="precision")
     _close(rx.tap("LLR", 0)[:m.cons_bits], tb.llr[:m.cons_bits], what="llr")
@@ -661,7 +669,7 @@ def test_waterfall_parity_at_scale():
     assert (out == oout).all() and (out[ok] == pays[ok]).all()
     for name in ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects"):
         assert (res[name] == ores[name]).all(), name
-    assert (np.abs(res["bit_flips"].astype(np.int64) - ores["bit_flips"]) <= 2).all()
+    assert (np.abs(res["bit_flips"].astype(np.int64) - ores["bit_flips"]) <= FLIPS_SLACK).all()
 
 
 def test_list_size_4():
@@ -769,4 +777,149 @@ def test_chunk_pipeline_at_16k():
     assert (o3 == o16).all() and (r3["status"] == 0).all() and (r3["sc_start"] == r16["sc_start"]).all()
     assert (o3 == np.stack(pays)).all()
     o, r = O.decode(pcm[7], rate=rate)
-    assert r.status == 0 and (o == o3[7]).all() and r.sc_start == int(r3["sc_start"][7]) and r.bit_flips == int(r3["bit_flips"][7])
+    assert r.status == 0 and (o == o3[7]).all() and r.sc_start == int(r3["sc_start"][7]) and abs(r.bit_flips - int(r3["bit_flips"][7])) <= FLIPS_SLACK
+
+
+def test_host_pointer_entry_runs_the_chunk_pipeline():
+    """ofdmrx_decode_batch (host pointers) goes through the same two-stream chunk pipeline as the device entry, with the
+    copies hung on its events: 23 mixed frames (good, noisy, silence, truncated, SKIP) in chunks of 5 (ragged tail, both
+    staging parities several times) must equal one chunk of 32, frame by frame, and the oracle on a noisy frame"""
+    import modem_amd
+    rng = np.random.default_rng(7)
+    pays = [O.payload_for(2200 + i) for i in range(4)]
+    base = [O.encode_pcm(pays[0], channels=2), O.impair(O.encode_pcm(pays[1], channels=2), noise_db=-16, seed=9, frame=1),
+            O.encode_pcm(np.concatenate([pays[2], pays[3]]), channels=2)]
+    n = max(x.shape[0] for x in base)
+    frames, skips = [], []
+    for i in range(23):
+        kind = i % 5
+        f = np.zeros((n, 2), np.int16)
+        if kind < 3:
+            f[:base[kind].shape[0]] = base[kind]
+        elif kind == 3:
+            f[:] = rng.integers(-200, 200, size=(n, 2))
+        else:
+            f[:40000] = base[0][:40000]
+        frames.append(f)
+        skips.append(1 if kind == 2 else 0)
+    batch, skips = np.stack(frames), np.asarray(skips, np.int32)
+    outs = []
+    for chunk in (5, 32):
+        r = modem_amd.Receiver(device=0, chunk_frames=chunk, max_samples=n)
+        outs.append(r.decode(batch, skip=skips))
+        outs.append(r.decode(batch, skip=skips))        # second call: staging buffers and events are reused
+        r.close()
+    (o5, r5), (o5b, r5b), (o32, r32), _ = outs
+    assert (o5 == o32).all() and (o5 == o5b).all()
+    for name in r5.dtype.names:
+        a, b = r5[name], r32[name]
+        assert ((a == b) | ((a != a) & (b != b))).all(), name
+    assert (o5[0] == pays[0]).all() and (o5[1] == pays[1]).all() and (o5[2] == pays[3]).all() and r5["status"][3] == 1
+    o, rr = O.decode(batch[1])
+    assert (o == o5[1]).all() and rr.sc_start == int(r5["sc_start"][1])
+
+
+def test_one_chunk_batches_are_split_for_the_pipeline():
+    """a batch that fits one chunk but is large enough (>= 2048 frames) is split in two so that the two-stream overlap
+    engages (strong scaling: 8192 frames per GPU).  Results must not depend on it: 2200 frames with the default chunk
+    (8192 -> split 1152 + 1048) equal the same frames decoded with OFDMRX_NO_OVERLAP-style single chunks of 2200"""
+    import os
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    n = 2200
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        rx = modem_amd.Receiver(device=0, stream=stream.cuda_stream)
+        spf = rx.tx_frame_samples(6)
+        g = torch.Generator(device=dev)
+        g.manual_seed(5)
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+        d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+        rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
+        rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, -16.0, 3, 0)
+        res = []
+        for chunk in (0, 4096):
+            r2 = rx if chunk == 0 else modem_amd.Receiver(device=0, stream=stream.cuda_stream, chunk_frames=chunk)
+            d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+            d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+            if chunk:
+                os.environ["OFDMRX_NO_OVERLAP"] = "1"
+            try:
+                r2.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+                r2.synchronize()
+            finally:
+                os.environ.pop("OFDMRX_NO_OVERLAP", None)
+            launches = r2.timing()["polar"][1]
+            res.append((d_out.cpu().numpy(), d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1), launches))
+            if chunk:
+                r2.close()
+        rx.close()
+    (oa, ra, la), (ob, rb, lb) = res
+    assert la == 2 and lb == 1, (la, lb)
+    assert (oa == ob).all() and (oa == d_pay.cpu().numpy()).all()
+    for name in ra.dtype.names:
+        assert ((ra[name] == rb[name]) | ((ra[name] != ra[name]) & (rb[name] != rb[name]))).all(), name
+
+
+def test_argument_errors_are_reported():
+    """SKIP counts outside 0..64 and channel delays outside the frame are argument errors, never silent clamps"""
+    import torch
+    import modem_amd
+    rx = modem_amd.Receiver(device=0, chunk_frames=4)
+    pcm = O.encode_pcm(O.payload_for(1), channels=2)[None]
+    for bad in (-1, 65):
+        with pytest.raises(modem_amd.OfdmRxError):
+            rx.decode(pcm, skip=[bad])
+    out, res = rx.decode(pcm, skip=[0])
+    assert res["status"][0] == 0
+    dev = torch.device("cuda:0")
+    d = torch.zeros((2, 1000, 2), dtype=torch.int16, device=dev)
+    e = torch.zeros_like(d)
+    for taps in ([(-1, 1 + 0j)], [(1000, 1 + 0j)]):
+        with pytest.raises(modem_amd.OfdmRxError):
+            rx.channel(d.data_ptr(), e.data_ptr(), 2, 1000, multipath=taps)
+    with pytest.raises(modem_amd.OfdmRxError):       # overlapping in / out
+        rx.channel(d.data_ptr(), d.data_ptr() + 2000, 1, 1000, multipath=[(0, 1 + 0j)])
+    rx.channel(d.data_ptr(), e.data_ptr(), 2, 1000, multipath=[(999, 1 + 0j)])
+    rx.synchronize()
+    rx.close()
+    L = modem_amd.load_library()
+    assert L.ofdmrx_callsign_value(b"ANONYMOUS") == O.lib().orc_base37_encode(b"ANONYMOUS")
+    assert L.ofdmrx_callsign_value(b"dl1abc 9") == O.lib().orc_base37_encode(b"DL1ABC 9") > 0
+    assert L.ofdmrx_callsign_value(b"BAD-SIGN") == -1 == O.lib().orc_base37_encode(b"BAD-SIGN")
+
+
+def test_ber_sweep_driver_counters_match_the_oracle(tmp_path):
+    """configs[4]'s driver (tools/ber_sweep.py: transmitter + channel of batch b+1 beside the decode of batch b, two
+    handles, counters kept on the device) on three noise levels - all decode, waterfall, none decode - with small
+    batches so that the pipeline wraps its two buffers several times: the FER / BER / lost counters it prints must be
+    exactly what the CPU oracle gives on the very same frames (kept with --dump)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    levels = [-30.0, -15.2, -14.0]
+    r = subprocess.run([sys.executable, os.path.join(O.ROOT, "tools", "ber_sweep.py"), "--frames", "96", "--batch", "40",
+                        "--levels"] + [str(x) for x in levels] + ["--dump", str(tmp_path)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    pts = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{") and "noise_db" in ln]
+    assert [p["noise_db"] for p in pts] == levels and all(p["frames"] == 96 for p in pts)
+    per_level = 3                                            # batches of 40 + 40 + 16 frames
+    for li, p in enumerate(pts):
+        ferr = berr = lost = 0
+        for b in range(li * per_level, (li + 1) * per_level):
+            pcm = np.load(tmp_path / ("pcm_r0_b%d.npy" % b))
+            pay = np.load(tmp_path / ("pay_r0_b%d.npy" % b))
+            got = np.load(tmp_path / ("out_r0_b%d.npy" % b))
+            for f in range(pcm.shape[0]):
+                o, res = O.decode(pcm[f])
+                assert (o == got[f]).all(), (li, b, f)
+                d = int(np.unpackbits(o ^ pay[f]).sum())
+                ferr += d > 0
+                berr += d
+                lost += res.status != 0
+        assert p["fer"] == ferr / 96 and p["declared_lost"] == lost and abs(p["ber"] - berr / (43040.0 * 96)) < 1e-12, (p, ferr, berr, lost)
+    assert pts[0]["fer"] == 0 and pts[2]["fer"] == 1.0

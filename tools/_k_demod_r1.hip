@@ -1,7 +1,7 @@
 // k_demod.hip -- D4 (51 x FFT1280 + time-differential demod), D5 (Theil-Sen phase-slope
 // correction), D6/D7 (cumulative SNR estimate + 8PSK soft demap), D8 (lengthen) for gfx950.
-#include "dev_common.h"
-#include "kernels.h"
+#include "../modem_amd/csrc/dev_common.h"
+#include "../modem_amd/csrc/kernels.h"
 
 namespace rx {
 
@@ -23,12 +23,8 @@ __device__ __forceinline__ cf psk8_hard_map(cf c)   // map(hard(c)): psk.hh:118-
 }
 
 // ---------------------------------------------------------------- D4
-#ifndef DEMOD_TPS
-#define DEMOD_TPS 256      // 8 kHz: threads per symbol transform.  256 (four waves share one 1280-point buffer, 126 VGPRs, 10 KB of LDS:
-                           // 4.0 ms per 8192 frames alone) beats one wave per symbol (64: 252 VGPRs, 40 KB, 4.3 ms) and 128 (166 VGPRs, 4.7 ms)
-#endif
-template <int RATE> struct DemodShared {                     // 8 kHz: one 1280-point buffer per symbol slot
-	cf fft[256 / DEMOD_TPS][RateCfg<RATE>::SL];
+template <int RATE> struct DemodShared {                     // 8 kHz: one 1280-point buffer per wave
+	cf fft[4][RateCfg<RATE>::SL];
 };
 template <int RATE> struct DemodSharedBlock {                // other rates: one buffer, the whole block per symbol
 	cf fft[RateCfg<RATE>::SL];
@@ -46,10 +42,7 @@ template <int RATE> struct DemodSharedBlock {                // other rates: one
 #endif
 template <int RATE> struct DemodCfg {
 	static constexpr int NT = DEMOD_WAVE_PER_SYMBOL(RATE) ? 256 : 1024;     // threads per frame
-#ifndef DEMOD_MINB
-#define DEMOD_MINB (DEMOD_TPS == 256 ? 4 : 2)
-#endif
-	static constexpr int MINB = DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_MINB : 1;        // waves per SIMD the register budget is set for
+	static constexpr int MINB = DEMOD_WAVE_PER_SYMBOL(RATE) ? 2 : 1;        // workgroups per CU the register budget is set for (4 would spill)
 };
 
 template <int RATE>
@@ -70,48 +63,28 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 	const int code_off = -md.cols / 2;                        // decode.cc:454
 	if constexpr (DEMOD_WAVE_PER_SYMBOL(RATE)) {
 		__shared__ DemodShared<RATE> sh;
-		constexpr int TPS = DEMOD_TPS, SLOTS = 256 / TPS;         // TPS threads share one transform; SLOTS symbols in flight per workgroup
-		const int slot = tid / TPS, lt = tid % TPS;
-		(void)wave; (void)lane;
-		// NCO as at the other rates: e^{j omega (k0 + lt + TPS q)} = one closed-form phasor per thread and symbol times a table
-		// of e^{j omega TPS q} built once per frame - a complex multiply per sample instead of a double-precision range
-		// reduction and a sincos (DEMOD_NCO_TABLE 0: the closed form for every sample)
-#ifndef DEMOD_NCO_TABLE
-#define DEMOD_NCO_TABLE 1
-#endif
-		__shared__ cf rot8[SYMBOL_LEN / TPS];
-		if (DEMOD_NCO_TABLE) {
-			if (tid < SYMBOL_LEN / TPS)
-				rot8[tid] = phasor(omega, (long)TPS * tid);
-			__syncthreads();
-		}
-		const int groups = (md.rows + 1 + SLOTS - 1) / SLOTS;
+		const int groups = (md.rows + 1 + 3) / 4;
 		for (int g = 0; g < groups; ++g) {
-			const int s = SLOTS * g + slot;                       // 0 = pilot, 1..rows = data rows
+			const int s = 4 * g + wave;                           // 0 = pilot, 1..rows = data rows
 			const bool valid = s <= md.rows;
-			cf *buf = sh.fft[slot];
-			const cf base = phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + lt);
+			cf *buf = sh.fft[wave];
 			#pragma unroll 2
-			for (int q = 0; q < SYMBOL_LEN / TPS; ++q) {
-				int i = lt + TPS * q;
+			for (int q = 0; q < SYMBOL_LEN / 64; ++q) {
+				int i = lane + 64 * q;
 				cf v = mk(0.f, 0.f);
 				if (valid)   // osc() call count: symbol_len (header) + s*stride + i, decode.cc:459-470
-					v = cmul(src.at(body0 + (long)s * SYM_STRIDE + i),
-						DEMOD_NCO_TABLE ? cmul(base, rot8[q]) : phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + i));
+					v = cmul(src.at(body0 + (long)s * SYM_STRIDE + i), phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + i));
 				buf[i] = v;
 			}
-			fft_sync<TPS>();
-			// TPS = 64: one wave, its own buffer, no workgroup barriers; otherwise the slots run in lock-step
-			fft_fwd<SYMBOL_LEN, TPS, SYMBOL_LEN>(buf, tb.tw_sym, lt);
+			fft_fwd<SYMBOL_LEN, 64, SYMBOL_LEN>(buf, tb.tw_sym, lane);   // one wave, its own buffer: no workgroup barriers
 			// the payload carriers of symbol s go to HBM (cols x 8 B); the time-differential step
 			// cons = X_j / X_{j-1} (decode.cc:474-475) happens where they are read (k_theil_sen): no carrier ring,
 			// no dependence between the waves, 40 KB of LDS per workgroup
 			if (valid) {
 				cf *carr = carr_all + (size_t)f * CARR_MAX + (size_t)s * md.cols;
-				for (int i = lt; i < md.cols; i += TPS)
+				for (int i = lane; i < md.cols; i += 64)
 					carr[i] = buf[(i + code_off + SYMBOL_LEN) % SYMBOL_LEN];
 			}
-			fft_sync<TPS>();                                      // the next group refills the buffer
 		}
 	} else {
 		__shared__ DemodSharedBlock<RATE> sh;
@@ -425,101 +398,69 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 			T_lo = select_rank<-1>(s, tid, rlo, sample);
 			T_hi = select_rank<+1>(s, tid, rhi, sample);
 		}
-		// ---- 2. classify every pair: lane = point i, loop = distance d (wave-uniform), sixteen distances per step.
-		// x is the integer grid (decode.cc:485), so "slope < T" is "y_j - T x_j < y_i - T x_i": the row is transformed ONCE
-		// per bound, zl = y - T_lo' x and zh = y - T_hi' x, and a pair costs two compares of the neighbour's (zl, zh)
-		// against the lane's own two values - no subtraction, no reciprocal table, no multiply per pair.  The bounds are
-		// moved outwards by 1e-6 relative (T_lo', T_hi') and the lane's values by four times the worst rounding error of
-		// the transform, so "below" implies that the correctly rounded slope is < T_lo and "above" that it is > T_hi;
-		// everything else is listed and gets the exact division.  The (zl, zh) pairs sit in the histogram's LDS (idle
-		// during this pass) and are padded with +3e38 beyond n, points i >= n compare against -3e38: pairs that do not
-		// exist drop out as "above" - no index clamps, no validity masks.  "below" is a scalar popcount of the compare
-		// mask; kept pairs go to a wave-private quarter of the LDS list (fill count in a scalar register, slot = fill +
-		// mbcnt) only when the keep mask of the wave instruction is not empty.  Every wave walks all blocks of 64 points
-		// and takes every fourth group of sixteen distances: the trip counts balance, and so do the kept pairs.
-		const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: uniform loops
+		// ---- 2. classify every pair: lane = point i (kept in a register), loop = distance d (wave-uniform),
+		// sixteen distances per step.  s.y is padded with +3e38 beyond n (and points i >= n read -3e38), so pairs
+		// that do not exist produce a huge positive slope and drop out as "above" - no index clamps, no
+		// validity masks; the eight phases are two ds_read2 pairs apart and the reciprocals of the distances
+		// come from a constant table through scalar loads.  Per pair: half a packed subtract, half a packed
+		// multiply, two compares straight into wave masks.  "below" is a scalar popcount.  Kept pairs go to a
+		// wave-private quarter of the LDS list (fill count in a scalar register, slot = fill + mbcnt), so the
+		// pass has no atomics and no block-level synchronisation.  Every wave walks all blocks of 64 points and
+		// takes every fourth group of sixteen distances: the trip counts balance, and so do the kept pairs (they
+		// come mostly from the long distances, whose slopes cluster around the median).
+		const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: uniform loops, s_load of the table
 		constexpr int WCAP = TS_LIST_CAP / 4;
 		int below = 0, cfill = 0;
-#if defined(TS_VARIANT_PERLANE)
-		int vcnt = 0, vcnt2 = 0;
-#endif
 		unsigned *list = (unsigned *)s.buf + wave * WCAP;
+		// q = a*rcp(d) is within 3*2^-24 relative of the correctly rounded quotient; thresholds moved
+		// outwards by 1e-6 relative (+ an absolute floor) make "q < T_lo_m" imply "exact < T_lo"
 		const float T_lo_m = T_lo - (1e-6f * fabsf(T_lo) + 1e-36f);
 		const float T_hi_m = T_hi + (1e-6f * fabsf(T_hi) + 1e-36f);
-		// |computed z - (y - T x)| <= 2^-24 (|T x| + |y - T x|) <= 2^-24 (pi + 2 * 216 |T|) for |y| <= pi, |x| <= 216 (cols <= 512:
-		// 256); two values are compared, and the margin doubles that again
-		const float tmax = fmaxf(fabsf(T_lo_m), fabsf(T_hi_m));
-		const float margin = 4.f * 5.97e-8f * (3.1416f + 1024.f * tmax) + 1e-37f;
-		float2 *z2 = (float2 *)s.hist;
-		{
-			const int xoff = n / 2;
-			for (int i = tid; i < n + 128; i += 256) {
-				float2 v = make_float2(3.0e38f, 3.0e38f);
-				if (i < n) {
-					const float x = (float)(i - xoff), yv = s.y[i];
-					v = make_float2(yv - T_lo_m * x, yv - T_hi_m * x);
-				}
-				z2[i] = v;
-			}
-		}
-		__syncthreads();
 #ifndef TS_PROBE_SKIP_MAIN
 		{
 			const int nblk = (n + 63) >> 6;
 			for (int b = 0; b < nblk; ++b) {
 				const int i = b * 64 + lane;
-				const float2 zi = z2[i];
-				const float zl_thr = i < n ? zi.x - margin : -3.0e38f;
-				const float zh_thr = i < n ? zi.y + margin : -3.0e38f;
+				const float yi = i < n ? s.y[i] : -3.0e38f;
 				const int dmax = n - 1 - b * 64;              // largest distance with any existing pair
-				const float2 *zp = z2 + i + 1;
+				const float *yp = s.y + i + 1;
 #ifndef TS_U
-#define TS_U 8
+#define TS_U 16
 #endif
 				constexpr int U = TS_U;
-				for (int d0 = wave * U; d0 < dmax; d0 += 4 * U) {   // distances d0+1 .. d0+U; wave w takes every 4th group
-					// all sixteen neighbours first: one LDS round trip per step instead of sixteen dependent ones
-					float2 zv[U];
+				for (int d0 = wave * U; d0 < dmax; d0 += 4 * U) {   // distances d0+1 .. d0+8; wave w takes every 4th group
+					unsigned long long kb[U];
+					bool keep[U];
+					// all sixteen phases first: one LDS round trip per step instead of eight dependent ones (the wave
+					// shares its SIMD with few others when the polar decoders are resident)
+					float yv[U];
 					#pragma unroll
 					for (int u = 0; u < U; ++u)
-						zv[u] = zp[d0 + u];
+						yv[u] = yp[d0 + u];
 					__builtin_amdgcn_sched_barrier(0);
-#if defined(TS_VARIANT_PERLANE)
-					// experiment: per-lane counters, no scalar work per pair (results wrong: timing only)
 					#pragma unroll
 					for (int u = 0; u < U; ++u) {
-						vcnt += (zv[u].x < zl_thr) ? 1 : 0;
-						vcnt2 += (zv[u].y > zh_thr) ? 1 : 0;
-					}
-#else
-					#pragma unroll
-					for (int u = 0; u < U; ++u) {
-						const bool lo = zv[u].x < zl_thr, hi = zv[u].y > zh_thr;   // certainly below T_lo / above T_hi
+						const float q = (yv[u] - yi) * TS_RCP.v[d0 + u];
+						const bool lo = q < T_lo_m, hi = q > T_hi_m;  // certainly below T_lo / above T_hi even after rounding
 						const unsigned long long mlo = __builtin_amdgcn_ballot_w64(lo);
 						const unsigned long long mhi = __builtin_amdgcn_ballot_w64(hi);
 						below += __popcll(mlo);                   // wave-uniform scalar count
-						const unsigned long long bal = ~(mlo | mhi);
-#ifndef TS_VARIANT_NOHIT
-						if (bal) {                                // rare for short distances, dense for the longest ones
-							if (!(lo | hi)) {
-								int slot = cfill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-								slot = slot < WCAP ? slot : WCAP - 1;     // an overflowing wave is detected below
-								list[slot] = (unsigned)i | ((unsigned)(d0 + u + 1) << 16);
-							}
-							cfill += __popcll(bal);
-						}
-#else
-						cfill += (int)(bal & 1);
-#endif
+						kb[u] = ~(mlo | mhi);                     // the same predicate as a wave mask (slots) ...
+						keep[u] = !(lo | hi);                     // ... and per lane (exec mask of the store)
 					}
-#endif
+					#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						const unsigned long long bal = kb[u];
+						if (keep[u]) {
+							int slot = cfill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+							slot = slot < WCAP ? slot : WCAP - 1;     // an overflowing wave is detected below
+							list[slot] = (unsigned)i | ((unsigned)(d0 + u + 1) << 16);
+						}
+						cfill += __popcll(bal);
+					}
 				}
 			}
 		}
-#endif
-#if defined(TS_VARIANT_PERLANE)
-		below = vcnt + (vcnt2 & 1);
-		(void)list;
 #endif
 		if (lane == 0) {
 			s.red[wave] = below;
@@ -583,10 +524,7 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 // decode.cc:479-504: one workgroup per (frame, row)
 // carr_all != nullptr (8 kHz): the row is formed here from the carriers of two consecutive symbols; cons_raw_all
 // (nullable) receives the unrotated row for the CONS_RAW tap
-#ifndef TS_WAVES
-#define TS_WAVES 5     // waves per SIMD the register budget is set for (5 -> <= 96 VGPRs, five workgroups per CU by LDS)
-#endif
-__global__ __launch_bounds__(256, TS_WAVES) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
+__global__ __launch_bounds__(256, 5) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
 	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all)
 {
 	// grid = frames x 50 (mode 6 has exactly 50 rows: one row per block); modes with more rows loop
@@ -641,7 +579,7 @@ __global__ __launch_bounds__(256, TS_WAVES) void k_theil_sen(const SyncState *__
 	}
 }
 
-__global__ __launch_bounds__(256, TS_WAVES) void k_theil_sen_raw(int cols, const float *__restrict__ y, float *__restrict__ slope_all,
+__global__ __launch_bounds__(256) void k_theil_sen_raw(int cols, const float *__restrict__ y, float *__restrict__ slope_all,
 	float *__restrict__ yint_all)
 {
 	const int r = blockIdx.x, tid = threadIdx.x;

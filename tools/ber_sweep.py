@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--step", type=float, default=1.0)
     ap.add_argument("--batch", type=int, default=32768, help="frames resident per decode call and rank")
     ap.add_argument("--seed", type=int, default=777)
+    ap.add_argument("--levels", type=float, nargs="*", default=None, help="explicit noise levels in dB (overrides --lo/--hi/--step)")
+    ap.add_argument("--dump", default=None, help="directory: keep every batch's PCM and payloads as .npy (tests, small runs only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -46,51 +48,88 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     rx = modem_amd.Receiver(device=local_rank, stream=stream.cuda_stream)
+    # a second handle + stream makes the inputs: the transmitter and the channel of batch b+1 run beside the decode of
+    # batch b (the transmitter alone is 60 % of a decode), two input buffers in rotation
+    tx_stream = torch.cuda.Stream(device=dev)
+    tx = modem_amd.Receiver(device=local_rank, stream=tx_stream.cuda_stream)
     spf = rx.tx_frame_samples(6)
     nb = min(args.batch, args.frames)
-    d_in = torch.empty((nb, spf, 2), dtype=torch.int16, device=dev)
+    d_in = [torch.empty((nb, spf, 2), dtype=torch.int16, device=dev) for _ in range(2)]
+    d_pay = [torch.empty((nb, 5380), dtype=torch.uint8, device=dev) for _ in range(2)]
     d_out = torch.zeros((nb, 5380), dtype=torch.uint8, device=dev)
     d_res = torch.zeros((nb, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     pop = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=dev)
     gen = torch.Generator(device=dev)
+    ev_ready = [torch.cuda.Event() for _ in range(2)]    # inputs of the batch in buffer q are complete (tx stream)
+    ev_free = [torch.cuda.Event() for _ in range(2)]     # the decode that read buffer q is done (decode stream)
 
-    levels = np.arange(args.lo, args.hi + 1e-9, args.step)
+    levels = np.asarray(args.levels) if args.levels else np.arange(args.lo, args.hi + 1e-9, args.step)
     lo, hi = shard.block_range(args.frames, rank, world)
-    summary = []
-    t_all = time.perf_counter()
+    # the whole job as one list of batches, so that the pipeline runs across noise levels too
+    work = []
     for li, db in enumerate(levels):
-        counters = [0, 0, 0, 0]          # frames, frame errors, bit errors, header/sync failures
-        t0 = time.perf_counter()
         f = lo
         while f < hi:
             n = min(nb, hi - f)
-            gidx = li * args.frames + f          # global frame index: distinct noise everywhere
-            gen.manual_seed(args.seed * 7919 + gidx)
-            d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=gen)
-            rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=2)
-            rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, float(db), args.seed, gidx)   # in place
-            rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
-            rx.synchronize()
-            biterr = torch.zeros(n, dtype=torch.int64, device=dev)
-            for lo2 in range(0, n, 8192):
-                hi2 = min(lo2 + 8192, n)
-                biterr[lo2:hi2] = pop[(d_out[lo2:hi2] ^ d_pay[lo2:hi2]).long()].sum(dim=1)
-            res = d_res[:n].cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
-            counters[0] += n
-            counters[1] += int((biterr > 0).sum().item())
-            # a frame the decoder declares lost returns zeros: count its payload bits as 50 % wrong would
-            # hide nothing - we count the actual differing bits against the transmitted payload
-            counters[2] += int(biterr.sum().item())
-            counters[3] += int((res["status"] != 0).sum())
+            work.append((li, float(db), f, n))
             f += n
-        secs = time.perf_counter() - t0
-        secs, counters = shard.reduce_counters((secs, counters), world, dist, dev)
-        if rank == 0:
-            pt = {"noise_db": float(db), "frames": counters[0], "fer": counters[1] / counters[0],
-                  "ber": counters[2] / (43040.0 * counters[0]), "declared_lost": counters[3],
-                  "frames_per_s": counters[0] / secs}
-            summary.append(pt)
-            print(json.dumps(pt), flush=True)
+
+    def make(w, q):
+        """random payloads -> device transmitter -> AWGN for batch w into buffer q, on the tx stream"""
+        li, db, f, n = w
+        gidx = li * args.frames + f              # global frame index: distinct noise everywhere
+        with torch.cuda.stream(tx_stream):
+            tx_stream.wait_event(ev_free[q])
+            gen.manual_seed(args.seed * 7919 + gidx)
+            d_pay[q][:n] = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=gen)
+            tx.tx_encode(d_pay[q].data_ptr(), n, d_in[q].data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=2)
+            tx.awgn_tile(d_in[q].data_ptr(), n, d_in[q].data_ptr(), n, spf, db, args.seed, gidx)   # in place
+            ev_ready[q].record(tx_stream)
+
+    summary = []
+    acc = torch.zeros((len(levels), 4), dtype=torch.int64, device=dev)   # frames, frame errors, bit errors, declared lost
+    t_all = time.perf_counter()
+    t_level = [None] * len(levels)
+    for q in range(2):
+        ev_free[q].record(stream)
+    if work:
+        make(work[0], 0)
+    for b, w in enumerate(work):
+        li, db, f, n = w
+        q = b & 1
+        if t_level[li] is None:
+            t_level[li] = time.perf_counter()
+        stream.wait_event(ev_ready[q])
+        rx.decode_device(d_in[q].data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+        # counters stay on the device (no host synchronisation per batch): differing bits against the transmitted
+        # payload (a frame the decoder declares lost returns zeros - its actual differing bits are counted)
+        biterr = torch.zeros(n, dtype=torch.int64, device=dev)
+        for lo2 in range(0, n, 8192):
+            hi2 = min(lo2 + 8192, n)
+            biterr[lo2:hi2] = pop[(d_out[lo2:hi2] ^ d_pay[q][lo2:hi2]).long()].sum(dim=1)
+        status = d_res[:n].view(torch.int32)[:, 0]
+        acc[li] += torch.stack([torch.tensor(n, device=dev), (biterr > 0).sum(), biterr.sum(), (status != 0).sum()])
+        if args.dump:
+            torch.cuda.synchronize()
+            os.makedirs(args.dump, exist_ok=True)
+            np.save(os.path.join(args.dump, "pcm_r%d_b%d.npy" % (rank, b)), d_in[q][:n].cpu().numpy())
+            np.save(os.path.join(args.dump, "pay_r%d_b%d.npy" % (rank, b)), d_pay[q][:n].cpu().numpy())
+            np.save(os.path.join(args.dump, "out_r%d_b%d.npy" % (rank, b)), d_out[:n].cpu().numpy())
+        ev_free[q].record(stream)
+        if b + 1 < len(work):
+            make(work[b + 1], q ^ 1)             # blocks the host while the transmitter runs - beside the decode above
+        last_of_level = b + 1 == len(work) or work[b + 1][0] != li
+        if last_of_level:
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t_level[li]
+            secs, counters = shard.reduce_counters((secs, acc[li].tolist()), world, dist, dev)
+            if rank == 0:
+                pt = {"noise_db": db, "frames": counters[0], "fer": counters[1] / counters[0],
+                      "ber": counters[2] / (43040.0 * counters[0]), "declared_lost": counters[3],
+                      "frames_per_s": counters[0] / secs}
+                summary.append(pt)
+                print(json.dumps(pt), flush=True)
+    tx.close()
     if rank == 0:
         tot = sum(p["frames"] for p in summary)
         print(json.dumps({"summary": "ber_sweep", "n_gpus": world, "total_frames": tot,

@@ -2,7 +2,10 @@
 #include <hip/hip_runtime.h>
 __device__ int g_fallbacks;
 #define TS_PROBE_COUNT (&g_fallbacks)
-#include "../modem_amd/csrc/k_demod.hip"
+#ifndef TS_SRC
+#define TS_SRC "../modem_amd/csrc/k_demod.hip"
+#endif
+#include TS_SRC
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
