@@ -86,20 +86,30 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 			__syncthreads();
 		}
 		const int groups = (md.rows + 1 + SLOTS - 1) / SLOTS;
+		// the samples of the NEXT symbol are fetched while the current one is transformed (a symbol is 5 KB of raw PCM: its
+		// HBM round trip is as long as the whole transform)
+		constexpr int NQ = SYMBOL_LEN / TPS;
+		cf pre[NQ];
+		auto fetch = [&](int sym) {
+			#pragma unroll
+			for (int q = 0; q < NQ; ++q)
+				pre[q] = sym <= md.rows ? src.at(body0 + (long)sym * SYM_STRIDE + lt + TPS * q) : mk(0.f, 0.f);
+		};
+		fetch(slot);
 		for (int g = 0; g < groups; ++g) {
 			const int s = SLOTS * g + slot;                       // 0 = pilot, 1..rows = data rows
 			const bool valid = s <= md.rows;
 			cf *buf = sh.fft[slot];
 			const cf base = phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + lt);
-			#pragma unroll 2
-			for (int q = 0; q < SYMBOL_LEN / TPS; ++q) {
+			#pragma unroll
+			for (int q = 0; q < NQ; ++q) {
 				int i = lt + TPS * q;
 				cf v = mk(0.f, 0.f);
 				if (valid)   // osc() call count: symbol_len (header) + s*stride + i, decode.cc:459-470
-					v = cmul(src.at(body0 + (long)s * SYM_STRIDE + i),
-						DEMOD_NCO_TABLE ? cmul(base, rot8[q]) : phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + i));
+					v = cmul(pre[q], DEMOD_NCO_TABLE ? cmul(base, rot8[q]) : phasor(omega, (long)SYMBOL_LEN + (long)s * SYM_STRIDE + i));
 				buf[i] = v;
 			}
+			fetch(s + SLOTS);
 			fft_sync<TPS>();
 			// TPS = 64: one wave, its own buffer, no workgroup barriers; otherwise the slots run in lock-step
 			fft_fwd<SYMBOL_LEN, TPS, SYMBOL_LEN>(buf, tb.tw_sym, lt);
@@ -309,6 +319,92 @@ __device__ float select_rank(TsShared &s, int tid, int rank, Each each)
 	return v;
 }
 
+// Exact order statistic by ONE linear histogram over [lo, hi] (values outside land in the two end bins) and a resolve among
+// the members of the bin that holds the rank.  The binning is monotone in v - fp32 subtraction, multiplication by a
+// positive constant and truncation all are - so every member of a lower bin is <= every member of a higher one and
+// the wanted value is the (rank - count of the lower bins)-th smallest of its bin.  One histogram pass instead of the
+// three digit passes of select_rank when the values are known to sit in a narrow range (the bracketed slopes).
+// Returns false - nothing decided, the caller uses select_rank - if that bin holds more than 256 values (ties).
+template <typename Each>
+__device__ bool select_rank_linear(TsShared &s, int tid, int rank, float lo, float hi, Each each, float &out)
+{
+	const float inv = 2046.f / (hi - lo);
+	if (!(hi > lo) || !(inv < 3.0e38f))
+		return false;                                         // block-uniform
+	auto bin = [&](float v) {
+		const float q = (v - lo) * inv;
+		return q < 0.f ? 0 : (q >= 2046.f ? 2047 : 1 + (int)q);
+	};
+	for (int i = tid; i < 2048; i += 256)
+		s.hist[i] = 0;
+	if (tid == 0)
+		s.list_n = 0;
+	__syncthreads();
+	each([&](float v) { atomicAdd(&s.hist[bin(v)], 1); });
+	__syncthreads();
+	{   // the bin that holds sorted position `rank`, and the position inside it
+		int acc = 0;
+		#pragma unroll
+		for (int q = 0; q < 8; ++q)
+			acc += s.hist[tid * 8 + q];
+		const int lane = tid & 63, wave = tid >> 6;
+		int incl = acc;
+		#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			int o = __shfl_up(incl, d);
+			if (lane >= d)
+				incl += o;
+		}
+		if (lane == 63)
+			s.red[wave] = incl;
+		if (tid == 0)
+			s.bin[0] = -1;
+		__syncthreads();
+		int off = 0;
+		for (int w = 0; w < wave; ++w)
+			off += s.red[w];
+		const int excl = incl - acc + off;
+		if (rank >= excl && rank < excl + acc) {
+			int rr = rank - excl, b = tid * 8;
+			while (rr >= s.hist[b]) { rr -= s.hist[b]; ++b; }
+			s.bin[0] = b;
+			s.rank = rr;
+		}
+		__syncthreads();
+	}
+	const int B = s.bin[0], rr = s.rank;
+	if (B < 0)
+		return false;
+	float *mem = (float *)s.part;
+	each([&](float v) {
+		if (bin(v) == B) {
+			const int idx = atomicAdd(&s.list_n, 1);
+			if (idx < 256)
+				mem[idx] = v;
+		}
+	});
+	__syncthreads();
+	const int cnt = s.list_n;
+	if (cnt > 256) {
+		__syncthreads();
+		return false;
+	}
+	if (tid < cnt) {
+		const float mine = mem[tid];
+		int pos = 0;
+		for (int m = 0; m < cnt; ++m) {
+			const float o = mem[m];
+			pos += (o < mine) | ((o == mine) & (m < tid));
+		}
+		if (pos == rr)
+			s.pick = mine;
+	}
+	__syncthreads();
+	out = s.pick;
+	__syncthreads();
+	return true;
+}
+
 // y - s*x with the product rounded on its own (HIP's __fmul_rn is a plain '*' and would be
 // contracted into an FMA): keeps the intercepts bit-identical to the CPU's
 __device__ __forceinline__ float sub_mul_nofma(float y, float s, float x)
@@ -440,9 +536,6 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 		const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: uniform loops
 		constexpr int WCAP = TS_LIST_CAP / 4;
 		int below = 0, cfill = 0;
-#if defined(TS_VARIANT_PERLANE)
-		int vcnt = 0, vcnt2 = 0;
-#endif
 		unsigned *list = (unsigned *)s.buf + wave * WCAP;
 		const float T_lo_m = T_lo - (1e-6f * fabsf(T_lo) + 1e-36f);
 		const float T_hi_m = T_hi + (1e-6f * fabsf(T_hi) + 1e-36f);
@@ -465,61 +558,64 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 		__syncthreads();
 #ifndef TS_PROBE_SKIP_MAIN
 		{
+			// Per pair: two subtractions and two v_alignbit - the SIGN of (zl_j - thr_lo) is "below", the sign of
+			// (thr_hi - zh_j) is "above", and acc = (acc << 1) | sign shifts each into a per-lane 32-bit history, so a
+			// window of 32 distances costs no compare, no scalar instruction and no branch (on this chip a VALU
+			// instruction costs a SIMD 3.3 cycles, a compare into an SGPR 5.3 and every scalar instruction 4.8 -
+			// tools/ubench_issue.hip).  Per window: below += popcount(history) per lane (one v_bcnt), the pairs that are
+			// neither below nor above (2-3 %) are peeled off bit by bit into the wave's list.
 			const int nblk = (n + 63) >> 6;
+			int cbl = 0;                                          // this lane's "below" count
+			constexpr int W = 32;                                 // distances per window = bits of the history registers
 			for (int b = 0; b < nblk; ++b) {
 				const int i = b * 64 + lane;
 				const float2 zi = z2[i];
-				const float zl_thr = i < n ? zi.x - margin : -3.0e38f;
-				const float zh_thr = i < n ? zi.y + margin : -3.0e38f;
+				const float thr_lo = i < n ? zi.x - margin : -3.0e38f;
+				const float thr_hi = i < n ? zi.y + margin : -3.0e38f;
 				const int dmax = n - 1 - b * 64;              // largest distance with any existing pair
 				const float2 *zp = z2 + i + 1;
-#ifndef TS_U
-#define TS_U 8
-#endif
-				constexpr int U = TS_U;
-				for (int d0 = wave * U; d0 < dmax; d0 += 4 * U) {   // distances d0+1 .. d0+U; wave w takes every 4th group
-					// all sixteen neighbours first: one LDS round trip per step instead of sixteen dependent ones
-					float2 zv[U];
-					#pragma unroll
-					for (int u = 0; u < U; ++u)
-						zv[u] = zp[d0 + u];
-					__builtin_amdgcn_sched_barrier(0);
-#if defined(TS_VARIANT_PERLANE)
-					// experiment: per-lane counters, no scalar work per pair (results wrong: timing only)
-					#pragma unroll
-					for (int u = 0; u < U; ++u) {
-						vcnt += (zv[u].x < zl_thr) ? 1 : 0;
-						vcnt2 += (zv[u].y > zh_thr) ? 1 : 0;
-					}
-#else
-					#pragma unroll
-					for (int u = 0; u < U; ++u) {
-						const bool lo = zv[u].x < zl_thr, hi = zv[u].y > zh_thr;   // certainly below T_lo / above T_hi
-						const unsigned long long mlo = __builtin_amdgcn_ballot_w64(lo);
-						const unsigned long long mhi = __builtin_amdgcn_ballot_w64(hi);
-						below += __popcll(mlo);                   // wave-uniform scalar count
-						const unsigned long long bal = ~(mlo | mhi);
-#ifndef TS_VARIANT_NOHIT
-						if (bal) {                                // rare for short distances, dense for the longest ones
-							if (!(lo | hi)) {
-								int slot = cfill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-								slot = slot < WCAP ? slot : WCAP - 1;     // an overflowing wave is detected below
-								list[slot] = (unsigned)i | ((unsigned)(d0 + u + 1) << 16);
-							}
-							cfill += __popcll(bal);
+				for (int d0 = wave * W; d0 < dmax; d0 += 4 * W) {   // distances d0+1 .. d0+32; wave w takes every 4th window
+					uint32_t accB = 0, accA = 0;
+					#pragma unroll 1
+					for (int s8 = 0; s8 < W; s8 += 8) {
+						float2 zv[8];
+						#pragma unroll
+						for (int u = 0; u < 8; ++u)
+							zv[u] = zp[d0 + s8 + u];
+						__builtin_amdgcn_sched_barrier(0);
+						#pragma unroll
+						for (int u = 0; u < 8; ++u) {
+							// (plain v_sub_f32 by hand: left to itself the compiler packs the two subtractions into one v_pk_add_f32
+							// plus two register moves, 13 SIMD cycles instead of 6.6)
+							float tb, ta;
+							asm("v_sub_f32_e32 %0, %1, %2" : "=v"(tb) : "v"(zv[u].x), "v"(thr_lo));
+							asm("v_sub_f32_e32 %0, %1, %2" : "=v"(ta) : "v"(thr_hi), "v"(zv[u].y));
+							accB = __builtin_amdgcn_alignbit(accB, __float_as_uint(tb), 31);   // (accB << 1) | sign(tb)
+							accA = __builtin_amdgcn_alignbit(accA, __float_as_uint(ta), 31);
 						}
-#else
-						cfill += (int)(bal & 1);
-#endif
 					}
-#endif
+					cbl += __popc(accB);
+					uint32_t in = ~(accB | accA);                 // bit 31-u: the pair at distance d0+u+1 needs the exact division
+					for (;;) {
+						const unsigned long long m = __builtin_amdgcn_ballot_w64(in != 0);
+						if (!m)
+							break;
+						if (in != 0) {
+							const int u = __clz(in);
+							int slot = cfill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+							slot = slot < WCAP ? slot : WCAP - 1;     // an overflowing wave is detected below
+							list[slot] = (unsigned)i | ((unsigned)(d0 + u + 1) << 16);
+							in &= ~(0x80000000u >> u);
+						}
+						cfill += __popcll(m);
+					}
 				}
 			}
+			#pragma unroll
+			for (int mm = 32; mm; mm >>= 1)
+				cbl += __shfl_xor(cbl, mm);
+			below = cbl;
 		}
-#endif
-#if defined(TS_VARIANT_PERLANE)
-		below = vcnt + (vcnt2 & 1);
-		(void)list;
 #endif
 		if (lane == 0) {
 			s.red[wave] = below;
@@ -551,7 +647,11 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 			});
 			__syncthreads();
 			auto lst = [&](auto emit) { segs([&](int i) { emit(s.buf[i]); }); };
-			float v = select_rank(s, tid, r, lst);
+			float v;
+#ifndef TS_NO_LINEAR_SELECT
+			if (!select_rank_linear(s, tid, r, T_lo, T_hi, lst, v))   // the listed slopes sit in or next to [T_lo, T_hi]
+#endif
+				v = select_rank(s, tid, r, lst);
 			if (v >= T_lo && v <= T_hi) {
 				slope = v;
 				done = true;
@@ -619,9 +719,11 @@ __global__ __launch_bounds__(256, TS_WAVES) void k_theil_sen(const SyncState *__
 		}
 		__syncthreads();
 		float slope, yint;
-		if (md.cols == CONS_COLS)                             // mode 6: compile-time trip counts
+#ifdef TS_SPECIALIZE_432
+		if (md.cols == CONS_COLS)                             // mode 6: compile-time trip counts (a second copy of the whole block)
 			theil_sen_block(s, CONS_COLS, tid, slope, yint);
 		else
+#endif
 			theil_sen_block(s, md.cols, tid, slope, yint);
 		#pragma unroll
 		for (int q = 0; q < 2; ++q) {                         // decode.cc:493-494

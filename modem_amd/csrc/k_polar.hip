@@ -156,9 +156,16 @@ struct PolarBufs {
 // the path's ancestor at t = 2^z, the very lane map the stored array would have been read with) with the same
 // g_add, so every value is bit-identical: 2 MB fewer writes and ~1.5 MB fewer reads per codeword.
 //   SRC_R 1: C = compact level m+2      SRC_R 2: C = the channel LLRs (m = 14)
-template <int D, int KIND, int NG, bool SRC_C = false, bool DST_C = false, bool SKIP0 = false, int SRC_R = 0>
-__device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int hb_g_off, int m, int lane, int gl)
+// TERM (D = 1 only): the produced level is the array of an all-information node of 512..2048 leaves that is DECIDED, not
+// walked: nothing is stored; the pass returns the lane's smallest magnitude (mu, for the stable-list test) and writes
+// the sign bits of all eight paths as the node's partial-sum bytes (bit k = path k) straight to the byte array.  If
+// the test fails the caller runs the ordinary pass and walks the node; the bytes are overwritten then.
+template <int D, int KIND, int NG, bool SRC_C = false, bool DST_C = false, bool SKIP0 = false, int SRC_R = 0, bool TERM = false>
+__device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int hb_g_off, int m, int lane, int gl,
+	uint32_t *mu_out = nullptr, uint8_t *hard_t = nullptr)
 {
+	static_assert(!TERM || (D == 1 && NG == 0), "terminal passes produce one level");
+	uint32_t mu = 0x7f800000u;
 	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
 #ifndef POLAR_XB3
 #define POLAR_XB3 2
@@ -217,6 +224,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 					if (KIND & 1)
 						h[xb][s2] = bload_u8(pb.hard, v_h + xb * 8, so_h[s2]);
 				}
+		unsigned long long mine = 0;
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
 			if (x0 + xb < S) {
@@ -224,7 +232,12 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 				#pragma unroll
 				for (int s2 = 0; s2 < NT; ++s2) {
 					v[s2] = (KIND & 1) ? g_add(a[xb][s2], b[xb][s2], (h[xb][s2] >> k) & 1) : f_minsum(a[xb][s2], b[xb][s2]);
-					if (SKIP0) {
+					if (TERM) {
+						mu = min(mu, __float_as_uint(v[s2]) & 0x7fffffffu);
+						const unsigned long long bal = __ballot(v[s2] < 0.f);
+						if (lane == xb)
+							mine = bal;
+					} else if (SKIP0) {
 					} else if (NG > 0) {
 						if (!DST_C) bstore<(((POLAR_NT == 1 || POLAR_NT == 3) && NG == 3) || POLAR_NT == 2) ? 2 : 0>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]);
 						else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[0][s2], v[s2]);
@@ -243,7 +256,11 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 					}
 				}
 			}
+		if (TERM && lane < XB && x0 + lane < S)               // XB positions x 8 bytes
+			*(unsigned long long *)(hard_t + (size_t)(x0 + lane) * 8) = mine;
 	}
+	if (TERM)
+		*mu_out = mu;
 }
 
 
@@ -536,9 +553,9 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 				ho_g = t - (1 << z);                          // left child's partial sums (published bytes)
 				cur = z; kind = z == 15 ? 3 : 1;
 			}
-			bool try_big = LtT >= 9, redo;
-			int stop = try_big ? LtT : 8;
-			do {
+			bool try_big = LtT >= 9;
+			int stop = try_big ? LtT + 1 : 8;
+			for (;;) {
 				while (cur >= stop) {
 					// produced levels stay >= 8: three per pass down to 10, then (9, 8) and (8); NG = how many are above level 8
 					const int D = cur >= 10 ? 3 : (cur == 9 ? 2 : 1);
@@ -548,11 +565,6 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 						if (cur == 15) FP(3, 2, 3, false, true);      // levels 15, 14, 13
 						else if (cur == 12) FP(3, 0, 3, true, true);  // 12, 11, 10
 						else FP(2, 0, 1, true, true);                 // 9 and 8 (LDS)
-					} else if (spine && cur == LtT) {
-						// right sibling on the left spine that is a node decided on its own array (below): stored
-						if (cur >= 11) FP(3, 1, 3, true);
-						else if (cur == 10) FP(3, 1, 2, true);
-						else FP(2, 1, 1, true);
 					} else if (spine) {
 						// right sibling on the left spine: its source was stored compact at t = 0; its own top level
 						// (if >= 9) is not stored, the one later reader recomputes it (SRC_R below)
@@ -586,46 +598,31 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 					kind = 0;
 					PROF(0);
 				}
-				redo = false;
-				if (try_big) {
-					// rate-1 node of 512..2048 leaves on its array in the level store (cnt = 64..256 values per lane); the sign
-					// bytes go straight to the partial-sum array.  None of the levels below it is ever needed.
-					try_big = false;
-					const int cnt = 1 << (LtT - 3), base = (8 << LtT) * 4;
+				if (!try_big)
+					break;
+				// All-information node of 512..2048 leaves that starts here: decided by a terminal pass over its SOURCE - the
+				// node's own array is never stored, none of the levels below it is computed.  (Taken when the node's level is
+				// the next one to produce - in both frozen tables every such node is a right child, so that is always; a
+				// node reached by an overshooting three-level pass is walked.)  If the list is not provably stable the
+				// ordinary pass runs and the node is walked.
+				try_big = false;
+				stop = 8;
+				if (cur == LtT) {
 					uint32_t mu = 0x7f800000u;
-					for (int x0 = 0; x0 < cnt; x0 += 16) {
-						float v[16];
-						#pragma unroll
-						for (int u = 0; u < 16; ++u)
-							v[u] = bload(pb.soft, lane * 4, base + (x0 + u) * 256);
-						#pragma unroll
-						for (int u = 0; u < 16; ++u)
-							mu = min(mu, __float_as_uint(v[u]) & 0x7fffffffu);
-					}
-					if (stable(mu)) {
-						for (int x0 = 0; x0 < cnt; x0 += 16) {
-							float v[16];
-							#pragma unroll
-							for (int u = 0; u < 16; ++u)
-								v[u] = bload(pb.soft, lane * 4, base + (x0 + u) * 256);
-							unsigned long long mine = 0;
-							#pragma unroll
-							for (int u = 0; u < 16; ++u) {
-								const unsigned long long bal = __ballot(v[u] < 0.f);
-								if (lane == u)
-									mine = bal;
-							}
-							if (lane < 16)                        // 16 positions x 8 bytes: one 128-byte store
-								*(unsigned long long *)(hard + t + (x0 + lane) * 8) = mine;
-						}
+					#define FT(...) fused_pass<1, __VA_ARGS__, true>(pb, ls8, ho_g, cur, lane, gl, &mu, hard + t)
+					if (kind == 1 && (t & (t - 1)) == 0) FT(1, 0, true, false, false, 0);          // spine: compact source
+					else if (kind == 1 && (t >> cur) == 3) FT(1, 0, false, false, false, 1);       // its right child: recomputed source
+					else if (kind == 1) FT(1, 0, false, false, false, 0);
+					else FT(0, 0, false, false, false, 0);
+					#undef FT
+					WAVE_ORDER();
+					if (stable(mu))
 						Ln = LtT;
-					} else {
-						stop = 8;
-						redo = cur >= 8;
-					}
 					PROF(2);
+					if (Ln)
+						break;
 				}
-			} while (redo);
+			}
 		}
 		if (!Ln && LtT == 8) {
 			// rate-1 node of 256 leaves on the LDS array (32 values per lane)

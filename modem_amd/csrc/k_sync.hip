@@ -145,12 +145,18 @@ __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, 
 }
 
 // ---------------------------------------------------------------- D2 + D3 sync
-constexpr int TILE = 1024, PER = 16, MRING = 2048;
+#ifndef SYNC_PER
+#define SYNC_PER 8     // sample times per lane and tile: 8 -> 224 VGPRs and 22 KB of LDS, so that a sync wave fits on a SIMD beside
+                       // three resident polar decoders (the whole front runs inside the polar phase); 16 -> 256 VGPRs, 30 KB
+#endif
+constexpr int PER = SYNC_PER, TILE = 64 * PER;
+// ring of the last TILE + match_len metric values (a power of two): 1024 at 8 / 16 kHz, 2048 at 44.1 / 48 kHz
+template <int RATE> struct SyncRing { static constexpr int N = TILE + RateCfg<RATE>::MATCH_LEN <= 1024 ? 1024 : 2048; };
 
 // 8 kHz: the two 640-point work arrays of the trigger part live in LDS.  Other rates (1280 / 3528 / 3840
 // points) keep them in a per-frame global scratch so the scanning loop's occupancy does not pay for them.
 template <int RATE> struct SyncShared {
-	double m[MRING];
+	double m[SyncRing<RATE>::N];
 	float timing[TILE];
 	cf buf[RATE == 8000 ? RateCfg<RATE>::HS : 1];
 	cf xr[RATE == 8000 ? RateCfg<RATE>::HS : 1];
@@ -275,6 +281,7 @@ __global__ __launch_bounds__(64) void k_sync(FrameBatch fb, const cf *__restrict
 	typedef RateCfg<RATE> RC;
 	constexpr int BUFFER_LEN = RC::BUFFER_LEN, SEARCH_POS = RC::SEARCH_POS, HALF_LEN = RC::HS, GUARD_LEN = RC::GL;
 	constexpr int MATCH_LEN = RC::MATCH_LEN, MATCH_DEL = RC::MATCH_DEL;
+	constexpr int MRING = SyncRing<RATE>::N;
 	static_assert(TILE + MATCH_LEN <= MRING, "m ring too small");
 	const int f = blockIdx.x, lane = threadIdx.x;
 	SyncState st = st_all[f];

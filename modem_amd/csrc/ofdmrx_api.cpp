@@ -226,7 +226,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		}
 		int cus = 0;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
-		int wpc = 12;             // polar waves per CU while the next chunk's Theil-Sen stage shares the machine
+		int wpc = 13;             // polar waves per CU while the next chunk's Theil-Sen stage shares the machine
 		if (const char *e2 = std::getenv("OFDMRX_POLAR_WPC"))
 			wpc = std::atoi(e2);
 		h->polar_grid = wpc > 0 && cus > 0 ? wpc * cus : 0;
@@ -539,9 +539,32 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, int fmt, int channel
 		return r;
 	const size_t NONE = (size_t)-1;
 	std::vector<size_t> ev_back(n_chunks, NONE), ev_f2(n_chunks, NONE), t0s(n_chunks, 0);
+	// back(c-1) is launched once sync / header / demod of chunk c are through: those kernels are short and latency-bound,
+	// and although each fits on a CU beside the resident polar grid (sync 224 VGPRs / 22 KB, header 216 / 18 KB, demod
+	// 128 / 10 KB against 12 decoders x 96 VGPRs / 8 KB) they starve there - measured: 138.7 k frames/s with the whole
+	// front inside the polar phase (OFDMRX_FRONT_OVERLAP=1) against 142.7 k with this order.
+	static const bool front_exclusive = std::getenv("OFDMRX_FRONT_OVERLAP") == nullptr;
+	auto enqueue_back = [&](size_t p, size_t ev_f1, bool last) -> int {
+		uint8_t *pay;
+		Result *res;
+		hooks.dst(p, &pay, &res);
+		HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f2[p]], 0));
+		if (ev_f1 != NONE)
+			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
+		int rr = run_back(h, h->stream_b, (int)(p & 1), n_of(p), last ? 0 : h->polar_grid, pay, res, true, t0s[p]);
+		if (rr)
+			return rr;
+		ev_back[p] = mark(h, h->stream_b);
+		return hooks.after_back(p, ev_back[p], h->stream_b);
+	};
 	for (size_t c = 0; c <= n_chunks; ++c) {
 		const int par = (int)(c & 1);
 		size_t ev_f1 = NONE;
+		if (c >= 1 && !front_exclusive) {                    // nothing left to share the machine with after the last chunk: all decoders resident
+			r = enqueue_back(c - 1, NONE, c == n_chunks);
+			if (r)
+				return r;
+		}
 		if (c < n_chunks) {
 			FrameBatch fb{ nullptr, stride, (long)spf, fmt, channels };
 			size_t ready = NONE;
@@ -560,20 +583,8 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, int fmt, int channel
 			if (r)
 				return r;
 		}
-		if (c >= 1) {
-			const size_t p = c - 1;
-			uint8_t *pay;
-			Result *res;
-			hooks.dst(p, &pay, &res);
-			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f2[p]], 0));
-			if (ev_f1 != NONE)
-				HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
-			const bool last = c == n_chunks;                 // nothing left to share the machine with: all decoders resident
-			r = run_back(h, h->stream_b, (int)(p & 1), n_of(p), last ? 0 : h->polar_grid, pay, res, true, t0s[p]);
-			if (r)
-				return r;
-			ev_back[p] = mark(h, h->stream_b);
-			r = hooks.after_back(p, ev_back[p], h->stream_b);
+		if (c >= 1 && front_exclusive) {
+			r = enqueue_back(c - 1, ev_f1, c == n_chunks);
 			if (r)
 				return r;
 		}

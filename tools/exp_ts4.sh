@@ -1,0 +1,13 @@
+#!/bin/bash
+O=$PWD/gpurun_out/ts4.txt; mkdir -p gpurun_out; : > $O
+pick='import json,sys
+d=json.loads(sys.stdin.readline()); s=d["stage_ms_per_step"]; print("value", round(d["value"]), "polar", round(s["polar"],1), "ts", round(s["theilsen"],2), "demod", round(s["demod"],2), "fer", d["fer"], "ok", d["frames_ok"])'
+V=$PWD/modem_amd/lib/variants
+for lib in default ts432; do
+	L=$V/libofdmrx_$lib.so; [ $lib = default ] && L=$PWD/modem_amd/lib/libofdmrx.so
+	echo -n "$lib one chunk alone: " >> $O
+	MODEM_AMD_LIB=$L OFDMRX_NO_OVERLAP=1 timeout 300 python3 bench.py --frames 8192 --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 2>&1 | tail -1 | python3 -c "$pick" >> $O 2>&1
+	echo -n "$lib overlapped: " >> $O
+	MODEM_AMD_LIB=$L timeout 300 python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 2>&1 | tail -1 | python3 -c "$pick" >> $O 2>&1
+done
+cat $O
