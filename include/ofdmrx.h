@@ -204,7 +204,8 @@ long ofdmrx_tx_frame_samples(int oper_mode);
 /* Streams of `count` payloads, as `encode OUT RATE BITS CHANNELS OFFSET MODE CALLSIGN file1 .. fileN` writes them
  * (encode.cc:288-313: pilot | count x (S&C, meta, pilot, rows) | zero symbol, `rate` samples of silence either side),
  * bits = 8 (unsigned, offset 128) or 16.  ofdmrx_stream_samples: sample frames of one such stream.
- * _device: n_streams x count x 5380 payload bytes in, n_streams x samples x channels PCM out, DEVICE pointers.
+ * _device: n_streams x count x 5380 payload bytes in, n_streams x samples x channels PCM out, DEVICE pointers;
+ * asynchronous on the handle's stream like the decode entry (scratch is kept in the handle: no allocation per call).
  * ofdmrx_tx_encode_stream: the same for ONE stream with HOST pointers (what the `encode` CLI calls). */
 long ofdmrx_stream_samples(int sample_rate, int oper_mode, int count);
 /* call sign -> the base-37 integer of the header (encode.cc:320-335: ' ' = 0, digits 1..10, letters of either case

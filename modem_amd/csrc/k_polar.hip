@@ -127,9 +127,10 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int bytes)
 {
 	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
-#ifndef POLAR_NT
-#define POLAR_NT 1     // 1 = the top level of every three-level pass (levels >= 11, written once and read once ~ms later) is stored
-                       // and loaded non-temporal: -5 % kernel time (r02 sweep: 0 off, 2 everything, 3 stores only, 4 loads only)
+#ifndef POLAR_NT_LEVEL
+#define POLAR_NT_LEVEL 10   // level-store accesses of levels >= this are non-temporal (written once, read once a long time later: keeping
+                            // them out of the caches leaves room for level 9, which is re-read soon).  r02 sweep, k_polar alone at 16
+                            // decoders per CU, ms per 65536 codewords: none 316, >= 13 312, >= 12 304, >= 11 300, >= 10 290, all 317
 #endif
 #ifndef POLAR_WAVES_PER_SIMD
 #define POLAR_WAVES_PER_SIMD 5     // register budget: 5 waves per SIMD = 96 VGPRs (13 dwords of scratch) so that Theil-Sen workgroups of the next
@@ -217,19 +218,13 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 						a[xb][s2] = g_add(a1, a2, (ha >> anc) & 1);
 						b[xb][s2] = g_add(b1, b2, (hb >> anc) & 1);
 					} else {
-#ifdef POLAR_NT_LEVEL
-						if (KIND < 2 && !SRC_C && m + 1 >= POLAR_NT_LEVEL) {
+						if (KIND < 2 && !SRC_C && m + 1 >= POLAR_NT_LEVEL) {      // loop-invariant: two copies of the load group
 							a[xb][s2] = bload<2>(C, v_src + xb * XS, so_a[s2]);
 							b[xb][s2] = bload<2>(C, v_src + xb * XS, so_a[s2] + hx);
 						} else {
 							a[xb][s2] = bload<0>(C, v_src + xb * XS, so_a[s2]);
 							b[xb][s2] = bload<0>(C, v_src + xb * XS, so_a[s2] + hx);
 						}
-#else
-						constexpr int AUXL = (((POLAR_NT == 1 || POLAR_NT == 4) && NG == 3) || POLAR_NT == 2) && KIND < 2 && !SRC_C ? 2 : 0;
-						a[xb][s2] = bload<AUXL>(C, v_src + xb * XS, so_a[s2]);
-						b[xb][s2] = bload<AUXL>(C, v_src + xb * XS, so_a[s2] + hx);
-#endif
 					}
 					if (KIND & 1)
 						h[xb][s2] = bload_u8(pb.hard, v_h + xb * 8, so_h[s2]);
@@ -249,11 +244,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 							mine = bal;
 					} else if (SKIP0) {
 					} else if (NG > 0) {
-#ifdef POLAR_NT_LEVEL
 						if (!DST_C) { if (m >= POLAR_NT_LEVEL) bstore<2>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]); else bstore<0>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]); }
-#else
-						if (!DST_C) bstore<(((POLAR_NT == 1 || POLAR_NT == 3) && NG == 3) || POLAR_NT == 2) ? 2 : 0>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]);
-#endif
 						else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[0][s2], v[s2]);
 					} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
 				}
@@ -264,11 +255,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 					for (int s2 = 0; s2 < n; ++s2) {
 						v[s2] = f_minsum(v[s2], v[s2 + n]);
 						if (NG > d) {
-#ifdef POLAR_NT_LEVEL
 							if (!DST_C) { if (m - d >= POLAR_NT_LEVEL) bstore<2>(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]); else bstore<0>(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]); }
-#else
-							if (!DST_C) bstore<POLAR_NT == 2 ? 2 : 0>(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]);
-#endif
 							else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[d][s2], v[s2]);
 						} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
 					}

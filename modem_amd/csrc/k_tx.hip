@@ -16,6 +16,7 @@ struct TxParams {
 	unsigned long long md;                     // (call_sign << 8) | mode  (encode.cc:291)
 	long frame_samples;
 	int count, bits;                           // payloads per stream (encode.cc:289 loop), 8 or 16 bit samples
+	int symbol_len;
 };
 
 // ---------------------------------------------------------------- polar systematic encoder
@@ -93,6 +94,44 @@ template <int RATE> struct TxCfg {
 	static constexpr bool BIG_IN_LDS = RATE <= 16000;
 	static constexpr int NT = BIG_IN_LDS ? 256 : 1024;
 };
+// The payload carriers of data row j are pilot x the product of the PSK symbols of rows 0..j (the transmitter's
+// differential step, encode.cc:304-309: fdom[] keeps multiplying).  One pass per payload forms all rows in that order -
+// the very sequence of fp32 complex products the reference runs - and parks them (rows x cols cf, 173 KB in mode 6), so a
+// symbol's block reads its row instead of redoing j products per carrier (that recomputation was 80 % of the
+// transmitter's instructions).
+__global__ __launch_bounds__(256) void k_tx_rows(const uint32_t *__restrict__ code_all, Tables tb, TxParams tp, cf *__restrict__ rowsym_all)
+{
+	const int fp = blockIdx.x, tid = threadIdx.x;             // one block per payload (stream x count)
+	const ModeDesc md = mode_desc(tp.oper_mode);
+	const int SL = tp.symbol_len;
+	const float code_fac = sqrtf((float)SL / (float)md.cols);    // encode.cc:135
+	const uint32_t *code = code_all + (size_t)fp * 2048;
+	cf *out = rowsym_all + (size_t)fp * CONS_MAX;
+	const float cos_pi_8 = 0.92387953251128675613f, sin_pi_8 = 0.38268343236508977173f, r2 = 0.70710678118654752440f;
+	for (int i = tid; i < md.cols; i += 256) {
+		cf acc = mk(code_fac * tb.mls2_nrz[i], 0.f);
+		for (int r = 0; r < md.rows; ++r) {
+			const int p = md.mod_bits * (md.cols * r + i);
+			float b[3];
+			#pragma unroll
+			for (int t = 0; t < 3; ++t) {
+				int q = p + t;
+				b[t] = t < md.mod_bits ? (float)(1 - 2 * (int)((code[q >> 5] >> (q & 31)) & 1)) : 1.f;
+			}
+			cf m;
+			if (md.mod_bits == 3) {                           // psk.hh:132-139
+				float re = cos_pi_8, im = sin_pi_8;
+				if (b[0] < 0.f) { re = sin_pi_8; im = cos_pi_8; }
+				m = mk(re * b[1], im * b[2]);
+			} else {
+				m = mk(r2 * b[0], r2 * b[1]);                 // psk.hh:82-85
+			}
+			acc = cmul(acc, m);
+			out[(size_t)r * md.cols + i] = acc;
+		}
+	}
+}
+
 template <int RATE> struct TxShared {
 	cf big[TxCfg<RATE>::BIG_IN_LDS ? 4 * RateCfg<RATE>::SL : 1];
 	cf fdom[RateCfg<RATE>::SL];
@@ -100,7 +139,7 @@ template <int RATE> struct TxShared {
 
 // symbol kinds in transmission order (encode.cc:288-313): pilot | S&C | meta | pilot | rows x data | zero
 template <int RATE>
-__global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const uint32_t *__restrict__ code_all, Tables tb, TxParams tp,
+__global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const cf *__restrict__ rowsym_all, Tables tb, TxParams tp,
 	const cf *__restrict__ tw5120, cf *__restrict__ tdom_all, cf *__restrict__ big_scratch)
 {
 	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, NT = TxCfg<RATE>::NT;
@@ -157,33 +196,13 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const uint32_t *_
 			}
 		}
 	} else if (sidx != last) {
-		// pilot (w == 2, and the leading one) or data row j = w - 3: fdom = pilot * product of the rows' PSK symbols (encode.cc:304-309)
+		// pilot (w == 2, and the leading one) or data row j = w - 3: fdom = pilot * product of the rows' PSK symbols
+		// (encode.cc:304-309), formed once per payload by k_tx_rows
 		const int j = w - 3;
 		const float code_fac = sqrtf((float)SYMBOL_LEN / (float)md.cols);   // encode.cc:135
-		const uint32_t *code = code_all + ((size_t)f * tp.count + pay) * 2048;
-		const float cos_pi_8 = 0.92387953251128675613f, sin_pi_8 = 0.38268343236508977173f, r2 = 0.70710678118654752440f;
-		for (int i = tid; i < md.cols; i += NT) {
-			cf acc = mk(code_fac * tb.mls2_nrz[i], 0.f);
-			for (int r = 0; r <= j; ++r) {
-				const int p = md.mod_bits * (md.cols * r + i);
-				float b[3];
-				#pragma unroll
-				for (int t = 0; t < 3; ++t) {
-					int q = p + t;
-					b[t] = t < md.mod_bits ? (float)(1 - 2 * (int)((code[q >> 5] >> (q & 31)) & 1)) : 1.f;
-				}
-				cf m;
-				if (md.mod_bits == 3) {                       // psk.hh:132-139
-					float re = cos_pi_8, im = sin_pi_8;
-					if (b[0] < 0.f) { re = sin_pi_8; im = cos_pi_8; }
-					m = mk(re * b[1], im * b[2]);
-				} else {
-					m = mk(r2 * b[0], r2 * b[1]);             // psk.hh:82-85
-				}
-				acc = cmul(acc, m);
-			}
-			sh.fdom[bin1280(i + code_off)] = acc;
-		}
+		const cf *rowsym = rowsym_all + ((size_t)f * tp.count + pay) * CONS_MAX + (size_t)(j < 0 ? 0 : j) * md.cols;
+		for (int i = tid; i < md.cols; i += NT)
+			sh.fdom[bin1280(i + code_off)] = j < 0 ? mk(code_fac * tb.mls2_nrz[i], 0.f) : rowsym[i];
 	}
 	__syncthreads();
 	// symbol(): encode.cc:101-109
@@ -290,12 +309,14 @@ size_t tx_big_scratch_bytes(int rate, int n, int nsym)
 }
 
 void launch_tx(hipStream_t s, int rate, int n, const uint8_t *payload, Tables tb, const void *tp_, const cf *tw5120,
-	uint32_t *code, cf *tdom, cf *big_scratch, void *pcm)
+	uint32_t *code, cf *rowsym, cf *tdom, cf *big_scratch, void *pcm)
 {
 	TxParams tp = *(const TxParams *)tp_;
+	tp.symbol_len = rate_symbol_len(rate);
 	hipLaunchKernelGGL(k_tx_code, dim3(n * tp.count), dim3(256), 0, s, payload, tb, tp, code);
+	hipLaunchKernelGGL(k_tx_rows, dim3(n * tp.count), dim3(256), 0, s, code, tb, tp, rowsym);
 	RX_RATE_SWITCH(rate,
-		hipLaunchKernelGGL(k_tx_symbol<RATE>, dim3(n * tp.nsym), dim3(TxCfg<RATE>::NT), 0, s, code, tb, tp, tw5120, tdom, big_scratch);
+		hipLaunchKernelGGL(k_tx_symbol<RATE>, dim3(n * tp.nsym), dim3(TxCfg<RATE>::NT), 0, s, rowsym, tb, tp, tw5120, tdom, big_scratch);
 		hipLaunchKernelGGL(k_tx_assemble<RATE>, dim3(n * (tp.nsym + 2)), dim3(256), 0, s, tdom, tp, pcm));
 }
 

@@ -89,7 +89,7 @@ void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t
 void launch_channel(hipStream_t s, int rate, const int16_t *in, int16_t *out, size_t n, size_t spf, const void *params);
 size_t tx_big_scratch_bytes(int rate, int n, int nsym);
 void launch_tx(hipStream_t s, int rate, int n, const uint8_t *payload, Tables tb, const void *tp, const cf *tw_sym4,
-	uint32_t *code, cf *tdom, cf *big_scratch, void *pcm);
+	uint32_t *code, cf *rowsym, cf *tdom, cf *big_scratch, void *pcm);
 void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts);
 
 }  // namespace rx

@@ -126,8 +126,10 @@ struct ofdmrx_handle {
 	DevBuf st, hdr_soft, cons, slope, yint, precision, llr, soft, hard, metric, lane_mesg, res, payload;
 	DevBuf st2, llr2;         // second parity of the two buffers that cross from the front stages to the polar stage
 	DevBuf payload2, res2;    // second parity of the device-side output staging (host-pointer entry)
+	DevBuf tx_code, tx_rowsym, tx_tdom, tx_big;   // transmitter scratch, kept between calls (no allocation, no synchronisation per call)
 	hipStream_t stream_b = nullptr;   // polar + finish of chunk c run here while the front stages of chunk c+1 run on `stream`
 	hipStream_t stream_c = nullptr;   // host-pointer entry: host-to-device copies of the next chunk
+	hipStream_t stream_f[2] = { nullptr, nullptr };   // sync / header / demod of a chunk run as four sub-batches over three streams
 	hipError_t sticky = hipSuccess;   // first failed hipEventRecord of the running call
 	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
 	int last_par = 0;         // parity used by the last chunk (taps)
@@ -224,6 +226,14 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 			ofdmrx_destroy(h);
 			return OFDMRX_E_HIP;
 		}
+		for (hipStream_t &sf : h->stream_f) {
+			e = hipStreamCreateWithFlags(&sf, hipStreamNonBlocking);
+			if (e != hipSuccess) {
+				g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+				ofdmrx_destroy(h);
+				return OFDMRX_E_HIP;
+			}
+		}
 		int cus = 0;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
 		int wpc = 13;             // polar waves per CU while the next chunk's Theil-Sen stage shares the machine
@@ -263,13 +273,13 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 	(void)hipSetDevice(h->cfg.device);
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
-	for (hipStream_t sx : { h->stream_b, h->stream_c })
+	for (hipStream_t sx : { h->stream_b, h->stream_c, h->stream_f[0], h->stream_f[1] })
 		if (sx) {
 			(void)hipStreamSynchronize(sx);
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2 })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -350,7 +360,7 @@ static size_t mark(ofdmrx_handle *h, hipStream_t on = nullptr)
 		h->sticky = e;
 	return i;
 }
-static size_t events_per_chunk(int max_skip) { return 20 + 3 * (size_t)(max_skip + 1); }
+static size_t events_per_chunk(int max_skip) { return 32 + 16 * (size_t)(max_skip + 1); }
 
 // One resident chunk = every stage of SURVEY 8(a) D1..D10 as kernels, in two halves:
 //   front (D1..D8: front end, sync/header rounds, demod, Theil-Sen, LLRs) -> st[par], llr[par]
@@ -369,33 +379,60 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, i
 		launch_front_end(s, h->rate, n, fb, h->host.front, nullptr, h->z.as<cf>());
 	}
 	size_t e1 = mark(h, s);
-	launch_init_sync(s, n, st, d_skip);
+	// sync, header and demod are short, latency-bound kernels with different shapes (1 wave x 224 VGPRs, 4 waves x 216, 4 waves
+	// x 128).  OFDMRX_FRONT_SPLIT=1 sends a chunk through them as four sub-batches over three streams, so that the sync of
+	// one sub-batch runs beside the header / demod of another (frames are independent; every per-frame array is offset).
+	// Measured neutral to slightly negative (147.9 k against 148.7 k frames/s), so it is off by default.
+	static const bool split_on = std::getenv("OFDMRX_FRONT_SPLIT") != nullptr;
+	const int parts = (n >= 2048 && split_on && h->stream_f[0] && h->stream_f[1]) ? 4 : 1;
+	const int per = (n + parts - 1) / parts;
+	const size_t sl = (size_t)rate_symbol_len(h->rate);
 	size_t e3 = e1;
-	for (int round = 0; round <= max_skip; ++round) {      // decode.cc:390-448 do { } while (skip_count--)
-		size_t a = mark(h, s);
-		{
-			Range r("ofdmrx:sync");
-			launch_sync(s, h->rate, n, fb, z, h->dev, st, h->sc_scratch.as<cf>());
+	for (int q = 0; q < parts; ++q) {
+		const int f0 = q * per, nq = std::min(per, n - f0);
+		if (nq <= 0)
+			break;
+		hipStream_t sq = q % 3 == 0 ? s : h->stream_f[q % 3 - 1];
+		if (sq != s)
+			HIP_OK(hipStreamWaitEvent(sq, h->ev_pool[e1], 0));
+		FrameBatch fbq = fb;
+		fbq.samples = (const char *)fb.samples + (size_t)f0 * fb.frame_stride_bytes;
+		SyncState *stq = st + f0;
+		const cf *zq = z ? z + (size_t)f0 * (size_t)fb.samples_per_frame : nullptr;
+		cf *scq = h->sc_scratch.p ? h->sc_scratch.as<cf>() + (size_t)f0 * sl : nullptr;
+		launch_init_sync(sq, nq, stq, d_skip ? d_skip + f0 : nullptr);
+		size_t last = e1;
+		for (int round = 0; round <= max_skip; ++round) {      // decode.cc:390-448 do { } while (skip_count--)
+			size_t a = mark(h, sq);
+			{
+				Range r("ofdmrx:sync");
+				launch_sync(sq, h->rate, nq, fbq, zq, h->dev, stq, scq);
+			}
+			size_t b = mark(h, sq);
+			{
+				Range r("ofdmrx:header_osd");
+				launch_header(sq, h->rate, nq, fbq, zq, h->dev, stq, h->hdr_soft.as<int8_t>() + (size_t)f0 * 256);
+			}
+			size_t c = mark(h, sq);
+			h->spans.push_back({ OFDMRX_T_SYNC, a, b });
+			h->spans.push_back({ OFDMRX_T_HEADER, b, c });
+			last = c;
 		}
-		size_t b = mark(h, s);
 		{
-			Range r("ofdmrx:header_osd");
-			launch_header(s, h->rate, n, fb, z, h->dev, st, h->hdr_soft.as<int8_t>());
+			Range r("ofdmrx:demod");
+			launch_demod(sq, h->rate, nq, fbq, zq, h->dev, stq, h->cons.as<cf>() + (size_t)f0 * CONS_MAX,
+				h->carr.p ? h->carr.as<cf>() + (size_t)f0 * CARR_MAX : nullptr);
 		}
-		size_t c = mark(h, s);
-		h->spans.push_back({ OFDMRX_T_SYNC, a, b });
-		h->spans.push_back({ OFDMRX_T_HEADER, b, c });
-		e3 = c;
-	}
-	{
-		Range r("ofdmrx:demod");
-		launch_demod(s, h->rate, n, fb, z, h->dev, st, h->cons.as<cf>(), h->carr.as<cf>());
+		size_t d = mark(h, sq);
+		h->spans.push_back({ OFDMRX_T_DEMOD, last, d });
+		if (sq != s)
+			HIP_OK(hipStreamWaitEvent(s, h->ev_pool[d], 0));
+		e3 = d;
 	}
 	if ((h->cfg.flags & 1) && !demod_writes_carriers(h->rate))
 		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
-	size_t e4 = mark(h, s);
+	(void)e3;
 	h->spans.push_back({ OFDMRX_T_FRONT, e0, e1 });
-	h->spans.push_back({ OFDMRX_T_DEMOD, e3, e4 });
 	*t_begin = e0;
 	HIP_OK(hipGetLastError());
 	h->last_n = n;
@@ -479,15 +516,38 @@ static int max_skip_of(const int32_t *skip, size_t n)
 	return m;
 }
 
-// Frames per pipeline stage of a call: the handle's chunk, but a batch that would fit ONE chunk is split in two (rounded
-// up to whole waves of 64 codewords) when it is large enough for the two-stream overlap to pay - e.g. 8192 frames per
-// GPU under strong scaling of a 65536-frame batch over 8 GPUs.
-static size_t pipeline_chunk(const ofdmrx_handle *h, size_t n_frames)
+// How a call's frames are cut into pipeline stages: the handle's chunk, uniformly; a batch that fits one chunk runs every
+// kernel back to back on the handle's stream.  OFDMRX_SPLIT_SMALL=1 cuts such a batch (>= 2048 frames) in two halves so
+// that the two-stream overlap engages - the round-1 verdict asked for that (8192 frames per GPU when 65536 are sharded
+// over 8), but it measures SLOWER than the plain sequence: 8192 frames in one call 132.6 k frames/s back to back, 129.4 k
+// as 4096 + 4096, 123.7 k as 3328 + 4864 (one whole round of the resident polar grid, then the rest): with two chunks
+// the pipeline is all fill and drain, and each polar launch pays its own ragged tail.  So it is off by default.
+struct ChunkPlan {
+	std::vector<size_t> start;                                // n_chunks + 1 frame indices
+	size_t count() const { return start.size() - 1; }
+	size_t first(size_t c) const { return start[c]; }
+	size_t size(size_t c) const { return start[c + 1] - start[c]; }
+	size_t largest() const
+	{
+		size_t m = 0;
+		for (size_t c = 0; c < count(); ++c)
+			m = std::max(m, size(c));
+		return m;
+	}
+};
+static ChunkPlan plan_chunks(const ofdmrx_handle *h, size_t n_frames)
 {
+	ChunkPlan p;
 	const size_t chunk = (size_t)h->chunk;
-	if (n_frames > chunk || n_frames < 2048 || std::getenv("OFDMRX_NO_OVERLAP"))
-		return chunk;
-	return std::min(chunk, ((n_frames + 1) / 2 + 63) & ~(size_t)63);
+	const bool split_small = std::getenv("OFDMRX_SPLIT_SMALL") != nullptr;
+	if (split_small && n_frames <= chunk && n_frames >= 2048 && !std::getenv("OFDMRX_NO_OVERLAP")) {
+		p.start = { 0, ((n_frames + 1) / 2 + 63) & ~(size_t)63, n_frames };
+		return p;
+	}
+	for (size_t f = 0; f < n_frames; f += chunk)
+		p.start.push_back(f);
+	p.start.push_back(n_frames);
+	return p;
 }
 
 // The chunk pipeline behind both entry points.  Chunk c's samples are at src(c) on the device when front1(c) runs
@@ -504,17 +564,17 @@ struct PipeHooks {
 	virtual int after_back(size_t, size_t /*event*/, hipStream_t /*stream the back half ran on*/) { return 0; }
 };
 
-static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, int fmt, int channels, size_t spf, size_t stride, size_t n_frames,
+static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &plan, int fmt, int channels, size_t spf, size_t stride,
 	const int32_t *d_skip, int max_skip)
 {
-	const size_t chunk = pipeline_chunk(h, n_frames), n_chunks = (n_frames + chunk - 1) / chunk;
+	const size_t n_chunks = plan.count(), chunk_max = plan.largest();
 	int r = ensure_events(h, h->ev_used + n_chunks * events_per_chunk(max_skip) + 8);
 	if (r)
 		return r;
-	auto n_of = [&](size_t c) { return (int)std::min(chunk, n_frames - c * chunk); };
+	auto n_of = [&](size_t c) { return (int)plan.size(c); };
 	static const bool force_grid = std::getenv("OFDMRX_POLAR_FORCE_GRID") != nullptr;   // experiments: limited grid without overlap
 	if (n_chunks == 1 || !h->stream_b || std::getenv("OFDMRX_NO_OVERLAP")) {
-		r = ensure_capacity(h, (int)std::min(chunk, n_frames), channels == 1, (long)spf);
+		r = ensure_capacity(h, (int)chunk_max, channels == 1, (long)spf);
 		for (size_t c = 0; c < n_chunks && !r; ++c) {
 			FrameBatch fb{ nullptr, stride, (long)spf, fmt, channels };
 			size_t ready = (size_t)-1, t0 = 0;
@@ -526,7 +586,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, int fmt, int channel
 			if (ready != (size_t)-1)
 				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ready], 0));
 			hooks.dst(c, &pay, &res);
-			r = run_front1(h, h->stream, 0, fb, n_of(c), d_skip ? d_skip + c * chunk : nullptr, max_skip, &t0);
+			r = run_front1(h, h->stream, 0, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0);
 			r = r ? r : hooks.after_front1(c, mark(h, h->stream));
 			r = r ? r : run_front2(h, h->stream, 0, n_of(c), res);
 			r = r ? r : run_back(h, h->stream, 0, n_of(c), force_grid ? h->polar_grid : 0, pay, res, true, t0);
@@ -534,7 +594,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, int fmt, int channel
 		}
 		return r;
 	}
-	r = ensure_capacity(h, (int)std::min(chunk, n_frames), channels == 1, (long)spf, true);
+	r = ensure_capacity(h, (int)chunk_max, channels == 1, (long)spf, true);
 	if (r)
 		return r;
 	const size_t NONE = (size_t)-1;
@@ -575,7 +635,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, int fmt, int channel
 				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ready], 0));
 			if (c >= 2 && ev_back[c - 2] != NONE)        // st[par] / llr[par] are free once back(c-2) is done
 				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c - 2]], 0));
-			r = run_front1(h, h->stream, par, fb, n_of(c), d_skip ? d_skip + c * chunk : nullptr, max_skip, &t0s[c]);
+			r = run_front1(h, h->stream, par, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0s[c]);
 			if (r)
 				return r;
 			ev_f1 = mark(h, h->stream);
@@ -634,17 +694,18 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	}
 	h->ev_used = 0;
 	h->spans.clear();
+	const ChunkPlan plan = plan_chunks(h, n_frames);
 	struct Dev : PipeHooks {
-		const char *samples; size_t stride, chunk; uint8_t *pay; Result *res;
-		int before_front1(size_t c, FrameBatch *fb, size_t *) override { fb->samples = samples + c * chunk * stride; return 0; }
-		void dst(size_t c, uint8_t **p, Result **r) override { *p = pay + c * chunk * PAYLOAD_BYTES; *r = res + c * chunk; }
+		const ChunkPlan *plan; const char *samples; size_t stride; uint8_t *pay; Result *res;
+		int before_front1(size_t c, FrameBatch *fb, size_t *) override { fb->samples = samples + plan->first(c) * stride; return 0; }
+		void dst(size_t c, uint8_t **p, Result **r) override { *p = pay + plan->first(c) * PAYLOAD_BYTES; *r = res + plan->first(c); }
 	} hooks;
+	hooks.plan = &plan;
 	hooks.samples = (const char *)d_samples;
 	hooks.stride = stride;
-	hooks.chunk = pipeline_chunk(h, n_frames);
 	hooks.pay = d_payload;
 	hooks.res = (Result *)d_results;
-	return finish_call(h, run_pipeline(h, hooks, fmt, channels, spf, stride, n_frames, d_skip, max_skip));
+	return finish_call(h, run_pipeline(h, hooks, plan, fmt, channels, spf, stride, d_skip, max_skip));
 }
 
 extern "C" int ofdmrx_synchronize(ofdmrx_handle *h)
@@ -675,7 +736,8 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 	}
 	h->ev_used = 0;
 	h->spans.clear();
-	const size_t chunk = pipeline_chunk(h, n_frames), n_chunks = (n_frames + chunk - 1) / chunk, nc = std::min(chunk, n_frames);
+	const ChunkPlan plan = plan_chunks(h, n_frames);
+	const size_t n_chunks = plan.count(), nc = plan.largest();
 	r = ensure_events(h, n_chunks * (events_per_chunk(max_skip) + 4) + 8);
 	r = r ? r : h->in_stage.ensure(nc * stride);
 	if (n_chunks > 1) {
@@ -704,17 +766,17 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 		HIP_OK(hipStreamSynchronize(h->stream));         // `skip` may be pageable and go out of scope
 	}
 	struct Host : PipeHooks {
-		ofdmrx_handle *h; const char *samples; size_t stride, chunk, n_frames, n_chunks, nc;
+		ofdmrx_handle *h; const ChunkPlan *plan; const char *samples; size_t stride, n_chunks, nc;
 		uint8_t *payload_out; ofdmrx_frame_result *results;
 		std::vector<size_t> ev_in, ev_f1, ev_out;
 		size_t copied_out = 0;
-		size_t n_of(size_t c) const { return std::min(chunk, n_frames - c * chunk); }
+		size_t n_of(size_t c) const { return plan->size(c); }
 		void *stage(size_t c) const { return (c & 1) ? h->in_stage2.p : h->in_stage.p; }
 		int copy_in(size_t c)
 		{
 			if (c >= 2 && ev_f1[c - 2] != (size_t)-1)    // the staging buffer was last read by front1(c-2)
 				HIP_OK(hipStreamWaitEvent(h->stream_c, h->ev_pool[ev_f1[c - 2]], 0));
-			HIP_OK(hipMemcpyAsync(stage(c), samples + c * chunk * stride, n_of(c) * stride, hipMemcpyHostToDevice, h->stream_c));
+			HIP_OK(hipMemcpyAsync(stage(c), samples + plan->first(c) * stride, n_of(c) * stride, hipMemcpyHostToDevice, h->stream_c));
 			ev_in[c] = mark(h, h->stream_c);
 			return 0;
 		}
@@ -722,8 +784,8 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 		{
 			HIP_OK(hipEventSynchronize(h->ev_pool[ev_out[c]]));
 			const char *src = (const char *)h->out_stage[c & 1];
-			std::memcpy(payload_out + c * chunk * PAYLOAD_BYTES, src, n_of(c) * PAYLOAD_BYTES);
-			std::memcpy(results + c * chunk, src + nc * PAYLOAD_BYTES, n_of(c) * sizeof(Result));
+			std::memcpy(payload_out + plan->first(c) * PAYLOAD_BYTES, src, n_of(c) * PAYLOAD_BYTES);
+			std::memcpy(results + plan->first(c), src + nc * PAYLOAD_BYTES, n_of(c) * sizeof(Result));
 			return 0;
 		}
 		int before_front1(size_t c, FrameBatch *fb, size_t *ready) override
@@ -768,8 +830,7 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 	hooks.h = h;
 	hooks.samples = (const char *)samples;
 	hooks.stride = stride;
-	hooks.chunk = chunk;
-	hooks.n_frames = n_frames;
+	hooks.plan = &plan;
 	hooks.n_chunks = n_chunks;
 	hooks.nc = nc;
 	hooks.payload_out = payload_out;
@@ -777,7 +838,7 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 	hooks.ev_in.assign(n_chunks, (size_t)-1);
 	hooks.ev_f1.assign(n_chunks, (size_t)-1);
 	hooks.ev_out.assign(n_chunks, (size_t)-1);
-	r = run_pipeline(h, hooks, fmt, channels, spf, stride, n_frames, skip ? h->skip_stage.as<int32_t>() : nullptr, max_skip);
+	r = run_pipeline(h, hooks, plan, fmt, channels, spf, stride, skip ? h->skip_stage.as<int32_t>() : nullptr, max_skip);
 	while (!r && hooks.copied_out < n_chunks)
 		r = hooks.copy_out(hooks.copied_out++);
 	if (!r)
@@ -1003,7 +1064,7 @@ extern "C" int ofdmrx_tx_encode_stream_device(ofdmrx_handle *h, const uint8_t *d
 	if (cs <= 0 || cs >= 129961739795077LL)               // encode.cc:358
 		return OFDMRX_E_ARG;
 	HIP_OK(hipSetDevice(h->cfg.device));
-	struct { int oper_mode, offset, channels, nsym; unsigned long long md; long frame_samples; int count, bits; } tp;
+	struct { int oper_mode, offset, channels, nsym; unsigned long long md; long frame_samples; int count, bits, symbol_len; } tp;
 	ModeDesc md = mode_desc(oper_mode);
 	const int SL = rate_symbol_len(h->rate);
 	tp.oper_mode = oper_mode;
@@ -1014,28 +1075,31 @@ extern "C" int ofdmrx_tx_encode_stream_device(ofdmrx_handle *h, const uint8_t *d
 	tp.frame_samples = ofdmrx_stream_samples(h->rate, oper_mode, count);
 	tp.count = count;
 	tp.bits = bits;
+	tp.symbol_len = SL;
 	// streams per launch: bounded scratch (44.1 / 48 kHz keep the 4x PAPR buffers in global scratch)
 	const size_t budget = h->rate <= 16000 ? 1024 : 128;
 	const size_t chunk = std::max<size_t>(1, budget / (size_t)count);
-	DevBuf code, tdom, big;
+	// scratch lives in the handle and grows on demand: the call only enqueues kernels on the handle's stream
+	DevBuf &code = h->tx_code, &rowsym = h->tx_rowsym, &tdom = h->tx_tdom, &big = h->tx_big;
 	const size_t nc = std::min(chunk, n_streams);
+	const bool grow = code.bytes < nc * (size_t)count * 2048 * sizeof(uint32_t) || rowsym.bytes < nc * (size_t)count * CONS_MAX * sizeof(cf)
+		|| tdom.bytes < nc * (size_t)tp.nsym * SL * sizeof(cf) || big.bytes < tx_big_scratch_bytes(h->rate, (int)nc, tp.nsym);
+	if (grow)
+		HIP_OK(hipStreamSynchronize(h->stream));              // a buffer about to be replaced may still be read by an earlier call
 	int r = code.ensure(nc * (size_t)count * 2048 * sizeof(uint32_t));
+	r = r ? r : rowsym.ensure(nc * (size_t)count * CONS_MAX * sizeof(cf));
 	r = r ? r : tdom.ensure(nc * (size_t)tp.nsym * SL * sizeof(cf));
 	if (tx_big_scratch_bytes(h->rate, (int)nc, tp.nsym))
 		r = r ? r : big.ensure(tx_big_scratch_bytes(h->rate, (int)nc, tp.nsym));
-	if (r) { code.release(); tdom.release(); big.release(); return r; }
+	if (r)
+		return r;
 	const size_t out_stride = (size_t)tp.frame_samples * channels * (bits / 8);
 	for (size_t f0 = 0; f0 < n_streams; f0 += chunk) {
 		int n = (int)std::min(chunk, n_streams - f0);
 		launch_tx(h->stream, h->rate, n, d_payload + f0 * (size_t)count * PAYLOAD_BYTES, h->dev, &tp, h->dev.tw_sym4,
-			code.as<uint32_t>(), tdom.as<cf>(), big.as<cf>(), (char *)d_pcm + f0 * out_stride);
+			code.as<uint32_t>(), rowsym.as<cf>(), tdom.as<cf>(), big.as<cf>(), (char *)d_pcm + f0 * out_stride);
 	}
-	hipError_t e = hipGetLastError();
-	e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;   // scratch is freed below
-	code.release();
-	tdom.release();
-	big.release();
-	if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return OFDMRX_E_HIP; }
+	HIP_OK(hipGetLastError());
 	return 0;
 }
 
@@ -1065,7 +1129,8 @@ extern "C" int ofdmrx_tx_encode_stream(ofdmrx_handle *h, const uint8_t *payload,
 	}
 	r = r ? r : ofdmrx_tx_encode_stream_device(h, dp.as<uint8_t>(), 1, count, oper_mode, freq_off, call_sign, channels, bits, dx.p);
 	if (!r) {
-		hipError_t e = hipMemcpy(pcm, dx.p, out_bytes, hipMemcpyDeviceToHost);
+		hipError_t e = hipStreamSynchronize(h->stream);       // the device entry only enqueues
+		e = e == hipSuccess ? hipMemcpy(pcm, dx.p, out_bytes, hipMemcpyDeviceToHost) : e;
 		if (e != hipSuccess) { g_last_error = hipGetErrorString(e); r = OFDMRX_E_HIP; }
 	}
 	dp.release();
