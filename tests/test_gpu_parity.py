@@ -923,3 +923,57 @@ def test_ber_sweep_driver_counters_match_the_oracle(tmp_path):
                 lost += res.status != 0
         assert p["fer"] == ferr / 96 and p["declared_lost"] == lost and abs(p["ber"] - berr / (43040.0 * 96)) < 1e-12, (p, ferr, berr, lost)
     assert pts[0]["fer"] == 0 and pts[2]["fer"] == 1.0
+
+
+@pytest.mark.parametrize("impair", [False, True])
+def test_configs_2_and_3_at_full_size(impair):
+    """BASELINE configs[2] (65 536 analytic frames, AWGN at -30 dB) and configs[3] (the same through multipath -> CFO
+    +234.567 Hz -> SFO +147 ppm first) at their FULL batch size through the default chunk pipeline (8 chunks of 8192, both
+    buffer parities several times): 65 536 distinct payloads made on the device; size-independent properties - every
+    payload comes back bit-exact, every status is OK, one sync position per configuration, the fine CFO estimate sits
+    on the impairment - and four frames spread over the batch are checked against the oracle (these
+    sizes used to run in bench.py only)."""
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    n = 65536
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        rx = modem_amd.Receiver(device=0, stream=stream.cuda_stream)
+        spf = rx.tx_frame_samples(6)
+        g = torch.Generator(device=dev)
+        g.manual_seed(65536 + int(impair))
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+        d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+        rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
+        if impair:
+            d_imp = torch.empty_like(d_in)
+            taps = [(0, 1 + 0j), (5, 0.35 - 0.1j), (11, -0.2 + 0.2j), (23, 0.1 + 0.05j)]
+            for lo in range(0, n, 8192):
+                rx.channel(d_in[lo:lo + 8192].data_ptr(), d_imp[lo:lo + 8192].data_ptr(), 8192, spf, cfo_hz=234.567, sfo_ppm=147.0, multipath=taps)
+            rx.awgn_tile(d_imp.data_ptr(), n, d_in.data_ptr(), n, spf, -30.0, 11, 0)
+            del d_imp
+        else:
+            rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, -30.0, 11, 0)
+        d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+        rx.synchronize()
+        assert rx.timing()["polar"][1] == 8                     # eight chunks went through the pipeline
+        same = (d_out == d_pay).all(dim=1)
+        assert bool(same.all()), "frames with a wrong payload: %s" % torch.nonzero(~same)[:8].flatten().tolist()
+        res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+        assert (res["status"] == 0).all() and (res["oper_mode"] == 6).all() and (res["best_lane"] == 0).all()
+        hz = res["cfo_fine"] * 8000 / (2 * np.pi)
+        assert np.abs(hz - (2000 + (234.567 if impair else 0.0))).max() < 1.5
+        if not impair:
+            assert len(set(res["sc_start"].tolist())) == 1
+        pick = [0, 8191, 30001, 65535]                          # first chunk, a chunk boundary, the middle, the last frame
+        frames = d_in[pick].cpu().numpy()
+        pays = d_pay[pick].cpu().numpy()
+    for f, p, r in zip(frames, pays, res[pick]):
+        o, orr = O.decode(f)
+        assert orr.status == 0 and (o == p).all() and orr.sc_start == int(r["sc_start"]) and orr.symbol_pos == int(r["symbol_pos"])
+        assert abs(orr.cfo_rad - float(r["cfo_rad"])) <= REL and abs(orr.bit_flips - int(r["bit_flips"])) <= FLIPS_SLACK
+    rx.close()

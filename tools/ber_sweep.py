@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--step", type=float, default=1.0)
     ap.add_argument("--batch", type=int, default=32768, help="frames resident per decode call and rank")
     ap.add_argument("--seed", type=int, default=777)
+    ap.add_argument("--tx-reuse", type=int, default=1,
+                    help="decode every transmitted batch this many times, each with fresh noise (1 = every frame freshly "
+                         "transmitted, the default; the noise realisations are always distinct)")
     ap.add_argument("--levels", type=float, nargs="*", default=None, help="explicit noise levels in dB (overrides --lo/--hi/--step)")
     ap.add_argument("--dump", default=None, help="directory: keep every batch's PCM and payloads as .npy (tests, small runs only)")
     args = ap.parse_args()
@@ -74,16 +77,29 @@ def main():
             work.append((li, float(db), f, n))
             f += n
 
+    d_clean = torch.empty((nb, spf, 2), dtype=torch.int16, device=dev) if args.tx_reuse > 1 else None
+    made, made_n = [0], [0]
+
     def make(w, q):
-        """random payloads -> device transmitter -> AWGN for batch w into buffer q, on the tx stream"""
+        """random payloads -> device transmitter -> AWGN for batch w into buffer q, on the tx stream.  With --tx-reuse K
+        the clean waveforms (and payloads) of a batch serve K consecutive batches of the same size, each with its own noise"""
         li, db, f, n = w
         gidx = li * args.frames + f              # global frame index: distinct noise everywhere
         with torch.cuda.stream(tx_stream):
             tx_stream.wait_event(ev_free[q])
-            gen.manual_seed(args.seed * 7919 + gidx)
-            d_pay[q][:n] = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=gen)
-            tx.tx_encode(d_pay[q].data_ptr(), n, d_in[q].data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=2)
-            tx.awgn_tile(d_in[q].data_ptr(), n, d_in[q].data_ptr(), n, spf, db, args.seed, gidx)   # in place
+            fresh = args.tx_reuse <= 1 or made[0] % args.tx_reuse == 0 or n != made_n[0]
+            if fresh:
+                gen.manual_seed(args.seed * 7919 + gidx)
+                d_pay[q][:n] = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=gen)
+                dst = d_clean if d_clean is not None else d_in[q]
+                tx.tx_encode(d_pay[q].data_ptr(), n, dst.data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=2)
+                made_n[0] = n
+                made[0] = 0
+            else:
+                d_pay[q][:n] = d_pay[q ^ 1][:n]
+            src = d_clean if d_clean is not None else d_in[q]
+            tx.awgn_tile(src.data_ptr(), n, d_in[q].data_ptr(), n, spf, db, args.seed, gidx)   # in place when not reusing
+            made[0] += 1
             ev_ready[q].record(tx_stream)
 
     summary = []
@@ -132,7 +148,7 @@ def main():
     tx.close()
     if rank == 0:
         tot = sum(p["frames"] for p in summary)
-        print(json.dumps({"summary": "ber_sweep", "n_gpus": world, "total_frames": tot,
+        print(json.dumps({"summary": "ber_sweep", "n_gpus": world, "total_frames": tot, "tx_reuse": args.tx_reuse,
                           "frames_per_s": tot / (time.perf_counter() - t_all), "points": len(summary)}), flush=True)
     rx.close()
     if dist:
