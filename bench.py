@@ -54,6 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--rate", type=int, default=8000, choices=[8000, 16000, 44100, 48000],
                     help="sample rate of the frames (the headline metric is 8000; the others are the N4 instantiations)")
     ap.add_argument("--mode", type=int, default=6, choices=range(6, 14), help="operation mode of the frames (headline: 6)")
+    ap.add_argument("--list", type=int, default=8, choices=[4, 8], help="SCL list size (headline: 8 = the reference's AVX2 build)")
     ap.add_argument("--impair", action="store_true",
                     help="configs[3]: every frame also goes through the device channel chain multipath -> CFO +234.567 Hz "
                          "-> SFO +147 ppm (README.md:49) before the AWGN")
@@ -197,7 +198,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     copy_stream = torch.cuda.Stream(device=dev)
-    rx = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=stream.cuda_stream, sample_rate=args.rate)
+    rx = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=stream.cuda_stream, sample_rate=args.rate,
+                            list_size=args.list)
     spf = rx.tx_frame_samples(args.mode)
     RES = M.RESULT_DTYPE.itemsize
     d_in = torch.empty((max(B, 1), spf, ch), dtype=torch.int16, device=dev)
@@ -382,12 +384,12 @@ def main():
             "config": {"workload": ("configs[%d]%s: batch %d analytic (2-ch int16) mode-%d %g kHz frames %s, AWGN noise "
                                     "level %g dB (a noise LEVEL: about +20 dB SNR, where every rate-1 node of the list decoder takes "
                                     "its shortcut), inputs resident in HBM; %s, on-device noise keyed by frame index"
-                                    % (3 if args.impair else 2, "" if (args.rate == 8000 and args.mode == 6) else " variant (not the headline workload)",
+                                    % (3 if args.impair else 2, "" if (args.rate == 8000 and args.mode == 6 and args.list == 8) else " variant (not the headline workload)",
                                        args.frames, args.mode, args.rate / 1000.0, "per GPU" if args.scaling == "weak" else "in total, sharded",
                                        args.noise_db, source)) if ch == 2 else
                                    ("configs[1] flavour: batch %d clean 16-bit mono mode-6 8 kHz frames per GPU, inputs resident "
                                     "in HBM; %s" % (B, source)),
-                       "frames_per_step": frames_step, "frames_rank0": B, "list_size": 8, "chunk_frames": rx.chunk_frames,
+                       "frames_per_step": frames_step, "frames_rank0": B, "list_size": args.list, "chunk_frames": rx.chunk_frames,
                        "parallelism": "frames x%d" % ranks},
             "ber": bit_err / (43040.0 * max(frames_step, 1)), "fer": frame_err / float(max(frames_step, 1)),
             "frames_ok": ok_status, "frames": frames_step,
