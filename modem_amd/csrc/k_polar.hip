@@ -432,11 +432,19 @@ __device__ unsigned long long g_polar_prof[8];
 template <int LN>
 __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
 	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev2,
-	float *__restrict__ metric_all)
+	float *__restrict__ metric_all, int *__restrict__ next_cw)
 {
 	const int lane = threadIdx.x, j = lane >> 3, k = lane & 7;
 	__shared__ float ls8[32 * 64];                            // level 8 of the current 256-leaf node: [x][lane]
-	for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
+	// Persistent decoders take codewords from a shared counter (zeroed before the launch): under the shared schedule
+	// the CUs are unevenly loaded, a fixed stride would leave the fast decoders idle in the last round.
+	for (;;) {
+	int cw = 0;
+	if (lane == 0)
+		cw = atomicAdd(next_cw, 1);
+	cw = __builtin_amdgcn_readfirstlane(cw);
+	if (cw >= n_cw)
+		break;
 	if (!st_all[cw].okay)
 		continue;                                             // no header -> nothing to decode (decode.cc:450-451)
 	const uint32_t *frozen = frozen2 + (st_all[cw].oper_mode >= 10 ? 2048 : 0);   // decode.cc:312,344
@@ -817,11 +825,13 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 	if (j == 0)
 		metric_all[(size_t)cw * LIST + k] = M;
 	WAVE_ORDER();
-	}   // next codeword of this block
+	}   // next codeword of this decoder
 }
 
-void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric)
+void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,
+	int *next_cw)
 {
+	(void)hipMemsetAsync(next_cw, 0, sizeof(int), s);
 	if (grid <= 0 || grid > n)
 		grid = n;
 #ifdef POLAR_PROF
@@ -829,9 +839,9 @@ void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st,
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_polar_prof), z8, sizeof(z8));
 #endif
 	if (list == 4)
-		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric);
+		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw);
 	else
-		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric);
+		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw);
 #ifdef POLAR_PROF
 	(void)hipStreamSynchronize(s);
 	(void)hipMemcpyFromSymbol(z8, HIP_SYMBOL(g_polar_prof), sizeof(z8));

@@ -80,7 +80,8 @@ void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
 void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, float *llr, Result *res);
-void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric);
+void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,
+	int *next_cw);
 void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
 	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res);
 void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb);

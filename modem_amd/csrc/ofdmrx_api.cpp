@@ -126,6 +126,7 @@ struct ofdmrx_handle {
 	DevBuf st, hdr_soft, cons, slope, yint, precision, llr, soft, hard, metric, lane_mesg, res, payload;
 	DevBuf st2, llr2;         // second parity of the two buffers that cross from the front stages to the polar stage
 	DevBuf payload2, res2;    // second parity of the device-side output staging (host-pointer entry)
+	DevBuf work_counter;      // k_polar's shared codeword counter (zeroed on the stream before every launch)
 	DevBuf tx_code, tx_rowsym, tx_tdom, tx_big;   // transmitter scratch, kept between calls (no allocation, no synchronisation per call)
 	hipStream_t stream_b = nullptr;   // polar + finish of chunk c run here while the front stages of chunk c+1 run on `stream`
 	hipStream_t stream_c = nullptr;   // host-pointer entry: host-to-device copies of the next chunk
@@ -236,7 +237,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		}
 		int cus = 0;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
-		int wpc = 13;             // polar waves per CU while the next chunk's Theil-Sen stage shares the machine
+		int wpc = 12;             // polar waves per CU while the next chunk's Theil-Sen stage shares the machine
 		if (const char *e2 = std::getenv("OFDMRX_POLAR_WPC"))
 			wpc = std::atoi(e2);
 		h->polar_grid = wpc > 0 && cus > 0 ? wpc * cus : 0;
@@ -279,7 +280,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -317,6 +318,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->soft.ensure(N * 8 * CODE_LEN * sizeof(float));
 		r = r ? r : h->hard.ensure(N * CODE_LEN);
 		r = r ? r : h->metric.ensure(N * LIST * sizeof(float));
+		r = r ? r : h->work_counter.ensure(256);
 		r = r ? r : h->lane_mesg.ensure(N * LIST * MESG_BYTES);
 		r = r ? r : h->res.ensure(N * sizeof(Result));
 		r = r ? r : h->payload.ensure(N * PAYLOAD_BYTES);
@@ -472,7 +474,7 @@ static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, int grid, u
 	size_t e6 = mark(h, s);
 	{
 		Range r("ofdmrx:polar_scl");
-		launch_polar(s, h->list, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+		launch_polar(s, h->list, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(), h->work_counter.as<int>());
 	}
 	size_t e7 = mark(h, s);
 	{
@@ -914,7 +916,8 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
-	launch_polar(h->stream, h->list, (int)n, 0, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>());
+	launch_polar(h->stream, h->list, (int)n, 0, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(),
+		h->work_counter.as<int>());
 	launch_finish(h->stream, h->list, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, 0,
 		h->lane_mesg.as<uint8_t>(), h->payload.as<uint8_t>(), h->res.as<Result>());
 	HIP_OK(hipGetLastError());
