@@ -9,7 +9,7 @@ namespace rx {
 // decode.cc:532-541 (first lane whose CRC-32 over 43072 bits is 0), decode.cc:546-555
 // (LE bit packing + flip count), decode.cc:613-615 (descramble).
 __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
-	const uint8_t *__restrict__ hard_all, Tables tb, int descramble, int list, uint8_t *__restrict__ lane_mesg_all,
+	const uint8_t *__restrict__ hard_all, Tables tb, int descramble, int list, int n_frames, uint8_t *__restrict__ lane_mesg_all,
 	uint8_t *__restrict__ payload_all, Result *__restrict__ res_all)
 {
 	const int f = blockIdx.x, tid = threadIdx.x;
@@ -43,7 +43,21 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 			res_all[f] = r;
 		return;
 	}
-	const uint8_t *hard = hard_all + (size_t)f * CODE_LEN;
+	// list 4: k_polar decodes the frames (2u, 2u+1) as a pair when both have a header and share the frozen table; the pair's
+	// partial sums are ONE byte array in the first frame's slot, bits 0..3 = first frame, bits 4..7 = second
+	int hshift = 0;
+	size_t hframe = (size_t)f;
+	if (list == 4) {
+		const int mate = f ^ 1;
+		if (mate < n_frames) {
+			const SyncState sm = st_all[mate];
+			if (sm.okay && (sm.oper_mode >= 10) == (st.oper_mode >= 10)) {
+				hframe = (size_t)(f & ~1);
+				hshift = (f & 1) * 4;
+			}
+		}
+	}
+	const uint8_t *hard = hard_all + hframe * CODE_LEN;
 	const float *llr = llr_all + (size_t)f * CODE_LEN;
 	const ModeDesc md = mode_desc(st.oper_mode);
 	const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
@@ -53,7 +67,7 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 		uint32_t o[LIST] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 		#pragma unroll
 		for (int b = 0; b < 8; ++b) {
-			uint32_t x = hard[info_pos[8 * bi + b]];
+			uint32_t x = (uint32_t)hard[info_pos[8 * bi + b]] >> hshift;
 			#pragma unroll
 			for (int k = 0; k < LIST; ++k)
 				o[k] |= ((x >> k) & 1u) << b;
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
 	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res)
 {
-	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, list == 4 ? 4 : 8, lane_mesg, payload, res);
+	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, list == 4 ? 4 : 8, n, lane_mesg, payload, res);
 }
 
 }  // namespace rx

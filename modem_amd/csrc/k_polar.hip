@@ -141,7 +141,12 @@ template <int AUX = 0> __device__ __forceinline__ void bstore(rsrc_t r, int voff
 __device__ __forceinline__ int bload_u8(rsrc_t r, int voff, int soff) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0); }
 
 struct PolarBufs {
-	rsrc_t soft, llr, hard;    // this codeword's 2 MiB level store, its 65536 channel LLRs, its 65536 partial-sum bytes
+	rsrc_t soft, llr, hard;    // this decoder's 2 MiB level store, the channel LLRs, the partial-sum bytes of what it decodes
+	// List 4 decodes TWO codewords per wave (paths 0..3 = the first, 4..7 = the second, see k_polar): everything that is
+	// shared by the paths of ONE codeword - the channel LLRs and the compact arrays of the first descent - exists twice
+	int half_sel;              // per lane: 1 for the lanes of the second codeword, else 0
+	int llr_half;              // byte distance of the second codeword's channel LLRs
+	int kmask;                 // (k & kmask) == 0: the lane that writes a compact array (7: one codeword, 3: two)
 };
 
 // Compact arrays.  Until the first fork all eight paths hold the same LLRs, so the first left descent (t = 0)
@@ -200,6 +205,10 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 	}
 	const int hx = half * XS;
 	int v_src = (KIND >= 2 || SRC_C || SRC_R) ? vo_j : vo_src, v_dst = DST_C ? vo_j : vo_lane, v_h = j;
+	if (KIND >= 2 || SRC_R == 2)
+		v_src += pb.half_sel * pb.llr_half;                   // the second codeword's channel LLRs
+	else if (SRC_C || SRC_R == 1)
+		v_src += pb.half_sel << ((SRC_R ? m + 2 : m + 1) + 2);   // its compact array sits behind the first one's (2^level floats)
 	const int anc = gl & 7;
 	#pragma unroll 1
 	for (int x0 = 0; x0 < S; x0 += XB, v_src += XB * XS, v_dst += XB * (DST_C ? 32 : 256), v_h += XB * 8) {
@@ -245,7 +254,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 					} else if (SKIP0) {
 					} else if (NG > 0) {
 						if (!DST_C) { if (m >= POLAR_NT_LEVEL) bstore<2>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]); else bstore<0>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]); }
-						else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[0][s2], v[s2]);
+						else if ((k & pb.kmask) == 0) bstore(pb.soft, v_dst + xb * 32 + (pb.half_sel << (m + 2)), so_d[0][s2], v[s2]);
 					} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
 				}
 				#pragma unroll
@@ -256,7 +265,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 						v[s2] = f_minsum(v[s2], v[s2 + n]);
 						if (NG > d) {
 							if (!DST_C) { if (m - d >= POLAR_NT_LEVEL) bstore<2>(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]); else bstore<0>(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]); }
-							else if (k == 0) bstore(pb.soft, v_dst + xb * 32, so_d[d][s2], v[s2]);
+							else if ((k & pb.kmask) == 0) bstore(pb.soft, v_dst + xb * 32 + (pb.half_sel << (m - d + 2)), so_d[d][s2], v[s2]);
 						} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
 					}
 				}
@@ -293,6 +302,7 @@ template <int LN> struct Block8 {
 	float r[4];
 	const uint32_t fz;
 	const int t, lane, j, k;
+	const bool hi_alive;       // list 4: paths 4..7 carry a second codeword (else they are dead: metric +inf)
 
 	template <int B> __device__ __forceinline__ float xjb(float v) const { return xj<B>(v, lane); }
 	__device__ __forceinline__ void reset_at(int p0) { const int tt = t + p0; A.reset_upto(tt ? __builtin_ctz(tt) : 16, k); }
@@ -300,7 +310,8 @@ template <int LN> struct Block8 {
 	{
 		const float P = M + mu;
 		const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
-		const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
+		const bool dead = LN == 4 && k >= 4 && !hi_alive, first = (k & (LN - 1)) == 0;   // list 4: each quad is its own list
+		const bool ok = dead || ((first || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
 		return __ballot(!ok) == 0;
 	}
 
@@ -327,16 +338,19 @@ template <int LN> struct Block8 {
 			for (int kk = 0; kk < 8; ++kk) {
 				const float o0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), kk));
 				const float o1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), kk));
-				rank += (o0 < val) | ((o0 == val) & (2 * kk < cidx));
-				rank += (o1 < val) | ((o1 == val) & (2 * kk + 1 < cidx));
+				const int mine = LN == 8 || (kk >> 2) == (k >> 2);   // list 4: the candidates of the lane's own codeword only
+				rank += mine & ((o0 < val) | ((o0 == val) & (2 * kk < cidx)));
+				rank += mine & ((o1 < val) | ((o1 == val) & (2 * kk + 1 < cidx)));
 			}
-			// every row of 16 lanes holds the 16 candidates at position (u << 3) | k: scatter inside the row
-			const int dst = (lane & 48) | rank;
+			// every row of 16 lanes holds the 16 candidates at position (u << 3) | k: scatter inside the row.  List 4: the
+			// four survivors of each codeword go to its own four positions, the four losers to the upper half of the row
+			const int pos = LN == 8 ? rank : (rank < 4 ? ((k & 4) | rank) : (8 | (k & 4) | (rank - 4)));
+			const int dst = (lane & 48) | pos;
 			int rc = __builtin_amdgcn_ds_permute(dst << 2, cidx);
 			int rv = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(val));
 			const int rcx = xor8_i(rc), rvx = xor8_i(rv);   // odd j sit at row position 8+k: take position k
 			if (j & 1) { rc = rcx; rv = rvx; }
-			M = k < LN ? __int_as_float(rv) : __builtin_inff();   // list 4: ranks 4..7 do not survive
+			M = __int_as_float(rv);                               // (a dead quad ranks its +inf metrics among themselves)
 			const int parent = rc >> 1;
 			ubit = rc & 1;
 			if (__ballot(parent != k)) {
@@ -438,25 +452,58 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 	__shared__ float ls8[32 * 64];                            // level 8 of the current 256-leaf node: [x][lane]
 	// Persistent decoders take codewords from a shared counter (zeroed before the launch): under the shared schedule
 	// the CUs are unevenly loaded, a fixed stride would leave the fast decoders idle in the last round.
+	// List 8: a unit of work is one codeword.  List 4 (the reference's 128-bit build): a unit is a PAIR of codewords
+	// (2u, 2u+1) decoded side by side - paths 0..3 of every 8-lane group belong to the first, paths 4..7 to the second:
+	// the same instructions, loads and stores serve two codewords, and every decision the code takes wave-wide (stable
+	// list, rate-1 node) is taken only when it holds for both (otherwise both take the general path, which is always
+	// right).  A pair is formed when both frames have a header and share the frozen table; a codeword without such a
+	// partner is decoded alone in the low half (the high half dead: metrics +inf) into its own partial-sum array.
+	const int n_units = LN == 4 ? (n_cw + 1) / 2 : n_cw;
 	for (;;) {
-	int cw = 0;
+	int unit = 0;
 	if (lane == 0)
-		cw = atomicAdd(next_cw, 1);
-	cw = __builtin_amdgcn_readfirstlane(cw);
-	if (cw >= n_cw)
+		unit = atomicAdd(next_cw, 1);
+	unit = __builtin_amdgcn_readfirstlane(unit);
+	if (unit >= n_units)
 		break;
-	if (!st_all[cw].okay)
-		continue;                                             // no header -> nothing to decode (decode.cc:450-451)
+	int cw_a = unit, cw_b = -1, n_pass = 1;
+	if (LN == 4) {
+		cw_a = 2 * unit;
+		cw_b = cw_a + 1 < n_cw ? cw_a + 1 : -1;
+		const bool ok_a = st_all[cw_a].okay, ok_b = cw_b >= 0 && st_all[cw_b].okay;
+		const bool paired = ok_a && ok_b && (st_all[cw_a].oper_mode >= 10) == (st_all[cw_b].oper_mode >= 10);
+		if (!paired) {
+			n_pass = (ok_a ? 1 : 0) + (ok_b ? 1 : 0);
+			if (!ok_a)
+				cw_a = cw_b;                                      // only the second one: it is decoded alone
+			if (n_pass < 2)
+				cw_b = -1;
+		}
+		if (paired)
+			n_pass = 1;
+		else if (n_pass == 2)
+			n_pass = 3;                                           // marker: two single passes, cw_a then cw_b
+	} else if (!st_all[cw_a].okay) {
+		continue;                                                 // no header -> nothing to decode (decode.cc:450-451)
+	}
+	for (int pass = 0; pass < (n_pass == 3 ? 2 : n_pass); ++pass) {
+	const int cw = (n_pass == 3 && pass == 1) ? cw_b : cw_a;
+	const int cw_hi = (LN == 4 && n_pass == 1) ? cw_b : -1;      // the codeword in paths 4..7, if any
+	const bool hi_alive = cw_hi >= 0;
 	const uint32_t *frozen = frozen2 + (st_all[cw].oper_mode >= 10 ? 2048 : 0);   // decode.cc:312,344
 	const uint8_t *node_lev = node_lev2 + (st_all[cw].oper_mode >= 10 ? 8192 : 0);
 	const float *llr = llr_all + (size_t)cw * CODE_LEN;
 	float *soft = soft_all + (size_t)blockIdx.x * (8 * CODE_LEN);   // level m >= 9 at soft + 8*2^m
-	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;
+	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;            // (a pair shares the first one's array: bits 0..3 | 4..7)
 	PolarBufs pb;
 	pb.soft = make_rsrc(soft, 8 * CODE_LEN * 4);
-	pb.llr = make_rsrc(llr, CODE_LEN * 4);
+	pb.llr = make_rsrc(llr, (hi_alive ? 2 : 1) * CODE_LEN * 4);
 	pb.hard = make_rsrc(hard, CODE_LEN);
-	float M = k == 0 ? 0.f : (k < LN ? 1000.f : __builtin_inff());   // lane 0 carries the only real path; k >= LN: dead
+	pb.half_sel = LN == 4 ? (k >> 2) : 0;
+	pb.llr_half = hi_alive ? CODE_LEN * 4 : 0;
+	pb.kmask = LN - 1;
+	// lane 0 of a codeword's paths carries its only real path; the others start 1000 behind; dead paths: +inf
+	float M = (LN == 4 && k >= 4 && !hi_alive) ? __builtin_inff() : ((k & (LN - 1)) == 0 ? 0.f : 1000.f);
 	Maps A;
 	A.w0 = ID0 * (uint32_t)k;
 	A.w1 = ID1 * (uint32_t)k;
@@ -469,7 +516,8 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 		mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
 		const float P = M + __uint_as_float(mu);
 		const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
-		const bool ok = k >= LN || ((k == 0 || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
+		const bool dead = LN == 4 && k >= 4 && !hi_alive, first = (k & (LN - 1)) == 0;
+		const bool ok = dead || ((first || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P));
 		return __ballot(!ok) == 0;
 	};
 	// A uniform node of 16..128 leaves decided in one step on its register array r (CNT = 2^(level-3) elements per
@@ -781,7 +829,7 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 					// uniform node it meets (8, 4 or 2 leaves all frozen / all information) in one step
 					int H = 0;
 					{
-						Block8<LN> blk{ M, A, H, { 0.f, 0.f, 0.f, r3 }, fz, tt, lane, j, k };
+						Block8<LN> blk{ M, A, H, { 0.f, 0.f, 0.f, r3 }, fz, tt, lane, j, k, hi_alive };
 						blk.template node<3, 0>();
 					}
 					HR = (HR & ~(1u << b)) | ((uint32_t)((H >> j) & 1) << b);   // this lane's own position, own path
@@ -822,10 +870,15 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 		PROF(5);
 	}
 	PROF_FLUSH();
-	if (j == 0)
-		metric_all[(size_t)cw * LIST + k] = M;
+	if (j == 0) {
+		if (LN == 8 || k < 4)
+			metric_all[(size_t)cw * LIST + k] = M;
+		else if (hi_alive)
+			metric_all[(size_t)cw_hi * LIST + (k - 4)] = M;
+	}
 	WAVE_ORDER();
-	}   // next codeword of this decoder
+	}   // second single pass of an unpaired unit
+	}   // next unit of this decoder
 }
 
 void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,

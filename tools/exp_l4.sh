@@ -1,0 +1,13 @@
+#!/bin/bash
+O=$PWD/gpurun_out/l4.txt; mkdir -p gpurun_out; : > $O
+make -C modem_amd/csrc -q all && echo "library up to date with sources" >> $O || echo "STALE LIBRARY" >> $O
+timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "list_size or polar or waterfall or mixed_mode or failure" 2>&1 | tail -12 >> $O
+pick='import json,sys
+d=json.loads(sys.stdin.readline()); s=d["stage_ms_per_step"]; print("value", round(d["value"]), "ts", round(s["theilsen"],1), "polar", round(s["polar"],1), "fer", d["fer"], "ok", d["frames_ok"])'
+echo -n "list 4 default: " >> $O
+timeout 300 python3 bench.py --list 4 --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 2>&1 | tail -1 | python3 -c "$pick" >> $O 2>&1
+echo -n "list 4 one chunk alone: " >> $O
+OFDMRX_NO_OVERLAP=1 timeout 300 python3 bench.py --list 4 --frames 8192 --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 2>&1 | tail -1 | python3 -c "$pick" >> $O 2>&1
+echo -n "list 8 default: " >> $O
+timeout 300 python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 2>&1 | tail -1 | python3 -c "$pick" >> $O 2>&1
+cat $O
