@@ -102,7 +102,7 @@ def cpu_baseline(pcm_sample, payload_ref, ch=2):
     n = pcm_sample.shape[0]
     pcm_sample = np.ascontiguousarray(pcm_sample)
     host_cores = os.cpu_count() or 1
-    threads = min(host_cores, 64)
+    threads = min(host_cores, 128)
 
     def run(lib, frames, thr):
         out = np.zeros((frames, 5380), np.uint8)

@@ -18,6 +18,7 @@
  *    once per row.
  */
 #include "modem_oracle.h"
+#include <malloc.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -614,6 +615,11 @@ int orc_decode_batch(const void *samples, int fmt, int channels, size_t frames_p
 {
 	int used = 1;
 	(void)threads;
+	/* every frame allocates and frees a few MB of work arrays: keep them in the threads' malloc arenas instead of one
+	 * mmap / munmap (and a page-fault storm) per array - with tens of threads that serialises in the kernel and the
+	 * batch scales 13x on 64 threads instead of ~50x */
+	mallopt(M_MMAP_THRESHOLD, 512 << 20);
+	mallopt(M_TRIM_THRESHOLD, 1 << 30);
 	#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
 	for (int f = 0; f < n; ++f)
 		orc_decode((const uint8_t *)samples + (size_t)f * stride_bytes, fmt, channels, frames_per,
