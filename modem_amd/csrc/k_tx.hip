@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256) void k_tx_code(const uint8_t *__restrict__ pay
 // global scratch, worked on by 1024 threads so the in-place radix stages still fit the register file.
 template <int RATE> struct TxCfg {
 	static constexpr bool BIG_IN_LDS = RATE <= 16000;
-	static constexpr int NT = BIG_IN_LDS ? 256 : 1024;
+#ifndef TX_NT_LDS
+#define TX_NT_LDS 256
+#endif
+	static constexpr int NT = BIG_IN_LDS ? TX_NT_LDS : 1024;
 };
 // The payload carriers of data row j are pilot x the product of the PSK symbols of rows 0..j (the transmitter's
 // differential step, encode.cc:304-309: fdom[] keeps multiplying).  One pass per payload forms all rows in that order -

@@ -977,3 +977,73 @@ def test_configs_2_and_3_at_full_size(impair):
         assert orr.status == 0 and (o == p).all() and orr.sc_start == int(r["sc_start"]) and orr.symbol_pos == int(r["symbol_pos"])
         assert abs(orr.cfo_rad - float(r["cfo_rad"])) <= REL and abs(orr.bit_flips - int(r["bit_flips"])) <= FLIPS_SLACK
     rx.close()
+
+
+def test_two_handles_decode_concurrently():
+    """Multi-GPU readiness in one process: two handles, each with its own streams and device state,
+    decode different halves of a batch at the same time (enqueued back to back, synchronised afterwards); every frame must
+    come out exactly as when one handle decodes the whole batch.  (One handle per GPU is the same code path with a
+    different device ordinal; the ranks of bench.py share nothing but the final counter reduction.)"""
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    n = 192
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    rxs = [modem_amd.Receiver(device=0, chunk_frames=32, stream=s.cuda_stream) for s in streams]
+    spf = rxs[0].tx_frame_samples(6)
+    with torch.cuda.stream(streams[0]):
+        g = torch.Generator(device=dev)
+        g.manual_seed(77)
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+        d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+        rxs[0].tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
+        rxs[0].awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, -15.0, 5, 0)      # at the waterfall: some frames fail
+        d_one = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+        r_one = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        rxs[0].decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_one.data_ptr(), r_one.data_ptr())
+        rxs[0].synchronize()
+    torch.cuda.synchronize()
+    d_two = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+    r_two = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    half = n // 2
+    for q, rx in enumerate(rxs):                              # both calls only enqueue: the two pipelines overlap on the device
+        lo = q * half
+        rx.decode_device(d_in[lo:].data_ptr(), M.FMT_S16, 2, spf, spf * 4, half, d_two[lo:].data_ptr(), r_two[lo:].data_ptr())
+    for rx in rxs:
+        rx.synchronize()
+    assert bool((d_one == d_two).all())
+    a = r_one.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+    b = r_two.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+    for name in a.dtype.names:
+        assert ((a[name] == b[name]) | ((a[name] != a[name]) & (b[name] != b[name]))).all(), name
+    assert 0 < int((a["status"] == 0).sum()) < n            # the batch really straddles the waterfall
+    for rx in rxs:
+        rx.close()
+
+
+def test_ber_sweep_driver_resumes(tmp_path):
+    """--resume: finished points are appended to a file and skipped on restart (SURVEY section 5 aux: resume for the
+    10^7-frame sweep); the noise of a frame is keyed by its level's place in the FULL list, so a point decoded after a
+    restart equals the same point of an uninterrupted run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    exe = [sys.executable, os.path.join(O.ROOT, "tools", "ber_sweep.py"), "--frames", "64", "--batch", "64"]
+    full = subprocess.run(exe + ["--levels", "-30", "-14.6"], capture_output=True, text=True, timeout=600)
+    assert full.returncode == 0, full.stdout + full.stderr
+    ref = [json.loads(ln) for ln in full.stdout.splitlines() if ln.startswith("{") and "noise_db" in ln]
+    rfile = str(tmp_path / "resume.jsonl")
+    first = subprocess.run(exe + ["--levels", "-30", "--resume", rfile], capture_output=True, text=True, timeout=600)
+    assert first.returncode == 0, first.stdout + first.stderr
+    # restart with the full list: only the second level is decoded; its numbers equal the uninterrupted run's
+    again = subprocess.run(exe + ["--levels", "-30", "-14.6", "--resume", rfile], capture_output=True, text=True, timeout=600)
+    assert again.returncode == 0, again.stdout + again.stderr
+    new = [json.loads(ln) for ln in again.stdout.splitlines() if ln.startswith("{") and "noise_db" in ln]
+    assert [p["noise_db"] for p in new] == [-14.6]
+    for key in ("frames", "fer", "ber", "declared_lost"):
+        assert new[0][key] == ref[1][key], key
+    summary = json.loads(again.stdout.strip().splitlines()[-1])
+    assert summary["points"] == 2 and summary["total_frames"] == 128
+    assert len(open(rfile).read().strip().splitlines()) == 2

@@ -30,6 +30,9 @@ def main():
                     help="decode every transmitted batch this many times, each with fresh noise (1 = every frame freshly "
                          "transmitted, the default; the noise realisations are always distinct)")
     ap.add_argument("--levels", type=float, nargs="*", default=None, help="explicit noise levels in dB (overrides --lo/--hi/--step)")
+    ap.add_argument("--resume", default=None,
+                    help="file: every finished point is appended to it as a JSON line; points already in it are skipped "
+                         "(a 10^7-frame sweep can be restarted; rank 0 reads and writes the file)")
     ap.add_argument("--dump", default=None, help="directory: keep every batch's PCM and payloads as .npy (tests, small runs only)")
     args = ap.parse_args()
 
@@ -67,6 +70,16 @@ def main():
     ev_free = [torch.cuda.Event() for _ in range(2)]     # the decode that read buffer q is done (decode stream)
 
     levels = np.asarray(args.levels) if args.levels else np.arange(args.lo, args.hi + 1e-9, args.step)
+    done_pts = []
+    if args.resume and os.path.exists(args.resume):
+        with open(args.resume) as fh:
+            done_pts = [json.loads(ln) for ln in fh if ln.startswith("{") and "noise_db" in ln]
+        done_pts = [p for p in done_pts if p.get("frames") == args.frames and p.get("seed", args.seed) == args.seed]
+    all_levels = levels
+    skip = {round(p["noise_db"], 6) for p in done_pts}
+    # (the noise seed of a frame is keyed by its level's index in the FULL list, so a resumed point equals a fresh one)
+    level_index = {round(float(db), 6): i for i, db in enumerate(all_levels)}
+    levels = np.asarray([db for db in all_levels if round(float(db), 6) not in skip])
     lo, hi = shard.block_range(args.frames, rank, world)
     # the whole job as one list of batches, so that the pipeline runs across noise levels too
     work = []
@@ -76,6 +89,7 @@ def main():
             n = min(nb, hi - f)
             work.append((li, float(db), f, n))
             f += n
+    gli = [level_index[round(float(db), 6)] for db in levels]   # position of each remaining level in the full list
 
     d_clean = torch.empty((nb, spf, 2), dtype=torch.int16, device=dev) if args.tx_reuse > 1 else None
     made, made_n = [0], [0]
@@ -84,7 +98,7 @@ def main():
         """random payloads -> device transmitter -> AWGN for batch w into buffer q, on the tx stream.  With --tx-reuse K
         the clean waveforms (and payloads) of a batch serve K consecutive batches of the same size, each with its own noise"""
         li, db, f, n = w
-        gidx = li * args.frames + f              # global frame index: distinct noise everywhere
+        gidx = gli[li] * args.frames + f         # global frame index: distinct noise everywhere
         with torch.cuda.stream(tx_stream):
             tx_stream.wait_event(ev_free[q])
             fresh = args.tx_reuse <= 1 or made[0] % args.tx_reuse == 0 or n != made_n[0]
@@ -142,11 +156,15 @@ def main():
             if rank == 0:
                 pt = {"noise_db": db, "frames": counters[0], "fer": counters[1] / counters[0],
                       "ber": counters[2] / (43040.0 * counters[0]), "declared_lost": counters[3],
-                      "frames_per_s": counters[0] / secs}
+                      "frames_per_s": counters[0] / secs, "seed": args.seed}
                 summary.append(pt)
                 print(json.dumps(pt), flush=True)
+                if args.resume:
+                    with open(args.resume, "a") as fh:
+                        fh.write(json.dumps(pt) + "\n")
     tx.close()
     if rank == 0:
+        summary = done_pts + summary
         tot = sum(p["frames"] for p in summary)
         print(json.dumps({"summary": "ber_sweep", "n_gpus": world, "total_frames": tot, "tx_reuse": args.tx_reuse,
                           "frames_per_s": tot / (time.perf_counter() - t_all), "points": len(summary)}), flush=True)
