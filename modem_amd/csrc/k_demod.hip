@@ -27,8 +27,14 @@ __device__ __forceinline__ cf psk8_hard_map(cf c)   // map(hard(c)): psk.hh:118-
 #define DEMOD_TPS 256      // 8 kHz: threads per symbol transform.  256 (four waves share one 1280-point buffer, 126 VGPRs, 10 KB of LDS:
                            // 4.0 ms per 8192 frames alone) beats one wave per symbol (64: 252 VGPRs, 40 KB, 4.3 ms) and 128 (166 VGPRs, 4.7 ms)
 #endif
+#ifndef DEMOD_NT8
+#define DEMOD_NT8 256      // 8 kHz: threads per workgroup (DEMOD_NT8 / DEMOD_TPS symbols in flight per workgroup)
+#endif
+#ifndef DEMOD_TW_LDS
+#define DEMOD_TW_LDS 1     // 8 kHz: the 1280 twiddles are copied to LDS once per frame (4.1 -> 3.4 ms per 8192 frames; 0 = read through L1)
+#endif
 template <int RATE> struct DemodShared {                     // 8 kHz: one 1280-point buffer per symbol slot
-	cf fft[256 / DEMOD_TPS][RateCfg<RATE>::SL];
+	cf fft[DEMOD_NT8 / DEMOD_TPS][RateCfg<RATE>::SL];
 };
 template <int RATE> struct DemodSharedBlock {                // other rates: one buffer, the whole block per symbol
 	cf fft[RateCfg<RATE>::SL];
@@ -45,7 +51,7 @@ template <int RATE> struct DemodSharedBlock {                // other rates: one
 #define DEMOD_WAVE_PER_SYMBOL(R) ((R) == 8000)
 #endif
 template <int RATE> struct DemodCfg {
-	static constexpr int NT = DEMOD_WAVE_PER_SYMBOL(RATE) ? 256 : 1024;     // threads per frame
+	static constexpr int NT = DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_NT8 : 1024;     // threads per frame
 #ifndef DEMOD_MINB
 #define DEMOD_MINB (DEMOD_TPS == 256 ? 4 : 2)
 #endif
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 	const int code_off = -md.cols / 2;                        // decode.cc:454
 	if constexpr (DEMOD_WAVE_PER_SYMBOL(RATE)) {
 		__shared__ DemodShared<RATE> sh;
-		constexpr int TPS = DEMOD_TPS, SLOTS = 256 / TPS;         // TPS threads share one transform; SLOTS symbols in flight per workgroup
+		constexpr int TPS = DEMOD_TPS, SLOTS = DEMOD_NT8 / TPS;   // TPS threads share one transform; SLOTS symbols in flight per workgroup
 		const int slot = tid / TPS, lt = tid % TPS;
 		(void)wave; (void)lane;
 		// NCO as at the other rates: e^{j omega (k0 + lt + TPS q)} = one closed-form phasor per thread and symbol times a table
@@ -80,6 +86,12 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 #define DEMOD_NCO_TABLE 1
 #endif
 		__shared__ cf rot8[SYMBOL_LEN / TPS];
+		__shared__ cf tw_l[DEMOD_TW_LDS ? SYMBOL_LEN : 1];
+		if (DEMOD_TW_LDS) {
+			for (int i = tid; i < SYMBOL_LEN; i += DEMOD_NT8)
+				tw_l[i] = tb.tw_sym[i];
+			__syncthreads();
+		}
 		if (DEMOD_NCO_TABLE) {
 			if (tid < SYMBOL_LEN / TPS)
 				rot8[tid] = phasor(omega, (long)TPS * tid);
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 			fetch(s + SLOTS);
 			fft_sync<TPS>();
 			// TPS = 64: one wave, its own buffer, no workgroup barriers; otherwise the slots run in lock-step
-			fft_fwd<SYMBOL_LEN, TPS, SYMBOL_LEN>(buf, tb.tw_sym, lt);
+			fft_fwd<SYMBOL_LEN, TPS, SYMBOL_LEN>(buf, DEMOD_TW_LDS ? tw_l : tb.tw_sym, lt);
 			// the payload carriers of symbol s go to HBM (cols x 8 B); the time-differential step
 			// cons = X_j / X_{j-1} (decode.cc:474-475) happens where they are read (k_theil_sen): no carrier ring,
 			// no dependence between the waves, 40 KB of LDS per workgroup
