@@ -125,6 +125,7 @@ struct ofdmrx_handle {
 	long cap_samples = 0;     // samples per frame the mono buffers are sized for
 	DevBuf st, hdr_soft, cons, slope, yint, precision, llr, soft, hard, metric, lane_mesg, res, payload;
 	DevBuf st2, llr2;         // second parity of the two buffers that cross from the front stages to the polar stage
+	DevBuf cons2, slope2, yint2, precision2;   // ... and of what the LLR kernel reads: it runs on the back stream, ahead of the list decoder
 	DevBuf payload2, res2;    // second parity of the device-side output staging (host-pointer entry)
 	DevBuf work_counter;      // k_polar's shared codeword counter (zeroed on the stream before every launch)
 	DevBuf tx_code, tx_rowsym, tx_tdom, tx_big;   // transmitter scratch, kept between calls (no allocation, no synchronisation per call)
@@ -135,6 +136,10 @@ struct ofdmrx_handle {
 	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
 	int last_par = 0;         // parity used by the last chunk (taps)
 	SyncState *st_of(int par) { return (par ? st2 : st).as<SyncState>(); }
+	cf *cons_of(int par) { return (par ? cons2 : cons).as<cf>(); }
+	float *slope_of(int par) { return (par ? slope2 : slope).as<float>(); }
+	float *yint_of(int par) { return (par ? yint2 : yint).as<float>(); }
+	float *precision_of(int par) { return (par ? precision2 : precision).as<float>(); }
 	float *llr_of(int par) { return (par ? llr2 : llr).as<float>(); }
 	DevBuf dc, z;             // mono front end only
 	DevBuf cons_raw;          // only with cfg.flags & 1 (keep the pre-rotation constellation for taps)
@@ -280,7 +285,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2 })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -303,6 +308,10 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		const size_t N2 = (size_t)std::max(n, h->cap);
 		r = r ? r : h->st2.ensure(N2 * sizeof(SyncState));
 		r = r ? r : h->llr2.ensure(N2 * CODE_LEN * sizeof(float));
+		r = r ? r : h->cons2.ensure(N2 * CONS_MAX * sizeof(cf));
+		r = r ? r : h->slope2.ensure(N2 * ROWS_MAX * sizeof(float));
+		r = r ? r : h->yint2.ensure(N2 * ROWS_MAX * sizeof(float));
+		r = r ? r : h->precision2.ensure(N2 * ROWS_MAX * sizeof(float));
 		if (r)
 			return r;
 	}
@@ -422,7 +431,7 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, i
 		}
 		{
 			Range r("ofdmrx:demod");
-			launch_demod(sq, h->rate, nq, fbq, zq, h->dev, stq, h->cons.as<cf>() + (size_t)f0 * CONS_MAX,
+			launch_demod(sq, h->rate, nq, fbq, zq, h->dev, stq, h->cons_of(par) + (size_t)f0 * CONS_MAX,
 				h->carr.p ? h->carr.as<cf>() + (size_t)f0 * CARR_MAX : nullptr);
 		}
 		size_t d = mark(h, sq);
@@ -432,7 +441,7 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, i
 		e3 = d;
 	}
 	if ((h->cfg.flags & 1) && !demod_writes_carriers(h->rate))
-		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons.p, (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
+		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons_of(par), (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
 	(void)e3;
 	h->spans.push_back({ OFDMRX_T_FRONT, e0, e1 });
 	*t_begin = e0;
@@ -444,25 +453,20 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, i
 	return 0;
 }
 
-static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_res)
+// front2 = the Theil-Sen stage (stream A).  The LLR kernel that follows it (D6-D8) is the first kernel of the back half:
+// it is short and HBM-bound, and every millisecond on stream A is on the critical path of a chunk.
+static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *)
 {
 	SyncState *st = h->st_of(par);
 	size_t e4 = mark(h, s);
 	const bool from_carr = demod_writes_carriers(h->rate);
 	{
 		Range r("ofdmrx:theil_sen");
-		launch_theil_sen(s, n, st, h->cons.as<cf>(), from_carr ? h->carr.as<cf>() : nullptr,
-			(from_carr && (h->cfg.flags & 1)) ? h->cons_raw.as<cf>() : nullptr, h->slope.as<float>(), h->yint.as<float>());
+		launch_theil_sen(s, n, st, h->cons_of(par), from_carr ? h->carr.as<cf>() : nullptr,
+			(from_carr && (h->cfg.flags & 1)) ? h->cons_raw.as<cf>() : nullptr, h->slope_of(par), h->yint_of(par));
 	}
 	size_t e5 = mark(h, s);
-	{
-		Range r("ofdmrx:llr");
-		launch_llr(s, h->rate, n, st, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
-			h->llr_of(par), d_res);
-	}
-	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_THEILSEN, e4, e5 });
-	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
 	HIP_OK(hipGetLastError());
 	return 0;
 }
@@ -471,7 +475,14 @@ static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, int grid, u
 	bool want_lane_mesg, size_t t_begin)
 {
 	SyncState *st = h->st_of(par);
+	size_t e5 = mark(h, s);
+	{
+		Range r("ofdmrx:llr");
+		launch_llr(s, h->rate, n, st, h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
+			h->llr_of(par), d_res);
+	}
 	size_t e6 = mark(h, s);
+	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
 	{
 		Range r("ofdmrx:polar_scl");
 		launch_polar(s, h->list, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(), h->work_counter.as<int>());
@@ -880,10 +891,10 @@ extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *
 		if (!(h->cfg.flags & 1))
 			return OFDMRX_E_ARG;
 		src = h->cons_raw.as<cf>() + frame * CONS_MAX; cap = CONS_MAX * sizeof(cf); break;
-	case OFDMRX_TAP_CONS_ROT: src = h->cons.as<cf>() + frame * CONS_MAX; cap = CONS_MAX * sizeof(cf); break;
-	case OFDMRX_TAP_SLOPE: src = h->slope.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
-	case OFDMRX_TAP_YINT: src = h->yint.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
-	case OFDMRX_TAP_PRECISION: src = h->precision.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
+	case OFDMRX_TAP_CONS_ROT: src = h->cons_of(h->last_par) + frame * CONS_MAX; cap = CONS_MAX * sizeof(cf); break;
+	case OFDMRX_TAP_SLOPE: src = h->slope_of(h->last_par) + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
+	case OFDMRX_TAP_YINT: src = h->yint_of(h->last_par) + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
+	case OFDMRX_TAP_PRECISION: src = h->precision_of(h->last_par) + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
 	case OFDMRX_TAP_LLR: src = h->llr_of(h->last_par) + frame * CODE_LEN; cap = CODE_LEN * 4; break;
 	case OFDMRX_TAP_METRIC: src = h->metric.as<float>() + frame * LIST; cap = LIST * 4; break;
 	case OFDMRX_TAP_LANE_MESG: src = h->lane_mesg.as<uint8_t>() + frame * LIST * MESG_BYTES; cap = LIST * MESG_BYTES; break;
