@@ -126,6 +126,7 @@ def cpu_baseline(pcm_sample, payload_ref, ch=2):
             L.orc_decode_batch.argtypes = O.lib().orc_decode_batch.argtypes
             libs[tag] = L
     for tag, L in libs.items():
+        run(L, min(n, threads), threads)        # untimed: one frame per thread populates the threads' malloc arenas and tables
         variants[tag] = run(L, n, threads)
     best = "o3_native" if "o3_native" in variants else "o2_strict"
     one = run(libs[best], min(n, max(8, int(variants[best]["frames_per_s"] / threads * 4))), 1)
