@@ -31,6 +31,7 @@ struct OsdShared {
 	int next_item;
 	int red_best[256], red_next[256], red_id[256];
 	int X;
+	uint32_t gen[BCH_K * 8];   // the generator's bit rows, copied from global memory once (the permutation below reads 255 bits of every row)
 };
 
 // After Gauss-Jordan the permuted generator is [I | P]: a candidate differs from the order-0
@@ -80,12 +81,16 @@ __device__ bool osd_certify(OsdShared &s, const uint32_t *cwbits, int tid)
 		w = c ? -(int)s.x[tid] : (int)s.x[tid];
 	}
 	s.red_id[tid] = w;
+	// sum of |w| over the negative positions and their count: packed (sum << 9 | count), one wave reduction + 4 LDS words
+	int pk = w < 0 ? ((-w) << 9) | 1 : 0;
+	#pragma unroll
+	for (int m = 32; m; m >>= 1)
+		pk += __shfl_xor(pk, m);
+	if ((tid & 63) == 0)
+		s.red_next[tid >> 6] = pk;
 	__syncthreads();
-	int neg = 0, nneg = 0;
-	for (int i = 0; i < BCH_N; ++i) {        // uniform loop, LDS broadcast reads
-		int v = s.red_id[i];
-		if (v < 0) { neg -= v; ++nneg; }
-	}
+	pk = s.red_next[0] + s.red_next[1] + s.red_next[2] + s.red_next[3];
+	const int neg = pk >> 9, nneg = pk & 511;
 	const int need = DMIN - nneg;
 	bool ok = false;
 	if (need > 0) {
@@ -132,7 +137,13 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 	if (tid == 255)
 		s.perm[255] = 255;
 	__syncthreads();
+#if defined(OSD_PROBE_STOP) && OSD_PROBE_STOP == 1
+	return false;                                             // timing probe: stop after the reliability sort
+#endif
 	// permuted generator: G[j] bit i = genmat[j][perm[i]]
+	for (int it = tid; it < BCH_K * 8; it += 256)
+		s.gen[it] = genmat_bits[it];
+	__syncthreads();
 	for (int it = tid; it < BCH_K * 8; it += 256) {
 		int j = it >> 3, w = it & 7;
 		uint32_t v = 0;
@@ -140,12 +151,15 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 			int i = 32 * w + b;
 			if (i < BCH_N) {
 				int c = s.perm[i];
-				v |= ((genmat_bits[j * 8 + (c >> 5)] >> (c & 31)) & 1u) << b;
+				v |= ((s.gen[j * 8 + (c >> 5)] >> (c & 31)) & 1u) << b;
 			}
 		}
 		s.G[j][w] = v;
 	}
 	__syncthreads();
+#if defined(OSD_PROBE_STOP) && OSD_PROBE_STOP == 2
+	return false;                                             // timing probe: stop after the permuted generator is built
+#endif
 	// Gauss-Jordan with the pivoting rule of row_echelon(): pivot = the first row >= k with a one in column k (found
 	// by all rows at once: LDS atomicMin), else the first later column that has a one in some row >= k (rare: serial)
 	if (tid == 0)
@@ -211,6 +225,9 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 		}
 		__syncthreads();
 	}
+#if defined(OSD_PROBE_STOP) && OSD_PROBE_STOP == 3
+	return false;                                             // timing probe: stop after Gauss-Jordan
+#endif
 	// permuted soft values and the byte-sliced table
 	if (tid < 256)
 		s.x[tid] = tid < BCH_N ? (short)max((int)s.soft[s.perm[tid]], -127) : 0;
@@ -233,16 +250,24 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 				v ^= s.G[i][tid];
 		s.cw[tid] = v;
 	}
+	{   // X = sum of x over all positions, S0 = sum of x over the negative systematic positions
+		int vx = tid < BCH_N ? (int)s.x[tid] : 0, v0 = (tid < BCH_K && vx < 0) ? vx : 0;
+		#pragma unroll
+		for (int m = 32; m; m >>= 1) {
+			vx += __shfl_xor(vx, m);
+			v0 += __shfl_xor(v0, m);
+		}
+		if ((tid & 63) == 0) {
+			s.red_best[tid >> 6] = vx;
+			s.red_next[tid >> 6] = v0;
+		}
+		if (tid == 0)
+			s.next_item = 0;
+	}
+	__syncthreads();
 	if (tid == 0) {
-		int X = 0, S0 = 0;
-		for (int i = 0; i < BCH_N; ++i)
-			X += s.x[i];
-		for (int i = 0; i < BCH_K; ++i)
-			if (s.x[i] < 0)
-				S0 += s.x[i];
-		s.X = X;
-		s.S0 = S0;
-		s.next_item = 0;
+		s.X = s.red_best[0] + s.red_best[1] + s.red_best[2] + s.red_best[3];
+		s.S0 = s.red_next[0] + s.red_next[1] + s.red_next[2] + s.red_next[3];
 	}
 	__syncthreads();
 	const int X = s.X, S0 = s.S0;
@@ -279,41 +304,65 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 		tr.update(X - 2 * (S0 + s.ax[a] + s.ax[b] + pl.eval(e)), (a + 1) | ((b + 1) << 7));
 	}
 	// reduce the per-thread (best, runner-up, id) triples; thread 0 rebuilds the best codeword into s.cw2
+	// Reduce the per-thread (best, runner-up, id) triples: gb = the largest best (its id from the LOWEST thread that holds
+	// it, as a serial scan would find it), gn = the largest value among all other bests and all runner-ups (gn = gb when
+	// two threads hold gb); then rebuild the best codeword into s.cw2.  Wave shuffles + four LDS slots, no serial scan.
 	auto reduce_tracks = [&]() {
-		s.red_best[tid] = tr.best;
-		s.red_next[tid] = tr.next;
-		s.red_id[tid] = tr.id;
-		__syncthreads();
-		if (tid == 0) {
-			int gb = -0x7fffffff, gi = 0, cnt = 0, gn = -1;
-			for (int t = 0; t < 256; ++t)
-				if (s.red_best[t] > gb) { gb = s.red_best[t]; gi = s.red_id[t]; }
-			for (int t = 0; t < 256; ++t) {
-				if (s.red_best[t] == gb) ++cnt;
-				else if (s.red_best[t] > gn) gn = s.red_best[t];
-				if (s.red_next[t] > gn) gn = s.red_next[t];
-			}
-			if (cnt > 1) gn = gb;
-			for (int w = 0; w < 8; ++w) s.cw2[w] = s.cw[w];
-			for (int q = 0; q < 4; ++q) {
-				int r = (gi >> (7 * q)) & 127;
-				if (r)
-					for (int w = 0; w < 8; ++w) s.cw2[w] ^= s.G[r - 1][w];
-			}
-			s.pivot_row = (gb != gn);
+		const int lane = tid & 63, wv = tid >> 6;
+		int b = tr.best, id = tr.id, t = tid;
+		#pragma unroll
+		for (int m = 32; m; m >>= 1) {
+			const int ob = __shfl_xor(b, m), oi = __shfl_xor(id, m), ot = __shfl_xor(t, m);
+			if (ob > b || (ob == b && ot < t)) { b = ob; id = oi; t = ot; }
 		}
+		if (lane == 0) { s.red_best[wv] = b; s.red_id[wv] = id; s.red_next[wv] = t; }
+		__syncthreads();
+		int gb = s.red_best[0], gi = s.red_id[0], gt = s.red_next[0];
+		#pragma unroll
+		for (int q = 1; q < 4; ++q)
+			if (s.red_best[q] > gb) { gb = s.red_best[q]; gi = s.red_id[q]; gt = s.red_next[q]; }
+		__syncthreads();
+		// runner-up: every other thread's best, every thread's runner-up; a second holder of gb makes the optimum ambiguous
+		int n2 = tr.next;
+		if (tid != gt && tr.best > n2)
+			n2 = tr.best;
+		#pragma unroll
+		for (int m = 32; m; m >>= 1)
+			n2 = max(n2, __shfl_xor(n2, m));
+		if (lane == 0)
+			s.red_next[wv] = n2;
+		__syncthreads();
+		const int gn = max(max(s.red_next[0], s.red_next[1]), max(s.red_next[2], s.red_next[3]));
+		if (tid < 8) {
+			uint32_t v = s.cw[tid];
+			#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int r = (gi >> (7 * q)) & 127;
+				if (r)
+					v ^= s.G[r - 1][tid];
+			}
+			s.cw2[tid] = v;
+		}
+		if (tid == 0)
+			s.pivot_row = (gb != gn);
 		__syncthreads();
 	};
 	auto emit = [&](bool unique) {
-		if (tid == 0) {
-			for (int i = 0; i < 32; ++i) hard_out[i] = 0;
-			for (int i = 0; i < BCH_N; ++i) {
-				int p = s.perm[i];
-				if ((s.cw2[i >> 5] >> (i & 31)) & 1)
-					hard_out[p >> 3] |= (uint8_t)(0x80 >> (p & 7));
-			}
-			s.pivot_row = unique;
+		// un-permute the best codeword: bit i of cw2 is code position perm[i]; big-endian bits in 32 bytes, assembled with
+		// LDS atomics on eight words (byte p >> 3 of the output = byte (p >> 3) & 3 of word p >> 5)
+		uint32_t *hw = (uint32_t *)s.red_best;
+		if (tid < 8)
+			hw[tid] = 0;
+		__syncthreads();
+		if (tid < BCH_N && ((s.cw2[tid >> 5] >> (tid & 31)) & 1)) {
+			const int p = s.perm[tid];
+			atomicOr(&hw[p >> 5], (0x80u >> (p & 7)) << (8 * ((p >> 3) & 3)));
 		}
+		__syncthreads();
+		if (tid < 32)
+			hard_out[tid] = (uint8_t)(hw[tid >> 2] >> (8 * (tid & 3)));
+		if (tid == 0)
+			s.pivot_row = unique;
 		__syncthreads();
 		return s.pivot_row != 0;
 	};

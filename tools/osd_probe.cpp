@@ -9,7 +9,7 @@ using namespace rx;
 template <typename T> const T *up(const std::vector<T> &v) { void *p; hipMalloc(&p, v.size() * sizeof(T)); hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return (const T *)p; }
 int main()
 {
-	HostTables h; build_tables(h);
+	HostTables h; build_tables(h, 8000);
 	Tables t{}; t.genmat_bits = up(h.genmat_bits); t.osd_pairs = up(h.osd_pairs); t.osd_triples = up(h.osd_triples);
 	const int n = getenv("PROBE_N") ? atoi(getenv("PROBE_N")) : 4096;
 	std::mt19937 rng(1); std::vector<int8_t> soft(n * 255);
