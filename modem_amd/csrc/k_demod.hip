@@ -482,16 +482,19 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 #ifndef TS_NO_LINEAR_HIST
 		{
 			const int lane = tid & 63, wave = tid >> 6;
+			// block sums through alternating LDS slots (red / bin-pair scratch in part[]): the slot of sum k is not written
+			// again before the barrier of sum k+1, so one barrier per sum is enough
+			int flip = 0;
 			auto block_sum = [&](float v) {
 				#pragma unroll
 				for (int mm = 32; mm; mm >>= 1)
 					v += __shfl_xor(v, mm);
+				int *slot = flip ? s.part : s.red;
+				flip ^= 1;
 				if (lane == 0)
-					s.red[wave] = __float_as_int(v);
+					slot[wave] = __float_as_int(v);
 				__syncthreads();
-				const float t = (__int_as_float(s.red[0]) + __int_as_float(s.red[1])) + (__int_as_float(s.red[2]) + __int_as_float(s.red[3]));
-				__syncthreads();
-				return t;
+				return (__int_as_float(slot[0]) + __int_as_float(slot[1])) + (__int_as_float(slot[2]) + __int_as_float(slot[3]));
 			};
 			auto pre = [&](auto emit) {
 				for (int d = 64; d < n; d += 64) {
@@ -500,9 +503,12 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 						emit((s.y[i + d] - s.y[i]) * rd);
 				}
 			};
-			float a0 = 0.f, cntf = 0.f;
-			pre([&](float q) { a0 += q; cntf += 1.f; });
-			const float cnt = block_sum(cntf);
+			int cnti = 0;
+			for (int d = 64; d < n; d += 64)
+				cnti += n - d;
+			const float cnt = (float)cnti;
+			float a0 = 0.f;
+			pre([&](float q) { a0 += q; });
 			const float c = block_sum(a0) / cnt;
 			float a1 = 0.f;
 			pre([&](float q) { a1 += fabsf(q - c); });
