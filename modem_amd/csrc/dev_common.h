@@ -111,6 +111,24 @@ __device__ __forceinline__ cf phasor(float omega, long k)
 }
 
 // ---- raw PCM access: what DSP::ReadWAV + next_sample() deliver for 2-channel input
+// x / 32767.f and x / 127.f for integer-valued x of the PCM's range, correctly rounded like the division the reference
+// runs (pcm.hh), in three instructions instead of the dozen of an IEEE fp32 division: q0 = x c with c = RN(1 / d), the
+// exact residual r = x - d q0 (one FMA) and q0 + r c (Markstein).  Checked against the division for every int16 and
+// uint8 input (tools/check_pcm_div.c).
+__device__ __forceinline__ float div_32767(float x)
+{
+	const float c = 1.0f / 32767.f;
+	const float q0 = x * c;
+	return __builtin_fmaf(__builtin_fmaf(-32767.f, q0, x), c, q0);
+}
+__device__ __forceinline__ float div_127(float x)
+{
+	const float c = 1.0f / 127.f;
+	const float q0 = x * c;
+	return __builtin_fmaf(__builtin_fmaf(-127.f, q0, x), c, q0);
+}
+
+template <int V> struct IntC { static constexpr int value = V; };
 struct SampleSrc {
 	const void *base;      // first sample of this frame
 	int fmt;               // OFDMRX_FMT_*
@@ -119,8 +137,8 @@ struct SampleSrc {
 	const cf *analytic;    // mono: output of the front-end kernel (D1), else nullptr
 	__device__ __forceinline__ float scalar(long idx) const
 	{
-		if (fmt == 0) return (float)((const int16_t *)base)[idx] / 32767.f;
-		if (fmt == 1) return (float)((int)((const uint8_t *)base)[idx] - 128) / 127.f;
+		if (fmt == 0) return div_32767((float)((const int16_t *)base)[idx]);
+		if (fmt == 1) return div_127((float)((int)((const uint8_t *)base)[idx] - 128));
 		return ((const float *)base)[idx];
 	}
 	__device__ __forceinline__ cf at(long i) const
@@ -131,9 +149,30 @@ struct SampleSrc {
 			return analytic[i];
 		if (fmt == 0) {
 			short2 v = ((const short2 *)base)[i];
-			return mk((float)v.x / 32767.f, (float)v.y / 32767.f);
+			return mk(div_32767((float)v.x), div_32767((float)v.y));
 		}
 		return mk(scalar(2 * i), scalar(2 * i + 1));
+	}
+	// the same with the format decided once per kernel instead of once per sample: 0 = analytic (mono), 1 = int16 pairs, 2 = the rest
+	__device__ __forceinline__ int mode() const { return analytic ? 0 : (fmt == 0 ? 1 : 2); }
+	template <int M> __device__ __forceinline__ cf at_m(long i) const
+	{
+		if (i < 0 || i >= n)
+			return mk(0.f, 0.f);
+		if (M == 0)
+			return analytic[i];
+		if (M == 1) {
+			short2 v = ((const short2 *)base)[i];
+			return mk(div_32767((float)v.x), div_32767((float)v.y));
+		}
+		return mk(scalar(2 * i), scalar(2 * i + 1));
+	}
+	template <class F> __device__ __forceinline__ void with_mode(F f) const
+	{
+		const int m = mode();
+		if (m == 0) f(IntC<0>{});
+		else if (m == 1) f(IntC<1>{});
+		else f(IntC<2>{});
 	}
 };
 
@@ -215,7 +254,11 @@ template <int NT> __device__ __forceinline__ void fft_sync()
 		__syncthreads();
 }
 
-template <int N, int R, int P, int NT, int TWN = 1280>
+// TWC < 0: tw = table of TWN roots e^{-j 2 pi m / TWN}, read at stride TWN / (P R) - fine through L1, but in LDS the strides
+// of the early stages are multiples of the 128-byte bank cycle (a 20-way conflict at P = 20).
+// TWC >= 0: tw = the plan's COMPACT table (fft_compact_twiddles below): stage (P, R) owns (R - 1) P consecutive entries
+// [TWC + (t - 1) P + k] = w^(t k TWN / (P R)), so consecutive butterflies read consecutive words.
+template <int N, int R, int P, int NT, int TWN = 1280, int TWC = -1>
 __device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
 {
 	constexpr int T = N / R;
@@ -231,7 +274,7 @@ __device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
 			for (int t = 0; t < R; ++t) {
 				cf x = buf[b + t * T];
 				if (t && P > 1)
-					x = cmul(x, tw[(t * k) * TWS]);
+					x = cmul(x, TWC >= 0 ? tw[TWC + (t - 1) * P + k] : tw[(t * k) * TWS]);
 				v[q][t] = x;
 			}
 			Bfly<R>::run(v[q]);
@@ -256,22 +299,47 @@ __device__ __forceinline__ void fft_stage(cf *buf, const cf *tw, int tid)
 // The radix plan is fixed at compile time: all 5s, then 7s, 3s, 4s and a final 2
 //   640 = 5.4.4.4.2   1280 = 5.4.4.4.4   2560 = 5.4.4.4.4.2   3528 = 7.7.3.3.4.2   3840 = 5.3.4.4.4.4
 //   5120 = 5.4^5   7056 = 7.7.3.3.4.4   7680 = 5.3.4.4.4.4.2
-// tw = table of TWN roots e^{-j 2 pi m / TWN}, N | TWN.
-template <int N, int REM, int P, int NT, int TWN> struct FftPlan {
+// tw = table of TWN roots e^{-j 2 pi m / TWN}, N | TWN (TWC < 0), or the compact table of this plan (TWC = 0).
+template <int N, int REM, int P, int NT, int TWN, int TWC> struct FftPlan {
 	static constexpr int R = REM % 5 == 0 ? 5 : REM % 7 == 0 ? 7 : REM % 3 == 0 ? 3 : REM % 4 == 0 ? 4 : 2;
+	static constexpr int OWN = P > 1 ? (R - 1) * P : 0;      // compact entries of this stage
+	using Next = FftPlan<N, REM / R, P * R, NT, TWN, (TWC >= 0 ? TWC + OWN : -1)>;
+	static constexpr int COMPACT = OWN + Next::COMPACT;
 	static __device__ __forceinline__ void run(cf *buf, const cf *tw, int tid)
 	{
-		fft_stage<N, R, P, NT, TWN>(buf, tw, tid);
-		FftPlan<N, REM / R, P * R, NT, TWN>::run(buf, tw, tid);
+		fft_stage<N, R, P, NT, TWN, TWC>(buf, tw, tid);
+		Next::run(buf, tw, tid);
+	}
+	// dst[TWC + (t - 1) P + k] = src[t k TWN / (P R)], every stage of the plan, NT threads
+	static __device__ __forceinline__ void fill(cf *dst, const cf *src, int tid)
+	{
+		if (P > 1)
+			for (int i = tid; i < OWN; i += NT)
+				dst[TWC + i] = src[((i / P + 1) * (i % P)) * (TWN / (P * R))];
+		Next::fill(dst, src, tid);
 	}
 };
-template <int N, int P, int NT, int TWN> struct FftPlan<N, 1, P, NT, TWN> {
+template <int N, int P, int NT, int TWN, int TWC> struct FftPlan<N, 1, P, NT, TWN, TWC> {
+	static constexpr int COMPACT = 0;
 	static __device__ __forceinline__ void run(cf *, const cf *, int) {}
+	static __device__ __forceinline__ void fill(cf *, const cf *, int) {}
 };
 template <int N, int NT, int TWN>
 __device__ __forceinline__ void fft_fwd(cf *buf, const cf *tw, int tid)
 {
-	FftPlan<N, N, 1, NT, TWN>::run(buf, tw, tid);
+	FftPlan<N, N, 1, NT, TWN, -1>::run(buf, tw, tid);
+}
+// the same with the plan's compact twiddle table (LDS): fft_compact_size<N, TWN>() entries, built by fft_compact_twiddles
+template <int N, int TWN> constexpr int fft_compact_size() { return FftPlan<N, N, 1, 64, TWN, 0>::COMPACT; }
+template <int N, int NT, int TWN>
+__device__ __forceinline__ void fft_compact_twiddles(cf *dst, const cf *tw, int tid)
+{
+	FftPlan<N, N, 1, NT, TWN, 0>::fill(dst, tw, tid);
+}
+template <int N, int NT, int TWN>
+__device__ __forceinline__ void fft_fwd_compact(cf *buf, const cf *twc, int tid)
+{
+	FftPlan<N, N, 1, NT, TWN, 0>::run(buf, twc, tid);
 }
 
 // ---- wave helpers ----------------------------------------------------------

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_awgn_tile(const short2 *__restrict__ ba
 		float sn, cs;
 		sincosf(TWO_PI_F * u2, &sn, &cs);
 		short2 v = src[i];
-		float re = (float)v.x / 32767.f + mag * cs, im = (float)v.y / 32767.f + mag * sn;
+		float re = div_32767((float)v.x) + mag * cs, im = div_32767((float)v.y) + mag * sn;
 		re = fminf(fmaxf(re, -1.f), 1.f);
 		im = fminf(fmaxf(im, -1.f), 1.f);
 		dst[i] = make_short2((short)nearbyintf(32767.f * re), (short)nearbyintf(32767.f * im));
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_channel(const short2 *__restrict__ in, 
 				if (idx < 0 || (size_t)idx >= spf)
 					continue;
 				short2 v = src[idx];
-				float xr = (float)v.x / 32767.f, xi = (float)v.y / 32767.f;
+				float xr = div_32767((float)v.x), xi = div_32767((float)v.y);
 				re += xr * cp.gre[t] - xi * cp.gim[t];
 				im += xr * cp.gim[t] + xi * cp.gre[t];
 			}

@@ -86,10 +86,11 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 #define DEMOD_NCO_TABLE 1
 #endif
 		__shared__ cf rot8[SYMBOL_LEN / TPS];
-		__shared__ cf tw_l[DEMOD_TW_LDS ? SYMBOL_LEN : 1];
+		// twiddles in LDS, in the transform plan's compact per-stage layout (the plain 1280-entry table read at the early
+		// stages' strides put every lane on one bank: 44 % of the kernel's LDS time was conflict replays)
+		__shared__ cf tw_l[DEMOD_TW_LDS ? fft_compact_size<SYMBOL_LEN, SYMBOL_LEN>() : 1];
 		if (DEMOD_TW_LDS) {
-			for (int i = tid; i < SYMBOL_LEN; i += DEMOD_NT8)
-				tw_l[i] = tb.tw_sym[i];
+			fft_compact_twiddles<SYMBOL_LEN, DEMOD_NT8, SYMBOL_LEN>(tw_l, tb.tw_sym, tid);
 			__syncthreads();
 		}
 		if (DEMOD_NCO_TABLE) {
@@ -101,11 +102,12 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 		// the samples of the NEXT symbol are fetched while the current one is transformed (a symbol is 5 KB of raw PCM: its
 		// HBM round trip is as long as the whole transform)
 		constexpr int NQ = SYMBOL_LEN / TPS;
+		src.with_mode([&](auto M) {
 		cf pre[NQ];
 		auto fetch = [&](int sym) {
 			#pragma unroll
 			for (int q = 0; q < NQ; ++q)
-				pre[q] = sym <= md.rows ? src.at(body0 + (long)sym * SYM_STRIDE + lt + TPS * q) : mk(0.f, 0.f);
+				pre[q] = sym <= md.rows ? src.template at_m<decltype(M)::value>(body0 + (long)sym * SYM_STRIDE + lt + TPS * q) : mk(0.f, 0.f);
 		};
 		fetch(slot);
 		for (int g = 0; g < groups; ++g) {
@@ -124,7 +126,10 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 			fetch(s + SLOTS);
 			fft_sync<TPS>();
 			// TPS = 64: one wave, its own buffer, no workgroup barriers; otherwise the slots run in lock-step
-			fft_fwd<SYMBOL_LEN, TPS, SYMBOL_LEN>(buf, DEMOD_TW_LDS ? tw_l : tb.tw_sym, lt);
+			if (DEMOD_TW_LDS)
+				fft_fwd_compact<SYMBOL_LEN, TPS, SYMBOL_LEN>(buf, tw_l, lt);
+			else
+				fft_fwd<SYMBOL_LEN, TPS, SYMBOL_LEN>(buf, tb.tw_sym, lt);
 			// the payload carriers of symbol s go to HBM (cols x 8 B); the time-differential step
 			// cons = X_j / X_{j-1} (decode.cc:474-475) happens where they are read (k_theil_sen): no carrier ring,
 			// no dependence between the waves, 40 KB of LDS per workgroup
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 			}
 			fft_sync<TPS>();                                      // the next group refills the buffer
 		}
+		});
 	} else {
 		__shared__ DemodSharedBlock<RATE> sh;
 		// NCO: e^{j omega (k0 + tid + 256 q)} = (one closed-form phasor per thread and symbol) x (a table of

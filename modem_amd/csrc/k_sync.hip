@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, 
 			const int w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
 			#pragma unroll
 			for (int q = 0; q < 8; ++q) {
-				x[1 + 2 * q] = (float)(short)(w[q] & 0xffff) / 32767.f;
-				x[2 + 2 * q] = (float)(short)(w[q] >> 16) / 32767.f;
+				x[1 + 2 * q] = div_32767((float)(short)(w[q] & 0xffff));
+				x[2 + 2 * q] = div_32767((float)(short)(w[q] >> 16));
 			}
 		} else {
 			#pragma unroll
