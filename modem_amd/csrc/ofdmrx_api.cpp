@@ -135,7 +135,8 @@ struct ofdmrx_handle {
 	hipError_t sticky = hipSuccess;   // first failed hipEventRecord of the running call
 	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
 	int last_par = 0;         // parity used by the last chunk (taps)
-	SyncState *st_of(int par) { return (par ? st2 : st).as<SyncState>(); }
+	DevBuf st3;               // third SyncState array: finish(c-1) still reads its own while sync / header of chunk c+1 write theirs
+	SyncState *st_of(int i) { return (i == 0 ? st : i == 1 ? st2 : st3).as<SyncState>(); }
 	cf *cons_of(int par) { return (par ? cons2 : cons).as<cf>(); }
 	float *slope_of(int par) { return (par ? slope2 : slope).as<float>(); }
 	float *yint_of(int par) { return (par ? yint2 : yint).as<float>(); }
@@ -285,7 +286,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2 })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3 })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -307,6 +308,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 	if (two_parities) {
 		const size_t N2 = (size_t)std::max(n, h->cap);
 		r = r ? r : h->st2.ensure(N2 * sizeof(SyncState));
+		r = r ? r : h->st3.ensure(N2 * sizeof(SyncState));
 		r = r ? r : h->llr2.ensure(N2 * CODE_LEN * sizeof(float));
 		r = r ? r : h->cons2.ensure(N2 * CONS_MAX * sizeof(cf));
 		r = r ? r : h->slope2.ensure(N2 * ROWS_MAX * sizeof(float));
@@ -378,11 +380,11 @@ static size_t events_per_chunk(int max_skip) { return 32 + 16 * (size_t)(max_ski
 //   back  (D9, D10: polar list decoder, systematic bits / CRC / pack)     <- st[par], llr[par]
 // A one-chunk call runs both on the handle's stream.  A longer batch is pipelined: back(c) runs on the
 // second stream while front(c+1) runs on the handle's stream.
-static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
+static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, int sti, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
 	size_t *t_begin)
 {
 	const bool mono = fb.channels == 1;
-	SyncState *st = h->st_of(par);
+	SyncState *st = h->st_of(sti);
 	const cf *z = mono ? h->z.as<cf>() : nullptr;
 	size_t e0 = mark(h, s);
 	if (mono) {
@@ -455,9 +457,9 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, FrameBatch fb, i
 
 // front2 = the Theil-Sen stage (stream A).  The LLR kernel that follows it (D6-D8) is the first kernel of the back half:
 // it is short and HBM-bound, and every millisecond on stream A is on the critical path of a chunk.
-static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *)
+static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Result *)
 {
-	SyncState *st = h->st_of(par);
+	SyncState *st = h->st_of(sti);
 	size_t e4 = mark(h, s);
 	const bool from_carr = demod_writes_carriers(h->rate);
 	{
@@ -471,23 +473,34 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *)
 	return 0;
 }
 
-static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, int grid, uint8_t *d_payload, Result *d_res,
-	bool want_lane_mesg, size_t t_begin)
+// The back half in two pieces, so that the pipeline can put an event between them: the LLR kernel (short, needs only the
+// Theil-Sen results) and polar + finish; *ev_polar (nullable) receives the event recorded right after the polar kernel.
+static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Result *d_res)
 {
-	SyncState *st = h->st_of(par);
 	size_t e5 = mark(h, s);
 	{
 		Range r("ofdmrx:llr");
-		launch_llr(s, h->rate, n, st, h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
+		launch_llr(s, h->rate, n, h->st_of(sti), h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
 			h->llr_of(par), d_res);
 	}
 	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
+	HIP_OK(hipGetLastError());
+	return 0;
+}
+
+static int run_polar_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, uint8_t *d_payload, Result *d_res,
+	bool want_lane_mesg, size_t t_begin, size_t *ev_polar)
+{
+	SyncState *st = h->st_of(sti);
+	size_t e6 = mark(h, s);
 	{
 		Range r("ofdmrx:polar_scl");
 		launch_polar(s, h->list, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(), h->work_counter.as<int>());
 	}
 	size_t e7 = mark(h, s);
+	if (ev_polar)
+		*ev_polar = e7;
 	{
 		Range r("ofdmrx:finish");
 		launch_finish(s, h->list, n, st, h->llr_of(par), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
@@ -499,6 +512,13 @@ static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, int grid, u
 	h->spans.push_back({ OFDMRX_T_TOTAL, t_begin, e8 });
 	HIP_OK(hipGetLastError());
 	return 0;
+}
+
+static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, uint8_t *d_payload, Result *d_res,
+	bool want_lane_mesg, size_t t_begin)
+{
+	int r = run_llr(h, s, par, sti, n, d_res);
+	return r ? r : run_polar_finish(h, s, par, sti, n, grid, d_payload, d_res, want_lane_mesg, t_begin, nullptr);
 }
 
 static int check_args(ofdmrx_handle *h, const void *samples, int fmt, int channels, size_t spf, size_t stride,
@@ -599,10 +619,10 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 			if (ready != (size_t)-1)
 				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ready], 0));
 			hooks.dst(c, &pay, &res);
-			r = run_front1(h, h->stream, 0, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0);
+			r = run_front1(h, h->stream, 0, 0, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0);
 			r = r ? r : hooks.after_front1(c, mark(h, h->stream));
-			r = r ? r : run_front2(h, h->stream, 0, n_of(c), res);
-			r = r ? r : run_back(h, h->stream, 0, n_of(c), force_grid ? h->polar_grid : 0, pay, res, true, t0);
+			r = r ? r : run_front2(h, h->stream, 0, 0, n_of(c), res);
+			r = r ? r : run_back(h, h->stream, 0, 0, n_of(c), force_grid ? h->polar_grid : 0, pay, res, true, t0);
 			r = r ? r : hooks.after_back(c, mark(h, h->stream), h->stream);
 		}
 		return r;
@@ -611,27 +631,40 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 	if (r)
 		return r;
 	const size_t NONE = (size_t)-1;
-	std::vector<size_t> ev_back(n_chunks, NONE), ev_f2(n_chunks, NONE), t0s(n_chunks, 0);
-	// back(c-1) is launched once sync / header / demod of chunk c are through: those kernels are short and latency-bound,
-	// and although each fits on a CU beside the resident polar grid (sync 224 VGPRs / 22 KB, header 216 / 18 KB, demod
-	// 128 / 10 KB against 12 decoders x 96 VGPRs / 8 KB) they starve there - measured: 138.7 k frames/s with the whole
-	// front inside the polar phase (OFDMRX_FRONT_OVERLAP=1) against 142.7 k with this order.
+	std::vector<size_t> ev_back(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_f2(n_chunks, NONE), t0s(n_chunks, 0);
+	// Order of a period (chunk c on stream A, chunk c-1 on stream B):
+	//   A: front1(c) = sync / header / demod, alone on the device
+	//   A: front2(c) = Theil-Sen                      B: back(c-1) = llr, polar, finish
+	// back(c-1) is launched once front1(c) is through, and front1(c+1) waits for back(c-1): the three front kernels are
+	// short and latency-bound, and although each fits on a CU beside the resident polar grid (12 decoders x 96 VGPRs / 8 KB)
+	// they starve there - measured: 134 k frames/s with the whole front inside the polar phase (OFDMRX_FRONT_OVERLAP=1)
+	// against 158 k with this order.  Even the two light HBM-bound kernels of the back half disturb them: llr(c-1) beside
+	// front1(c) (OFDMRX_LLR_EARLY=1) costs sync 1.25 -> 1.9 ms: 154.6 k; front1(c+1) beside finish(c-1)
+	// (OFDMRX_FINISH_LATE=1; SyncState has three buffers, c mod 3, to allow it) is neutral: 158.7 k against 158.5 k.
 	static const bool front_exclusive = std::getenv("OFDMRX_FRONT_OVERLAP") == nullptr;
+	// experiments: the LLR kernel of chunk c-1 beside front1(c) / front1(c+1) not waiting for finish(c-1)
+	static const bool llr_early = std::getenv("OFDMRX_LLR_EARLY") != nullptr, finish_late = std::getenv("OFDMRX_FINISH_LATE") != nullptr;
 	auto enqueue_back = [&](size_t p, size_t ev_f1, bool last) -> int {
 		uint8_t *pay;
 		Result *res;
 		hooks.dst(p, &pay, &res);
+		const int par = (int)(p & 1), sti = (int)(p % 3);
 		HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f2[p]], 0));
-		if (ev_f1 != NONE)
+		if (ev_f1 != NONE && !llr_early)
 			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
-		int rr = run_back(h, h->stream_b, (int)(p & 1), n_of(p), last ? 0 : h->polar_grid, pay, res, true, t0s[p]);
+		int rr = run_llr(h, h->stream_b, par, sti, n_of(p), res);
+		if (rr)
+			return rr;
+		if (ev_f1 != NONE && llr_early)
+			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
+		rr = run_polar_finish(h, h->stream_b, par, sti, n_of(p), last ? 0 : h->polar_grid, pay, res, true, t0s[p], &ev_polar[p]);
 		if (rr)
 			return rr;
 		ev_back[p] = mark(h, h->stream_b);
 		return hooks.after_back(p, ev_back[p], h->stream_b);
 	};
 	for (size_t c = 0; c <= n_chunks; ++c) {
-		const int par = (int)(c & 1);
+		const int par = (int)(c & 1), sti = (int)(c % 3);
 		size_t ev_f1 = NONE;
 		if (c >= 1 && !front_exclusive) {                    // nothing left to share the machine with after the last chunk: all decoders resident
 			r = enqueue_back(c - 1, NONE, c == n_chunks);
@@ -646,9 +679,12 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 				return r;
 			if (ready != NONE)
 				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ready], 0));
-			if (c >= 2 && ev_back[c - 2] != NONE)        // st[par] / llr[par] are free once back(c-2) is done
-				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c - 2]], 0));
-			r = run_front1(h, h->stream, par, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0s[c]);
+			// cons / slope / yint [par] are free once llr(c-2) has read them, st[sti] once finish(c-3) is done: both precede
+			// polar(c-2) on stream B
+			const std::vector<size_t> &gate = (front_exclusive && finish_late) ? ev_polar : ev_back;
+			if (c >= 2 && gate[c - 2] != NONE)
+				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[gate[c - 2]], 0));
+			r = run_front1(h, h->stream, par, sti, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0s[c]);
 			if (r)
 				return r;
 			ev_f1 = mark(h, h->stream);
@@ -665,7 +701,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 			uint8_t *pay;
 			Result *res;
 			hooks.dst(c, &pay, &res);
-			r = run_front2(h, h->stream, par, n_of(c), res);
+			r = run_front2(h, h->stream, par, sti, n_of(c), res);
 			if (r)
 				return r;
 			ev_f2[c] = mark(h, h->stream);
