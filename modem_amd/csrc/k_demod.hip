@@ -50,10 +50,14 @@ template <int RATE> struct DemodSharedBlock {                // other rates: one
 #ifndef DEMOD_WAVE_PER_SYMBOL
 #define DEMOD_WAVE_PER_SYMBOL(R) ((R) == 8000)
 #endif
+#ifndef DEMOD_DIF5
+#define DEMOD_DIF5 1       // 8 kHz: radix-5 decimation in frequency in registers, then five wave-private 256-point transforms (5 waves)
+#endif
 template <int RATE> struct DemodCfg {
-	static constexpr int NT = DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_NT8 : 1024;     // threads per frame
+	static constexpr bool DIF5 = DEMOD_DIF5 && RATE == 8000;
+	static constexpr int NT = DIF5 ? 320 : DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_NT8 : 1024;     // threads per frame
 #ifndef DEMOD_MINB
-#define DEMOD_MINB (DEMOD_TPS == 256 ? 4 : 2)
+#define DEMOD_MINB (DEMOD_DIF5 ? 3 : DEMOD_TPS == 256 ? 4 : 2)
 #endif
 	static constexpr int MINB = DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_MINB : 1;        // waves per SIMD the register budget is set for
 };
@@ -74,7 +78,95 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 	const long body0 = st.sc_start + 2 * SYM_STRIDE;          // pilot body, decode.cc:456-459
 	const float omega = -st.cfo_rad;                          // decode.cc:403
 	const int code_off = -md.cols / 2;                        // decode.cc:454
-	if constexpr (DEMOD_WAVE_PER_SYMBOL(RATE)) {
+	if constexpr (DemodCfg<RATE>::DIF5) {
+		// 1280 = 5 x 256.  X[5q + r] = sum_n' w256^(n' q) [ w1280^(n' r) sum_a x[n' + 256 a] w5^(a r) ]: thread n' < 256 loads its
+		// five samples (stride 256: the raw PCM is read coalesced), runs the radix-5 butterfly in registers, applies the four
+		// twiddles and parks output r in row r of an LDS buffer; wave r (five waves) then transforms row r - 256 points, four
+		// radix-4 stages of ONE butterfly per lane, wave barriers only, twiddles from a compact LDS table.  Two workgroup
+		// barriers per symbol (after the rows are written, before the carriers are read) against twelve of the cooperative
+		// 1280-point transform; the rows are double-buffered so that the next symbol's rows need no third one.
+		static_assert(SYMBOL_LEN == 1280, "5 x 256");
+		constexpr int NT = DemodCfg<RATE>::NT, NR = 5, NS = 256;
+		constexpr int TWC = fft_compact_size<NS, SYMBOL_LEN>();
+		__shared__ cf rows[2][NR][NS];
+		__shared__ cf tw_sub[TWC];                            // compact twiddles of the 256-point plan
+		__shared__ cf tw_r[NR - 1][NS];                       // w1280^(n' r), r = 1..4
+		__shared__ cf rot5[NR], symrot[ROWS_MAX + 1];
+		fft_compact_twiddles<NS, NT, SYMBOL_LEN>(tw_sub, tb.tw_sym, tid);
+		for (int i = tid; i < (NR - 1) * NS; i += NT)
+			tw_r[i / NS][i % NS] = tb.tw_sym[((i / NS + 1) * (i % NS)) % SYMBOL_LEN];
+		// NCO e^{j omega (symbol_len + s stride + n' + 256 a)} = (per thread and a, once per frame: q[a]) x (per symbol: symrot[s]); the
+		// transform is linear, so the per-symbol factor multiplies the 432 carriers on their way out instead of the 1280 samples
+		if (tid < NR)
+			rot5[tid] = phasor(omega, (long)NS * tid);
+		if (tid <= md.rows)
+			symrot[tid] = phasor(omega, (long)tid * SYM_STRIDE);
+		const cf p0 = phasor(omega, (long)SYMBOL_LEN + (tid & (NS - 1)));
+		__syncthreads();
+		const bool loader = tid < NS;
+		cf q[NR];
+		#pragma unroll
+		for (int a = 0; a < NR; ++a)
+			q[a] = a ? cmul(p0, rot5[a]) : p0;
+		// the (at most two) carriers of this thread sit at the same place of the rows in every symbol
+		int coff[2];
+		#pragma unroll
+		for (int e = 0; e < 2; ++e) {
+			const int i = tid + NT * e, k = (i + code_off + SYMBOL_LEN) % SYMBOL_LEN;
+			coff[e] = i < md.cols ? (k % NR) * NS + k / NR : -1;
+		}
+		src.with_mode([&](auto M) {
+		constexpr int MODE = decltype(M)::value;
+		cf pre[NR];
+		auto fetch = [&](int sym) {
+			const long t0 = body0 + (long)sym * SYM_STRIDE;       // wave-uniform
+			if (MODE == 1 && sym <= md.rows && t0 >= 0 && t0 + SYMBOL_LEN <= src.n) {
+				// the whole symbol lies inside the frame (the rule): int16 pairs straight from a uniform base, no per-sample checks
+				const short2 *p = (const short2 *)src.base + t0;
+				if (loader) {
+					#pragma unroll
+					for (int a = 0; a < NR; ++a) {
+						const short2 v = p[tid + NS * a];
+						pre[a] = mk(div_32767((float)v.x), div_32767((float)v.y));
+					}
+				}
+			} else {
+				#pragma unroll
+				for (int a = 0; a < NR; ++a)
+					pre[a] = (loader && sym <= md.rows) ? src.template at_m<MODE>(t0 + tid + NS * a) : mk(0.f, 0.f);
+			}
+		};
+		fetch(0);
+		cf *carr = carr_all + (size_t)f * CARR_MAX;
+		for (int s = 0; s <= md.rows; ++s) {
+			cf *row = &rows[s & 1][0][0];
+			if (loader) {
+				cf v[NR];
+				#pragma unroll
+				for (int a = 0; a < NR; ++a)
+					v[a] = cmul(pre[a], q[a]);
+				Bfly<5>::run(v);
+				row[tid] = v[0];
+				#pragma unroll
+				for (int r = 1; r < NR; ++r)
+					row[r * NS + tid] = cmul(v[r], tw_r[r - 1][tid]);
+			}
+			fetch(s + 1);
+			__syncthreads();
+			fft_fwd_compact<NS, 64, SYMBOL_LEN>(row + wave * NS, tw_sub, lane);
+			__syncthreads();
+			// the payload carriers of symbol s go to HBM (cols x 8 B); the time-differential step cons = X_j / X_{j-1}
+			// (decode.cc:474-475) happens where they are read (k_theil_sen).  osc() call count: symbol_len (header) + s*stride
+			// + i, decode.cc:459-470
+			const cf w = symrot[s];
+			#pragma unroll
+			for (int e = 0; e < 2; ++e)
+				if (coff[e] >= 0)
+					carr[tid + NT * e] = cmul(row[coff[e]], w);
+			carr += md.cols;
+		}
+		});
+	} else if constexpr (DEMOD_WAVE_PER_SYMBOL(RATE)) {
 		__shared__ DemodShared<RATE> sh;
 		constexpr int TPS = DEMOD_TPS, SLOTS = DEMOD_NT8 / TPS;   // TPS threads share one transform; SLOTS symbols in flight per workgroup
 		const int slot = tid / TPS, lt = tid % TPS;
@@ -713,6 +805,9 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 __global__ __launch_bounds__(256, TS_WAVES) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
 	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all)
 {
+#ifdef TS_PRIO
+	__builtin_amdgcn_s_setprio(TS_PRIO);                      // experiments: issue priority against the co-resident polar decoders
+#endif
 	// grid = frames x 50 (mode 6 has exactly 50 rows: one row per block); modes with more rows loop
 	const int f = blockIdx.x / TS_GRID_ROWS, tid = threadIdx.x;
 	if (!st_all[f].okay)

@@ -448,6 +448,9 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev2,
 	float *__restrict__ metric_all, int *__restrict__ next_cw)
 {
+#ifdef POLAR_PRIO
+	__builtin_amdgcn_s_setprio(POLAR_PRIO);                   // experiments: issue priority against the co-resident Theil-Sen waves
+#endif
 	const int lane = threadIdx.x, j = lane >> 3, k = lane & 7;
 	__shared__ float ls8[32 * 64];                            // level 8 of the current 256-leaf node: [x][lane]
 	// Persistent decoders take codewords from a shared counter (zeroed before the launch): under the shared schedule

@@ -136,8 +136,9 @@ __global__ __launch_bounds__(256) void k_tx_rows(const uint32_t *__restrict__ co
 }
 
 template <int RATE> struct TxShared {
-	cf big[TxCfg<RATE>::BIG_IN_LDS ? 4 * RateCfg<RATE>::SL : 1];
+	cf big[TxCfg<RATE>::BIG_IN_LDS ? 4 * RateCfg<RATE>::SL : 1];   // LDS path: four decimated sequences [r][symbol_len]
 	cf fdom[RateCfg<RATE>::SL];
+	cf twc[TxCfg<RATE>::BIG_IN_LDS ? fft_compact_size<RateCfg<RATE>::SL, RateCfg<RATE>::SL>() : 1];   // compact twiddles of the symbol_len plan
 };
 
 // symbol kinds in transmission order (encode.cc:288-313): pilot | S&C | meta | pilot | rows x data | zero
@@ -209,59 +210,126 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const cf *__restr
 	}
 	__syncthreads();
 	// symbol(): encode.cc:101-109
-	cf *temp = TxCfg<RATE>::BIG_IN_LDS ? big : sh.fdom;       // LDS: big reused after the PAPR step; else fdom itself
-	if (papr && sidx != last) {
-		// improve_papr(): encode.cc:80-100
-		for (int i = tid; i < 4 * SYMBOL_LEN; i += NT)
-			big[i] = mk(0.f, 0.f);
-		__syncthreads();
-		for (int i = tid; i < SYMBOL_LEN; i += NT) {
-			int c = i - SYMBOL_LEN / 2;
-			big[bin5120(c)] = cconj(sh.fdom[bin1280(c)]);  // conj in, conj out = backward transform
-		}
-		__syncthreads();
-		fft_fwd<4 * SYMBOL_LEN, NT, 4 * SYMBOL_LEN>(big, tw5120, tid);
-		const float s4 = sqrtf((float)(4 * SYMBOL_LEN));
-		for (int i = tid; i < 4 * SYMBOL_LEN; i += NT) {
-			cf v = cconj(big[i]);
-			v = mk(v.re / s4, v.im / s4);
-			float amp = fmaxf(fabsf(v.re), fabsf(v.im));
-			if (amp > 1.f)
-				v = mk(v.re / amp, v.im / amp);
-			big[i] = v;
-		}
-		__syncthreads();
-		fft_fwd<4 * SYMBOL_LEN, NT, 4 * SYMBOL_LEN>(big, tw5120, tid);
-		constexpr int NK = (SYMBOL_LEN + NT - 1) / NT;
-		cf keep[NK];
-		#pragma unroll
-		for (int q = 0; q < NK; ++q) {
-			int i = tid + NT * q, c = i - SYMBOL_LEN / 2;
-			keep[q] = mk(0.f, 0.f);
-			if (i < SYMBOL_LEN) {
-				cf o = sh.fdom[bin1280(c)], v = big[bin5120(c)];
-				if (cnorm(o) != 0.f)
-					keep[q] = mk(v.re / s4, v.im / s4);
-			}
-		}
-		__syncthreads();
-		#pragma unroll
-		for (int q = 0; q < NK; ++q) {
-			int i = tid + NT * q, c = i - SYMBOL_LEN / 2;
-			if (i < SYMBOL_LEN)
-				temp[bin1280(c)] = cconj(keep[q]);
-		}
-	} else {
-		for (int i = tid; i < SYMBOL_LEN; i += NT)
-			temp[i] = cconj(sh.fdom[i]);
-	}
-	__syncthreads();
-	fft_fwd<SYMBOL_LEN, NT, SYMBOL_LEN>(temp, tb.tw_sym, tid);
 	const float s8 = sqrtf((float)(8 * SYMBOL_LEN));
 	cf *out = tdom_all + ((size_t)f * tp.nsym + sidx) * SYMBOL_LEN;
-	for (int i = tid; i < SYMBOL_LEN; i += NT) {
-		cf v = cconj(temp[i]);
-		out[i] = mk(v.re / s8, v.im / s8);
+	if constexpr (TxCfg<RATE>::BIG_IN_LDS) {
+		// improve_papr() (encode.cc:80-100) runs a 4x oversampled transform pair: backward 4 N points of the N-bin spectrum,
+		// clip, forward 4 N points of which only the N original bins are kept.  Decimated by four both are FOUR independent
+		// N-point transforms: x[4m + r] = IFFT_N(F[c] w^(c r))[m] and X[c] = sum_r w^(c r) FFT_N(x[4m + r])[c], w = e^{-j 2 pi /
+		// 4N}.  Wave r owns residue r: its two transforms run in its own quarter of LDS with wave barriers only (no
+		// workgroup barrier between the spectrum and the combine), N-point stages instead of 4N-point ones, twiddles from
+		// the compact LDS table.
+		const int wave = tid >> 6, lane = tid & 63;
+		fft_compact_twiddles<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.twc, tb.tw_sym, tid);
+		const float s4 = sqrtf((float)(4 * SYMBOL_LEN)), r4 = 1.f / s4;
+		auto div_s4 = [&](float x) { const float q0 = x * r4; return __builtin_fmaf(__builtin_fmaf(-s4, q0, x), r4, q0); };   // x / s4
+		__syncthreads();
+		if (papr && sidx != last) {
+			static_assert(NT == 256, "one wave per residue");
+			cf *sub = big + wave * SYMBOL_LEN;
+			auto w4 = [&](int c) {                            // w^(c * wave)
+				int t = (c * wave) % (4 * SYMBOL_LEN);
+				return tw5120[t < 0 ? t + 4 * SYMBOL_LEN : t];
+			};
+			for (int i = lane; i < SYMBOL_LEN; i += 64) {
+				const int c = i - SYMBOL_LEN / 2, b = bin1280(c);
+				const cf o = sh.fdom[b];
+				cf g = mk(0.f, 0.f);
+				if (o.re != 0.f || o.im != 0.f)
+					g = wave ? cmul(cconj(o), w4(c)) : cconj(o);   // conj in, conj out = backward transform
+				sub[b] = g;
+			}
+			__builtin_amdgcn_wave_barrier();
+			fft_fwd_compact<SYMBOL_LEN, 64, SYMBOL_LEN>(sub, sh.twc, lane);
+			for (int i = lane; i < SYMBOL_LEN; i += 64) {
+				cf v = cconj(sub[i]);
+				v = mk(div_s4(v.re), div_s4(v.im));
+				const float amp = fmaxf(fabsf(v.re), fabsf(v.im));
+				if (amp > 1.f)
+					v = mk(v.re / amp, v.im / amp);
+				sub[i] = v;
+			}
+			__builtin_amdgcn_wave_barrier();
+			fft_fwd_compact<SYMBOL_LEN, 64, SYMBOL_LEN>(sub, sh.twc, lane);
+			__syncthreads();
+			for (int i = tid; i < SYMBOL_LEN; i += NT) {
+				const int c = i - SYMBOL_LEN / 2, b = bin1280(c);
+				const cf o = sh.fdom[b];
+				cf keep = mk(0.f, 0.f);
+				if (cnorm(o) != 0.f) {
+					cf acc = big[b];
+					#pragma unroll
+					for (int r = 1; r < 4; ++r) {
+						int t = (c * r) % (4 * SYMBOL_LEN);
+						acc = cadd(acc, cmul(big[r * SYMBOL_LEN + b], tw5120[t < 0 ? t + 4 * SYMBOL_LEN : t]));
+					}
+					keep = mk(div_s4(acc.re), div_s4(acc.im));
+				}
+				sh.fdom[b] = cconj(keep);
+			}
+		} else {
+			for (int i = tid; i < SYMBOL_LEN; i += NT)
+				sh.fdom[i] = cconj(sh.fdom[i]);
+		}
+		__syncthreads();
+		fft_fwd_compact<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fdom, sh.twc, tid);
+		for (int i = tid; i < SYMBOL_LEN; i += NT) {
+			cf v = cconj(sh.fdom[i]);
+			out[i] = mk(v.re / s8, v.im / s8);
+		}
+	} else {
+		cf *temp = sh.fdom;                                   // global scratch for the 4N-point buffer, fdom itself for the symbol
+		if (papr && sidx != last) {
+			// improve_papr(): encode.cc:80-100
+			for (int i = tid; i < 4 * SYMBOL_LEN; i += NT)
+				big[i] = mk(0.f, 0.f);
+			__syncthreads();
+			for (int i = tid; i < SYMBOL_LEN; i += NT) {
+				int c = i - SYMBOL_LEN / 2;
+				big[bin5120(c)] = cconj(sh.fdom[bin1280(c)]);  // conj in, conj out = backward transform
+			}
+			__syncthreads();
+			fft_fwd<4 * SYMBOL_LEN, NT, 4 * SYMBOL_LEN>(big, tw5120, tid);
+			const float s4 = sqrtf((float)(4 * SYMBOL_LEN));
+			for (int i = tid; i < 4 * SYMBOL_LEN; i += NT) {
+				cf v = cconj(big[i]);
+				v = mk(v.re / s4, v.im / s4);
+				float amp = fmaxf(fabsf(v.re), fabsf(v.im));
+				if (amp > 1.f)
+					v = mk(v.re / amp, v.im / amp);
+				big[i] = v;
+			}
+			__syncthreads();
+			fft_fwd<4 * SYMBOL_LEN, NT, 4 * SYMBOL_LEN>(big, tw5120, tid);
+			constexpr int NK = (SYMBOL_LEN + NT - 1) / NT;
+			cf keep[NK];
+			#pragma unroll
+			for (int q = 0; q < NK; ++q) {
+				int i = tid + NT * q, c = i - SYMBOL_LEN / 2;
+				keep[q] = mk(0.f, 0.f);
+				if (i < SYMBOL_LEN) {
+					cf o = sh.fdom[bin1280(c)], v = big[bin5120(c)];
+					if (cnorm(o) != 0.f)
+						keep[q] = mk(v.re / s4, v.im / s4);
+				}
+			}
+			__syncthreads();
+			#pragma unroll
+			for (int q = 0; q < NK; ++q) {
+				int i = tid + NT * q, c = i - SYMBOL_LEN / 2;
+				if (i < SYMBOL_LEN)
+					temp[bin1280(c)] = cconj(keep[q]);
+			}
+		} else {
+			for (int i = tid; i < SYMBOL_LEN; i += NT)
+				temp[i] = cconj(sh.fdom[i]);
+		}
+		__syncthreads();
+		fft_fwd<SYMBOL_LEN, NT, SYMBOL_LEN>(temp, tb.tw_sym, tid);
+		for (int i = tid; i < SYMBOL_LEN; i += NT) {
+			cf v = cconj(temp[i]);
+			out[i] = mk(v.re / s8, v.im / s8);
+		}
 	}
 }
 
