@@ -99,6 +99,23 @@ __device__ __forceinline__ cf demod_or_erase(cf curr, cf prev)
 	return c;
 }
 
+// ---- psk.hh:90-140 PhaseShiftKeying<8, cmplx, float> ---------------------------------
+// psk.hh:49-88 PhaseShiftKeying<4>: map(hard(c)) (psk.hh:70-74,82-85)
+__device__ __forceinline__ cf psk4_hard_map(cf c)
+{
+	const float r = 0.70710678118654752440f;
+	return mk(r * (c.re < 0.f ? -1.f : 1.f), r * (c.im < 0.f ? -1.f : 1.f));
+}
+__device__ __forceinline__ cf psk8_hard_map(cf c)   // map(hard(c)): psk.hh:118-123,132-139
+{
+	const float cos_pi_8 = 0.92387953251128675613f, sin_pi_8 = 0.38268343236508977173f;
+	float b1 = c.re < 0.f ? -1.f : 1.f;
+	float b2 = c.im < 0.f ? -1.f : 1.f;
+	bool swap = fabsf(c.re) < fabsf(c.im);
+	float real = swap ? sin_pi_8 : cos_pi_8, imag = swap ? cos_pi_8 : sin_pi_8;
+	return mk(real * b1, imag * b2);
+}
+
 // unit phasor e^{j*omega*k}; phase in double like the oracle's closed form of DSP::Phasor
 __device__ __forceinline__ cf phasor(float omega, long k)
 {

@@ -3,7 +3,7 @@
 __device__ int g_fallbacks;
 #define TS_PROBE_COUNT (&g_fallbacks)
 #ifndef TS_SRC
-#define TS_SRC "../modem_amd/csrc/k_demod.hip"
+#define TS_SRC "../modem_amd/csrc/k_theilsen.hip"
 #endif
 #include TS_SRC
 #include <cstdio>
