@@ -408,8 +408,13 @@ __device__ __forceinline__ unsigned crc16_u64(unsigned long long data)
 	return crc & 0xffffu;
 }
 
+#ifndef HDR_WAVES
+#define HDR_WAVES 5        // waves per SIMD the register budget is set for: 96 VGPRs (a few spills) instead of 216 - the kernel is a chain of short
+                           // barrier-separated steps, latency-bound: 1.48 ms per 8192 frames at 2, 0.88 at 4, 0.79 at 5; the uncertified order-3
+                           // search (OSD_NO_CERTIFICATE: 30 ms) does not care
+#endif
 template <int RATE>
-__global__ __launch_bounds__(256, 2) void k_header(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
+__global__ __launch_bounds__(256, HDR_WAVES) void k_header(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
 	SyncState *__restrict__ st_all, int8_t *__restrict__ hdr_soft)
 {
 	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, SYM_STRIDE = RateCfg<RATE>::STRIDE;

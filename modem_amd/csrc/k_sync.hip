@@ -155,11 +155,18 @@ template <int RATE> struct SyncRing { static constexpr int N = TILE + RateCfg<RA
 
 // 8 kHz: the two 640-point work arrays of the trigger part live in LDS.  Other rates (1280 / 3528 / 3840
 // points) keep them in a per-frame global scratch so the scanning loop's occupancy does not pay for them.
+#ifndef SYNC_FFT_IN_LDS
+#define SYNC_FFT_IN_LDS 1    // 8 kHz: the two 640-point buffers of the S&C trigger part in LDS (0: global scratch like the other rates)
+#endif
+#define SYNC_FFT_LDS(R) ((R) == 8000 && SYNC_FFT_IN_LDS)
+#ifndef SYNC_WAVES
+#define SYNC_WAVES 2
+#endif
 template <int RATE> struct SyncShared {
 	double m[SyncRing<RATE>::N];
 	float timing[TILE];
-	cf buf[RATE == 8000 ? RateCfg<RATE>::HS : 1];
-	cf xr[RATE == 8000 ? RateCfg<RATE>::HS : 1];
+	cf buf[SYNC_FFT_LDS(RATE) ? RateCfg<RATE>::HS : 1];
+	cf xr[SYNC_FFT_LDS(RATE) ? RateCfg<RATE>::HS : 1];
 };
 
 __device__ __forceinline__ int first_index(const float *timing, int T0, int lane, int lo_t, int hi_t, bool greater, float thr)
@@ -275,7 +282,7 @@ __device__ bool sc_process(cf *buf, cf *xr, const SampleSrc &src, const cf *tw, 
 }
 
 template <int RATE>
-__global__ __launch_bounds__(64) void k_sync(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
+__global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
 	const cf *__restrict__ kern, SyncState *__restrict__ st_all, cf *__restrict__ scratch)
 {
 	typedef RateCfg<RATE> RC;
@@ -291,8 +298,8 @@ __global__ __launch_bounds__(64) void k_sync(FrameBatch fb, const cf *__restrict
 	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, n,
 		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
 	__shared__ SyncShared<RATE> sh;
-	cf *fbuf = RATE == 8000 ? sh.buf : scratch + (size_t)f * 2 * HALF_LEN;
-	cf *fxr = RATE == 8000 ? sh.xr : scratch + (size_t)f * 2 * HALF_LEN + HALF_LEN;
+	cf *fbuf = SYNC_FFT_LDS(RATE) ? sh.buf : scratch + (size_t)f * 2 * HALF_LEN;
+	cf *fxr = SYNC_FFT_LDS(RATE) ? sh.xr : scratch + (size_t)f * 2 * HALF_LEN + HALF_LEN;
 	for (int i = lane; i < MRING; i += 64)
 		sh.m[i] = 0.0;
 	const float thr_lo = (float)(0.17 * MATCH_LEN), thr_hi = (float)(0.19 * MATCH_LEN);   // decode.cc:76

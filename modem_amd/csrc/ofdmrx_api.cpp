@@ -337,7 +337,10 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 			r = r ? r : h->cons_raw.ensure(N * CONS_MAX * sizeof(cf));
 		if (demod_writes_carriers(h->rate))
 			r = r ? r : h->carr.ensure(N * CARR_MAX * sizeof(cf));
-		if (h->rate != 8000)
+#ifndef SYNC_FFT_IN_LDS
+#define SYNC_FFT_IN_LDS 1
+#endif
+		if (h->rate != 8000 || !SYNC_FFT_IN_LDS)
 			r = r ? r : h->sc_scratch.ensure(N * (size_t)rate_symbol_len(h->rate) * sizeof(cf));
 		if (r)
 			return r;
