@@ -35,16 +35,38 @@ template <int RATE> struct DemodSharedBlock {                // other rates: one
 #ifndef DEMOD_WAVE_PER_SYMBOL
 #define DEMOD_WAVE_PER_SYMBOL(R) ((R) == 8000)
 #endif
-#ifndef DEMOD_DIF5
-#define DEMOD_DIF5 1       // 8 kHz: radix-5 decimation in frequency in registers, then five wave-private 256-point transforms (5 waves)
+#ifndef DEMOD_DIF
+#define DEMOD_DIF 1        // radix-5 / radix-7 decimation in frequency in registers, then 5 / 7 wave-private transforms (all rates)
 #endif
+// symbol_len = R1 x NS: 1280 = 5 x 256, 2560 = 5 x 512, 7056 = 7 x 1008, 7680 = 5 x 1536
+template <int RATE> struct DifCfg {
+	static constexpr int SL = RateCfg<RATE>::SL;
+#ifndef DEMOD_DIF_W
+#define DEMOD_DIF_W(R) ((R) == 48000 ? 3 : (R) == 44100 ? 2 : 1)
+#endif
+	static constexpr int W = DEMOD_DIF_W(RATE);              // waves that share one row's transform (1: wave-private, wave barriers only)
+	static constexpr int R1 = SL % 5 == 0 ? 5 : 7, NS = SL / R1, NT = 64 * W * R1;
+	static constexpr int NQ = (NS + NT - 1) / NT;             // points n' per loader thread
+#ifndef DEMOD_TWR_BYTES
+#define DEMOD_TWR_BYTES 8192
+#endif
+#ifndef DEMOD_DBL_BYTES
+#define DEMOD_DBL_BYTES 0
+#endif
+#ifndef DEMOD_DIF_WAVES
+#define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : 4)
+#endif
+	static constexpr bool TWR_LDS = (R1 - 1) * NS * 8 <= DEMOD_TWR_BYTES;   // w^(n' r) table in LDS (8 / 16 kHz) or read from the global root table
+	static constexpr bool DOUBLE = 2 * SL * 8 <= DEMOD_DBL_BYTES;       // two row buffers (8 / 16 kHz): no third barrier per symbol
+	static constexpr int WAVES = DEMOD_DIF_WAVES(RATE);      // waves per SIMD the register budget is set for (two workgroups per CU at 44.1 / 48 kHz)
+};
 template <int RATE> struct DemodCfg {
-	static constexpr bool DIF5 = DEMOD_DIF5 && RATE == 8000;
-	static constexpr int NT = DIF5 ? 320 : DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_NT8 : 1024;     // threads per frame
+	static constexpr bool DIF = DEMOD_DIF != 0;
+	static constexpr int NT = DIF ? DifCfg<RATE>::NT : DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_NT8 : 1024;     // threads per frame
 #ifndef DEMOD_MINB
-#define DEMOD_MINB (DEMOD_DIF5 ? 3 : DEMOD_TPS == 256 ? 4 : 2)
+#define DEMOD_MINB (DEMOD_DIF ? 2 : DEMOD_TPS == 256 ? 4 : 2)
 #endif
-	static constexpr int MINB = DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_MINB : 1;        // waves per SIMD the register budget is set for
+	static constexpr int MINB = DIF ? DifCfg<RATE>::WAVES : DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_MINB : 1;        // waves per SIMD the register budget is set for
 };
 
 template <int RATE>
@@ -63,82 +85,112 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 	const long body0 = st.sc_start + 2 * SYM_STRIDE;          // pilot body, decode.cc:456-459
 	const float omega = -st.cfo_rad;                          // decode.cc:403
 	const int code_off = -md.cols / 2;                        // decode.cc:454
-	if constexpr (DemodCfg<RATE>::DIF5) {
-		// 1280 = 5 x 256.  X[5q + r] = sum_n' w256^(n' q) [ w1280^(n' r) sum_a x[n' + 256 a] w5^(a r) ]: thread n' < 256 loads its
-		// five samples (stride 256: the raw PCM is read coalesced), runs the radix-5 butterfly in registers, applies the four
-		// twiddles and parks output r in row r of an LDS buffer; wave r (five waves) then transforms row r - 256 points, four
-		// radix-4 stages of ONE butterfly per lane, wave barriers only, twiddles from a compact LDS table.  Two workgroup
-		// barriers per symbol (after the rows are written, before the carriers are read) against twelve of the cooperative
-		// 1280-point transform; the rows are double-buffered so that the next symbol's rows need no third one.
-		static_assert(SYMBOL_LEN == 1280, "5 x 256");
-		constexpr int NT = DemodCfg<RATE>::NT, NR = 5, NS = 256;
+	if constexpr (DemodCfg<RATE>::DIF) {
+		// symbol_len = R1 x NS.  X[R1 q + r] = sum_n' wNS^(n' q) [ w^(n' r) sum_a x[n' + NS a] wR1^(a r) ], w = e^{-j 2 pi / symbol_len}:
+		// a loader thread takes the R1 samples n' + NS a (stride NS: the raw PCM is read coalesced), runs the radix-R1 butterfly in
+		// registers, applies the R1 - 1 twiddles and parks output r in row r of an LDS buffer; wave r (R1 waves) then transforms
+		// row r - NS points, NS / (64 R) butterflies per lane and stage, wave barriers only, twiddles from a compact LDS table.
+		// Two workgroup barriers per symbol (after the rows are written, before the carriers are read) against two per radix
+		// stage of a cooperative transform; at 8 / 16 kHz the rows are double-buffered, at 44.1 / 48 kHz (56 / 61 KB) a third
+		// barrier protects the single buffer.
+		typedef DifCfg<RATE> DC;
+		constexpr int NT = DC::NT, R1 = DC::R1, NS = DC::NS, NQ = DC::NQ;
+		static_assert(R1 * NS == SYMBOL_LEN && NT == DemodCfg<RATE>::NT, "plan");
 		constexpr int TWC = fft_compact_size<NS, SYMBOL_LEN>();
-		__shared__ cf rows[2][NR][NS];
-		__shared__ cf tw_sub[TWC];                            // compact twiddles of the 256-point plan
-		__shared__ cf tw_r[NR - 1][NS];                       // w1280^(n' r), r = 1..4
-		__shared__ cf rot5[NR], symrot[ROWS_MAX + 1];
+		__shared__ cf rows[DC::DOUBLE ? 2 : 1][R1 * NS];
+		__shared__ cf tw_sub[TWC];                            // compact twiddles of the NS-point plan
+		__shared__ cf tw_r[DC::TWR_LDS ? (R1 - 1) * NS : 1];  // w^(n' r), r = 1..R1-1
+		__shared__ cf rotA[R1], rotQ[NQ], symrot[ROWS_MAX + 1];
 		fft_compact_twiddles<NS, NT, SYMBOL_LEN>(tw_sub, tb.tw_sym, tid);
-		for (int i = tid; i < (NR - 1) * NS; i += NT)
-			tw_r[i / NS][i % NS] = tb.tw_sym[((i / NS + 1) * (i % NS)) % SYMBOL_LEN];
-		// NCO e^{j omega (symbol_len + s stride + n' + 256 a)} = (per thread and a, once per frame: q[a]) x (per symbol: symrot[s]); the
-		// transform is linear, so the per-symbol factor multiplies the 432 carriers on their way out instead of the 1280 samples
-		if (tid < NR)
-			rot5[tid] = phasor(omega, (long)NS * tid);
+		if (DC::TWR_LDS)
+			for (int i = tid; i < (R1 - 1) * NS; i += NT)
+				tw_r[i] = tb.tw_sym[(i / NS + 1) * (i % NS)];
+		// NCO e^{j omega (symbol_len + s stride + n' + NS a)}, n' = tid + NT q: (per thread, once per frame) x (per q) x (per a) and, per
+		// symbol, symrot[s]: the transform is linear, so that factor multiplies the <= 512 carriers on their way out instead of
+		// the symbol_len samples
+		if (tid < R1)
+			rotA[tid] = phasor(omega, (long)NS * tid);
+		if (tid >= 64 && tid < 64 + NQ)
+			rotQ[tid - 64] = phasor(omega, (long)NT * (tid - 64));
 		if (tid <= md.rows)
 			symrot[tid] = phasor(omega, (long)tid * SYM_STRIDE);
-		const cf p0 = phasor(omega, (long)SYMBOL_LEN + (tid & (NS - 1)));
+		const cf p0 = phasor(omega, (long)SYMBOL_LEN + tid);
 		__syncthreads();
-		const bool loader = tid < NS;
-		cf q[NR];
-		#pragma unroll
-		for (int a = 0; a < NR; ++a)
-			q[a] = a ? cmul(p0, rot5[a]) : p0;
+		cf qa[NQ == 1 ? R1 : 1];                             // one point per loader: the R1 phasors stay in registers
+		if (NQ == 1) {
+			#pragma unroll
+			for (int a = 0; a < R1; ++a)
+				qa[a] = a ? cmul(p0, rotA[a]) : p0;
+		}
 		// the (at most two) carriers of this thread sit at the same place of the rows in every symbol
 		int coff[2];
 		#pragma unroll
 		for (int e = 0; e < 2; ++e) {
 			const int i = tid + NT * e, k = (i + code_off + SYMBOL_LEN) % SYMBOL_LEN;
-			coff[e] = i < md.cols ? (k % NR) * NS + k / NR : -1;
+			coff[e] = i < md.cols ? (k % R1) * NS + k / R1 : -1;
 		}
 		src.with_mode([&](auto M) {
 		constexpr int MODE = decltype(M)::value;
-		cf pre[NR];
+		cf pre[NQ][R1];
 		auto fetch = [&](int sym) {
 			const long t0 = body0 + (long)sym * SYM_STRIDE;       // wave-uniform
 			if (MODE == 1 && sym <= md.rows && t0 >= 0 && t0 + SYMBOL_LEN <= src.n) {
-				// the whole symbol lies inside the frame (the rule): int16 pairs straight from a uniform base, no per-sample checks
+				// the whole symbol lies inside the frame (the rule): int16 pairs from a uniform base, no per-sample checks
 				const short2 *p = (const short2 *)src.base + t0;
-				if (loader) {
-					#pragma unroll
-					for (int a = 0; a < NR; ++a) {
-						const short2 v = p[tid + NS * a];
-						pre[a] = mk(div_32767((float)v.x), div_32767((float)v.y));
+				#pragma unroll
+				for (int q = 0; q < NQ; ++q) {
+					const int np = tid + NT * q;
+					if (np < NS) {
+						#pragma unroll
+						for (int a = 0; a < R1; ++a) {
+							const short2 x = p[np + NS * a];
+							pre[q][a] = mk(div_32767((float)x.x), div_32767((float)x.y));
+						}
 					}
 				}
 			} else {
 				#pragma unroll
-				for (int a = 0; a < NR; ++a)
-					pre[a] = (loader && sym <= md.rows) ? src.template at_m<MODE>(t0 + tid + NS * a) : mk(0.f, 0.f);
+				for (int q = 0; q < NQ; ++q) {
+					const int np = tid + NT * q;
+					#pragma unroll
+					for (int a = 0; a < R1; ++a)
+						pre[q][a] = (np < NS && sym <= md.rows) ? src.template at_m<MODE>(t0 + np + NS * a) : mk(0.f, 0.f);
+				}
 			}
 		};
-		fetch(0);
+		if (NQ == 1)
+			fetch(0);
 		cf *carr = carr_all + (size_t)f * CARR_MAX;
 		for (int s = 0; s <= md.rows; ++s) {
-			cf *row = &rows[s & 1][0][0];
-			if (loader) {
-				cf v[NR];
-				#pragma unroll
-				for (int a = 0; a < NR; ++a)
-					v[a] = cmul(pre[a], q[a]);
-				Bfly<5>::run(v);
-				row[tid] = v[0];
-				#pragma unroll
-				for (int r = 1; r < NR; ++r)
-					row[r * NS + tid] = cmul(v[r], tw_r[r - 1][tid]);
+			cf *row = rows[DC::DOUBLE ? (s & 1) : 0];
+			if (NQ > 1)
+				fetch(s);                                         // several points per thread: their loads overlap each other
+			#pragma unroll
+			for (int q = 0; q < NQ; ++q) {
+				const int np = tid + NT * q;
+				if (np < NS) {
+					cf v[R1];
+					if (NQ == 1) {
+						#pragma unroll
+						for (int a = 0; a < R1; ++a)
+							v[a] = cmul(pre[q][a], qa[a]);
+					} else {
+						const cf pq = q ? cmul(p0, rotQ[q]) : p0;
+						#pragma unroll
+						for (int a = 0; a < R1; ++a)
+							v[a] = cmul(pre[q][a], a ? cmul(pq, rotA[a]) : pq);
+					}
+					Bfly<R1>::run(v);
+					row[np] = v[0];
+					#pragma unroll
+					for (int r = 1; r < R1; ++r)
+						row[r * NS + np] = cmul(v[r], DC::TWR_LDS ? tw_r[(r - 1) * NS + np] : tb.tw_sym[r * np]);
+				}
 			}
-			fetch(s + 1);
+			if (NQ == 1)
+				fetch(s + 1);
 			__syncthreads();
-			fft_fwd_compact<NS, 64, SYMBOL_LEN>(row + wave * NS, tw_sub, lane);
+			fft_fwd_compact<NS, 64 * DC::W, SYMBOL_LEN>(row + (tid / (64 * DC::W)) * NS, tw_sub, tid % (64 * DC::W));
 			__syncthreads();
 			// the payload carriers of symbol s go to HBM (cols x 8 B); the time-differential step cons = X_j / X_{j-1}
 			// (decode.cc:474-475) happens where they are read (k_theil_sen).  osc() call count: symbol_len (header) + s*stride
@@ -149,6 +201,8 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 				if (coff[e] >= 0)
 					carr[tid + NT * e] = cmul(row[coff[e]], w);
 			carr += md.cols;
+			if (!DC::DOUBLE)
+				__syncthreads();
 		}
 		});
 	} else if constexpr (DEMOD_WAVE_PER_SYMBOL(RATE)) {
@@ -347,7 +401,7 @@ __global__ __launch_bounds__(256) void k_fft_debug(int len, int sign, const cf *
 		out[(size_t)f * len + i] = sign > 0 ? cconj(buf[i]) : buf[i];
 }
 
-bool demod_writes_carriers(int rate) { return DEMOD_WAVE_PER_SYMBOL(rate); }
+bool demod_writes_carriers(int rate) { return DEMOD_DIF || DEMOD_WAVE_PER_SYMBOL(rate); }
 void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons, cf *carr)
 {
 	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(DemodCfg<RATE>::NT), 0, s, fb, z, tb, st, cons, carr));

@@ -323,20 +323,30 @@ __global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf
 		double dr[PER], di[PER], dp[PER];
 		{
 			const long tb = T0 + lane * PER;
-			#pragma unroll
-			for (int e = 0; e < PER; ++e) {
-				long a = tb + e - (BUFFER_LEN - 1 - (SEARCH_POS + HALF_LEN));
-				cf zA = src.at(a - HALF_LEN), zB = src.at(a), zC = src.at(a + HALF_LEN);
-				double inr = (double)zB.re * zC.re + (double)zB.im * zC.im;
-				double ini = (double)zB.im * zC.re - (double)zB.re * zC.im;
-				double outr = (double)zA.re * zB.re + (double)zA.im * zB.im;
-				double outi = (double)zA.im * zB.re - (double)zA.re * zB.im;
-				double pin = (double)zC.re * zC.re + (double)zC.im * zC.im;
-				double pout = (double)zA.re * zA.re + (double)zA.im * zA.im;
-				double pr = inr - outr, pi = ini - outi, pp = pin - pout;
-				dr[e] = (e ? dr[e - 1] : 0.0) + pr;
-				di[e] = (e ? di[e - 1] : 0.0) + pi;
-				dp[e] = (e ? dp[e - 1] : 0.0) + pp;
+			auto phase1 = [&](auto at) {
+				#pragma unroll
+				for (int e = 0; e < PER; ++e) {
+					long a = tb + e - (BUFFER_LEN - 1 - (SEARCH_POS + HALF_LEN));
+					cf zA = at(a - HALF_LEN), zB = at(a), zC = at(a + HALF_LEN);
+					double inr = (double)zB.re * zC.re + (double)zB.im * zC.im;
+					double ini = (double)zB.im * zC.re - (double)zB.re * zC.im;
+					double outr = (double)zA.re * zB.re + (double)zA.im * zB.im;
+					double outi = (double)zA.im * zB.re - (double)zA.re * zB.im;
+					double pin = (double)zC.re * zC.re + (double)zC.im * zC.im;
+					double pout = (double)zA.re * zA.re + (double)zA.im * zA.im;
+					double pr = inr - outr, pi = ini - outi, pp = pin - pout;
+					dr[e] = (e ? dr[e - 1] : 0.0) + pr;
+					di[e] = (e ? di[e - 1] : 0.0) + pi;
+					dp[e] = (e ? dp[e - 1] : 0.0) + pp;
+				}
+			};
+			// the whole tile's sample window inside the frame and int16 pairs (the rule): no format switch, no bounds checks
+			const long w_lo = T0 - (BUFFER_LEN - 1 - (SEARCH_POS + HALF_LEN)) - HALF_LEN, w_hi = w_lo + TILE + 2 * HALF_LEN;
+			if (src.mode() == 1 && w_lo >= 0 && w_hi <= n) {
+				const short2 *p = (const short2 *)src.base;
+				phase1([&](long i) { const short2 v = p[i]; return mk(div_32767((float)v.x), div_32767((float)v.y)); });
+			} else {
+				phase1([&](long i) { return src.at(i); });
 			}
 		}
 		double or_ = wave_scan_incl(dr[PER - 1], lane) - dr[PER - 1] + Wr;
@@ -347,8 +357,9 @@ __global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf
 			float Pre = (float)(or_ + dr[e]), Pim = (float)(oi_ + di[e]);
 			float R = 0.5f * (float)(op_ + dp[e]);
 			R = fmaxf(R, min_R);
-			double m = ((double)Pre * Pre + (double)Pim * Pim) / ((double)R * R);   // decode.cc:90
-			sh.m[(T0 + lane * PER + e) & (MRING - 1)] = m;
+			// decode.cc:90: the fp32 expression of the reference, term by term (no contraction); only its moving sum runs in double
+			const float mf = __fdiv_rn(__fadd_rn(__fmul_rn(Pre, Pre), __fmul_rn(Pim, Pim)), __fmul_rn(R, R));
+			sh.m[(T0 + lane * PER + e) & (MRING - 1)] = (double)mf;
 		}
 		Wr = shfl_d(or_ + dr[PER - 1], 63);
 		Wi = shfl_d(oi_ + di[PER - 1], 63);

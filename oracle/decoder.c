@@ -203,7 +203,7 @@ static void sc_prepare(sc_t *s, const orc_cf *z, size_t n)
 		float R = 0.5f * (float)(PFX(s->Sp, hp) - PFX(s->Sp, hp - 2 * HS));
 		float min_R = 0.0001f * HS;                      /* decode.cc:88 */
 		R = fmaxf(R, min_R);
-		double m = ((double)Pre * Pre + (double)Pim * Pim) / ((double)R * R);   /* decode.cc:90 */
+		double m = (double)((Pre * Pre + Pim * Pim) / (R * R));   /* decode.cc:90: the fp32 expression; only the moving sum is double */
 		s->Sm[t + 1] = s->Sm[t] + m;
 		s->timing[t] = (float)(s->Sm[t + 1] - PFX(s->Sm, (long)t + 1 - MATCH_LEN));
 	}
