@@ -118,11 +118,26 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 			res_all[f] = r;
 		return;
 	}
+	// decode.cc:546-554: received hard decision against decoded bit over the data bits.  Message bit i is x at the i-th
+	// unfrozen position (ascending), so the walk runs over CODE positions - coalesced reads of the LLRs, the partial-sum
+	// bytes and the frozen bitmap instead of two dependent gathers per bit: positions below the one of data bit DATA_BITS
+	// that are not frozen.
 	int flips = 0;
-	for (int i = tid; i < DATA_BITS; i += 256) {              // decode.cc:546-554
-		int received = llr[info_pos[i]] < 0.f;
-		int decoded = (mesg[best][i >> 3] >> (i & 7)) & 1;
-		flips += received != decoded;
+	{
+		const uint32_t *frozen = tb.frozen + (md.table ? CODE_LEN / 32 : 0);
+		const int p_end = info_pos[DATA_BITS];
+		for (int p = 4 * tid; p < p_end; p += 4 * 256) {         // four positions per thread and step: 16 B of LLRs, 4 partial-sum bytes
+			const float4 l = *(const float4 *)(llr + p);
+			const uint32_t h = (*(const uint32_t *)(hard + p) >> hshift) >> best;
+			const uint32_t fz = frozen[p >> 5] >> (p & 31);
+			const float lv[4] = { l.x, l.y, l.z, l.w };
+			#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const int received = lv[e] < 0.f, decoded = (h >> (8 * e)) & 1;
+				const int counts = (p + e < p_end) & !((fz >> e) & 1);
+				flips += counts & (received != decoded);
+			}
+		}
 	}
 	#pragma unroll
 	for (int m = 32; m; m >>= 1)

@@ -580,7 +580,16 @@ static ChunkPlan plan_chunks(const ofdmrx_handle *h, size_t n_frames)
 		p.start = { 0, ((n_frames + 1) / 2 + 63) & ~(size_t)63, n_frames };
 		return p;
 	}
-	for (size_t f = 0; f < n_frames; f += chunk)
+	// a short first chunk shortens the pipeline's fill (its sync / header / demod / Theil-Sen run with no polar stage beside them)
+	size_t first = chunk;
+	if (const char *e = std::getenv("OFDMRX_FIRST_CHUNK"))
+		first = std::min(chunk, std::max<size_t>(64, (size_t)std::atol(e)));
+	size_t f = 0;
+	if (n_frames > chunk && first < chunk) {
+		p.start.push_back(0);
+		f = first;
+	}
+	for (; f < n_frames; f += chunk)
 		p.start.push_back(f);
 	p.start.push_back(n_frames);
 	return p;

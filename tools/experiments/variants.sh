@@ -4,7 +4,7 @@
 O=$PWD/gpurun_out/${OUT:-variants.txt}; mkdir -p gpurun_out; : > $O
 make -C modem_amd/csrc -q all && echo "library up to date with sources" >> $O || echo "STALE LIBRARY" >> $O
 pick='import json,sys
-d=json.loads(sys.stdin.readline()); s=d["stage_ms_per_step"]; print("value", round(d["value"]), "sync", round(s["sync"],2), "header", round(s["header"],2), "demod", round(s["demod"],2), "ts", round(s["theilsen"],1), "polar", round(s["polar"],1), "fer", d["fer"], "ok", d["frames_ok"])'
+d=json.loads(sys.stdin.readline()); s=d["stage_ms_per_step"]; print("value", round(d["value"]), "sync", round(s["sync"],2), "header", round(s["header"],2), "demod", round(s["demod"],2), "ts", round(s["theilsen"],1), "polar", round(s["polar"],1), "llr", round(s.get("llr",0),2), "finish", round(s.get("finish",0),2), "fer", d["fer"], "ok", d["frames_ok"])'
 V=$PWD/modem_amd/lib/variants
 for lib in default $1; do
 	L=$V/libofdmrx_$lib.so; [ $lib = default ] && L=$PWD/modem_amd/lib/libofdmrx.so
