@@ -219,19 +219,20 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const cf *__restr
 		// 4N}.  Wave r owns residue r: its two transforms run in its own quarter of LDS with wave barriers only (no
 		// workgroup barrier between the spectrum and the combine), N-point stages instead of 4N-point ones, twiddles from
 		// the compact LDS table.
-		const int wave = tid >> 6, lane = tid & 63;
+		constexpr int RT = NT / 4;                            // threads per residue (64: wave-private transforms, wave barriers only)
+		static_assert(RT % 64 == 0 && RT >= 64, "whole waves per residue");
+		const int wave = tid / RT, lane = tid % RT;           // residue, thread within it
 		fft_compact_twiddles<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.twc, tb.tw_sym, tid);
 		const float s4 = sqrtf((float)(4 * SYMBOL_LEN)), r4 = 1.f / s4;
 		auto div_s4 = [&](float x) { const float q0 = x * r4; return __builtin_fmaf(__builtin_fmaf(-s4, q0, x), r4, q0); };   // x / s4
 		__syncthreads();
 		if (papr && sidx != last) {
-			static_assert(NT == 256, "one wave per residue");
 			cf *sub = big + wave * SYMBOL_LEN;
 			auto w4 = [&](int c) {                            // w^(c * wave)
 				int t = (c * wave) % (4 * SYMBOL_LEN);
 				return tw5120[t < 0 ? t + 4 * SYMBOL_LEN : t];
 			};
-			for (int i = lane; i < SYMBOL_LEN; i += 64) {
+			for (int i = lane; i < SYMBOL_LEN; i += RT) {
 				const int c = i - SYMBOL_LEN / 2, b = bin1280(c);
 				const cf o = sh.fdom[b];
 				cf g = mk(0.f, 0.f);
@@ -239,9 +240,9 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const cf *__restr
 					g = wave ? cmul(cconj(o), w4(c)) : cconj(o);   // conj in, conj out = backward transform
 				sub[b] = g;
 			}
-			__builtin_amdgcn_wave_barrier();
-			fft_fwd_compact<SYMBOL_LEN, 64, SYMBOL_LEN>(sub, sh.twc, lane);
-			for (int i = lane; i < SYMBOL_LEN; i += 64) {
+			fft_sync<RT>();
+			fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, sh.twc, lane);
+			for (int i = lane; i < SYMBOL_LEN; i += RT) {
 				cf v = cconj(sub[i]);
 				v = mk(div_s4(v.re), div_s4(v.im));
 				const float amp = fmaxf(fabsf(v.re), fabsf(v.im));
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const cf *__restr
 					v = mk(v.re / amp, v.im / amp);
 				sub[i] = v;
 			}
-			__builtin_amdgcn_wave_barrier();
-			fft_fwd_compact<SYMBOL_LEN, 64, SYMBOL_LEN>(sub, sh.twc, lane);
+			fft_sync<RT>();
+			fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, sh.twc, lane);
 			__syncthreads();
 			for (int i = tid; i < SYMBOL_LEN; i += NT) {
 				const int c = i - SYMBOL_LEN / 2, b = bin1280(c);
