@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, HDR_WAVES) void k_header(FrameBatch fb, const 
 		st.status = status;
 		st.okay = status == 0;
 		st.hdr_rounds += 1;
-		if (st.skip_left > 0) { st.skip_left -= 1; st.active = 1; }   // decode.cc:448
+		if (st.skip_left > 0) { st.skip_left -= 1; st.active = 1; st.found = 0; }   // decode.cc:448: the search goes on behind this preamble
 		else st.active = 0;
 		st_all[f] = st;
 	}

@@ -225,10 +225,23 @@ __device__ bool sc_process(cf *buf, cf *xr, const SampleSrc &src, const cf *tw, 
 	constexpr int BUFFER_LEN = RC::BUFFER_LEN, SEARCH_POS = RC::SEARCH_POS, HALF_LEN = RC::HS, GUARD_LEN = RC::GL;
 	const float frac_cfo = phase_max / (float)HALF_LEN;       // decode.cc:110
 	int symbol_pos = SEARCH_POS - index_max;                   // decode.cc:114
+#ifdef SYNC_PROBE_NO_SC
+	symbol_pos_out = symbol_pos; cfo_out = 0.f; return true;   // timing probe: the trigger scan without the accept path
+#endif
 	const long base = t - (BUFFER_LEN - 1);
 	__syncthreads();
-	for (int i = lane; i < HALF_LEN; i += 64)                  // decode.cc:117-118
-		buf[i] = cmul(src.at(base + i + symbol_pos + HALF_LEN), phasor(frac_cfo, i));
+	{   // decode.cc:117-118.  e^{j frac_cfo i}, i = 64 q + lane: one closed-form phasor per lane times one per q (lane q holds the
+		// q-th: HALF_LEN / 64 <= 64), instead of a double-precision range reduction and a sincos per sample
+		static_assert(HALF_LEN <= 64 * 64, "one lane per block of 64 samples");
+		const cf p_lane = phasor(frac_cfo, lane), p_blk = phasor(frac_cfo, 64L * lane);
+		for (int q = 0; q * 64 < HALF_LEN; ++q) {
+			const int i = q * 64 + lane;
+			const cf r = mk(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_blk.re), q)),
+				__int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_blk.im), q)));
+			if (i < HALF_LEN)
+				buf[i] = cmul(src.at(base + i + symbol_pos + HALF_LEN), cmul(p_lane, r));
+		}
+	}
 	__syncthreads();
 	fft_fwd<HALF_LEN, 64, RC::SL>(buf, tw, lane);
 	for (int i = lane; i < HALF_LEN; i += 64)                  // decode.cc:120-121
@@ -281,7 +294,11 @@ __device__ bool sc_process(cf *buf, cf *xr, const SampleSrc &src, const cf *tw, 
 	return true;
 }
 
-template <int RATE>
+// SPLIT = false: the whole of decode.cc:86-151 for one frame by one wave (8 kHz, and the catch-all at the other rates).
+// SPLIT = true: the scan stops at the first trigger and leaves (g, index_max, phase_max) in the frame's state; the accept
+// path runs as k_sync_accept with a whole workgroup per frame.  At 44.1 / 48 kHz the three 3528 / 3840-point transforms of
+// the accept path by ONE wave through global scratch (256 VGPRs + spills) were 60 % of this kernel's time.
+template <int RATE, bool SPLIT>
 __global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
 	const cf *__restrict__ kern, SyncState *__restrict__ st_all, cf *__restrict__ scratch)
 {
@@ -292,9 +309,9 @@ __global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf
 	static_assert(TILE + MATCH_LEN <= MRING, "m ring too small");
 	const int f = blockIdx.x, lane = threadIdx.x;
 	SyncState st = st_all[f];
-	if (!st.active)
-		return;
 	const long n = fb.samples_per_frame;
+	if (!st.active || st.found || st.t_next >= n)              // found: accepted earlier in this round (split schedule)
+		return;
 	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, n,
 		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
 	__shared__ SyncShared<RATE> sh;
@@ -313,12 +330,12 @@ __global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf
 		direct_P<RATE>(src, T0 - 1, lane, Wr, Wi);
 		Wp = direct_R<RATE>(src, T0 - 1, lane);
 	}
-	bool collecting = false, found = false;
+	bool collecting = false, found = false, pending = false;
 	float tmax = 0.f;
 	long nmax = 0;
 	int rejects = st.rejects;
 	__syncthreads();
-	for (; T0 < n && !found; T0 += TILE) {
+	for (; T0 < n && !found && !pending; T0 += TILE) {
 		// ---- phase 1: P, R, m for the 16 times of this lane
 		double dr[PER], di[PER], dp[PER];
 		{
@@ -383,7 +400,7 @@ __global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf
 		// ---- trigger logic on the tile (decode.cc:93-108)
 		long cur = T0 > t_start ? T0 : t_start;
 		long tile_end = T0 + TILE < n ? T0 + TILE : n;
-		while (cur < tile_end && !found) {
+		while (cur < tile_end && !found && !pending) {
 			if (!collecting) {
 				int fr = first_index(sh.timing, (int)T0, lane, (int)cur, (int)tile_end, true, thr_hi);
 				if (fr == 0x7fffffff)
@@ -426,16 +443,24 @@ __global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf
 				}
 			}
 			tmax = 0.f;                                        // decode.cc:115-116
-			int sp;
-			float cfo;
-			if (sc_process<RATE>(fbuf, fxr, src, tw, kern, g, index_max, phase_max, lane, sp, cfo)) {
-				found = true;
-				st.symbol_pos = sp;
-				st.cfo_rad = cfo;
-				st.sc_start = (long)g - (BUFFER_LEN - 1) + sp;
+			if constexpr (SPLIT) {
+				pending = true;                                // k_sync_accept decides; a rejected frame resumes at g + 1
+				st.pend_g = g;
+				st.pend_index_max = index_max;
+				st.pend_phase = phase_max;
 				st.t_next = (long)g + 1;
 			} else {
-				++rejects;
+				int sp;
+				float cfo;
+				if (sc_process<RATE>(fbuf, fxr, src, tw, kern, g, index_max, phase_max, lane, sp, cfo)) {
+					found = true;
+					st.symbol_pos = sp;
+					st.cfo_rad = cfo;
+					st.sc_start = (long)g - (BUFFER_LEN - 1) + sp;
+					st.t_next = (long)g + 1;
+				} else {
+					++rejects;
+				}
 			}
 			cur = (long)g + 1;
 		}
@@ -443,10 +468,112 @@ __global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf
 	}
 	st.rejects = rejects;
 	st.found = found ? 1 : 0;
-	if (!found)
+	st.pending = pending ? 1 : 0;
+	if (!found && !pending)
 		st.t_next = n;
 	if (lane == 0)
 		st_all[f] = st;
+}
+
+// decode.cc:110-151 for a pending trigger, one workgroup per frame: the same arithmetic as sc_process (the transforms
+// are the same Stockham stages, butterfly by butterfly - only shared among 256 threads, in LDS), bit-identical results.
+template <int RATE>
+__global__ __launch_bounds__(256) void k_sync_accept(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
+	const cf *__restrict__ kern, SyncState *__restrict__ st_all)
+{
+	typedef RateCfg<RATE> RC;
+	constexpr int BUFFER_LEN = RC::BUFFER_LEN, SEARCH_POS = RC::SEARCH_POS, HALF_LEN = RC::HS, GUARD_LEN = RC::GL, NT = 256;
+	const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	SyncState st = st_all[f];
+	if (!st.active || st.found || !st.pending)
+		return;
+	const long n = fb.samples_per_frame;
+	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, n,
+		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
+	__shared__ cf buf[HALF_LEN], xr[HALF_LEN];
+	__shared__ cf rot[(HALF_LEN + NT - 1) / NT];
+	__shared__ float red_p[4];
+	__shared__ int red_i[4];
+	const long g = st.pend_g;
+	const float phase_max = st.pend_phase;
+	const float frac_cfo = phase_max / (float)HALF_LEN;       // decode.cc:110
+	int symbol_pos = SEARCH_POS - st.pend_index_max;           // decode.cc:114
+	const long base = g - (BUFFER_LEN - 1);
+	if (tid < (HALF_LEN + NT - 1) / NT)
+		rot[tid] = phasor(frac_cfo, (long)NT * tid);
+	const cf p_thread = phasor(frac_cfo, tid);
+	__syncthreads();
+	for (int i = tid; i < HALF_LEN; i += NT)                   // decode.cc:117-118
+		buf[i] = cmul(src.at(base + i + symbol_pos + HALF_LEN), cmul(p_thread, rot[i / NT]));
+	__syncthreads();
+	fft_fwd<HALF_LEN, NT, RC::SL>(buf, tw, tid);
+	for (int i = tid; i < HALF_LEN; i += NT)                   // decode.cc:120-121
+		xr[i] = demod_or_erase(buf[i], buf[(i + HALF_LEN - 1) % HALF_LEN]);
+	__syncthreads();
+	fft_fwd<HALF_LEN, NT, RC::SL>(xr, tw, tid);
+	// x kern, then backward transform as conj(FFT(conj(.)))
+	for (int i = tid; i < HALF_LEN; i += NT)
+		xr[i] = cconj(cmul(xr[i], kern[i]));
+	__syncthreads();
+	fft_fwd<HALF_LEN, NT, RC::SL>(xr, tw, tid);
+	// decode.cc:127-139: peak = max, shift = first index of it, next = runner-up
+	float pk = -1.f;
+	int sh_i = 0x7fffffff;
+	for (int i = tid; i < HALF_LEN; i += NT) {
+		float p = cnorm(xr[i]);
+		if (p > pk) { pk = p; sh_i = i; }
+	}
+	#pragma unroll
+	for (int m = 32; m; m >>= 1) {
+		float op = __shfl_xor(pk, m);
+		int oi = __shfl_xor(sh_i, m);
+		if (op > pk || (op == pk && oi < sh_i)) { pk = op; sh_i = oi; }
+	}
+	if (lane == 0) { red_p[wave] = pk; red_i[wave] = sh_i; }
+	__syncthreads();
+	pk = red_p[0]; sh_i = red_i[0];
+	#pragma unroll
+	for (int w = 1; w < 4; ++w)
+		if (red_p[w] > pk || (red_p[w] == pk && red_i[w] < sh_i)) { pk = red_p[w]; sh_i = red_i[w]; }
+	__syncthreads();
+	float nx = 0.f;
+	for (int i = tid; i < HALF_LEN; i += NT) {
+		float p = cnorm(xr[i]);
+		if (i != sh_i && p > nx) nx = p;
+	}
+	#pragma unroll
+	for (int m = 32; m; m >>= 1)
+		nx = fmaxf(nx, __shfl_xor(nx, m));
+	if (lane == 0)
+		red_p[wave] = nx;
+	__syncthreads();
+	nx = fmaxf(fmaxf(red_p[0], red_p[1]), fmaxf(red_p[2], red_p[3]));
+	const float peak = fmaxf(pk, 0.f);
+	const int shift = peak > 0.f ? sh_i : 0;
+	bool accept = peak > nx * 4.f;                             // decode.cc:140-141
+	int pos_err = 0;
+	if (accept) {
+		cf v = cconj(xr[shift]);
+		pos_err = (int)nearbyintf(atan2f(v.im, v.re) * (float)HALF_LEN / TWO_PI_F);
+		if (abs(pos_err) > GUARD_LEN / 2)                      // decode.cc:144-145
+			accept = false;
+	}
+	if (tid == 0) {
+		st.pending = 0;
+		if (accept) {
+			symbol_pos -= pos_err;
+			float cfo_rad = (float)shift * (TWO_PI_F / (float)HALF_LEN) - frac_cfo;   // decode.cc:148
+			if (cfo_rad >= PI_F)
+				cfo_rad -= TWO_PI_F;
+			st.found = 1;
+			st.symbol_pos = symbol_pos;
+			st.cfo_rad = cfo_rad;
+			st.sc_start = g - (BUFFER_LEN - 1) + symbol_pos;
+		} else {
+			st.rejects += 1;
+		}
+		st_all[f] = st;
+	}
 }
 
 }  // namespace rx
@@ -472,6 +599,10 @@ __global__ void k_init_sync(int n, SyncState *st, const int32_t *skip)
 	s.call_sign = 0;
 	s.hdr_rounds = 0;
 	s.okay = 0;
+	s.pend_g = 0;
+	s.pend_index_max = 0;
+	s.pend_phase = 0.f;
+	s.pending = 0;
 	st[f] = s;
 }
 
@@ -483,9 +614,23 @@ void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef c
 {
 	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_front_end<RATE>, dim3(n), dim3(256), 0, s, fb, co, dc, z));
 }
+#ifndef SYNC_SPLIT_ROUNDS
+#define SYNC_SPLIT_ROUNDS 2   // rates above 8 kHz: scan + accept pairs before the one-wave catch-all (a frame needs the catch-all only
+                              // after that many rejected triggers; finished frames leave every later launch at once)
+#endif
 void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, cf *scratch)
 {
-	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_sync<RATE>, dim3(n), dim3(64), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, scratch));
+#ifndef SYNC_SPLIT_8K
+#define SYNC_SPLIT_8K 0
+#endif
+	if (rate != 8000 || SYNC_SPLIT_8K) {
+		for (int r = 0; r < SYNC_SPLIT_ROUNDS; ++r) {
+			RX_RATE_SWITCH(rate,
+				hipLaunchKernelGGL((k_sync<RATE, true>), dim3(n), dim3(64), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, scratch);
+				hipLaunchKernelGGL(k_sync_accept<RATE>, dim3(n), dim3(256), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st));
+		}
+	}
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_sync<RATE, false>), dim3(n), dim3(64), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, scratch));
 }
 
 }  // namespace rx

@@ -34,6 +34,11 @@ struct SyncState {                 // per frame, across sync rounds (decode.cc:3
 	unsigned long long call_sign;
 	int hdr_rounds;                // header attempts so far
 	int okay;
+	// a trigger found by the scanning kernel and not yet examined by the accept kernel (rates above 8 kHz, k_sync.hip)
+	long pend_g;
+	int pend_index_max;
+	float pend_phase;
+	int pending;
 };
 
 struct Tables {                    // device-resident constants, built once per handle
