@@ -67,7 +67,7 @@ typedef struct {
 	int32_t list_size;         /* SCL list = SIMD width of the reference build (decode.cc:164-169): 8 (AVX2, the
 	                            * benchmarked configuration; 0 = 8) or 4 (the 128-bit build) */
 	int32_t device;            /* HIP device ordinal */
-	int32_t chunk_frames;      /* frames resident per pass (0 = default) */
+	int32_t chunk_frames;      /* frames resident per pass (0 = default: 8192) */
 	int32_t max_samples;       /* max samples per frame (0 = ofdmrx_frame_samples(sample_rate, 6)) */
 	int32_t descramble;        /* 1 = XOR payload with Xorshift32 like main(), decode.cc:613-615 */
 	int32_t flags;             /* bit 0: keep the pre-rotation constellation (OFDMRX_TAP_CONS_RAW) */

@@ -205,9 +205,12 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	h->cfg = *cfg;
 	h->rate = cfg->sample_rate;
 	h->list = cfg->list_size == 4 ? 4 : 8;
-	// default chunk: 8192 frames (4096 at 44.1 / 48 kHz, whose frames are six times longer): the per-frame decoder
-	// state does not grow with the rate, and the polar stage needs a few thousand codewords per launch to fill the chip
-	h->chunk = cfg->chunk_frames > 0 ? cfg->chunk_frames : (cfg->sample_rate <= 16000 ? 8192 : 4096);
+	// default chunk: 8192 frames at every rate: the per-frame decoder state does not grow with the rate, and the two-stream
+	// schedule wants a few thousand codewords per polar launch (44.1 / 48 kHz: 121 k / 125 k frames/s against 111 k / 112 k
+	// with 4096).  What does grow is the per-chunk input: a 48 kHz frame is 4.2 MB of int16 pairs (34.6 GB per 8192 frames; the
+	// host-pointer entry stages two such chunks, mono input adds a 69 GB analytic-signal buffer) - buffers are sized to
+	// min(batch, chunk), so only a large batch pays that; cfg.chunk_frames lowers it.
+	h->chunk = cfg->chunk_frames > 0 ? cfg->chunk_frames : 8192;
 	h->max_samples = cfg->max_samples > 0 ? cfg->max_samples : ofdmrx_frame_samples(cfg->sample_rate, 6);
 	if (cfg->stream) {
 		h->stream = (hipStream_t)cfg->stream;
