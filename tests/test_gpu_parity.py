@@ -513,6 +513,39 @@ def test_other_rates_decode_matches_oracle(rx_rate, mode, channels, freq, noise)
     _close(rx_rate.tap("LLR", 0)[:m.cons_bits], tb.llr[:m.cons_bits], what="llr")
 
 
+def _with_false_triggers(pcm, rate, bursts, seed):
+    """`bursts` noise segments of symbol_len / 2 samples, each repeated three times (period = the correlator's length: the
+    Schmidl-Cox metric fires on them, the MLS correlation of the accept path does not), in front of the real frame"""
+    hs = 640 * rate // 8000
+    rng = np.random.default_rng(seed)
+    parts = []
+    for b in range(bursts):
+        seg = (rng.normal(0, 0.12, (hs, 2)) * 32767).astype(np.int16)
+        parts += [np.zeros((3 * hs, 2), np.int16), seg, seg, seg]
+    return np.concatenate(parts + [pcm], axis=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bursts", [1, 4])
+def test_rejected_triggers_match_oracle_at_every_rate(rx, rx_rate, bursts):
+    """decode.cc:110-146: a trigger whose correlation peak fails the test is passed over and the search goes on.  One and
+    four false triggers in front of the frame: at 16 / 44.1 / 48 kHz the first two are handled by the scan + accept kernel
+    pairs, the rest by the one-wave catch-all kernel (k_sync.hip); at 8 kHz by the one-wave kernel alone"""
+    for r in (rx, rx_rate):
+        rate = r.sample_rate
+        p = O.payload_for(1200 + bursts + rate // 1000)
+        pcm = O.encode_pcm(p, channels=2, freq_off=1500, call_sign="REJECT", mode=6, rate=rate)
+        pcm = _with_false_triggers(pcm, rate, bursts, seed=rate + bursts)
+        out, res = r.decode(pcm[None])
+        oout, ores, _ = O.decode(pcm, taps=True, rate=rate)
+        g = res[0]
+        assert ores.status == 0 and ores.n_sync_rejects >= bursts, (rate, ores.status, ores.n_sync_rejects)
+        assert int(g["status"]) == 0 and int(g["n_sync_rejects"]) == ores.n_sync_rejects
+        assert int(g["sc_start"]) == ores.sc_start and int(g["symbol_pos"]) == ores.symbol_pos
+        assert abs(float(g["cfo_rad"]) - ores.cfo_rad) <= 2e-7
+        assert (out[0] == p).all() and (out[0] == oout).all()
+
+
 def test_other_rates_device_transmitter(rx_rate):
     """N2 at 16 / 44.1 / 48 kHz: Encoder<value,cmplx,rate> on the device (4x PAPR buffers of 10240 / 28224 / 30720
     points) within +-1 LSB of the oracle encoder; decodes on both sides"""
