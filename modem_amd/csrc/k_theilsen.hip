@@ -434,7 +434,10 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 				const float2 *zp = z2 + i + 1;
 				for (int d0 = wave * W; d0 < dmax; d0 += 4 * W) {   // distances d0+1 .. d0+32; wave w takes every 4th window
 					uint32_t accB = 0, accA = 0;
-					#pragma unroll 1
+#ifndef TS_S8_UNROLL
+#define TS_S8_UNROLL 1
+#endif
+					#pragma unroll TS_S8_UNROLL
 					for (int s8 = 0; s8 < W; s8 += 8) {
 						float2 zv[8];
 						#pragma unroll
