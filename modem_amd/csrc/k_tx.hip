@@ -160,6 +160,9 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const cf *__restr
 		sh.fdom[i] = mk(0.f, 0.f);
 	__syncthreads();
 	bool papr = true;
+#ifdef TX_PROBE_NO_PAPR
+	papr = false;                                             // timing probe: symbols without the PAPR step
+#endif
 	const int last = tp.nsym - 1;
 	// stream layout (encode.cc:288-313): pilot | count x (S&C, meta, pilot, rows x data) | zero symbol
 	const int per = 3 + md.rows, q = sidx - 1, pay = (sidx > 0 && sidx < last) ? q / per : 0, w = (sidx > 0 && sidx < last) ? q % per : 2;
