@@ -91,7 +91,11 @@ typedef struct {
 	int32_t bit_flips;         /* decode.cc:555: sign(LLR) != decoded bit over the payload positions.  LLRs are fp32 values
 	                            * within the 1e-5 intermediate tolerance of a scalar build's; one that sits that close to
 	                            * zero may carry either sign, so this diagnostic can differ by a count or two (observed:
-	                            * +-2 in 0.3 % of the frames near the waterfall, never above it) */
+	                            * +-2 in 0.3 % of the frames near the waterfall, never above it).  Far below the waterfall of
+	                            * the HEADER (48 kHz frames with 5 % raw bit errors) one frame in 192 differed by 5: cfo_rad
+	                            * differs in its last bits (1.5e-7 rad/sample), over 440 000 samples that is 0.07 rad of
+	                            * carrier phase, which the Theil-Sen stage absorbs with different hard decisions for points
+	                            * on a decision boundary; payload, lane and every other field were identical */
 	float esn0_db_last;        /* decode.cc:517-519, cumulative Es/N0 after the last row */
 	int32_t n_sync_rejects;    /* falling edges rejected at decode.cc:140-145 */
 } ofdmrx_frame_result;

@@ -66,7 +66,11 @@ for li, db in enumerate(levels):
           "(oracle %.1f s on %d threads)" % (db, n, nok, int(same.sum()), flips_equal, dt, threads), flush=True)
     if not same.all():
         i = int(np.argmin(same))
-        print("   first mismatch frame %d: gpu status %d lane %d flips %d | oracle status %d lane %d flips %d" % (
-            i, res["status"][i], res["best_lane"][i], res["bit_flips"][i], ores["status"][i], ores["best_lane"][i], ores["bit_flips"][i]))
+        differ = [nm for nm in ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects") if res[nm][i] != ores[nm][i]]
+        if not (out[i] == oout[i]).all():
+            differ.append("payload")
+        print("   first mismatch frame %d: gpu status %d lane %d flips %d | oracle status %d lane %d flips %d | fields that differ: %s; "
+              "cfo gpu %.9g oracle %.9g" % (i, res["status"][i], res["best_lane"][i], res["bit_flips"][i], ores["status"][i],
+              ores["best_lane"][i], ores["bit_flips"][i], ", ".join(differ) or "none but the flip count", res["cfo_rad"][i], ores["cfo_rad"][i]))
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
