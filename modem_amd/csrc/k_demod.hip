@@ -158,12 +158,16 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 				}
 			}
 		};
-		if (NQ == 1)
+#ifndef DEMOD_PREFETCH_NQ
+#define DEMOD_PREFETCH_NQ 1   // loader points per thread up to which the NEXT symbol's samples are fetched during the transform
+#endif
+		constexpr bool AHEAD = NQ <= DEMOD_PREFETCH_NQ;
+		if (AHEAD)
 			fetch(0);
 		cf *carr = carr_all + (size_t)f * CARR_MAX;
 		for (int s = 0; s <= md.rows; ++s) {
 			cf *row = rows[DC::DOUBLE ? (s & 1) : 0];
-			if (NQ > 1)
+			if (!AHEAD)
 				fetch(s);                                         // several points per thread: their loads overlap each other
 			#pragma unroll
 			for (int q = 0; q < NQ; ++q) {
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 						row[r * NS + np] = cmul(v[r], DC::TWR_LDS ? tw_r[(r - 1) * NS + np] : tb.tw_sym[r * np]);
 				}
 			}
-			if (NQ == 1)
+			if (AHEAD)
 				fetch(s + 1);
 			__syncthreads();
 			fft_fwd_compact<NS, 64 * DC::W, SYMBOL_LEN>(row + (tid / (64 * DC::W)) * NS, tw_sub, tid % (64 * DC::W));
