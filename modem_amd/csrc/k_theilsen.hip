@@ -449,8 +449,13 @@ __device__ void theil_sen_block(TsShared &s, int n, int tid, float &slope, float
 							// (plain v_sub_f32 by hand: left to itself the compiler packs the two subtractions into one v_pk_add_f32
 							// plus two register moves, 13 SIMD cycles instead of 6.6)
 							float tb, ta;
+#ifdef TS_PLAIN_SUB
+							tb = zv[u].x - thr_lo;                       // needs -fno-slp-vectorize, or the two become one v_pk_add_f32 + moves
+							ta = thr_hi - zv[u].y;
+#else
 							asm("v_sub_f32_e32 %0, %1, %2" : "=v"(tb) : "v"(zv[u].x), "v"(thr_lo));
 							asm("v_sub_f32_e32 %0, %1, %2" : "=v"(ta) : "v"(thr_hi), "v"(zv[u].y));
+#endif
 							accB = __builtin_amdgcn_alignbit(accB, __float_as_uint(tb), 31);   // (accB << 1) | sign(tb)
 							accA = __builtin_amdgcn_alignbit(accA, __float_as_uint(ta), 31);
 						}

@@ -143,7 +143,10 @@ template <int RATE> struct TxShared {
 
 // symbol kinds in transmission order (encode.cc:288-313): pilot | S&C | meta | pilot | rows x data | zero
 template <int RATE>
-__global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const cf *__restrict__ rowsym_all, Tables tb, TxParams tp,
+#ifndef TX_WAVES
+#define TX_WAVES 2        // waves per SIMD the register budget of k_tx_symbol is set for
+#endif
+__global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVES : 1)) void k_tx_symbol(const cf *__restrict__ rowsym_all, Tables tb, TxParams tp,
 	const cf *__restrict__ tw5120, cf *__restrict__ tdom_all, cf *__restrict__ big_scratch)
 {
 	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, NT = TxCfg<RATE>::NT;
@@ -277,9 +280,13 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT) void k_tx_symbol(const cf *__restr
 		}
 		__syncthreads();
 		fft_fwd_compact<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fdom, sh.twc, tid);
+		const float r8 = 1.f / s8;
 		for (int i = tid; i < SYMBOL_LEN; i += NT) {
 			cf v = cconj(sh.fdom[i]);
-			out[i] = mk(v.re / s8, v.im / s8);
+			// v / s8 as q0 = v r8, q0 + fma(-s8, q0, v) r8: the correctly rounded quotient in three instructions (Markstein; within the
+			// +-1 LSB contract of this path in any case)
+			const float qr = v.re * r8, qi = v.im * r8;
+			out[i] = mk(__builtin_fmaf(__builtin_fmaf(-s8, qr, v.re), r8, qr), __builtin_fmaf(__builtin_fmaf(-s8, qi, v.im), r8, qi));
 		}
 	} else {
 		cf *temp = sh.fdom;                                   // global scratch for the 4N-point buffer, fdom itself for the symbol

@@ -1,6 +1,6 @@
 #!/bin/bash
 # build_variant.sh NAME "EXTRA HIPCC FLAGS" [files...] -- an alternative build of libofdmrx.so for A/B runs
-# (MODEM_AMD_LIB=modem_amd/lib/variants/libofdmrx_NAME.so).  Objects go to /tmp; only the .so lands in-tree
+# (MODEM_AMD_LIB=modem_amd/lib/variants/libofdmrx_NAME.so).  PERFILE_<stem>="flags" in the environment adds flags to one file.  Objects go to /tmp; only the .so lands in-tree
 # (git-ignored, travels with gpurun).  Files default to every source of the library.
 set -e
 NAME=$1; FLAGS=$2; shift 2 || true
@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd); S=$R/modem_amd/csrc; O=/tmp/variant_$NAME; 
 SRC="k_sync.hip k_header.hip k_demod.hip k_theilsen.hip k_polar.hip k_finish.hip k_channel.hip k_tx.hip ofdmrx_api.cpp tables.cpp"
 pids=()
 for f in $SRC; do
-	( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-unused-result $FLAGS $( [ $f = k_demod.hip ] && echo -fno-slp-vectorize ) -c $S/$f -o $O/${f%.*}.o ) &
+	( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-unused-result $FLAGS $( [ $f = k_demod.hip ] && echo -fno-slp-vectorize ) $(eval echo \$PERFILE_${f%.*}) -c $S/$f -o $O/${f%.*}.o ) &
 	pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
