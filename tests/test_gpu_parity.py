@@ -78,6 +78,40 @@ def test_theil_sen_bit_exact(rx):
             assert s[r] == np.float32(os_) and yi[r] == np.float32(oy)
 
 
+def test_theil_sen_rank_search_rows(rx):
+    """the rank-counting search of k_theilsen.hip on the kinds of rows it has special paths for: every row length of the
+    mode table, quiet / noisy / wrapped phases, erased carriers (exact zeros: tied slopes), equal values, exact lines
+    (every pair inside the rounding margin), a steep trend, short rows - slope and intercept bit-identical to the oracle"""
+    rng = np.random.default_rng(33)
+    for cols in (432, 400, 360, 512, 384, 256):
+        x = np.arange(cols, dtype=np.float64) - cols // 2
+        rows = []
+        for sigma in (1e-6, 0.003, 0.03, 0.1, 0.25):
+            for rep in range(4):
+                rows.append(rng.normal(0, 1e-3) * x + rng.normal(0, 0.05) + rng.normal(0, sigma, cols))
+        rows.append(rng.uniform(-0.39, 0.39, cols))                                         # garbage (8PSK residuals)
+        rows.append(np.where(rng.random(cols) < 0.1, rng.uniform(-0.39, 0.39, cols), rng.normal(0, 0.2, cols)))
+        r = rng.normal(0, 0.1, cols); r[rng.integers(0, cols, 12)] = 0.0; rows.append(r)    # a dozen erased carriers
+        r = rng.normal(0, 0.1, cols); r[rng.integers(0, cols, cols // 3)] = 0.0; rows.append(r)   # a third erased: the median is the tie
+        r = rng.normal(0, 0.1, cols); r[::2] = 0.0; rows.append(r)                          # half erased
+        rows.append(np.round(rng.normal(0, 0.1, cols), 2))                                  # few distinct values
+        rows.append(0.007 * x + 0.1)                                                        # exact line
+        rows.append(0.007 * x + rng.normal(0, 1e-7, cols))                                  # line + rounding noise
+        rows.append(0.01 * x + rng.normal(0, 0.02, cols))                                   # steep trend
+        rows.append(np.full(cols, 0.25))
+        rows = np.stack(rows).astype(np.float32)
+        s, yi = rx.theil_sen(rows)
+        for r in range(rows.shape[0]):
+            os_, oy = O.theil_sen(rows[r])
+            assert s[r] == np.float32(os_) and yi[r] == np.float32(oy), (cols, r, s[r], os_, yi[r], oy)
+    for cols in (2, 3, 8, 9, 63, 65, 127, 129):
+        y = rng.normal(0, 0.3, (4, cols)).astype(np.float32)
+        s, yi = rx.theil_sen(y)
+        for r in range(4):
+            os_, oy = O.theil_sen(y[r])
+            assert s[r] == np.float32(os_) and yi[r] == np.float32(oy), (cols, r)
+
+
 def _bch_codeword(rng):
     data = rng.integers(0, 256, 9, dtype=np.uint8)
     data[8] &= 0xfe

@@ -1,7 +1,8 @@
 // ts_probe.cpp -- timing probe for the Theil-Sen kernel (tools only)
 #include <hip/hip_runtime.h>
-__device__ int g_fallbacks;
+__device__ int g_fallbacks, g_iters;
 #define TS_PROBE_COUNT (&g_fallbacks)
+#define TS_PROBE_ITERS (&g_iters)
 #ifndef TS_SRC
 #define TS_SRC "../modem_amd/csrc/k_theilsen.hip"
 #endif
@@ -25,7 +26,8 @@ int main()
 		launch_theil_sen_raw(0, rows, cols, dy, ds, di);
 		hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
 		int fb; hipMemcpyFromSymbol(&fb, HIP_SYMBOL(g_fallbacks), 4);
-		printf("%s: %d rows %.2f ms (fallbacks so far %d)\n", VARIANT, rows, ms, fb);
+		int it = 0; hipMemcpyFromSymbol(&it, HIP_SYMBOL(g_iters), 4);
+		printf("%s: %d rows %.2f ms (fallbacks so far %d, rank counts so far %d)\n", VARIANT, rows, ms, fb, it);
 	}
 	return 0;
 }
