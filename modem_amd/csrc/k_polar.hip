@@ -436,23 +436,36 @@ template <int LN> struct Block8 {
 __device__ unsigned long long g_polar_prof[8];
 #define PROF_DECL() unsigned long long pc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tl_ = __builtin_readcyclecounter()
 #define PROF(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pc_[i] += n_ - tl_; tl_ = n_; } while (0)
-#define PROF_FLUSH() do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 7; ++q_) atomicAdd(&g_polar_prof[q_], pc_[q_]); atomicAdd(&g_polar_prof[7], 1ull); } } while (0)
+#define PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 7; ++q_) atomicAdd(&g_polar_prof[q_], pc_[q_]); atomicAdd(&g_polar_prof[7], 1ull); } } while (0)
 #else
 #define PROF_DECL() do { } while (0)
 #define PROF(i) do { } while (0)
 #define PROF_FLUSH() do { } while (0)
 #endif
 
+// Decoders per workgroup.  A decoder is one wave and never meets another one (no barrier, its own 8 KB of LDS).  The
+// hardware places at most 16 WORKGROUPS on a CU: sixteen one-wave decoders fill every slot, and whatever kernel another
+// stream launches beside them waits until decoders leave (round 3: the first kernel queued behind a polar launch took
+// 27 ms instead of 1, whichever kernel it was).  With four decoders per workgroup the other kernels do run beside the
+// decoders - and the list decoder slows down by exactly their time alone (36.2 -> 43.6 ms per 8192 codewords, 178 k
+// frames/s against 194 k): the machine has no idle issue slots to give.  So the default stays one decoder per workgroup,
+// and the pipeline treats a polar launch as owning the machine (ofdmrx_api.cpp: run_pipeline).
+#ifndef POLAR_WPB
+#define POLAR_WPB 1
+#endif
 template <int LN>
-__global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
+__global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
 	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev2,
 	float *__restrict__ metric_all, int *__restrict__ next_cw)
 {
 #ifdef POLAR_PRIO
 	__builtin_amdgcn_s_setprio(POLAR_PRIO);                   // experiments: issue priority against the co-resident Theil-Sen waves
 #endif
-	const int lane = threadIdx.x, j = lane >> 3, k = lane & 7;
-	__shared__ float ls8[32 * 64];                            // level 8 of the current 256-leaf node: [x][lane]
+	const int lane = threadIdx.x & 63, j = lane >> 3, k = lane & 7;
+	const int wave_in_block = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+	const int decoder = (int)blockIdx.x * POLAR_WPB + wave_in_block;
+	__shared__ float ls8_all[POLAR_WPB][32 * 64];              // level 8 of the current 256-leaf node: [x][lane], one per decoder
+	float *ls8 = ls8_all[wave_in_block];
 	// Persistent decoders take codewords from a shared counter (zeroed before the launch): under the shared schedule
 	// the CUs are unevenly loaded, a fixed stride would leave the fast decoders idle in the last round.
 	// List 8: a unit of work is one codeword.  List 4 (the reference's 128-bit build): a unit is a PAIR of codewords
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(64, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, co
 	const uint32_t *frozen = frozen2 + (st_all[cw].oper_mode >= 10 ? 2048 : 0);   // decode.cc:312,344
 	const uint8_t *node_lev = node_lev2 + (st_all[cw].oper_mode >= 10 ? 8192 : 0);
 	const float *llr = llr_all + (size_t)cw * CODE_LEN;
-	float *soft = soft_all + (size_t)blockIdx.x * (8 * CODE_LEN);   // level m >= 9 at soft + 8*2^m
+	float *soft = soft_all + (size_t)decoder * (8 * CODE_LEN);   // level m >= 9 at soft + 8*2^m
 	uint8_t *hard = hard_all + (size_t)cw * CODE_LEN;            // (a pair shares the first one's array: bits 0..3 | 4..7)
 	PolarBufs pb;
 	pb.soft = make_rsrc(soft, 8 * CODE_LEN * 4);
@@ -890,14 +903,15 @@ void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st,
 	(void)hipMemsetAsync(next_cw, 0, sizeof(int), s);
 	if (grid <= 0 || grid > n)
 		grid = n;
+	grid = (grid + POLAR_WPB - 1) / POLAR_WPB;                // workgroups of POLAR_WPB decoders
 #ifdef POLAR_PROF
 	unsigned long long z8[8] = { 0 };
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_polar_prof), z8, sizeof(z8));
 #endif
 	if (list == 4)
-		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw);
+		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw);
 	else
-		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw);
+		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw);
 #ifdef POLAR_PROF
 	(void)hipStreamSynchronize(s);
 	(void)hipMemcpyFromSymbol(z8, HIP_SYMBOL(g_polar_prof), sizeof(z8));

@@ -31,7 +31,7 @@
 namespace rx {
 
 #ifndef TS_CAP
-#define TS_CAP 64          // pairs the final bracket may hold
+#define TS_CAP 56          // pairs the final bracket may hold (the list holds 64: a few candidates fall outside after the exact division)
 #endif
 #ifndef TS_MARGIN
 #define TS_MARGIN 12       // a secant step aims this many ranks past the target, on the side still open
@@ -42,17 +42,31 @@ namespace rx {
 constexpr int TS_QBITS = 22;
 constexpr uint32_t TS_QREAL = (1u << TS_QBITS) - 8192u;   // quanta [0, TS_QREAL) for the row's points
 constexpr uint32_t TS_QPAD0 = (1u << TS_QBITS) - 4096u;   // slots beyond n: above every real key, 8 quanta apart
-constexpr uint32_t TS_MQ = 6;                             // |q_i - q_j| <= TS_MQ: the pair gets the exact division
-constexpr uint32_t TS_MQ1S = (TS_MQ + 1) << 9;
-constexpr int TS_LIST = 128;                              // candidate pairs of the final bracket
+// |q_i - q_j| <= TS_MQ: the pair gets the exact division.  Why 2 is enough: |q_i - q_j| >= 3 means the fp64 values differ by
+// more than 2 quanta, the exact ones by more than 2 - 2^-27; the two fp32 roundings of s_ij move it by at most
+// 2^-22 |y_j - y_i| relative to T d, i.e. by less than one quantum (scale <= 2^22 / (ymax - ymin)).
+constexpr uint32_t TS_MQ = 2;
+constexpr int TS_MQ1S = (int)((TS_MQ + 1) << 9);
+constexpr int TS_LIST = 64;                               // candidate pairs of the final bracket: one per lane
 constexpr int TS_MAX_IT = 48;
+#ifdef TS_PROBE_REASON
+#define TS_REASON(r) do { if (threadIdx.x == 0) atomicAdd(TS_PROBE_REASON + (r), 1); } while (0)
+#else
+#define TS_REASON(r) do { } while (0)
+#endif
+constexpr uint32_t TS_SENTINEL = 0x7fffffffu;             // above every key, and differences to it stay positive as int32
 
+// LDS images are "register major": element e = 8 * lane + t lives at row t, column lane, so that "my elements" and "the
+// elements kk places after mine" are consecutive words across the lanes (index 8 * lane + t would put 8 lanes on a bank).
+// Row strides 68 / 76 words keep column accesses AND the row-crossing writes of the loader (i = lane + 64 q) conflict-free.
+constexpr int TS_YS = 68, TS_PS = 76;                     // sk: columns 64..75 hold sentinels (positions past the end)
 struct TsLds {
-	float y[512];
-	uint32_t sk[512];          // sorted keys of the last count
-	uint32_t so[512];          // the same elements keyed at the other end of the bracket; radix histogram of the slow path
+	float y[8 * TS_YS];
+	uint2 sk[8 * TS_PS];       // .x sorted keys of the last count; .y the same elements keyed at the other end of the bracket
 	uint32_t lst[TS_LIST];
 };
+__device__ __forceinline__ int ts_yaddr(int i) { return (i & 7) * TS_YS + (i >> 3); }
+__device__ __forceinline__ int ts_paddr(int p) { return (p & 7) * TS_PS + (p >> 3); }
 
 __device__ __forceinline__ unsigned fkey(float v)
 {
@@ -254,10 +268,24 @@ __device__ __forceinline__ TsQuant ts_quant(float T, float ymin, float ymax, int
 	q.off = -lo * scale;
 	return q;
 }
-__device__ __forceinline__ uint32_t ts_key(float y, int idx, int n, double Td, const TsQuant &q)
+// keys of the eight points idx0 .. idx0 + 7 (values yv) at threshold T: q = floor(y scale + (off - T scale x))
+__device__ __forceinline__ void ts_keys_run(uint32_t (&k)[8], const float (&yv)[8], int idx0, int n, float T, const TsQuant &q)
 {
-	const double z = fma(-Td, (double)(idx - n / 2), (double)y);
-	const uint32_t qv = (uint32_t)fma(z, q.scale, q.off);       // v_cvt_u32_f64: truncates, clamps below zero
+	const double tds = (double)T * q.scale;
+	double c = fma(-tds, (double)(idx0 - n / 2), q.off);
+	#pragma unroll
+	for (int t = 0; t < 8; ++t) {
+		const uint32_t qv = (uint32_t)fma((double)yv[t], q.scale, c);   // v_cvt_u32_f64: truncates, clamps below zero
+		const int idx = idx0 + t;
+		const uint32_t pad = TS_QPAD0 + 8u * (uint32_t)(idx - n + 1);
+		k[t] = ((idx < n ? qv : pad) << 9) | (uint32_t)idx;
+		c -= tds;
+	}
+}
+__device__ __forceinline__ uint32_t ts_key(float y, int idx, int n, float T, const TsQuant &q)
+{
+	const double c = fma(-(double)T * q.scale, (double)(idx - n / 2), q.off);
+	const uint32_t qv = (uint32_t)fma((double)y, q.scale, c);
 	const uint32_t pad = TS_QPAD0 + 8u * (uint32_t)(idx - n + 1);
 	return ((idx < n ? qv : pad) << 9) | (uint32_t)idx;
 }
@@ -266,16 +294,16 @@ __device__ __forceinline__ uint32_t ts_key(float y, int idx, int n, double Td, c
 __device__ __forceinline__ float ts_pair_slope(const TsLds &s, int a, int b)
 {
 	const int i = a < b ? a : b, j = a < b ? b : a;
-	return (s.y[j] - s.y[i]) / (float)(j - i);
+	return (s.y[ts_yaddr(j)] - s.y[ts_yaddr(i)]) / (float)(j - i);
 }
 
 // Exact order statistic over ALL pairs by an 8-bit radix select with true divisions (one wave): the way out for rows the
 // rank search cannot finish - hundreds of tied slopes (erased carriers), NaNs.  ~120 k instructions.
-__device__ float ts_slow_select(TsLds &s, int n, int lane, int target)
+__device__ __noinline__ float ts_slow_select(TsLds &s, int n, int lane, int target)
 {
 	uint32_t prefix = 0, mask = 0;
 	int rank = target;
-	uint32_t *hist = s.so;
+	uint32_t *hist = (uint32_t *)s.sk;
 	for (int shift = 24; shift >= 0; shift -= 8) {
 		for (int b = lane; b < 256; b += 64)
 			hist[b] = 0;
@@ -283,7 +311,7 @@ __device__ float ts_slow_select(TsLds &s, int n, int lane, int target)
 		for (int d = 1; d < n; ++d) {
 			const float fd = (float)d;
 			for (int i = lane; i < n - d; i += 64) {
-				const unsigned key = fkey((s.y[i + d] - s.y[i]) / fd);
+				const unsigned key = fkey((s.y[ts_yaddr(i + d)] - s.y[ts_yaddr(i)]) / fd);
 				if ((key & mask) == prefix)
 					atomicAdd(&hist[(key >> shift) & 255u], 1u);
 			}
@@ -318,23 +346,59 @@ __device__ float ts_slow_select(TsLds &s, int n, int lane, int target)
 	return fkey_inv(prefix);
 }
 
-// y[0..n) in s.y (every lane's writes visible); x[i] = i - n/2.  Returns slope and yint in all lanes.
+// one key per lane, ascending over the lanes: the same network on single registers (21 steps of one move + one median)
+__device__ __forceinline__ uint32_t ts_sort_lanes(uint32_t v, const TsLane &L)
+{
+	v = med3u(v, dpp_u<DPP_XOR1>(v), L.c1);
+	v = med3u(v, dpp_u<DPP_XOR3>(v), L.c2); v = med3u(v, dpp_u<DPP_XOR1>(v), L.c1);
+	v = med3u(v, dpp_u<DPP_HALF_MIRROR>(v), L.c4); v = med3u(v, dpp_u<DPP_XOR2>(v), L.c2); v = med3u(v, dpp_u<DPP_XOR1>(v), L.c1);
+	v = med3u(v, dpp_u<DPP_MIRROR>(v), L.c8); v = med3u(v, swz_u<SWZ_XOR4>(v), L.c4); v = med3u(v, dpp_u<DPP_XOR2>(v), L.c2);
+	v = med3u(v, dpp_u<DPP_XOR1>(v), L.c1);
+	v = med3u(v, swz_u<SWZ_XOR31>(v), L.c16); v = med3u(v, dpp_u<DPP_ROR8>(v), L.c8); v = med3u(v, swz_u<SWZ_XOR4>(v), L.c4);
+	v = med3u(v, dpp_u<DPP_XOR2>(v), L.c2); v = med3u(v, dpp_u<DPP_XOR1>(v), L.c1);
+	v = med3u(v, (uint32_t)__builtin_amdgcn_ds_bpermute(L.a63, (int)v), L.c32); v = med3u(v, swz_u<SWZ_XOR16>(v), L.c16);
+	v = med3u(v, dpp_u<DPP_ROR8>(v), L.c8); v = med3u(v, swz_u<SWZ_XOR4>(v), L.c4); v = med3u(v, dpp_u<DPP_XOR2>(v), L.c2);
+	v = med3u(v, dpp_u<DPP_XOR1>(v), L.c1);
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t v)
+{
+	uint32_t o;
+	o = dpp_u<DPP_XOR1>(v); v = v > o ? v : o;
+	o = dpp_u<DPP_XOR2>(v); v = v > o ? v : o;
+	o = dpp_u<DPP_HALF_MIRROR>(v); v = v > o ? v : o;
+	o = dpp_u<DPP_MIRROR>(v); v = v > o ? v : o;
+	const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+	const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+	return ab > cd ? ab : cd;
+}
+
+// y[0..n) in s.y (register-major, every lane's writes visible); x[i] = i - n/2.  Returns (slope, yint) in all lanes.
 __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 {
 	const TsLane L = ts_lane(lane);
 	const int count = n * (n - 1) / 2, target = count / 2, xoff = n / 2;
 	float slope = 0.f;
 	uint32_t k[8];
+	float yv[8];
+	#pragma unroll
+	for (int t = 0; t < 8; ++t)
+		yv[t] = 8 * lane + t < n ? s.y[t * TS_YS + lane] : 0.f;
+	if (lane < TS_PS - 64) {                                      // positions past the end
+		#pragma unroll
+		for (int t = 0; t < 8; ++t)
+			s.sk[t * TS_PS + 64 + lane] = make_uint2(TS_SENTINEL, TS_SENTINEL);
+	}
+	bool sorted_z = false;                                        // k holds the row's keys sorted at a threshold next to the slope
 	if (count > 0) {
-		// ---- row statistics: range, least-squares slope
+		// ---- row statistics: range, least-squares slope (a starting point only: fp32)
 		float ymin = 3.0e38f, ymax = -3.0e38f, sy = 0.f, sxy = 0.f;
 		#pragma unroll
 		for (int t = 0; t < 8; ++t) {
 			const int i = 8 * lane + t;
 			if (i < n) {
-				const float v = s.y[i];
-				ymin = fminf(ymin, v); ymax = fmaxf(ymax, v);
-				sy += v; sxy += v * (float)(i - xoff);
+				ymin = fminf(ymin, yv[t]); ymax = fmaxf(ymax, yv[t]);
+				sy += yv[t]; sxy += yv[t] * (float)(i - xoff);
 			}
 		}
 		ymin = wave_reduce_f(ymin, [](float a, float b) { return fminf(a, b); });
@@ -342,72 +406,74 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 		sy = wave_reduce_f(sy, [](float a, float b) { return a + b; });
 		sxy = wave_reduce_f(sxy, [](float a, float b) { return a + b; });
 		bool done = false, slow = false;
-		if (ymin == ymax) {                                       // every slope is +0
+		if (ymin == ymax)                                         // every slope is +0
 			done = true;
-		} else if (!(ymax - ymin < 3.0e38f)) {                    // NaN / inf in the row
-			slow = true;
+		else if (!(ymax - ymin < 3.0e38f)) {                      // NaN / inf in the row
+			slow = true; TS_REASON(1);
 		}
-		float Ta = 0.f, Tb = 0.f, T;
+		float Ta = 0.f, Tb = 0.f, T = 0.f;
 		int ca = 0, cb = count;
-		bool hasA = false, hasB = false, atA = false;
+		bool hasA = false, hasB = false;
 		TsQuant qs = {0.0, 0.0};
+		const unsigned long long real_lanes = n >= 512 ? ~0ull : (1ull << ((n + 7) >> 3)) - 1ull;
 		if (!done && !slow) {
-			const double dn = (double)n, sx = dn * (dn - 1.0) * 0.5 - dn * (double)xoff;
-			const double sxx = (dn - 1.0) * dn * (2.0 * dn - 1.0) / 6.0 - 2.0 * (double)xoff * (dn * (dn - 1.0) * 0.5) + dn * (double)xoff * (double)xoff;
-			T = (float)(((double)sxy - sx * (double)sy / dn) / (sxx - sx * sx / dn));
-			if (!(fabsf(T) < 1.0e30f))
-				T = 0.f;
-			float Tp = 0.f;
+			{
+				const float fn = (float)n, sx = fn * (fn - 1.f) * 0.5f - fn * (float)xoff;
+				const float sxx = (fn - 1.f) * fn * (2.f * fn - 1.f) * (1.f / 6.f) - 2.f * (float)xoff * (fn * (fn - 1.f) * 0.5f) + fn * (float)xoff * (float)xoff;
+				const float rn = __builtin_amdgcn_rcpf(fn);
+				T = (sxy - sx * sy * rn) * __builtin_amdgcn_rcpf(sxx - sx * sx * rn);
+				if (!(fabsf(T) < 1.0e30f))
+					T = 0.f;
+			}
+			float Tp = 0.f, irho = 0.f;                           // irho = 1 / (slopes per unit of T around the target)
 			int cp = 0;
 			bool hasP = false;
-			double rho = 0.0;
 			for (int it = 0;; ++it) {
-				if (it >= TS_MAX_IT) { slow = true; break; }
+				if (it >= TS_MAX_IT) { slow = true; TS_REASON(2); break; }
 #ifdef TS_PROBE_ITERS
 				if (lane == 0) atomicAdd(TS_PROBE_ITERS, 1);
 #endif
 				// ---- exact #{s < T}, #{s <= T}
 				qs = ts_quant(T, ymin, ymax, n);
-				const double Td = (double)T;
-				#pragma unroll
-				for (int t = 0; t < 8; ++t) {
-					const int i = 8 * lane + t;
-					k[t] = ts_key(i < n ? s.y[i] : 0.f, i, n, Td, qs);
-				}
+				ts_keys_run(k, yv, 8 * lane, n, T, qs);
 				const int share = ts_sort(k, L, true, 6);
 				int c_lt = TS_INV_CONST + wave_sum_i(share), c_le;
 				__syncthreads();                                  // earlier readers of sk are done
-				*(uint4 *)&s.sk[8 * lane] = make_uint4(k[0], k[1], k[2], k[3]);
-				*(uint4 *)&s.sk[8 * lane + 4] = make_uint4(k[4], k[5], k[6], k[7]);
+				#pragma unroll
+				for (int t = 0; t < 8; ++t)
+					s.sk[t * TS_PS + lane].x = k[t];
 				__syncthreads();
 				{   // uncertain pairs: neighbours in sorted order whose keys are within TS_MQ quanta
-					uint32_t nxt = lane < 63 ? s.sk[8 * lane + 8] : 0xffffffffu;
-					uint32_t dmin = nxt - k[7];
+					int dmin = (int)(s.sk[lane + 1].x - k[7]);
 					#pragma unroll
 					for (int t = 0; t < 7; ++t) {
-						const uint32_t d = k[t + 1] - k[t];
+						const int d = (int)(k[t + 1] - k[t]);
 						dmin = d < dmin ? d : dmin;
 					}
 					int dlt = 0, dle = 0;
 					if (__builtin_amdgcn_ballot_w64(dmin < TS_MQ1S)) {
+#ifdef TS_PROBE_UNC
+						if (lane == 0) atomicAdd(TS_PROBE_UNC, 1);
+#endif
 						for (int kk = 1;; ++kk) {
-							if (kk > TS_UNC_STEPS) { slow = true; break; }
-							bool any = false;
+							if (kk > TS_UNC_STEPS) { slow = true; TS_REASON(3); break; }
+							uint32_t h = 0;                       // bit 7 - t: the key kk places after my t-th one is within the margin
 							#pragma unroll
-							for (int t = 0; t < 8; ++t) {
-								const int pp = 8 * lane + t + kk;
-								const uint32_t o = pp < 512 ? s.sk[pp] : 0xffffffffu;
-								if (o - k[t] < TS_MQ1S) {
-									any = true;
-									const int a = (int)(k[t] & 511u), b = (int)(o & 511u);
+							for (int t = 0; t < 8; ++t)
+								h = __builtin_amdgcn_alignbit(h, s.sk[((t + kk) & 7) * TS_PS + lane + ((t + kk) >> 3)].x - k[t] - (uint32_t)TS_MQ1S, 31);
+							if (!__builtin_amdgcn_ballot_w64(h != 0))
+								break;
+							while (__builtin_amdgcn_ballot_w64(h != 0)) {   // one pair per lane and round: the exact division
+								if (h != 0) {
+									const int bit = 31 - __clz(h), p = 8 * lane + 7 - bit;
+									h &= ~(1u << bit);
+									const int a = (int)(s.sk[ts_paddr(p)].x & 511u), b = (int)(s.sk[ts_paddr(p + kk)].x & 511u);
 									const int counted = a > b;    // the earlier key belongs to the later point: an inversion
 									const float sl = ts_pair_slope(s, a, b);
 									dlt += (sl < T) - counted;
 									dle += (sl <= T) - counted;
 								}
 							}
-							if (!__builtin_amdgcn_ballot_w64(any))
-								break;
 						}
 						if (slow)
 							break;
@@ -417,9 +483,10 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 					c_le = c_lt + dle;
 					c_lt += dlt;
 				}
+				sorted_z = true;
 				if (c_lt <= target && target < c_le) { slope = T; done = true; break; }
-				if (c_lt <= target) { Ta = T; ca = c_lt; hasA = true; atA = true; }
-				else { Tb = T; cb = c_lt; hasB = true; atA = false; }
+				if (c_lt <= target) { Ta = T; ca = c_lt; hasA = true; }
+				else { Tb = T; cb = c_lt; hasB = true; }
 				if (hasA && hasB) {
 					if (cb - ca <= TS_CAP)
 						break;
@@ -427,21 +494,22 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 				}
 				// ---- next threshold: secant on the last two exact counts (first step: density from the interquartile range)
 				if (it == 0) {
-					const uint32_t q1 = s.sk[n / 4] >> 9, q3 = s.sk[(3 * n) / 4] >> 9;
-					const double iqr = (double)(q3 > q1 ? q3 - q1 : 1u) / qs.scale;
+					const uint32_t q1 = s.sk[ts_paddr(n / 4)].x >> 9, q3 = s.sk[ts_paddr((3 * n) / 4)].x >> 9;
+					const float iqr = (float)(q3 > q1 ? q3 - q1 : 1u) * __builtin_amdgcn_rcpf((float)qs.scale);
 					// gaussian noise sigma = IQR / 1.349: density of slopes at their median = sum_d (n - d) d / (2 sigma sqrt(pi))
-					rho = (double)n * ((double)n * (double)n - 1.0) / 6.0 * 1.349 / (2.0 * 1.7724538509055159 * iqr);
+					const float fn = (float)n;
+					irho = iqr * (2.f * 1.7724539f * 6.f / 1.349f) * __builtin_amdgcn_rcpf(fn * (fn * fn - 1.f));
 				}
 				if (hasP && c_lt != cp && T != Tp)
-					rho = (double)(c_lt - cp) / ((double)T - (double)Tp);
+					irho = (T - Tp) * __builtin_amdgcn_rcpf((float)(c_lt - cp));
 				int goal;
 				if (!hasA) goal = target - TS_MARGIN;
 				else if (!hasB) goal = target + TS_MARGIN;
 				else goal = (target - ca > cb - target) ? target - TS_MARGIN : target + TS_MARGIN;
 				float Tn = T;
 				bool ok = false;
-				if (rho > 0.0 && it < 10) {
-					Tn = (float)((double)T + ((double)(goal - c_lt) + 0.5) / rho);
+				if (irho > 0.f && it < 10) {
+					Tn = T + ((float)(goal - c_lt) + 0.5f) * irho;
 					ok = fabsf(Tn) < 1.0e30f && Tn != T && (!hasA || Tn > Ta) && (!hasB || Tn < Tb);
 				}
 				if (!ok) {                                        // bisection in key space: always terminates
@@ -450,111 +518,156 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 					if (km == ka)
 						km = kb;                                  // (only when one side is still open)
 					Tn = fkey_inv(km);
-					if (Tn == T) { slow = true; break; }
+					if (Tn == T) { slow = true; TS_REASON(4); break; }
 				}
 				Tp = T; cp = c_lt; hasP = true;
 				T = Tn;
 			}
 		}
 		if (!done && !slow) {
-			// ---- the pairs inside [Ta, Tb): their order differs between the keys at Ta and at Tb.  The keys in k / s.sk are
-			// sorted at one end (Ts); key the same elements at the other end and look for neighbours that are out of order there.
-			const float To = atA ? Tb : Ta;
+			// ---- the pairs inside [Ta, Tb): their order differs between the keys at Ta and at Tb.  The keys in k / s.sk.x are
+			// sorted at one end (T); key the same elements at the other end and look for neighbours that are not clearly
+			// ascending there (sorted at Ta: s < Tb <=> the later key is not larger at Tb; sorted at Tb: s >= Ta <=> the same
+			// at Ta), plus the pairs that are uncertain at T itself.
+			const float To = T == Ta ? Tb : Ta;
 			const TsQuant qo = ts_quant(To, ymin, ymax, n);
-			const double Tod = (double)To;
-			uint32_t kom[8];
+			int kom[8], km[8];
 			#pragma unroll
 			for (int t = 0; t < 8; ++t) {
 				const int i = (int)(k[t] & 511u);
-				const uint32_t ko = ts_key(i < n ? s.y[i] : 0.f, i, n, Tod, qo);
-				s.so[8 * lane + t] = ko;
-				kom[t] = ko + TS_MQ1S;
+				const uint32_t ko = ts_key(i < n ? s.y[ts_yaddr(i)] : 0.f, i, n, To, qo);
+				s.sk[t * TS_PS + lane].y = ko;
+				kom[t] = (int)ko + TS_MQ1S;
+				km[t] = (int)k[t] + TS_MQ1S;
 			}
-			// a pair inside the bracket is at most this far apart in the sorted keys
-			const double wq = fabs((double)Tb - (double)Ta) * qs.scale * (double)(n - 1) + (double)(TS_MQ + 3u);
-			const uint32_t ws = wq < 4.0e6 ? ((uint32_t)wq << 9) | 511u : 0x7fffffffu;
+			// a pair inside the bracket is at most this far apart in the sorted keys (minus the margin: compared with o - km)
+			const float wq = fabsf(Tb - Ta) * (float)qs.scale * (float)(n - 1) * 1.0001f + 4.f;
+			const int ws = wq < 4.0e6f ? (int)(((uint32_t)wq << 9) | 511u) : 0x7fffffff;
 			__syncthreads();
 			int nc = 0;
-			for (int kk = 1; kk < 512; ++kk) {
-				bool cont = false;
+			for (int kk = 1;; ++kk) {
+				if (kk > 8 * (TS_PS - 64)) { slow = true; TS_REASON(5); break; }
+				uint32_t h = 0;
+				int gmin = 0x7fffffff;
 				#pragma unroll
 				for (int t = 0; t < 8; ++t) {
-					const int pp = 8 * lane + t + kk;
-					const bool in = pp < 512;
-					const uint32_t os = in ? s.sk[pp] : 0xffffffffu, oo = in ? s.so[pp] : 0xffffffffu;
-					const uint32_t gap = os - k[t];
-					cont |= gap <= ws;
-					// sorted at Ta: inside the bracket <=> the pair is NOT clearly ascending at Tb; sorted at Tb: <=> NOT clearly
-					// ascending at Ta - the same test either way.  Plus the pairs uncertain at Ts itself.
-					const bool hit = in && (kom[t] > oo || gap < TS_MQ1S);
-					const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-					if (m) {
-						const int slot = nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-						if (hit && slot < TS_LIST)
-							s.lst[slot] = (uint32_t)(8 * lane + t) | ((uint32_t)pp << 16);
-						nc += __popcll(m);
-					}
+					const uint2 o = s.sk[((t + kk) & 7) * TS_PS + lane + ((t + kk) >> 3)];
+					const int x2 = (int)o.x - km[t];              // < 0: uncertain at T
+					const int x1 = (int)o.y - kom[t];             // < 0: not clearly ascending at the other end
+					gmin = x2 < gmin ? x2 : gmin;
+					h = __builtin_amdgcn_alignbit(h, (uint32_t)(x1 | x2), 31);
 				}
-				if (!__builtin_amdgcn_ballot_w64(cont))
+				unsigned long long hm = __builtin_amdgcn_ballot_w64(h != 0);
+				while (hm) {                                      // one candidate per lane and round
+					const bool mine = h != 0;
+					const int slot = nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0));
+					if (mine) {
+						const int bit = 31 - __clz(h), p = 8 * lane + 7 - bit;
+						h &= ~(1u << bit);
+						if (slot < TS_LIST)
+							s.lst[slot] = (uint32_t)p | ((uint32_t)(p + kk) << 16);
+					}
+					nc += __popcll(hm);
+					hm = __builtin_amdgcn_ballot_w64(h != 0);
+				}
+				if (!(__builtin_amdgcn_ballot_w64(gmin <= ws) & real_lanes))
 					break;
 			}
 			__syncthreads();
 			if (nc > TS_LIST) {
-				slow = true;
-			} else {
-				int kept = 0;
-				#pragma unroll
-				for (int c0 = 0; c0 < TS_LIST; c0 += 64) {
-					const int c = c0 + lane;
-					bool in = false;
-					uint32_t key = 0xffffffffu;
-					if (c < nc) {
-						const uint32_t e = s.lst[c];
-						const float sl = ts_pair_slope(s, (int)(s.sk[e & 0xffffu] & 511u), (int)(s.sk[e >> 16] & 511u));
-						in = sl >= Ta && sl < Tb;
-						if (in)
-							key = fkey(sl);
-					}
-					s.lst[c] = key;
-					kept += __popcll(__builtin_amdgcn_ballot_w64(in));
+				slow = true; TS_REASON(6);
+			}
+			if (!slow) {
+				bool in = false;
+				uint32_t key = 0xffffffffu;
+				if (lane < nc) {
+					const uint32_t e = s.lst[lane];
+					const float sl = ts_pair_slope(s, (int)(s.sk[ts_paddr(e & 0xffffu)].x & 511u), (int)(s.sk[ts_paddr(e >> 16)].x & 511u));
+					in = sl >= Ta && sl < Tb;
+					if (in)
+						key = fkey(sl);
 				}
-				__syncthreads();
-				if (kept != cb - ca) {
-					slow = true;                                  // (cannot happen: the counts are exact)
+				if (__popcll(__builtin_amdgcn_ballot_w64(in)) != cb - ca) {
+					slow = true; TS_REASON(7);                                  // (cannot happen: the counts are exact)
 				} else {
-					#pragma unroll
-					for (int t = 0; t < 8; ++t)
-						k[t] = lane < TS_LIST / 8 ? s.lst[8 * lane + t] : 0xffffffffu;
-					ts_sort(k, L, false, 4);
-					__syncthreads();
-					if (lane < TS_LIST / 8) {
-						*(uint4 *)&s.so[8 * lane] = make_uint4(k[0], k[1], k[2], k[3]);
-						*(uint4 *)&s.so[8 * lane + 4] = make_uint4(k[4], k[5], k[6], k[7]);
-					}
-					__syncthreads();
-					slope = fkey_inv(s.so[target - ca]);
+					key = ts_sort_lanes(key, L);
+					slope = fkey_inv(__builtin_amdgcn_readlane(key, target - ca));
 				}
 			}
 		}
 #ifdef TS_PROBE_COUNT
 		if (slow && lane == 0) atomicAdd(TS_PROBE_COUNT, 1);
 #endif
-		if (slow)
+		if (slow) {
 			slope = ts_slow_select(s, n, lane, target);
+			sorted_z = false;
+		}
 	}
-	// ---- intercepts y - slope*x, median (sorted position n/2): one 512-key sort
-	#pragma unroll
-	for (int t = 0; t < 8; ++t) {
-		const int i = 8 * lane + t;
-		k[t] = i < n ? fkey(sub_mul_nofma(s.y[i], slope, (float)(i - xoff))) : 0xffffffffu;
+	// ---- intercepts b = y - slope*x, median (sorted position n/2)
+	float yint = 0.f;
+	bool have = false;
+	if (sorted_z) {
+		// The keys in k are the row sorted by y - T x with T within a few ulps' worth of ranks of the slope: b in that order is
+		// sorted up to swaps of close neighbours, so the element on position n/2 is the median or next to it.  Its exact rank
+		// is counted; if it is off, the next value below / above is tried (a few rounds), else the full sort below decides.
+		uint32_t bk[8];
+		#pragma unroll
+		for (int t = 0; t < 8; ++t) {
+			const int i = (int)(k[t] & 511u);
+			bk[t] = i < n ? fkey(sub_mul_nofma(s.y[ts_yaddr(i)], slope, (float)(i - xoff))) : 0xffffffffu;
+		}
+		__syncthreads();
+		if (lane == (n / 2) >> 3) {
+			#pragma unroll
+			for (int t = 0; t < 8; ++t)
+				if (t == ((n / 2) & 7))
+					s.lst[0] = bk[t];
+		}
+		__syncthreads();
+		uint32_t cand = s.lst[0];
+		for (int round = 0; round < 6 && !have; ++round) {
+			int lt = 0, le = 0;
+			#pragma unroll
+			for (int t = 0; t < 8; ++t) {
+				lt += bk[t] < cand;
+				le += bk[t] <= cand;
+			}
+			lt = wave_sum_i(lt);
+			le = wave_sum_i(le);
+			if (lt <= n / 2 && n / 2 < le) {
+				have = true;
+			} else if (lt > n / 2) {                              // too high: the largest value below it
+				uint32_t m = 0;
+				#pragma unroll
+				for (int t = 0; t < 8; ++t)
+					m = (bk[t] < cand && bk[t] > m) ? bk[t] : m;
+				cand = wave_max_u(m);
+			} else {                                              // too low: the smallest value above it
+				uint32_t m = 0;
+				#pragma unroll
+				for (int t = 0; t < 8; ++t)
+					m = (bk[t] > cand && ~bk[t] > m) ? ~bk[t] : m;
+				cand = ~wave_max_u(m);
+			}
+		}
+		yint = fkey_inv(cand);
 	}
-	ts_sort(k, L, false, 6);
-	__syncthreads();
-	*(uint4 *)&s.sk[8 * lane] = make_uint4(k[0], k[1], k[2], k[3]);
-	*(uint4 *)&s.sk[8 * lane + 4] = make_uint4(k[4], k[5], k[6], k[7]);
-	__syncthreads();
-	return make_float2(slope, n > 0 ? fkey_inv(s.sk[n / 2]) : 0.f);
+	if (!have) {                                                  // one 512-key sort
+		#pragma unroll
+		for (int t = 0; t < 8; ++t) {
+			const int i = 8 * lane + t;
+			k[t] = i < n ? fkey(sub_mul_nofma(yv[t], slope, (float)(i - xoff))) : 0xffffffffu;
+		}
+		ts_sort(k, L, false, 6);
+		__syncthreads();
+		#pragma unroll
+		for (int t = 0; t < 8; ++t)
+			s.sk[t * TS_PS + lane].x = k[t];
+		__syncthreads();
+		yint = n > 0 ? fkey_inv(s.sk[ts_paddr(n / 2)].x) : 0.f;
+	}
 	// the key order treats -0 < +0; nth_element would return whichever sits there: same value
+	return make_float2(slope, yint);
 }
 
 // decode.cc:479-504: one wave per (frame, row)
@@ -574,41 +687,39 @@ __global__ __launch_bounds__(64) void k_theil_sen(const SyncState *__restrict__ 
 		return;
 	const int cols = md.cols;
 	__shared__ TsLds s;
-	{
-		cf *row = cons_all + (size_t)f * CONS_MAX + (size_t)j * cols;
-		const cf *cr = carr_all ? carr_all + (size_t)f * CARR_MAX + (size_t)j * cols : nullptr;
-		auto cons_at = [&](int i) {                                // decode.cc:474-475
-			return cr ? demod_or_erase(cr[cols + i], cr[i]) : row[i];
-		};
-		#pragma unroll 1
-		for (int q = 0; q < 8; ++q) {                             // decode.cc:482-487
-			const int i = lane + 64 * q;
-			if (i < cols) {
-				const cf c = cons_at(i);
-				if (cr && cons_raw_all)
-					cons_raw_all[(size_t)f * CONS_MAX + (size_t)j * cols + i] = c;
-				cf d = cmul(c, cconj(md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c)));
-				s.y[i] = atan2f(d.im, d.re);
-			}
+	cf *row = cons_all + (size_t)f * CONS_MAX + (size_t)j * cols;
+	const cf *cr = carr_all ? carr_all + (size_t)f * CARR_MAX + (size_t)j * cols : nullptr;
+	auto cons_at = [&](int i) {                                    // decode.cc:474-475
+		return cr ? demod_or_erase(cr[cols + i], cr[i]) : row[i];
+	};
+	#pragma unroll 1
+	for (int q = 0; q < 8; ++q) {                                 // decode.cc:482-487
+		const int i = lane + 64 * q;
+		if (i < cols) {
+			const cf c = cons_at(i);
+			if (cr && cons_raw_all)
+				cons_raw_all[(size_t)f * CONS_MAX + (size_t)j * cols + i] = c;
+			cf d = cmul(c, cconj(md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c)));
+			s.y[ts_yaddr(i)] = atan2f(d.im, d.re);
 		}
-		__syncthreads();
-		const float2 sy = theil_sen_wave(s, cols, lane);
-		const float slope = sy.x, yint = sy.y;
-		// (the row is formed a second time here instead of being held in 16 registers across the search: its carriers are in L2)
-		#pragma unroll 1
-		for (int q = 0; q < 8; ++q) {                             // decode.cc:493-494
-			const int i = lane + 64 * q;
-			if (i < cols) {
-				float a = -(yint + slope * (float)(i - cols / 2));
-				float sn, cs;
-				sincosf(a, &sn, &cs);
-				row[i] = cmul(cons_at(i), mk(cs, sn));
-			}
+	}
+	__syncthreads();
+	const float2 sy = theil_sen_wave(s, cols, lane);
+	const float slope = sy.x, yint = sy.y;
+	// (the row is formed a second time here instead of being held in 16 registers across the search: its carriers are in L2)
+	#pragma unroll 1
+	for (int q = 0; q < 8; ++q) {                                 // decode.cc:493-494
+		const int i = lane + 64 * q;
+		if (i < cols) {
+			float a = -(yint + slope * (float)(i - cols / 2));
+			float sn, cs;
+			sincosf(a, &sn, &cs);
+			row[i] = cmul(cons_at(i), mk(cs, sn));
 		}
-		if (lane == 0) {
-			slope_all[(size_t)f * ROWS_MAX + j] = slope;
-			yint_all[(size_t)f * ROWS_MAX + j] = yint;
-		}
+	}
+	if (lane == 0) {
+		slope_all[(size_t)f * ROWS_MAX + j] = slope;
+		yint_all[(size_t)f * ROWS_MAX + j] = yint;
 	}
 }
 
@@ -618,11 +729,10 @@ __global__ __launch_bounds__(64) void k_theil_sen_raw(int cols, const float *__r
 	const int r = blockIdx.x, lane = threadIdx.x;
 	__shared__ TsLds s;
 	for (int i = lane; i < cols; i += 64)
-		s.y[i] = y[(size_t)r * cols + i];
+		s.y[ts_yaddr(i)] = y[(size_t)r * cols + i];
 	__syncthreads();
 	const float2 sy = theil_sen_wave(s, cols, lane);
-	const float slope = sy.x, yint = sy.y;
-	if (lane == 0) { slope_all[r] = slope; yint_all[r] = yint; }
+	if (lane == 0) { slope_all[r] = sy.x; yint_all[r] = sy.y; }
 }
 
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint)

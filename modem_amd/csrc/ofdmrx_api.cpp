@@ -135,6 +135,8 @@ struct ofdmrx_handle {
 	hipError_t sticky = hipSuccess;   // first failed hipEventRecord of the running call
 	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
 	int last_par = 0;         // parity used by the last chunk (taps)
+	DevBuf hard2;             // second parity of the list decoder's output: finish(c) reads its own while polar(c+1) writes
+	uint8_t *hard_of(int par) { return (par ? hard2 : hard).as<uint8_t>(); }
 	DevBuf st3;               // third SyncState array: finish(c-1) still reads its own while sync / header of chunk c+1 write theirs
 	SyncState *st_of(int i) { return (i == 0 ? st : i == 1 ? st2 : st3).as<SyncState>(); }
 	cf *cons_of(int par) { return (par ? cons2 : cons).as<cf>(); }
@@ -224,7 +226,12 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		h->own_stream = true;
 	}
 	{
-		hipError_t e = hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking);
+		// OFDMRX_POLAR_PRIO=n (experiments): stream priority of the list decoder's queue (numerically larger = lower)
+		int prio_lo = 0, prio_hi = 0;
+		(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+		const char *pe = std::getenv("OFDMRX_POLAR_PRIO");
+		hipError_t e = pe ? hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, std::max(prio_hi, std::min(prio_lo, std::atoi(pe))))
+			: hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking);
 		if (e != hipSuccess) {
 			g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
 			ofdmrx_destroy(h);
@@ -246,7 +253,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		}
 		int cus = 0;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
-		int wpc = 12;             // polar waves per CU while the next chunk's Theil-Sen stage shares the machine
+		int wpc = 16;             // resident list decoders per CU (the front stages of the next chunks share the machine with them)
 		if (const char *e2 = std::getenv("OFDMRX_POLAR_WPC"))
 			wpc = std::atoi(e2);
 		h->polar_grid = wpc > 0 && cus > 0 ? wpc * cus : 0;
@@ -289,7 +296,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3 })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2 })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -317,6 +324,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->slope2.ensure(N2 * ROWS_MAX * sizeof(float));
 		r = r ? r : h->yint2.ensure(N2 * ROWS_MAX * sizeof(float));
 		r = r ? r : h->precision2.ensure(N2 * ROWS_MAX * sizeof(float));
+		r = r ? r : h->hard2.ensure(N2 * CODE_LEN);
 		if (r)
 			return r;
 	}
@@ -329,7 +337,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->yint.ensure(N * ROWS_MAX * sizeof(float));
 		r = r ? r : h->precision.ensure(N * ROWS_MAX * sizeof(float));
 		r = r ? r : h->llr.ensure(N * CODE_LEN * sizeof(float));
-		r = r ? r : h->soft.ensure(N * 8 * CODE_LEN * sizeof(float));
+		r = r ? r : h->soft.ensure((N + 8) * 8 * CODE_LEN * sizeof(float));   // one 2 MiB level store per decoder; workgroups hold up to 8 decoders
 		r = r ? r : h->hard.ensure(N * CODE_LEN);
 		r = r ? r : h->metric.ensure(N * LIST * sizeof(float));
 		r = r ? r : h->work_counter.ensure(256);
@@ -386,8 +394,10 @@ static size_t events_per_chunk(int max_skip) { return 32 + 16 * (size_t)(max_ski
 //   back  (D9, D10: polar list decoder, systematic bits / CRC / pack)     <- st[par], llr[par]
 // A one-chunk call runs both on the handle's stream.  A longer batch is pipelined: back(c) runs on the
 // second stream while front(c+1) runs on the handle's stream.
+// wait_before_sync (event index or -1): the first sync launch waits for it; *ev_after_sync (nullable) receives the event
+// recorded right after that launch - the three-queue schedule gives the scan a slot of its own between two polar launches.
 static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, int sti, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
-	size_t *t_begin)
+	size_t *t_begin, size_t wait_before_sync = (size_t)-1, size_t *ev_after_sync = nullptr, int excl_level = 1)
 {
 	const bool mono = fb.channels == 1;
 	SyncState *st = h->st_of(sti);
@@ -422,17 +432,23 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, int sti, FrameBa
 		launch_init_sync(sq, nq, stq, d_skip ? d_skip + f0 : nullptr);
 		size_t last = e1;
 		for (int round = 0; round <= max_skip; ++round) {      // decode.cc:390-448 do { } while (skip_count--)
+			if (round == 0 && q == 0 && wait_before_sync != (size_t)-1)
+				HIP_OK(hipStreamWaitEvent(sq, h->ev_pool[wait_before_sync], 0));
 			size_t a = mark(h, sq);
 			{
 				Range r("ofdmrx:sync");
 				launch_sync(sq, h->rate, nq, fbq, zq, h->dev, stq, scq);
 			}
 			size_t b = mark(h, sq);
+			if (round == 0 && q == 0 && ev_after_sync && excl_level == 1)
+				*ev_after_sync = b;
 			{
 				Range r("ofdmrx:header_osd");
 				launch_header(sq, h->rate, nq, fbq, zq, h->dev, stq, h->hdr_soft.as<int8_t>() + (size_t)f0 * 256);
 			}
 			size_t c = mark(h, sq);
+			if (round == 0 && q == 0 && ev_after_sync && excl_level == 2)
+				*ev_after_sync = c;
 			h->spans.push_back({ OFDMRX_T_SYNC, a, b });
 			h->spans.push_back({ OFDMRX_T_HEADER, b, c });
 			last = c;
@@ -443,6 +459,8 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, int sti, FrameBa
 				h->carr.p ? h->carr.as<cf>() + (size_t)f0 * CARR_MAX : nullptr);
 		}
 		size_t d = mark(h, sq);
+		if (q == 0 && ev_after_sync && excl_level == 3)
+			*ev_after_sync = d;
 		h->spans.push_back({ OFDMRX_T_DEMOD, last, d });
 		if (sq != s)
 			HIP_OK(hipStreamWaitEvent(s, h->ev_pool[d], 0));
@@ -495,29 +513,42 @@ static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Res
 	return 0;
 }
 
-static int run_polar_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, uint8_t *d_payload, Result *d_res,
-	bool want_lane_mesg, size_t t_begin, size_t *ev_polar)
+static int run_polar(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, size_t *ev_begin, size_t *ev_end)
 {
-	SyncState *st = h->st_of(sti);
 	size_t e6 = mark(h, s);
 	{
 		Range r("ofdmrx:polar_scl");
-		launch_polar(s, h->list, n, grid, st, h->llr_of(par), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(), h->work_counter.as<int>());
+		launch_polar(s, h->list, n, grid, h->st_of(sti), h->llr_of(par), h->soft.as<float>(), h->hard_of(par), h->dev, h->metric.as<float>(), h->work_counter.as<int>());
 	}
 	size_t e7 = mark(h, s);
-	if (ev_polar)
-		*ev_polar = e7;
+	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
+	if (ev_begin)
+		*ev_begin = e6;
+	if (ev_end)
+		*ev_end = e7;
+	HIP_OK(hipGetLastError());
+	return 0;
+}
+static int run_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, uint8_t *d_payload, Result *d_res, bool want_lane_mesg,
+	size_t t_begin)
+{
+	size_t e7 = mark(h, s);
 	{
 		Range r("ofdmrx:finish");
-		launch_finish(s, h->list, n, st, h->llr_of(par), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble,
+		launch_finish(s, h->list, n, h->st_of(sti), h->llr_of(par), h->hard_of(par), h->dev, h->cfg.descramble,
 			want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res);
 	}
 	size_t e8 = mark(h, s);
-	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
 	h->spans.push_back({ OFDMRX_T_FINISH, e7, e8 });
 	h->spans.push_back({ OFDMRX_T_TOTAL, t_begin, e8 });
 	HIP_OK(hipGetLastError());
 	return 0;
+}
+static int run_polar_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, uint8_t *d_payload, Result *d_res,
+	bool want_lane_mesg, size_t t_begin, size_t *ev_polar)
+{
+	int r = run_polar(h, s, par, sti, n, grid, nullptr, ev_polar);
+	return r ? r : run_finish(h, s, par, sti, n, d_payload, d_res, want_lane_mesg, t_begin);
 }
 
 static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, uint8_t *d_payload, Result *d_res,
@@ -646,6 +677,84 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 	if (r)
 		return r;
 	const size_t NONE = (size_t)-1;
+	static const bool sched_r2 = std::getenv("OFDMRX_SCHED_R2") != nullptr;   // the two-stream schedule of round 2 (below), for A/B runs
+	if (!sched_r2 && h->stream_f[0]) {
+		// Three queues, each chunk passes through all of them (round 3: since the Theil-Sen stage went from 15 ms to 3 ms per
+		// chunk the list decoder IS the period, so its stream should wait for nothing but its own input):
+		//   A (the handle's stream):  sync | header+OSD | demod | Theil-Sen | LLRs   of chunk c
+		//   B:                        polar(c - 1), back to back
+		//   C:                        finish(c - 2)
+		// Header, demodulator, Theil-Sen and LLR kernels run beside the resident decoders at 1.1-1.6x their time alone.  The
+		// scan does not: its 20 KB of LDS fit once per CU beside sixteen decoders and the lone wave starves (30 ms instead of
+		// 0.85).  So sync(c) gets a slot of its own: it waits for polar(c-2) to end and polar(c-1) waits for it
+		// (OFDMRX_SYNC_SHARED=1 drops both waits).
+		// Buffers: llr / cons / slope / yint / precision / hard by parity c & 1, SyncState by c mod 3.  LLRs(c) overwrite what
+		// polar(c-2) and finish(c-2) read; init_sync(c) overwrites what finish(c-3) read.
+		static const int excl = std::getenv("OFDMRX_EXCL") ? std::atoi(std::getenv("OFDMRX_EXCL")) : 1;   // 0 none, 1 sync, 2 + header, 3 + demod
+		static const bool sync_shared = excl == 0;
+		hipStream_t sa = h->stream, sb = h->stream_b, sc = h->stream_f[0];
+		std::vector<size_t> ev_done(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_llr(n_chunks, NONE), t0s(n_chunks, 0);
+		auto enqueue_polar = [&](size_t p, size_t ev_sync_next) -> int {   // polar(p) on B, finish(p) on C
+			const int par = (int)(p & 1), sti = (int)(p % 3);
+			uint8_t *pay;
+			Result *res;
+			hooks.dst(p, &pay, &res);
+			HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_llr[p]], 0));
+			if (ev_sync_next != NONE)
+				HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_sync_next], 0));
+			if (p >= 2)
+				HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_done[p - 2]], 0));   // hard[par] is free
+			int rr = run_polar(h, sb, par, sti, n_of(p), h->polar_grid, nullptr, &ev_polar[p]);
+			if (rr)
+				return rr;
+			HIP_OK(hipStreamWaitEvent(sc, h->ev_pool[ev_polar[p]], 0));
+			rr = run_finish(h, sc, par, sti, n_of(p), pay, res, true, t0s[p]);
+			if (rr)
+				return rr;
+			ev_done[p] = mark(h, sc);
+			return hooks.after_back(p, ev_done[p], sc);
+		};
+		for (size_t c = 0; c < n_chunks; ++c) {
+			const int par = (int)(c & 1), sti = (int)(c % 3);
+			FrameBatch fb{ nullptr, stride, (long)spf, fmt, channels };
+			size_t ready = NONE, ev_sync = NONE;
+			uint8_t *pay;
+			Result *res;
+			r = hooks.before_front1(c, &fb, &ready);
+			if (r)
+				return r;
+			hooks.dst(c, &pay, &res);
+			if (ready != NONE)
+				HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ready], 0));
+			if (c >= 3)
+				HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_done[c - 3]], 0));
+			r = run_front1(h, sa, par, sti, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0s[c],
+				(c >= 2 && !sync_shared) ? ev_polar[c - 2] : NONE, &ev_sync, excl);
+			if (r)
+				return r;
+			if (c >= 1) {                                         // polar(c-1): its LLRs are on their way, sync(c) is in the queue
+				r = enqueue_polar(c - 1, sync_shared ? NONE : ev_sync);
+				if (r)
+					return r;
+			}
+			r = hooks.after_front1(c, mark(h, sa));
+			r = r ? r : run_front2(h, sa, par, sti, n_of(c), res);
+			if (r)
+				return r;
+			if (c >= 2)
+				HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_done[c - 2]], 0));
+			r = run_llr(h, sa, par, sti, n_of(c), res);
+			if (r)
+				return r;
+			ev_llr[c] = mark(h, sa);
+		}
+		r = enqueue_polar(n_chunks - 1, NONE);
+		if (r)
+			return r;
+		for (size_t c = n_chunks >= 3 ? n_chunks - 3 : 0; c < n_chunks; ++c)   // the caller's stream sees the finished batch
+			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_done[c]], 0));
+		return 0;
+	}
 	std::vector<size_t> ev_back(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_f2(n_chunks, NONE), t0s(n_chunks, 0);
 	// Order of a period (chunk c on stream A, chunk c-1 on stream B):
 	//   A: front1(c) = sync / header / demod, alone on the device

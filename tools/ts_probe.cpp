@@ -1,8 +1,10 @@
 // ts_probe.cpp -- timing probe for the Theil-Sen kernel (tools only)
 #include <hip/hip_runtime.h>
-__device__ int g_fallbacks, g_iters;
+__device__ int g_fallbacks, g_iters, g_unc, g_reason[8];
 #define TS_PROBE_COUNT (&g_fallbacks)
 #define TS_PROBE_ITERS (&g_iters)
+#define TS_PROBE_UNC (&g_unc)
+#define TS_PROBE_REASON g_reason
 #ifndef TS_SRC
 #define TS_SRC "../modem_amd/csrc/k_theilsen.hip"
 #endif
@@ -27,7 +29,9 @@ int main()
 		hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
 		int fb; hipMemcpyFromSymbol(&fb, HIP_SYMBOL(g_fallbacks), 4);
 		int it = 0; hipMemcpyFromSymbol(&it, HIP_SYMBOL(g_iters), 4);
-		printf("%s: %d rows %.2f ms (fallbacks so far %d, rank counts so far %d)\n", VARIANT, rows, ms, fb, it);
+		int rs[8]; hipMemcpyFromSymbol(rs, HIP_SYMBOL(g_reason), 32); printf("slow-path reasons 1..7: %d %d %d %d %d %d %d\n", rs[1], rs[2], rs[3], rs[4], rs[5], rs[6], rs[7]);
+		int un = 0; hipMemcpyFromSymbol(&un, HIP_SYMBOL(g_unc), 4);
+		printf("%s: %d rows %.2f ms (fallbacks so far %d, rank counts so far %d, of which with uncertain pairs %d)\n", VARIANT, rows, ms, fb, it, un);
 	}
 	return 0;
 }

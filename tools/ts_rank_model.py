@@ -17,8 +17,8 @@ import sys
 import numpy as np
 
 f32 = np.float32
-QBITS = 23
-MQ = 6          # |q_i - q_j| <= MQ -> the pair is resolved by the exact division
+QBITS = 22
+MQ = 2          # |q_i - q_j| <= MQ -> the pair is resolved by the exact division
 
 
 def all_slopes(y):
@@ -47,7 +47,7 @@ class Row:
         lo = self.ymin - half
         hi = self.ymax + half
         span = max(hi - lo, 1e-30) * (1.0 + 2.0 ** -20)
-        scale = (2.0 ** QBITS - 1) / span
+        scale = (2.0 ** QBITS - 8192 - 2) / span
         z = self.y.astype(np.float64) - T * self.x
         q = np.floor((z - lo) * scale).astype(np.int64)
         assert q.min() >= 0 and q.max() < 2 ** QBITS
