@@ -58,6 +58,9 @@ enum {
 	OFDMRX_E_ARG = -1, OFDMRX_E_NOMEM = -2, OFDMRX_E_HIP = -3, OFDMRX_E_NODEV = -4, OFDMRX_E_UNSUPPORTED = -5
 };
 
+#define OFDMRX_FLAG_KEEP_RAW_CONS 1
+#define OFDMRX_FLAG_SCL_ALWAYS 2
+
 typedef struct ofdmrx_handle ofdmrx_handle;
 
 typedef struct {
@@ -70,7 +73,12 @@ typedef struct {
 	int32_t chunk_frames;      /* frames resident per pass (0 = default: 8192) */
 	int32_t max_samples;       /* max samples per frame (0 = ofdmrx_frame_samples(sample_rate, 6)) */
 	int32_t descramble;        /* 1 = XOR payload with Xorshift32 like main(), decode.cc:613-615 */
-	int32_t flags;             /* bit 0: keep the pre-rotation constellation (OFDMRX_TAP_CONS_RAW) */
+	int32_t flags;             /* bit 0: debug taps: keep the pre-rotation constellation (OFDMRX_TAP_CONS_RAW) and run the list
+	                            * decoder for every frame, so that OFDMRX_TAP_LANE_MESG / _METRIC hold all eight lanes;
+	                            * bit 1 (OFDMRX_FLAG_SCL_ALWAYS): run the list decoder for every frame.  Without either, a frame
+	                            * whose channel hard decisions already form a codeword with a valid CRC-32 is decided by that
+	                            * syndrome check - the list decoder's lane 0 provably is that codeword - with
+	                            * identical payload, status, best_lane and bit_flips */
 	void *stream;              /* hipStream_t to run on, NULL = library-owned stream.  Batches longer than one chunk
 	                            * also use a second, library-owned stream for the polar stage (two-stage chunk
 	                            * pipeline); the given stream waits for it, so work enqueued on `stream` after a
@@ -167,6 +175,11 @@ int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *dst, size_t
 /* D9+D10: CODE::PolarListDecoder + systematic() (decode.cc:530-531) */
 int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n,
 	uint8_t *lane_mesg /*n*8*5476*/, float *metric /*n*8*/);
+/* D8 output (n x 65536 channel LLRs, mode 6) -> payloads + results through the syndrome certificate (use_cert != 0), the list
+ * decoder, finish and the retry launch, chained as in the pipeline; cert_out (nullable): 0 = list decoder, 1 = decided by the
+ * certificate, 2 = certified codeword failed the CRC-32 and the list decoder ran after all (decode.cc:530-555) */
+int ofdmrx_debug_decode_llr(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n, int use_cert,
+	uint8_t *payload /*n*5380*/, ofdmrx_frame_result *results /*n*/, int32_t *cert_out /*n*/);
 /* DSP::TheilSenEstimator::compute on rows of y[cols], x = i - cols/2 (decode.cc:488) */
 int ofdmrx_debug_theil_sen(ofdmrx_handle *h, const float *y, size_t rows, int cols,
 	float *slope, float *yint);

@@ -4,15 +4,118 @@
 
 namespace rx {
 
+// ---------------------------------------------------------------- syndrome certificate (in front of D9)
+// If the hard decisions x = [llr < 0] of the 65536 channel LLRs already ARE a codeword - u = x F^(x16) is zero on every frozen
+// position - and no LLR is zero, the list decoder's answer is known without running it (any list size):
+//   * along the path that follows the hard decisions every node's LLR vector carries the signs of that node's sub-codeword
+//     (f: sign = product of the signs = a xor b; g with the matching left partial sum: b and +-a have the same sign, so the
+//     sum keeps the sign of b), no magnitude is ever zero, so every frozen leaf sees a positive LLR (no penalty) and every
+//     information leaf's matching candidate costs nothing: the path keeps metric 0 from start to end;
+//   * metrics are sums of non-negative penalties (the seven placeholder paths start at 1000), every other candidate costs
+//     more than 0, candidates are ranked by (metric, index): the metric-0 path is lane 0 after every fork and at the end.
+// So lane 0's re-encoded codeword is x itself, its metric 0, its flip count (decode.cc:546-555) 0.  k_finish then runs as
+// usual on a partial-sum array in which all eight lanes are x: lane 0 passes the CRC-32 or nobody does.  In the second case
+// (x a polar codeword, but not the transmitted one) the reference would go on to lanes 1..7: the frame is marked (cert = 2)
+// and a retry launch runs the real list decoder for it.  cert: 0 = decode, 1 = decided here, 2 = decided here but CRC failed.
+// At the benchmark's noise level (-30 dB) every frame is decided here; from -24 dB on almost none (tools/flips_probe.py).
+__global__ __launch_bounds__(256) void k_syndrome(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
+	const uint32_t *__restrict__ frozen2, uint8_t *__restrict__ hard_all, int *__restrict__ cert_all)
+{
+	const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	if (f == 0 && tid == 0)
+		cert_all[gridDim.x] = 0;                                  // "some frame needs the retry": set by k_finish
+	if (!st_all[f].okay) {
+		if (tid == 0)
+			cert_all[f] = 0;
+		return;
+	}
+	__shared__ uint32_t bits[CODE_LEN / 32];
+	const float *llr = llr_all + (size_t)f * CODE_LEN;
+	const uint32_t *frozen = frozen2 + (st_all[f].oper_mode >= 10 ? CODE_LEN / 32 : 0);
+	// hard decisions: one ballot per 64 positions
+	bool odd = false;                                             // zero or NaN somewhere
+	for (int c = wave; c < CODE_LEN / 64; c += 4) {
+		const float l = llr[64 * c + lane];
+		odd |= !(fabsf(l) > 0.f);
+		const unsigned long long m = __ballot(l < 0.f);
+		if (lane == 0) {
+			bits[2 * c] = (uint32_t)m;
+			bits[2 * c + 1] = (uint32_t)(m >> 32);
+		}
+	}
+	__syncthreads();
+	// u = x F: at every level the left half of a block takes the XOR with the right half (the involution the partial-sum
+	// combines of the decoder apply the other way round).  Word a = tid + 256 q: distances >= 256 words are inside the thread.
+	uint32_t x[8], w[8];
+	#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		uint32_t v = bits[tid + 256 * q];
+		x[q] = v;
+		v ^= (v >> 1) & 0x55555555u;
+		v ^= (v >> 2) & 0x33333333u;
+		v ^= (v >> 4) & 0x0f0f0f0fu;
+		v ^= (v >> 8) & 0x00ff00ffu;
+		v ^= (v >> 16) & 0x0000ffffu;
+		w[q] = v;
+	}
+	#pragma unroll
+	for (int q = 0; q < 4; ++q) w[q] ^= w[q + 4];               // 1024 words
+	w[0] ^= w[2]; w[1] ^= w[3]; w[4] ^= w[6]; w[5] ^= w[7];       // 512
+	w[0] ^= w[1]; w[2] ^= w[3]; w[4] ^= w[5]; w[6] ^= w[7];       // 256
+	for (int dw = 128; dw >= 1; dw >>= 1) {
+		__syncthreads();
+		#pragma unroll
+		for (int q = 0; q < 8; ++q)
+			bits[tid + 256 * q] = w[q];
+		__syncthreads();
+		if ((tid & dw) == 0) {
+			#pragma unroll
+			for (int q = 0; q < 8; ++q)
+				w[q] ^= bits[tid + dw + 256 * q];
+		}
+	}
+	uint32_t syn = 0;
+	#pragma unroll
+	for (int q = 0; q < 8; ++q)
+		syn |= w[q] & frozen[tid + 256 * q];
+	const int bad = __syncthreads_or((syn != 0) | (odd ? 1 : 0));
+	if (tid == 0)
+		cert_all[f] = bad ? 0 : 1;
+	if (bad)
+		return;
+	// all eight lanes of the partial-sum bytes = x
+	uint32_t *hard = (uint32_t *)(hard_all + (size_t)f * CODE_LEN);
+	#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		const int a = tid + 256 * q;
+		uint4 lo, hi;
+		uint32_t o[8];
+		#pragma unroll
+		for (int e = 0; e < 8; ++e)
+			o[e] = ((((x[q] >> (4 * e)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;   // 4 bits -> 4 bytes of 0x00 / 0xff
+		lo = make_uint4(o[0], o[1], o[2], o[3]);
+		hi = make_uint4(o[4], o[5], o[6], o[7]);
+		*(uint4 *)(hard + 8 * a) = lo;
+		*(uint4 *)(hard + 8 * a + 4) = hi;
+	}
+}
+
 // ---------------------------------------------------------------- D10
 // decode.cc:254-261 (systematic message = codeword at the unfrozen positions),
 // decode.cc:532-541 (first lane whose CRC-32 over 43072 bits is 0), decode.cc:546-555
 // (LE bit packing + flip count), decode.cc:613-615 (descramble).
 __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
 	const uint8_t *__restrict__ hard_all, Tables tb, int descramble, int list, int n_frames, uint8_t *__restrict__ lane_mesg_all,
-	uint8_t *__restrict__ payload_all, Result *__restrict__ res_all)
+	uint8_t *__restrict__ payload_all, Result *__restrict__ res_all, int *__restrict__ cert_all, int retry)
 {
+	// cert_all (nullable): the syndrome certificate's verdict per frame (k_syndrome).  retry: only the frames whose certified
+	// codeword failed the CRC (2), after the list decoder has run for them
 	const int f = blockIdx.x, tid = threadIdx.x;
+	if (retry && cert_all[n_frames] == 0)
+		return;                                                   // (the flag behind the verdicts: some frame needs the retry)
+	const int cert = cert_all ? cert_all[f] : 0;
+	if (retry && cert != 2)
+		return;
 	const SyncState st = st_all[f];
 	uint8_t *payload = payload_all + (size_t)f * PAYLOAD_BYTES;
 	__shared__ uint8_t mesg[LIST][MESG_BYTES_MAX];
@@ -111,6 +214,10 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 			best = k;
 	r.best_lane = best;
 	if (best < 0) {
+		if (cert == 1 && !retry && tid == 0) {
+			cert_all[f] = 2;                                  // the certified codeword is not the message: the list decoder has to look
+			atomicExch(cert_all + n_frames, 1);
+		}
 		r.status = 6;                                         // decode.cc:542-545
 		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
 			payload[i] = 0;
@@ -154,9 +261,14 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 }
 
 void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
-	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res)
+	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res, int *cert, int retry)
 {
-	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, list == 4 ? 4 : 8, n, lane_mesg, payload, res);
+	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, list == 4 ? 4 : 8, n, lane_mesg, payload, res,
+		cert, retry);
+}
+void launch_syndrome(hipStream_t s, int n, const SyncState *st, const float *llr, Tables tb, uint8_t *hard, int *cert)
+{
+	hipLaunchKernelGGL(k_syndrome, dim3(n), dim3(256), 0, s, st, llr, tb.frozen, hard, cert);
 }
 
 }  // namespace rx

@@ -361,6 +361,72 @@ template <int LN> struct Block8 {
 		H = (H & ~(1 << P0)) | (ubit << P0);
 	}
 
+	// ---- the same walk for a frozen pattern known at compile time, under the assumption that no fork of the block
+	// reorders the list (every information leaf / node passes the stable-list test): then the lane maps of levels 0..2 stay
+	// the identity, every gather and every map reset inside the block is a no-op, and the block is straight-line code - f / g
+	// butterflies, frozen penalties and sign bits, with the stable-list tests ORed into one flag.  Same arithmetic in the
+	// same order as node<3, 0>(); the caller checks the flag once and, if a test failed anywhere, restores the metric and
+	// walks the block with node<3, 0>() (every speculative result is lane-local and thrown away).
+	__device__ __forceinline__ bool unstable_lane(float mu) const
+	{
+		const float P = M + mu;
+		const float Mprev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(M), __float_as_int(M), 0x111, 0xf, 0xf, false));   // row_shr:1
+		const bool dead = LN == 4 && k >= 4 && !hi_alive, first = (k & (LN - 1)) == 0;
+		return !(dead || ((first || Mprev <= M) && group8_max<LN>(M) < group8_min<LN>(P)));
+	}
+	template <uint32_t FZ, int LV, int P0> __device__ __forceinline__ void fast_node(bool &bad)
+	{
+		constexpr int N = 1 << LV, HALF = N / 2;
+		constexpr uint32_t MASK = ((1u << N) - 1u) << P0, pat = FZ & MASK;
+		if constexpr (pat == MASK) {
+			if constexpr (LV == 0) {
+				if (r[0] < 0.f)
+					M -= r[0];
+			} else {
+				float pen = r[LV] < 0.f ? -r[LV] : 0.f;
+				if constexpr (LV >= 3) pen = pen + xjb<2>(pen);
+				if constexpr (LV >= 2) pen = pen + xjb<1>(pen);
+				pen = pen + xjb<0>(pen);
+				M += pen;
+			}
+		} else if constexpr (pat == 0) {
+			uint32_t mu = __float_as_uint(r[LV]) & 0x7fffffffu;
+			if constexpr (LV >= 3) mu = min(mu, (uint32_t)xor32_i((int)mu, lane));
+			if constexpr (LV >= 2) mu = min(mu, (uint32_t)xor16_i((int)mu, lane));
+			if constexpr (LV >= 1) mu = min(mu, (uint32_t)xor8_i((int)mu));
+			bad |= unstable_lane(__uint_as_float(mu));
+			H |= r[LV] < 0.f ? (int)MASK : 0;
+		} else {
+			r[LV - 1] = f_minsum(r[LV], xjb<LV - 1>(r[LV]));
+			fast_node<FZ, LV - 1, P0>(bad);
+			{
+				const float own = r[LV], oth = xjb<LV - 1>(own);
+				const bool hi = (j >> (LV - 1)) & 1;
+				const float a = hi ? oth : own, b = hi ? own : oth;
+				const int ub = (H >> (P0 + (j & (HALF - 1)))) & 1;
+				r[LV - 1] = g_add(a, b, ub);
+			}
+			fast_node<FZ, LV - 1, P0 + HALF>(bad);
+			constexpr int lmask = ((1 << HALF) - 1) << P0;
+			H = (H & ~lmask) | ((H ^ (H >> HALF)) & lmask);
+		}
+	}
+	// true: the block is decided (H, M final); false: nothing has changed, walk it
+	template <uint32_t FZ> __device__ __forceinline__ bool fast_block()
+	{
+		const float M0 = M, r3 = r[3];
+		reset_at(0);
+		H = 0;
+		bool bad = false;
+		fast_node<FZ, 3, 0>(bad);
+		if (__ballot(bad) == 0)
+			return true;
+		M = M0;
+		H = 0;
+		r[3] = r3;
+		return false;
+	}
+
 	template <int LV, int P0> __device__ __forceinline__ void node()
 	{
 		if constexpr (LV == 0) {
@@ -456,7 +522,7 @@ __device__ unsigned long long g_polar_prof[8];
 template <int LN>
 __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
 	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev2,
-	float *__restrict__ metric_all, int *__restrict__ next_cw)
+	float *__restrict__ metric_all, int *__restrict__ next_cw, const int *__restrict__ cert_all, int retry)
 {
 #ifdef POLAR_PRIO
 	__builtin_amdgcn_s_setprio(POLAR_PRIO);                   // experiments: issue priority against the co-resident Theil-Sen waves
@@ -475,6 +541,8 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 	// right).  A pair is formed when both frames have a header and share the frozen table; a codeword without such a
 	// partner is decoded alone in the low half (the high half dead: metrics +inf) into its own partial-sum array.
 	const int n_units = LN == 4 ? (n_cw + 1) / 2 : n_cw;
+	if (retry && cert_all && cert_all[n_cw] == 0)
+		return;                                                   // no certified frame failed its CRC (the flag behind the verdicts): nothing to retry
 	for (;;) {
 	int unit = 0;
 	if (lane == 0)
@@ -501,6 +569,12 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 			n_pass = 3;                                           // marker: two single passes, cw_a then cw_b
 	} else if (!st_all[cw_a].okay) {
 		continue;                                                 // no header -> nothing to decode (decode.cc:450-451)
+	} else if (cert_all) {
+		// the syndrome certificate (k_finish.hip: k_syndrome) has decided this frame (1) - unless its codeword then failed the
+		// CRC (2): those frames, and only those, are decoded by the retry launch
+		const int cert = cert_all[cw_a];
+		if (retry ? cert != 2 : cert == 1)
+			continue;
 	}
 	for (int pass = 0; pass < (n_pass == 3 ? 2 : n_pass); ++pass) {
 	const int cw = (n_pass == 3 && pass == 1) ? cw_b : cw_a;
@@ -846,7 +920,18 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 					int H = 0;
 					{
 						Block8<LN> blk{ M, A, H, { 0.f, 0.f, 0.f, r3 }, fz, tt, lane, j, k, hi_alive };
-						blk.template node<3, 0>();
+#ifndef POLAR_NO_FAST_BLOCKS
+						// the five patterns that make up 97 % of the 8-leaf blocks of both frozen tables (0x01: 673 of 2108, 0x17: 447,
+						// 0x00: 429, 0x7f: 323, 0xff: 164) as straight-line code; the rest, and any block with a reordering fork, is walked
+						bool decided = false;
+						if (fz == 0x01u) decided = blk.template fast_block<0x01u>();
+						else if (fz == 0x17u) decided = blk.template fast_block<0x17u>();
+						else if (fz == 0x00u) decided = blk.template fast_block<0x00u>();
+						else if (fz == 0x7fu) decided = blk.template fast_block<0x7fu>();
+						else if (fz == 0xffu) decided = blk.template fast_block<0xffu>();
+						if (!decided)
+#endif
+							blk.template node<3, 0>();
 					}
 					HR = (HR & ~(1u << b)) | ((uint32_t)((H >> j) & 1) << b);   // this lane's own position, own path
 					PROF(3);
@@ -898,8 +983,10 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 }
 
 void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,
-	int *next_cw)
+	int *next_cw, const int *cert, int retry)
 {
+	if (list == 4)
+		cert = nullptr;                                       // (pairs of codewords per wave: the certificate is not wired into the pairing)
 	(void)hipMemsetAsync(next_cw, 0, sizeof(int), s);
 	if (grid <= 0 || grid > n)
 		grid = n;
@@ -909,9 +996,9 @@ void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st,
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_polar_prof), z8, sizeof(z8));
 #endif
 	if (list == 4)
-		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw);
+		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw, cert, retry);
 	else
-		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw);
+		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw, cert, retry);
 #ifdef POLAR_PROF
 	(void)hipStreamSynchronize(s);
 	(void)hipMemcpyFromSymbol(z8, HIP_SYMBOL(g_polar_prof), sizeof(z8));

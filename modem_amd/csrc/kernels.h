@@ -85,10 +85,13 @@ void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
 void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, float *llr, Result *res);
+// cert (nullable): per-frame verdict of the syndrome certificate (launch_syndrome): frames with 1 are skipped; retry != 0:
+// only the frames with 2 are decoded
 void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,
-	int *next_cw);
+	int *next_cw, const int *cert = nullptr, int retry = 0);
+void launch_syndrome(hipStream_t s, int n, const SyncState *st, const float *llr, Tables tb, uint8_t *hard, int *cert);
 void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
-	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res);
+	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res, int *cert = nullptr, int retry = 0);
 void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb);
 void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t *out, size_t n_out,
 	size_t spf, float sigma, uint64_t seed, uint64_t first_frame);

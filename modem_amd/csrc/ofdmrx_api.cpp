@@ -135,6 +135,10 @@ struct ofdmrx_handle {
 	hipError_t sticky = hipSuccess;   // first failed hipEventRecord of the running call
 	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
 	int last_par = 0;         // parity used by the last chunk (taps)
+	DevBuf cert, cert2;       // syndrome certificate: verdict per frame (+ one flag), by parity
+	DevBuf soft_retry, retry_counter;   // level stores + work counter of the retry launch (frames whose certified codeword failed the CRC)
+	bool use_cert = true;     // list 8, no debug taps, not switched off
+	int *cert_of(int par) { return use_cert ? (par ? cert2 : cert).as<int>() : nullptr; }
 	DevBuf hard2;             // second parity of the list decoder's output: finish(c) reads its own while polar(c+1) writes
 	uint8_t *hard_of(int par) { return (par ? hard2 : hard).as<uint8_t>(); }
 	DevBuf st3;               // third SyncState array: finish(c-1) still reads its own while sync / header of chunk c+1 write theirs
@@ -207,6 +211,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	h->cfg = *cfg;
 	h->rate = cfg->sample_rate;
 	h->list = cfg->list_size == 4 ? 4 : 8;
+	h->use_cert = h->list == 8 && !(cfg->flags & (OFDMRX_FLAG_KEEP_RAW_CONS | OFDMRX_FLAG_SCL_ALWAYS)) && !std::getenv("OFDMRX_NO_CERT");
 	// default chunk: 8192 frames at every rate: the per-frame decoder state does not grow with the rate, and the two-stream
 	// schedule wants a few thousand codewords per polar launch (44.1 / 48 kHz: 121 k / 125 k frames/s against 111 k / 112 k
 	// with 4096).  What does grow is the per-chunk input: a 48 kHz frame is 4.2 MB of int16 pairs (34.6 GB per 8192 frames; the
@@ -296,7 +301,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2 })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2, &h->cert, &h->cert2, &h->soft_retry, &h->retry_counter })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -312,6 +317,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 
 extern "C" int ofdmrx_chunk_frames(ofdmrx_handle *h) { return h ? h->chunk : OFDMRX_E_ARG; }
 
+constexpr int RETRY_DECODERS = 64;   // list decoders of the retry launch (it almost never has a frame to decode)
 static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, bool two_parities = false)
 {
 	int r = 0;
@@ -325,6 +331,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->yint2.ensure(N2 * ROWS_MAX * sizeof(float));
 		r = r ? r : h->precision2.ensure(N2 * ROWS_MAX * sizeof(float));
 		r = r ? r : h->hard2.ensure(N2 * CODE_LEN);
+		r = r ? r : h->cert2.ensure((N2 + 1) * sizeof(int));
 		if (r)
 			return r;
 	}
@@ -341,6 +348,9 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->hard.ensure(N * CODE_LEN);
 		r = r ? r : h->metric.ensure(N * LIST * sizeof(float));
 		r = r ? r : h->work_counter.ensure(256);
+		r = r ? r : h->cert.ensure((N + 1) * sizeof(int));
+		r = r ? r : h->retry_counter.ensure(256);
+		r = r ? r : h->soft_retry.ensure((size_t)RETRY_DECODERS * 8 * CODE_LEN * sizeof(float));
 		r = r ? r : h->lane_mesg.ensure(N * LIST * MESG_BYTES);
 		r = r ? r : h->res.ensure(N * sizeof(Result));
 		r = r ? r : h->payload.ensure(N * PAYLOAD_BYTES);
@@ -506,6 +516,8 @@ static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Res
 		Range r("ofdmrx:llr");
 		launch_llr(s, h->rate, n, h->st_of(sti), h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
 			h->llr_of(par), d_res);
+		if (h->use_cert)
+			launch_syndrome(s, n, h->st_of(sti), h->llr_of(par), h->dev, h->hard_of(par), h->cert_of(par));
 	}
 	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
@@ -518,7 +530,8 @@ static int run_polar(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, i
 	size_t e6 = mark(h, s);
 	{
 		Range r("ofdmrx:polar_scl");
-		launch_polar(s, h->list, n, grid, h->st_of(sti), h->llr_of(par), h->soft.as<float>(), h->hard_of(par), h->dev, h->metric.as<float>(), h->work_counter.as<int>());
+		launch_polar(s, h->list, n, grid, h->st_of(sti), h->llr_of(par), h->soft.as<float>(), h->hard_of(par), h->dev, h->metric.as<float>(), h->work_counter.as<int>(),
+			h->cert_of(par), 0);
 	}
 	size_t e7 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
@@ -536,7 +549,15 @@ static int run_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, 
 	{
 		Range r("ofdmrx:finish");
 		launch_finish(s, h->list, n, h->st_of(sti), h->llr_of(par), h->hard_of(par), h->dev, h->cfg.descramble,
-			want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res);
+			want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res, h->cert_of(par), 0);
+		if (h->use_cert) {
+			// frames whose certified codeword failed the CRC-32 (the flag behind the verdicts; practically never): the real list
+			// decoder, on its own level stores and counter (the next chunk's polar launch may be running), and their finish again
+			launch_polar(s, h->list, n, std::min(n, RETRY_DECODERS), h->st_of(sti), h->llr_of(par), h->soft_retry.as<float>(), h->hard_of(par), h->dev,
+				h->metric.as<float>(), h->retry_counter.as<int>(), h->cert_of(par), 1);
+			launch_finish(s, h->list, n, h->st_of(sti), h->llr_of(par), h->hard_of(par), h->dev, h->cfg.descramble,
+				want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res, h->cert_of(par), 1);
+		}
 	}
 	size_t e8 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_FINISH, e7, e8 });
@@ -1097,6 +1118,48 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 		HIP_OK(hipMemcpy(lane_mesg, h->lane_mesg.p, n * LIST * MESG_BYTES, hipMemcpyDeviceToHost));
 	if (metric)
 		HIP_OK(hipMemcpy(metric, h->metric.p, n * LIST * sizeof(float), hipMemcpyDeviceToHost));
+	h->last_n = (int)n;
+	return 0;
+}
+
+// D8 output -> payload: the syndrome certificate (use_cert != 0), the list decoder, finish and the retry launch exactly as the
+// pipeline chains them; cert_out (nullable) receives the certificate's verdict per frame (0 / 1 / 2)
+extern "C" int ofdmrx_debug_decode_llr(ofdmrx_handle *h, const float *llr, size_t n, int use_cert, uint8_t *payload,
+	ofdmrx_frame_result *results, int32_t *cert_out)
+{
+	if (!h || !llr || !n || n > (size_t)h->chunk || !payload || !results || h->list != 8)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	int r = ensure_capacity(h, (int)n, false, 0);
+	if (r)
+		return r;
+	std::vector<SyncState> st(n);
+	std::memset(st.data(), 0, n * sizeof(SyncState));
+	for (auto &s : st) { s.okay = 1; s.oper_mode = 6; }
+	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
+	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
+	HIP_OK(hipMemsetAsync(h->cert.p, 0, (n + 1) * sizeof(int), h->stream));
+	int *cert = use_cert ? h->cert.as<int>() : nullptr;
+	SyncState *dst = h->st.as<SyncState>();
+	if (cert)
+		launch_syndrome(h->stream, (int)n, dst, h->llr.as<float>(), h->dev, h->hard.as<uint8_t>(), cert);
+	launch_polar(h->stream, 8, (int)n, 0, dst, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(),
+		h->work_counter.as<int>(), cert, 0);
+	launch_finish(h->stream, 8, (int)n, dst, h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble, nullptr,
+		h->payload.as<uint8_t>(), h->res.as<Result>(), cert, 0);
+	if (cert) {
+		launch_polar(h->stream, 8, (int)n, std::min((int)n, RETRY_DECODERS), dst, h->llr.as<float>(), h->soft_retry.as<float>(), h->hard.as<uint8_t>(),
+			h->dev, h->metric.as<float>(), h->retry_counter.as<int>(), cert, 1);
+		launch_finish(h->stream, 8, (int)n, dst, h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble, nullptr,
+			h->payload.as<uint8_t>(), h->res.as<Result>(), cert, 1);
+	}
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipStreamSynchronize(h->stream));
+	HIP_OK(hipMemcpy(payload, h->payload.p, n * PAYLOAD_BYTES, hipMemcpyDeviceToHost));
+	HIP_OK(hipMemcpy(results, h->res.p, n * sizeof(Result), hipMemcpyDeviceToHost));
+	if (cert_out)
+		HIP_OK(hipMemcpy(cert_out, h->cert.p, n * sizeof(int), hipMemcpyDeviceToHost));
 	h->last_n = (int)n;
 	return 0;
 }

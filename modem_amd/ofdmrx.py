@@ -21,7 +21,7 @@ STAGES = ["front", "sync", "header", "demod", "theilsen", "llr", "polar", "finis
 EXPORTS = [
     "ofdmrx_abi_version", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
     "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames",
-    "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
+    "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_decode_llr", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
     "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
     "ofdmrx_tx_encode_device", "ofdmrx_stream_samples", "ofdmrx_tx_encode_stream_device", "ofdmrx_tx_encode_stream",
     "ofdmrx_callsign_value",
@@ -109,6 +109,7 @@ def load_library():
     L.ofdmrx_chunk_frames.argtypes = [C.c_void_p]
     L.ofdmrx_debug_dump.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
     L.ofdmrx_debug_polar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ofdmrx_debug_decode_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_theil_sen.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_osd.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
@@ -150,13 +151,13 @@ class Receiver:
     """
 
     def __init__(self, device=0, chunk_frames=0, max_samples=0, descramble=True, keep_raw_cons=False, stream=None,
-                 sample_rate=8000, list_size=8):
+                 sample_rate=8000, list_size=8, scl_always=False):
         self._lib = load_library()
         if self._lib.ofdmrx_abi_version() != 1:
             raise OfdmRxError("ABI mismatch")
         self.sample_rate = int(sample_rate)
         cfg = Config(1, self.sample_rate, int(list_size), device, chunk_frames, max_samples, 1 if descramble else 0,
-                     1 if keep_raw_cons else 0, stream)
+                     (1 if keep_raw_cons else 0) | (2 if scl_always else 0), stream)
         self._h = C.c_void_p()
         self._check(self._lib.ofdmrx_create(C.byref(cfg), C.byref(self._h)))
 
@@ -234,6 +235,16 @@ class Receiver:
         metric = np.zeros((n, 8), np.float32)
         self._check(self._lib.ofdmrx_debug_polar(self._h, _ptr(llr), n, _ptr(mesg), _ptr(metric)))
         return mesg, metric
+
+    def decode_llr(self, llr, use_cert=True):
+        """channel LLRs (n x 65536, mode 6) -> payloads, results and the syndrome certificate's verdict per frame"""
+        llr = np.ascontiguousarray(llr, dtype=np.float32).reshape(-1, 65536)
+        n = llr.shape[0]
+        out = np.zeros((n, 5380), np.uint8)
+        res = np.zeros(n, RESULT_DTYPE)
+        cert = np.zeros(n, np.int32)
+        self._check(self._lib.ofdmrx_debug_decode_llr(self._h, _ptr(llr), n, 1 if use_cert else 0, _ptr(out), _ptr(res), _ptr(cert)))
+        return out, res, cert
 
     def theil_sen(self, y):
         y = np.ascontiguousarray(y, dtype=np.float32)
