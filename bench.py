@@ -29,7 +29,11 @@ sys.path.insert(0, ROOT)
 
 B_FRAME_2CH = 95200 * 2 * 2 + 5380      # algorithmic bytes per frame, SURVEY 8(d): 386180
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_FILES = ["r02_traffic.json", "r01_v10_traffic.json"]   # PMC bytes of k_polar, written by tools/profile_round.sh
+TRAFFIC_FILE = "r03_traffic.json"       # PMC bytes per kernel and launch, written by tools/profile_round.sh
+# stage of ofdmrx_get_timing -> (kernel, source file whose hash guards the committed traffic figure)
+STAGE_KERNELS = {"sync": ("k_sync", "k_sync.hip"), "header": ("k_header", "k_header.hip"), "demod": ("k_demod", "k_demod.hip"),
+                 "theilsen": ("k_theil_sen", "k_theilsen.hip"), "llr": ("k_llr + k_syndrome", "k_demod.hip"),
+                 "polar": ("k_polar", "k_polar.hip"), "finish": ("k_finish", "k_finish.hip")}
 METRIC = "decoded frames/sec + BER, mode-6 8kHz OFDM, batch 65536, 1/2/4/8 MI355X"
 
 
@@ -58,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--impair", action="store_true",
                     help="configs[3]: every frame also goes through the device channel chain multipath -> CFO +234.567 Hz "
                          "-> SFO +147 ppm (README.md:49) before the AWGN")
+    ap.add_argument("--scl-steps", type=int, default=-1,
+                    help="steps of the extra leg with the list decoder forced for every frame (value_scl_forced); -1 = min(steps, 5), 0 = off")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks only rendezvous (gloo), shard the frames and reduce counters (launcher test)")
     return ap.parse_args(argv)
@@ -287,26 +293,68 @@ def main():
         step(s, True)
     fence()
     # ---- timed region 1 (the headline `value`): samples resident in HBM -> payload bytes resident on the host
-    polar_ms, polar_launches = 0.0, 0
-    stage_ms = {}
+    stage_ms, stage_launches = {}, {}
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(s, True)
         if B:
             t = rx.timing()      # hipEvents on the streams the kernels run on; syncs the handle's stream
-            polar_ms += t["polar"][0]
-            polar_launches += t["polar"][1]
             for k, v in t.items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v[0]
+                stage_launches[k] = stage_launches.get(k, 0) + v[1]
     fence()
     secs = time.perf_counter() - t0
     last = (args.steps - 1) & 1
+    list_decoded = rx.list_decoded_frames() if B else 0      # of the last step; -1: no certificate on this handle
+    # one extra, untimed step with every kernel alone on the device (OFDMRX_NO_OVERLAP is read per call): under the pipeline a
+    # stage's event span includes the time it shares the machine with others; the kernel that takes the most time ALONE is
+    # the one the roofline object describes
+    alone_ms = {}
+    if B:
+        prev = os.environ.get("OFDMRX_NO_OVERLAP")
+        os.environ["OFDMRX_NO_OVERLAP"] = "1"
+        step(0, False)
+        alone_ms = {k: v[0] / max(v[1], 1) for k, v in rx.timing().items()}
+        if prev is None:
+            del os.environ["OFDMRX_NO_OVERLAP"]
+        else:
+            os.environ["OFDMRX_NO_OVERLAP"] = prev
     # ---- timed region 2: the kernels alone (payloads stay in HBM)
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(s, False)
     fence()
     secs_k = time.perf_counter() - t0
+
+    # ---- timed region 3: the same batch with the list decoder forced for every frame (cfg.flags bit 1): what the path costs
+    # when the syndrome certificate decides nothing (it decides every frame at this noise level, none from -24 dB on)
+    scl = None
+    scl_steps = min(args.steps, 5) if args.scl_steps < 0 else args.scl_steps
+    if scl_steps > 0 and args.list == 8 and not os.environ.get("OFDMRX_NO_CERT"):     # (the same decision on every rank: barriers inside)
+        sm2, sl2 = {}, {}
+        same = True
+        if B:
+            rx2 = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=stream.cuda_stream, sample_rate=args.rate,
+                                     list_size=args.list, scl_always=True)
+            d_out2 = torch.zeros((B, 5380), dtype=torch.uint8, device=dev)
+            d_res2 = torch.zeros((B, RES), dtype=torch.uint8, device=dev)
+            rx2.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out2.data_ptr(), d_res2.data_ptr())
+        fence()
+        t0 = time.perf_counter()
+        for s in range(scl_steps):
+            if B:
+                rx2.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out2.data_ptr(), d_res2.data_ptr())
+                t = rx2.timing()
+                for k, v in t.items():
+                    sm2[k] = sm2.get(k, 0.0) + v[0]
+                    sl2[k] = sl2.get(k, 0) + v[1]
+        fence()
+        secs2 = time.perf_counter() - t0
+        if B:
+            same = bool((d_out2 == d_out[last][:B]).all().item()) and bool((d_res2 == d_res[last][:B]).all().item())
+            rx2.close()
+            del d_out2, d_res2
+        scl = {"secs": secs2, "steps": scl_steps, "stage_ms": sm2, "stage_launches": sl2, "identical": same}
 
     # ---- error counters from the HOST copy of the last timed step (that is what a consumer would see)
     res = h_res.numpy().view(M.RESULT_DTYPE).reshape(-1)[:B]
@@ -344,65 +392,89 @@ def main():
         (secs, [B * args.steps, frame_err, bit_err, ok_status, 1, B]), world, dist, dev)
     secs_k_max, _ = shard.reduce_counters((secs_k, [0]), world, dist, dev)
 
+    secs2_max = None
+    if scl is not None:
+        secs2_max, _ = shard.reduce_counters((scl["secs"], [0]), world, dist, dev)
+
     if rank == 0:
         value = frames_total / secs_max
-        frames_per_launch = B * args.steps / max(polar_launches, 1)
-        avg_launch_s = polar_ms / 1e3 / max(polar_launches, 1)
         b_frame = spf * 2 * ch + 5380          # compulsory input + output bytes per frame (386180 for the headline)
-        achieved = b_frame * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # HBM bytes per k_polar launch from the committed PMC passes (bench.py cannot run the profiler on itself):
-        # scaled to this run's frames per launch; null when the file is absent; flagged stale when k_polar.hip has
-        # changed since the passes were taken
-        traffic, traffic_src, traffic_stale = None, None, None
-        for tf in TRAFFIC_FILES:
-            try:
-                with open(os.path.join(ROOT, "profiles", tf)) as fh:
-                    tj = json.load(fh)
-                # counted KiB -> bytes with the calibration of the same session (FETCH_SIZE counts half of this access
-                # pattern's bytes on gfx950, WRITE_SIZE all of them: tools/pmc_calib.hip)
-                traffic = ((tj["fetch_KiB"] * tj.get("fetch_scale", 1.0) + tj["write_KiB"] * tj.get("write_scale", 1.0))
-                           * 1024.0 * frames_per_launch / tj["frames_per_launch"])
-                traffic_src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE x %.2f + WRITE_SIZE x %.2f (separate passes, one 8192-frame "
-                               "chunk, kernels back to back; calibrated on tools/pmc_calib.hip), scaled to this run's frames per launch; "
-                               "the launch duration beside it is this run's (overlapped schedule)"
-                               % (tf, tj.get("fetch_scale", 1.0), tj.get("write_scale", 1.0)))
-                sha = file_sha(os.path.join(ROOT, "modem_amd", "csrc", "k_polar.hip"))
-                traffic_stale = (tj.get("k_polar_src_sha") != sha) if tj.get("k_polar_src_sha") else None
-                break
-            except (OSError, KeyError, ValueError):
-                continue
+        try:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as fh:
+                traffic_db = json.load(fh)
+        except (OSError, ValueError):
+            traffic_db = {}
+
+        def roofline(sm, sl, steps, alone=None):
+            """the roofline object of the stage that takes the most time in a run: achieved = ALGORITHMIC bytes of the whole path
+            per launch / the kernel's average launch duration (hipEvents on its stream); traffic = HBM bytes per launch from the
+            committed PMC passes (bench.py cannot run the profiler on itself), scaled to this run's frames per launch"""
+            cand = {k: v for k, v in sm.items() if k in STAGE_KERNELS and sl.get(k)}
+            if not cand:
+                return None
+            pick = {k: alone[k] for k in cand if alone and k in alone} or cand
+            st = max(pick, key=pick.get)
+            kern, src = STAGE_KERNELS[st]
+            launches = sl[st]
+            fpl = B * steps / launches
+            avg_s = sm[st] / 1e3 / launches
+            ach = b_frame * fpl / avg_s / 1e9 if avg_s > 0 else 0.0
+            tj = traffic_db.get("kernels", {}).get(st)
+            traffic = stale = tsrc = None
+            if tj:
+                traffic = (tj["fetch_KiB"] * traffic_db.get("fetch_scale", 2.0) + tj["write_KiB"] * traffic_db.get("write_scale", 1.0)) \
+                    * 1024.0 * fpl / traffic_db["frames_per_launch"]
+                stale = tj.get("src_sha") != file_sha(os.path.join(ROOT, "modem_amd", "csrc", src))
+                tsrc = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE x %.2f + WRITE_SIZE x %.2f (separate passes, one %d-frame chunk, kernels "
+                        "back to back; scales calibrated in the same session on tools/pmc_calib.hip), scaled to this run's frames per launch"
+                        % (TRAFFIC_FILE, traffic_db.get("fetch_scale", 2.0), traffic_db.get("write_scale", 1.0), traffic_db["frames_per_launch"]))
+            return {"bound": "hbm", "kernel": kern, "stage": st, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS,
+                    "achieved_definition": "ALGORITHMIC bytes of the whole path (B_frame x frames per launch) / average launch duration of "
+                                           "the run's dominant kernel (hipEvents on the launch stream); its REAL HBM rate is traffic_GBps",
+                    "traffic": traffic, "traffic_source": tsrc, "traffic_stale": stale,
+                    "traffic_GBps": (traffic / avg_s / 1e9) if (traffic and avg_s > 0) else None,
+                    "frames_per_launch": fpl, "avg_launch_ms": 1e3 * avg_s,
+                    "avg_launch_ms_alone": alone.get(st) if alone else None, "algorithmic_bytes_per_frame": b_frame}
+
+        cert_note = ""
+        if list_decoded >= 0:
+            cert_note = ("; the syndrome certificate (hard decisions already a codeword with a valid CRC-32 => the list decoder's "
+                         "answer is known, DESIGN.md 4c) decided %d of rank 0's %d frames in the last step, the list decoder the other %d "
+                         "- value_scl_forced is the same batch with the list decoder run for every frame" % (B - list_decoded, B, list_decoded))
         line = {
             "metric": METRIC,
             "value": value, "unit": "frames/s", "n_gpus": ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * secs_max / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "value_definition": "samples resident in HBM -> payload bytes + result records resident in pinned host memory (D2H on a "
-                                "copy stream, overlapped with the next step)",
+                                "copy stream, overlapped with the next step); the library's default behaviour",
             "value_kernel_only": frames_total / secs_k_max,
+            "value_scl_forced": (frames_step * scl["steps"] / secs2_max) if (scl and secs2_max) else None,
+            "value_scl_forced_definition": ("the same batch, OFDMRX_FLAG_SCL_ALWAYS: polar SCL for every frame (what the reference does), "
+                                            "%d steps, payloads left in HBM; outputs identical to the default path: %s"
+                                            % (scl["steps"], scl["identical"])) if scl else None,
+            "list_decoded_frames_rank0": list_decoded,
             "value_host": host_fps,
             "value_host_definition": ("ofdmrx_decode_batch: %d frames from PINNED host memory -> payload bytes on the host, "
                                       "PCIe both ways inside the time, rank 0 only" % nh) if host_fps else None,
             "config": {"workload": ("configs[%d]%s: batch %d analytic (2-ch int16) mode-%d %g kHz frames %s, AWGN noise "
-                                    "level %g dB (a noise LEVEL: about +20 dB SNR, where every rate-1 node of the list decoder takes "
-                                    "its shortcut), inputs resident in HBM; %s, on-device noise keyed by frame index"
+                                    "level %g dB (a noise LEVEL: about +20 dB SNR), inputs resident in HBM; %s, on-device noise keyed "
+                                    "by frame index%s"
                                     % (3 if args.impair else 2, "" if (args.rate == 8000 and args.mode == 6 and args.list == 8) else " variant (not the headline workload)",
                                        args.frames, args.mode, args.rate / 1000.0, "per GPU" if args.scaling == "weak" else "in total, sharded",
-                                       args.noise_db, source)) if ch == 2 else
+                                       args.noise_db, source, cert_note)) if ch == 2 else
                                    ("configs[1] flavour: batch %d clean 16-bit mono mode-6 8 kHz frames per GPU, inputs resident "
-                                    "in HBM; %s" % (B, source)),
+                                    "in HBM; %s%s" % (B, source, cert_note)),
                        "frames_per_step": frames_step, "frames_rank0": B, "list_size": args.list, "chunk_frames": rx.chunk_frames,
                        "parallelism": "frames x%d" % ranks},
             "ber": bit_err / (43040.0 * max(frames_step, 1)), "fer": frame_err / float(max(frames_step, 1)),
             "frames_ok": ok_status, "frames": frames_step,
-            "roofline": {"bound": "hbm", "kernel": "k_polar (D9 SCL)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "achieved_definition": "ALGORITHMIC bytes of the whole path (B_frame x frames per launch) / average k_polar launch "
-                                                "duration (hipEvents on the launch stream); the kernel's REAL HBM rate is traffic_GBps",
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
-                         "traffic_GBps": (traffic / avg_launch_s / 1e9) if (traffic and avg_launch_s > 0) else None,
-                         "frames_per_launch": frames_per_launch, "avg_launch_ms": 1e3 * avg_launch_s,
-                         "algorithmic_bytes_per_frame": b_frame},
+            "roofline": roofline(stage_ms, stage_launches, args.steps, alone_ms),
+            "roofline_scl_forced": roofline(scl["stage_ms"], scl["stage_launches"], scl["steps"]) if scl else None,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+            "stage_ms_per_launch_alone": alone_ms,
+            "stage_ms_per_step_scl_forced": {k: v / scl["steps"] for k, v in scl["stage_ms"].items()} if scl else None,
             "input_generation_s": gen_s,
         }
         ncpu = args.cpu_frames

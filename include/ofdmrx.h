@@ -153,6 +153,9 @@ int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int samp
 int ofdmrx_synchronize(ofdmrx_handle *h);
 int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t);
 int ofdmrx_chunk_frames(ofdmrx_handle *h);
+/* frames of the last decode call that went through the list decoder; the rest were decided by the syndrome certificate
+ * (see ofdmrx_config.flags).  -1 if the certificate is off for this handle.  Synchronises the handle's stream. */
+long long ofdmrx_list_decoded_frames(ofdmrx_handle *h);
 
 /* ---- stage taps for parity tests (host destination buffers) --------------
  * Valid for frames of the LAST chunk processed (frame index relative to that

@@ -22,8 +22,8 @@ __global__ __launch_bounds__(256) void k_syndrome(const SyncState *__restrict__ 
 	const uint32_t *__restrict__ frozen2, uint8_t *__restrict__ hard_all, int *__restrict__ cert_all)
 {
 	const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	if (f == 0 && tid == 0)
-		cert_all[gridDim.x] = 0;                                  // "some frame needs the retry": set by k_finish
+	// cert_all[n] = "some frame needs the retry" (set by k_finish), cert_all[n + 1] = frames the list decoder has to decode:
+	// both zeroed on the stream before this launch (launch_syndrome)
 	if (!st_all[f].okay) {
 		if (tid == 0)
 			cert_all[f] = 0;
@@ -79,8 +79,11 @@ __global__ __launch_bounds__(256) void k_syndrome(const SyncState *__restrict__ 
 	for (int q = 0; q < 8; ++q)
 		syn |= w[q] & frozen[tid + 256 * q];
 	const int bad = __syncthreads_or((syn != 0) | (odd ? 1 : 0));
-	if (tid == 0)
+	if (tid == 0) {
 		cert_all[f] = bad ? 0 : 1;
+		if (bad)
+			atomicAdd(cert_all + gridDim.x + 1, 1);
+	}
 	if (bad)
 		return;
 	// all eight lanes of the partial-sum bytes = x
@@ -266,9 +269,15 @@ void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const fl
 	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, list == 4 ? 4 : 8, n, lane_mesg, payload, res,
 		cert, retry);
 }
-void launch_syndrome(hipStream_t s, int n, const SyncState *st, const float *llr, Tables tb, uint8_t *hard, int *cert)
+__global__ void k_cert_clear(int *__restrict__ counters) { counters[threadIdx.x] = 0; }
+__global__ void k_cert_log(const int *__restrict__ counters, int *__restrict__ log) { *log = counters[1]; }
+void launch_syndrome(hipStream_t s, int n, const SyncState *st, const float *llr, Tables tb, uint8_t *hard, int *cert, int *log)
 {
+	// (two one-thread kernels instead of hipMemsetAsync / a 4-byte hipMemcpyAsync: the runtime's blit copy cost 0.26 ms of stream time each)
+	hipLaunchKernelGGL(k_cert_clear, dim3(1), dim3(2), 0, s, cert + n);
 	hipLaunchKernelGGL(k_syndrome, dim3(n), dim3(256), 0, s, st, llr, tb.frozen, hard, cert);
+	if (log)
+		hipLaunchKernelGGL(k_cert_log, dim3(1), dim3(1), 0, s, cert + n, log);
 }
 
 }  // namespace rx

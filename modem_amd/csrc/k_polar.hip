@@ -541,8 +541,10 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 	// right).  A pair is formed when both frames have a header and share the frozen table; a codeword without such a
 	// partner is decoded alone in the low half (the high half dead: metrics +inf) into its own partial-sum array.
 	const int n_units = LN == 4 ? (n_cw + 1) / 2 : n_cw;
-	if (retry && cert_all && cert_all[n_cw] == 0)
-		return;                                                   // no certified frame failed its CRC (the flag behind the verdicts): nothing to retry
+	// two counters behind the verdicts: [n] certified frames that failed their CRC (the retry launch's work), [n + 1] frames the
+	// certificate did not decide (this launch's work)
+	if (cert_all && cert_all[n_cw + (retry ? 0 : 1)] == 0)
+		return;
 	for (;;) {
 	int unit = 0;
 	if (lane == 0)

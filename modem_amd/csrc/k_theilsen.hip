@@ -50,7 +50,7 @@ constexpr int TS_MQ1S = (int)((TS_MQ + 1) << 9);
 constexpr int TS_LIST = 64;                               // candidate pairs of the final bracket: one per lane
 constexpr int TS_MAX_IT = 48;
 #ifdef TS_PROBE_REASON
-#define TS_REASON(r) do { if (threadIdx.x == 0) atomicAdd(TS_PROBE_REASON + (r), 1); } while (0)
+#define TS_REASON(r) do { if ((threadIdx.x & 63) == 0) atomicAdd(TS_PROBE_REASON + (r), 1); } while (0)
 #else
 #define TS_REASON(r) do { } while (0)
 #endif
@@ -60,6 +60,21 @@ constexpr uint32_t TS_SENTINEL = 0x7fffffffu;             // above every key, an
 // elements kk places after mine" are consecutive words across the lanes (index 8 * lane + t would put 8 lanes on a bank).
 // Row strides 68 / 76 words keep column accesses AND the row-crossing writes of the loader (i = lane + 64 q) conflict-free.
 constexpr int TS_YS = 68, TS_PS = 76;                     // sk: columns 64..75 hold sentinels (positions past the end)
+// Rows (waves) per workgroup.  A row's wave never meets another wave: LDS operations of one wave execute in program order, so a
+// value written by one lane is visible to a later read by any lane of the same wave; TS_SYNC only has to keep the compiler from
+// moving LDS accesses across the point.  With one row per workgroup that is __syncthreads() (no s_barrier is emitted for a
+// one-wave workgroup); with several rows it must not be a barrier (rows take different paths).  The hardware holds at most
+// 16 workgroups per CU, so one-wave workgroups cap the kernel at 16 waves per CU where its registers would allow 20 - and
+// still 1 row per workgroup is the fastest: 3.3 ms per 8192 frames against 3.5 (2 rows) and 4.1 (4 rows; a workgroup's LDS
+// and slots are released only when its slowest row is through), profiles/r03_v3_theil_sen_rows_per_workgroup.txt.
+#ifndef TS_ROWS_PER_WG
+#define TS_ROWS_PER_WG 1
+#endif
+#if TS_ROWS_PER_WG == 1
+#define TS_SYNC() __syncthreads()
+#else
+#define TS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 struct TsLds {
 	float y[8 * TS_YS];
 	uint2 sk[8 * TS_PS];       // .x sorted keys of the last count; .y the same elements keyed at the other end of the bracket
@@ -307,7 +322,7 @@ __device__ __noinline__ float ts_slow_select(TsLds &s, int n, int lane, int targ
 	for (int shift = 24; shift >= 0; shift -= 8) {
 		for (int b = lane; b < 256; b += 64)
 			hist[b] = 0;
-		__syncthreads();
+		TS_SYNC();
 		for (int d = 1; d < n; ++d) {
 			const float fd = (float)d;
 			for (int i = lane; i < n - d; i += 64) {
@@ -316,7 +331,7 @@ __device__ __noinline__ float ts_slow_select(TsLds &s, int n, int lane, int targ
 					atomicAdd(&hist[(key >> shift) & 255u], 1u);
 			}
 		}
-		__syncthreads();
+		TS_SYNC();
 		// lane b handles bins 4b .. 4b+3
 		const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
 		const int mine = (int)(h0 + h1 + h2 + h3);
@@ -341,7 +356,7 @@ __device__ __noinline__ float ts_slow_select(TsLds &s, int n, int lane, int targ
 		rank = __builtin_amdgcn_readlane(rr, src);
 		prefix |= (uint32_t)bin << shift;
 		mask |= 255u << shift;
-		__syncthreads();
+		TS_SYNC();
 	}
 	return fkey_inv(prefix);
 }
@@ -438,11 +453,11 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 				ts_keys_run(k, yv, 8 * lane, n, T, qs);
 				const int share = ts_sort(k, L, true, 6);
 				int c_lt = TS_INV_CONST + wave_sum_i(share), c_le;
-				__syncthreads();                                  // earlier readers of sk are done
+				TS_SYNC();                                  // earlier readers of sk are done
 				#pragma unroll
 				for (int t = 0; t < 8; ++t)
 					s.sk[t * TS_PS + lane].x = k[t];
-				__syncthreads();
+				TS_SYNC();
 				{   // uncertain pairs: neighbours in sorted order whose keys are within TS_MQ quanta
 					int dmin = (int)(s.sk[lane + 1].x - k[7]);
 					#pragma unroll
@@ -543,7 +558,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 			// a pair inside the bracket is at most this far apart in the sorted keys (minus the margin: compared with o - km)
 			const float wq = fabsf(Tb - Ta) * (float)qs.scale * (float)(n - 1) * 1.0001f + 4.f;
 			const int ws = wq < 4.0e6f ? (int)(((uint32_t)wq << 9) | 511u) : 0x7fffffff;
-			__syncthreads();
+			TS_SYNC();
 			int nc = 0;
 			for (int kk = 1;; ++kk) {
 				if (kk > 8 * (TS_PS - 64)) { slow = true; TS_REASON(5); break; }
@@ -573,7 +588,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 				if (!(__builtin_amdgcn_ballot_w64(gmin <= ws) & real_lanes))
 					break;
 			}
-			__syncthreads();
+			TS_SYNC();
 			if (nc > TS_LIST) {
 				slow = true; TS_REASON(6);
 			}
@@ -616,14 +631,14 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 			const int i = (int)(k[t] & 511u);
 			bk[t] = i < n ? fkey(sub_mul_nofma(s.y[ts_yaddr(i)], slope, (float)(i - xoff))) : 0xffffffffu;
 		}
-		__syncthreads();
+		TS_SYNC();
 		if (lane == (n / 2) >> 3) {
 			#pragma unroll
 			for (int t = 0; t < 8; ++t)
 				if (t == ((n / 2) & 7))
 					s.lst[0] = bk[t];
 		}
-		__syncthreads();
+		TS_SYNC();
 		uint32_t cand = s.lst[0];
 		for (int round = 0; round < 6 && !have; ++round) {
 			int lt = 0, le = 0;
@@ -659,11 +674,11 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 			k[t] = i < n ? fkey(sub_mul_nofma(yv[t], slope, (float)(i - xoff))) : 0xffffffffu;
 		}
 		ts_sort(k, L, false, 6);
-		__syncthreads();
+		TS_SYNC();
 		#pragma unroll
 		for (int t = 0; t < 8; ++t)
 			s.sk[t * TS_PS + lane].x = k[t];
-		__syncthreads();
+		TS_SYNC();
 		yint = n > 0 ? fkey_inv(s.sk[ts_paddr(n / 2)].x) : 0.f;
 	}
 	// the key order treats -0 < +0; nth_element would return whichever sits there: same value
@@ -673,20 +688,22 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 // decode.cc:479-504: one wave per (frame, row)
 // carr_all != nullptr (8 kHz): the row is formed here from the carriers of two consecutive symbols; cons_raw_all
 // (nullable) receives the unrotated row for the CONS_RAW tap
-__global__ __launch_bounds__(64) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
-	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all)
+__global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
+	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames)
 {
 	// grid = frames x ROWS_MAX, one row per wave; the waves of rows a frame's mode does not have leave at once (mode 6: 50 of
 	// 126 stay).  A loop over rows inside the wave costs 30 registers: everything that depends on the row length and the
 	// lane alone is hoisted out of it and stays live.
-	const int f = blockIdx.x / ROWS_MAX, j = blockIdx.x % ROWS_MAX, lane = threadIdx.x;
-	if (!st_all[f].okay)
+	const int unit = (int)blockIdx.x * TS_ROWS_PER_WG + ((int)threadIdx.x >> 6);
+	const int f = unit / ROWS_MAX, j = unit % ROWS_MAX, lane = threadIdx.x & 63;
+	if (f >= n_frames || !st_all[f].okay)
 		return;
 	const ModeDesc md = mode_desc(st_all[f].oper_mode);
 	if (j >= md.rows)
 		return;
 	const int cols = md.cols;
-	__shared__ TsLds s;
+	__shared__ TsLds s_all[TS_ROWS_PER_WG];
+	TsLds &s = s_all[threadIdx.x >> 6];
 	cf *row = cons_all + (size_t)f * CONS_MAX + (size_t)j * cols;
 	const cf *cr = carr_all ? carr_all + (size_t)f * CARR_MAX + (size_t)j * cols : nullptr;
 	auto cons_at = [&](int i) {                                    // decode.cc:474-475
@@ -703,7 +720,7 @@ __global__ __launch_bounds__(64) void k_theil_sen(const SyncState *__restrict__ 
 			s.y[ts_yaddr(i)] = atan2f(d.im, d.re);
 		}
 	}
-	__syncthreads();
+	TS_SYNC();
 	const float2 sy = theil_sen_wave(s, cols, lane);
 	const float slope = sy.x, yint = sy.y;
 	// (the row is formed a second time here instead of being held in 16 registers across the search: its carriers are in L2)
@@ -723,25 +740,28 @@ __global__ __launch_bounds__(64) void k_theil_sen(const SyncState *__restrict__ 
 	}
 }
 
-__global__ __launch_bounds__(64) void k_theil_sen_raw(int cols, const float *__restrict__ y, float *__restrict__ slope_all,
+__global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen_raw(int cols, int rows, const float *__restrict__ y, float *__restrict__ slope_all,
 	float *__restrict__ yint_all)
 {
-	const int r = blockIdx.x, lane = threadIdx.x;
-	__shared__ TsLds s;
+	const int r = (int)blockIdx.x * TS_ROWS_PER_WG + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (r >= rows)
+		return;
+	__shared__ TsLds s_all[TS_ROWS_PER_WG];
+	TsLds &s = s_all[threadIdx.x >> 6];
 	for (int i = lane; i < cols; i += 64)
 		s.y[ts_yaddr(i)] = y[(size_t)r * cols + i];
-	__syncthreads();
+	TS_SYNC();
 	const float2 sy = theil_sen_wave(s, cols, lane);
 	if (lane == 0) { slope_all[r] = sy.x; yint_all[r] = sy.y; }
 }
 
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint)
 {
-	hipLaunchKernelGGL(k_theil_sen, dim3(n * ROWS_MAX), dim3(64), 0, s, st, cons, carr, cons_raw, slope, yint);
+	hipLaunchKernelGGL(k_theil_sen, dim3((n * ROWS_MAX + TS_ROWS_PER_WG - 1) / TS_ROWS_PER_WG), dim3(64 * TS_ROWS_PER_WG), 0, s, st, cons, carr, cons_raw, slope, yint, n);
 }
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint)
 {
-	hipLaunchKernelGGL(k_theil_sen_raw, dim3(rows), dim3(64), 0, s, cols, y, slope, yint);
+	hipLaunchKernelGGL(k_theil_sen_raw, dim3((rows + TS_ROWS_PER_WG - 1) / TS_ROWS_PER_WG), dim3(64 * TS_ROWS_PER_WG), 0, s, cols, rows, y, slope, yint);
 }
 
 }  // namespace rx

@@ -89,7 +89,8 @@ void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *c
 // only the frames with 2 are decoded
 void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,
 	int *next_cw, const int *cert = nullptr, int retry = 0);
-void launch_syndrome(hipStream_t s, int n, const SyncState *st, const float *llr, Tables tb, uint8_t *hard, int *cert);
+// log (nullable): receives the number of frames the certificate left to the list decoder
+void launch_syndrome(hipStream_t s, int n, const SyncState *st, const float *llr, Tables tb, uint8_t *hard, int *cert, int *log = nullptr);
 void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
 	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res, int *cert = nullptr, int retry = 0);
 void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb);

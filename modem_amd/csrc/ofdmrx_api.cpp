@@ -138,6 +138,8 @@ struct ofdmrx_handle {
 	DevBuf cert, cert2;       // syndrome certificate: verdict per frame (+ one flag), by parity
 	DevBuf soft_retry, retry_counter;   // level stores + work counter of the retry launch (frames whose certified codeword failed the CRC)
 	bool use_cert = true;     // list 8, no debug taps, not switched off
+	DevBuf cert_log;          // per chunk of the last call: frames the certificate left to the list decoder
+	int cert_chunks = 0;
 	int *cert_of(int par) { return use_cert ? (par ? cert2 : cert).as<int>() : nullptr; }
 	DevBuf hard2;             // second parity of the list decoder's output: finish(c) reads its own while polar(c+1) writes
 	uint8_t *hard_of(int par) { return (par ? hard2 : hard).as<uint8_t>(); }
@@ -301,7 +303,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2, &h->cert, &h->cert2, &h->soft_retry, &h->retry_counter })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2, &h->cert, &h->cert2, &h->soft_retry, &h->retry_counter, &h->cert_log })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -317,6 +319,26 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 
 extern "C" int ofdmrx_chunk_frames(ofdmrx_handle *h) { return h ? h->chunk : OFDMRX_E_ARG; }
 
+// frames of the last decode call that went through the list decoder (the others were decided by the syndrome
+// certificate); -1: the certificate is off for this handle (every frame with a header is list-decoded)
+extern "C" long long ofdmrx_list_decoded_frames(ofdmrx_handle *h)
+{
+	if (!h)
+		return OFDMRX_E_ARG;
+	if (!h->use_cert)
+		return -1;
+	if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+		return OFDMRX_E_HIP;
+	std::vector<int> v((size_t)h->cert_chunks);
+	if (!v.empty() && hipMemcpy(v.data(), h->cert_log.p, v.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+		return OFDMRX_E_HIP;
+	long long sum = 0;
+	for (int x : v)
+		sum += x;
+	return sum;
+}
+
+constexpr int CERT_LOG_MAX = 4096;   // chunks per call whose list-decoder counts are kept (ofdmrx_list_decoded_frames)
 constexpr int RETRY_DECODERS = 64;   // list decoders of the retry launch (it almost never has a frame to decode)
 static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, bool two_parities = false)
 {
@@ -331,7 +353,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->yint2.ensure(N2 * ROWS_MAX * sizeof(float));
 		r = r ? r : h->precision2.ensure(N2 * ROWS_MAX * sizeof(float));
 		r = r ? r : h->hard2.ensure(N2 * CODE_LEN);
-		r = r ? r : h->cert2.ensure((N2 + 1) * sizeof(int));
+		r = r ? r : h->cert2.ensure((N2 + 2) * sizeof(int));
 		if (r)
 			return r;
 	}
@@ -348,8 +370,9 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->hard.ensure(N * CODE_LEN);
 		r = r ? r : h->metric.ensure(N * LIST * sizeof(float));
 		r = r ? r : h->work_counter.ensure(256);
-		r = r ? r : h->cert.ensure((N + 1) * sizeof(int));
+		r = r ? r : h->cert.ensure((N + 2) * sizeof(int));
 		r = r ? r : h->retry_counter.ensure(256);
+		r = r ? r : h->cert_log.ensure(CERT_LOG_MAX * sizeof(int));
 		r = r ? r : h->soft_retry.ensure((size_t)RETRY_DECODERS * 8 * CODE_LEN * sizeof(float));
 		r = r ? r : h->lane_mesg.ensure(N * LIST * MESG_BYTES);
 		r = r ? r : h->res.ensure(N * sizeof(Result));
@@ -516,8 +539,12 @@ static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Res
 		Range r("ofdmrx:llr");
 		launch_llr(s, h->rate, n, h->st_of(sti), h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
 			h->llr_of(par), d_res);
-		if (h->use_cert)
-			launch_syndrome(s, n, h->st_of(sti), h->llr_of(par), h->dev, h->hard_of(par), h->cert_of(par));
+		if (h->use_cert) {
+			launch_syndrome(s, n, h->st_of(sti), h->llr_of(par), h->dev, h->hard_of(par), h->cert_of(par),
+				(h->cert_chunks < CERT_LOG_MAX && h->cert_log.p) ? h->cert_log.as<int>() + h->cert_chunks : nullptr);
+			if (h->cert_chunks < CERT_LOG_MAX)
+				++h->cert_chunks;
+		}
 	}
 	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
@@ -887,6 +914,7 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 			return max_skip;
 	}
 	h->ev_used = 0;
+	h->cert_chunks = 0;
 	h->spans.clear();
 	const ChunkPlan plan = plan_chunks(h, n_frames);
 	struct Dev : PipeHooks {
@@ -929,6 +957,7 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 			return max_skip;
 	}
 	h->ev_used = 0;
+	h->cert_chunks = 0;
 	h->spans.clear();
 	const ChunkPlan plan = plan_chunks(h, n_frames);
 	const size_t n_chunks = plan.count(), nc = plan.largest();
@@ -1139,7 +1168,7 @@ extern "C" int ofdmrx_debug_decode_llr(ofdmrx_handle *h, const float *llr, size_
 	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
-	HIP_OK(hipMemsetAsync(h->cert.p, 0, (n + 1) * sizeof(int), h->stream));
+	HIP_OK(hipMemsetAsync(h->cert.p, 0, (n + 2) * sizeof(int), h->stream));
 	int *cert = use_cert ? h->cert.as<int>() : nullptr;
 	SyncState *dst = h->st.as<SyncState>();
 	if (cert)

@@ -20,7 +20,7 @@ STAGES = ["front", "sync", "header", "demod", "theilsen", "llr", "polar", "finis
 # every symbol include/ofdmrx.h declares
 EXPORTS = [
     "ofdmrx_abi_version", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
-    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames",
+    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_list_decoded_frames",
     "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_decode_llr", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
     "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
     "ofdmrx_tx_encode_device", "ofdmrx_stream_samples", "ofdmrx_tx_encode_stream_device", "ofdmrx_tx_encode_stream",
@@ -107,6 +107,8 @@ def load_library():
     L.ofdmrx_synchronize.argtypes = [C.c_void_p]
     L.ofdmrx_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ofdmrx_chunk_frames.argtypes = [C.c_void_p]
+    L.ofdmrx_list_decoded_frames.argtypes = [C.c_void_p]
+    L.ofdmrx_list_decoded_frames.restype = C.c_longlong
     L.ofdmrx_debug_dump.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
     L.ofdmrx_debug_polar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_decode_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -207,6 +209,10 @@ class Receiver:
         """device pointers (ints); asynchronous on the handle's stream"""
         self._check(self._lib.ofdmrx_decode_batch_device(self._h, d_samples, fmt, channels, spf, stride, n,
                                                          d_skip, d_payload, d_results))
+
+    def list_decoded_frames(self):
+        """frames of the last decode call the syndrome certificate left to the list decoder (-1: certificate off)"""
+        return int(self._lib.ofdmrx_list_decoded_frames(self._h))
 
     def synchronize(self):
         self._check(self._lib.ofdmrx_synchronize(self._h))

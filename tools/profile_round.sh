@@ -1,26 +1,39 @@
 #!/bin/bash
 # profile_round.sh TAG -- everything profiles/TAG_* holds, collected on the GPU box from the repo root:
-#   kernel trace of the default bench line (overlapped schedule) and of the same with kernels back to back,
-#   PMC passes (FETCH_SIZE, WRITE_SIZE, instruction counters: separate runs, one 8192-frame chunk, kernels back to back),
-#   the FETCH_SIZE / WRITE_SIZE calibration in k_polar's access pattern (tools/pmc_calib.hip).
-# Only text leaves the box: gpurun_out/TAG_summary.txt, TAG_bench_n1*.json, TAG_traffic.json
-TAG=${1:-r01_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
+#   kernel traces of the default bench line (pipeline), of the same with kernels back to back, and of the same with the list
+#   decoder forced for every frame (OFDMRX_NO_CERT=1: no syndrome certificate);
+#   PMC passes (FETCH_SIZE, WRITE_SIZE, instruction counters: separate runs, one 8192-frame chunk, kernels back to back), in both modes;
+#   the FETCH_SIZE / WRITE_SIZE calibration (tools/pmc_calib.hip).
+# Only text leaves the box: gpurun_out/TAG_summary.txt, TAG_bench_n1*.json, TAG_traffic.json (copy the last one to
+# profiles/r03_traffic.json: bench.py reads the per-kernel HBM bytes from it)
+TAG=${1:-r03_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
 S=$G/${TAG}_summary.txt; : > $S
+make -C modem_amd/csrc -q all && echo "# library up to date with sources" >> $S || echo "# STALE LIBRARY" >> $S
 cd /tmp; export TMPDIR=/tmp
-echo "# $TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0   (default: overlapped schedule)" >> $S
-rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o trace -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 > $G/${TAG}_bench_n1_under_profiler.json 2>/dev/null
+B="python3 $R/bench.py --cpu-frames 0 --host-frames 0 --scl-steps 0"
+echo "# $TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 --scl-steps 0   (default: pipeline, syndrome certificate on)" >> $S
+rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o trace -- $B --steps 2 --warmup 1 > $G/${TAG}_bench_n1_under_profiler.json 2>/dev/null
 python3 $R/profiles/summarize.py $(find /tmp/prof_e -name "*.db" | head -1) >> $S 2>&1
 echo "# same with OFDMRX_NO_OVERLAP=1 (every kernel alone on the device)" >> $S
-OFDMRX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_n -o trace -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 > /dev/null 2>&1
+OFDMRX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_n -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 python3 $R/profiles/summarize.py $(find /tmp/prof_n -name "*.db" | head -1) >> $S 2>&1
+echo "# OFDMRX_NO_CERT=1 (list decoder for every frame), pipeline" >> $S
+OFDMRX_NO_CERT=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
+python3 $R/profiles/summarize.py $(find /tmp/prof_s -name "*.db" | head -1) >> $S 2>&1
+echo "# OFDMRX_NO_CERT=1 OFDMRX_NO_OVERLAP=1" >> $S
+OFDMRX_NO_CERT=1 OFDMRX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_sn -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
+python3 $R/profiles/summarize.py $(find /tmp/prof_sn -name "*.db" | head -1) >> $S 2>&1
 export OFDMRX_NO_OVERLAP=1
-echo "# PMC passes: rocprofv3 --pmc <counters> -- python3 bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 (OFDMRX_NO_OVERLAP=1)" >> $S
-for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"; do
-	d=/tmp/pmc_$(echo $c | tr ' ' '_')
-	rocprofv3 --pmc $c -d $d -o x -- python3 $R/bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 --host-frames 0 > /dev/null 2>&1
-	python3 $R/tools/pmc_kernel.py $(find $d -name "*.db" | head -1) rx:: >> $S 2>&1
+for mode in cert scl; do
+	[ $mode = scl ] && export OFDMRX_NO_CERT=1
+	echo "# PMC passes [$mode]: rocprofv3 --pmc <counters> -- python3 bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 --host-frames 0 --scl-steps 0 (OFDMRX_NO_OVERLAP=1$([ $mode = scl ] && echo ' OFDMRX_NO_CERT=1'))" >> $S
+	for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS SQ_WAIT_INST_ANY"; do
+		d=/tmp/pmc_${mode}_$(echo $c | tr ' ' '_')
+		rocprofv3 --pmc $c -d $d -o x -- $B --frames 8192 --steps 1 --warmup 0 > /dev/null 2>&1
+		python3 $R/tools/pmc_kernel.py $(find $d -name "*.db" | head -1) rx:: | sed "s/^/[$mode] /" >> $S 2>&1
+	done
 done
-unset OFDMRX_NO_OVERLAP
+unset OFDMRX_NO_OVERLAP OFDMRX_NO_CERT
 echo "# calibration: tools/pmc_calib.hip, 2 GiB read / 2 GiB written / 2+2 GiB copied per kernel, one 256-byte row per wave instruction" >> $S
 hipcc -w --offload-arch=gfx950 -O3 $R/tools/pmc_calib.hip -o /tmp/pmc_calib && /tmp/pmc_calib >> $S 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -29,20 +42,37 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python3 bench.py > $G/${TAG}_bench_n1.json 2>/dev/null
-OFDMRX_NO_OVERLAP=1 python3 bench.py --cpu-frames 0 --host-frames 0 > $G/${TAG}_bench_n1_no_overlap.json 2>/dev/null
 R=$R python3 - "$S" "$G/${TAG}_traffic.json" <<'PY'
 import hashlib, json, os, re, sys
 txt = open(sys.argv[1]).read()
-sha = hashlib.sha256(open(os.path.join(os.environ.get("R", "."), "modem_amd", "csrc", "k_polar.hip"), "rb").read()).hexdigest()[:16]
-def grab(kern, ctr):
+root = os.environ.get("R", ".")
+def sha(f):
+    return hashlib.sha256(open(os.path.join(root, "modem_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+def grab(mode, kern, ctr):
+    """average per launch of the LAST-but-warm launches: sum / calls"""
+    tot = n = 0.0
+    for m in re.finditer(r"^\[%s\] (\S.*?)\s+%s\s+calls\s+(\d+)\s+sum\s+([0-9.]+)" % (mode, ctr), txt, re.M):
+        if kern in m.group(1):
+            tot += float(m.group(3)); n = max(n, int(m.group(2)))
+    return tot / n if n else None
+def calib(kern, ctr):
     m = re.search(r"^%s\s+%s\s+calls\s+(\d+)\s+sum\s+([0-9.]+)" % (re.escape(kern), ctr), txt, re.M)
     return float(m.group(2)) / int(m.group(1))
-f, w = grab("void rx::k_polar<8>", "FETCH_SIZE"), grab("void rx::k_polar<8>", "WRITE_SIZE")
-cf, cw = grab("calib_read", "FETCH_SIZE"), grab("calib_write", "WRITE_SIZE")
-json.dump({"kernel": "rx::k_polar<8>", "frames_per_launch": 8192, "fetch_KiB": f, "write_KiB": w, "k_polar_src_sha": sha,
-           "fetch_scale": 2097152.0 / cf, "write_scale": 2097152.0 / cw,
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --frames 8192 --steps 1 --warmup 0 "
-                     "--cpu-frames 0, kernels back to back; scales = true bytes / counted bytes of tools/pmc_calib.hip (2 GiB per kernel, "
-                     "the decoder's access pattern) in the same session"}, open(sys.argv[2], "w"), indent=1)
+stages = {"sync": ("cert", "k_sync", "k_sync.hip"), "header": ("cert", "k_header", "k_header.hip"), "demod": ("cert", "k_demod", "k_demod.hip"),
+          "theilsen": ("cert", "k_theil_sen", "k_theilsen.hip"), "llr": ("cert", "k_llr", "k_demod.hip"), "finish": ("cert", "k_finish", "k_finish.hip"),
+          "polar": ("scl", "k_polar", "k_polar.hip")}
+out = {"frames_per_launch": 8192, "fetch_scale": 2097152.0 / calib("calib_read", "FETCH_SIZE"), "write_scale": 2097152.0 / calib("calib_write", "WRITE_SIZE"),
+       "kernels": {},
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 "
+                 "--host-frames 0 --scl-steps 0, kernels back to back (k_polar: with OFDMRX_NO_CERT=1); KiB per launch; scales = true bytes / counted "
+                 "bytes of tools/pmc_calib.hip (2 GiB per kernel, one dword per lane) in the same session"}
+for st, (mode, kern, src) in stages.items():
+    f, w = grab(mode, kern, "FETCH_SIZE"), grab(mode, kern, "WRITE_SIZE")
+    if st == "llr":      # the stage timer spans k_llr + k_syndrome
+        f2, w2 = grab(mode, "k_syndrome", "FETCH_SIZE"), grab(mode, "k_syndrome", "WRITE_SIZE")
+        f, w = (f or 0) + (f2 or 0), (w or 0) + (w2 or 0)
+    if f is not None and w is not None:
+        out["kernels"][st] = {"kernel": kern, "fetch_KiB": f, "write_KiB": w, "src_sha": sha(src)}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
 PY
-tail -5 $S; cat $G/${TAG}_traffic.json; cat $G/${TAG}_bench_n1.json | cut -c1-400
+tail -5 $S; cat $G/${TAG}_traffic.json; cat $G/${TAG}_bench_n1.json | cut -c1-600
