@@ -32,6 +32,11 @@ extern "C" {
 #endif
 
 #define OFDMRX_ABI_VERSION 1
+/* Minor revisions keep every struct and signature of OFDMRX_ABI_VERSION 1 and add entry points or tighten a check:
+ *   1: skip counts outside 0..OFDMRX_MAX_SKIP fail the call with OFDMRX_E_ARG (they used to be clamped)
+ *   2: ofdmrx_set_esn0_rows, ofdmrx_list_decoded_frames, ofdmrx_debug_decode_llr, ofdmrx_config.flags bit 1 (OFDMRX_FLAG_SCL_ALWAYS);
+ *      frames whose hard decisions already form a codeword are decided by a syndrome check (same outputs) */
+#define OFDMRX_ABI_MINOR 2
 
 #define OFDMRX_PAYLOAD_BYTES 5380     /* decode.cc:587  data_len = 43040/8 */
 #define OFDMRX_CODE_LEN 65536         /* decode.cc:309  code_order 16 */
@@ -121,6 +126,7 @@ typedef struct {
 } ofdmrx_timing;
 
 int ofdmrx_abi_version(void);
+int ofdmrx_abi_minor(void);
 const char *ofdmrx_strerror(int err);
 
 /* replaces `new Decoder<value,cmplx,8000>` (decode.cc:592): allocates device
@@ -153,6 +159,12 @@ int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int samp
 int ofdmrx_synchronize(ofdmrx_handle *h);
 int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t);
 int ofdmrx_chunk_frames(ofdmrx_handle *h);
+/* decode.cc:506-523 prints one Es/N0 value per constellation row.  rows = n_frames x OFDMRX_ROWS_MAX floats (dB; rows a frame's
+ * mode does not have, and frames without a header: 0) in the memory space of the RESULTS of the decode calls that follow: a
+ * device pointer for ofdmrx_decode_batch_device, a host pointer for ofdmrx_decode_batch.  NULL (the default) turns it off;
+ * ofdmrx_frame_result.esn0_db_last always carries the last row's value. */
+#define OFDMRX_ROWS_MAX 126    /* decode.cc:181 rows_max */
+int ofdmrx_set_esn0_rows(ofdmrx_handle *h, float *rows);
 /* frames of the last decode call that went through the list decoder; the rest were decided by the syndrome certificate
  * (see ofdmrx_config.flags).  -1 if the certificate is off for this handle.  Synchronises the handle's stream. */
 long long ofdmrx_list_decoded_frames(ofdmrx_handle *h);

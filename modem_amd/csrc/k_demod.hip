@@ -57,7 +57,8 @@ template <int RATE> struct DifCfg {
 #define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : 4)
 #endif
 	static constexpr bool TWR_LDS = (R1 - 1) * NS * 8 <= DEMOD_TWR_BYTES;   // w^(n' r) table in LDS (8 / 16 kHz) or read from the global root table
-	static constexpr bool DOUBLE = 2 * SL * 8 <= DEMOD_DBL_BYTES;       // two row buffers (8 / 16 kHz): no third barrier per symbol
+	static constexpr bool DOUBLE = 2 * SL * 8 <= DEMOD_DBL_BYTES;       // two row buffers, no third barrier per symbol: OFF by default (DEMOD_DBL_BYTES 0:
+	                                                                     // the second buffer cost a workgroup per CU and measured slower); -DDEMOD_DBL_BYTES=20480 turns it on at 8 kHz
 	static constexpr int WAVES = DEMOD_DIF_WAVES(RATE);      // waves per SIMD the register budget is set for (two workgroups per CU at 44.1 / 48 kHz)
 };
 template <int RATE> struct DemodCfg {
@@ -313,12 +314,15 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 // then the row's soft bits are emitted with that row's cumulative precision.
 __global__ __launch_bounds__(256) void k_llr(int sym_stride, const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
 	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
-	float *__restrict__ llr_all, Result *__restrict__ res_all)
+	float *__restrict__ llr_all, Result *__restrict__ res_all, float *__restrict__ esn0_rows)
 {
 	const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	const SyncState st = st_all[f];
+	if (esn0_rows && tid < ROWS_MAX)
+		esn0_rows[(size_t)f * ROWS_MAX + tid] = 0.f;             // rows this frame does not have (all of them without a header)
 	if (!st.okay)
 		return;
+	__syncthreads();
 	__shared__ double red[2][4];
 	const ModeDesc md = mode_desc(st.oper_mode);
 	const cf *cons = cons_all + (size_t)f * CONS_MAX;
@@ -351,8 +355,11 @@ __global__ __launch_bounds__(256) void k_llr(int sym_stride, const SyncState *__
 		sp = (float)((double)sp + dsp);
 		np = (float)((double)np + dnp);
 		precision = sp / np;                                  // decode.cc:516
-		if (tid == 0)
+		if (tid == 0) {
 			precision_all[(size_t)f * ROWS_MAX + j] = precision;
+			if (esn0_rows)
+				esn0_rows[(size_t)f * ROWS_MAX + j] = 10.f * log10f(precision);   // decode.cc:518
+		}
 		#pragma unroll
 		for (int q = 0; q < 2; ++q) {
 			int i = tid + 256 * q;
@@ -411,10 +418,10 @@ void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Ta
 	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(DemodCfg<RATE>::NT), 0, s, fb, z, tb, st, cons, carr));
 }
 void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
-	float *precision, float *llr, Result *res)
+	float *precision, float *llr, Result *res, float *esn0_rows)
 {
 	const int sym_stride = rate_symbol_len(rate) + rate_symbol_len(rate) / 8;
-	hipLaunchKernelGGL(k_llr, dim3(n), dim3(256), 0, s, sym_stride, st, cons, slope, yint, precision, llr, res);
+	hipLaunchKernelGGL(k_llr, dim3(n), dim3(256), 0, s, sym_stride, st, cons, slope, yint, precision, llr, res, esn0_rows);
 }
 void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb)
 {

@@ -989,7 +989,8 @@ void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st,
 {
 	if (list == 4)
 		cert = nullptr;                                       // (pairs of codewords per wave: the certificate is not wired into the pairing)
-	(void)hipMemsetAsync(next_cw, 0, sizeof(int), s);
+	if (hipMemsetAsync(next_cw, 0, sizeof(int), s) != hipSuccess)
+		return;                                               // (the caller's hipGetLastError reports it)
 	if (grid <= 0 || grid > n)
 		grid = n;
 	grid = (grid + POLAR_WPB - 1) / POLAR_WPB;                // workgroups of POLAR_WPB decoders

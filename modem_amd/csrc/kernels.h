@@ -24,7 +24,9 @@ struct SyncState {                 // per frame, across sync rounds (decode.cc:3
 	long t_next;                   // next sample time to examine
 	long sc_start;                 // stream index of the S&C body
 	int active;                    // still searching in this round
-	int found;
+	int found;                     // a preamble was accepted in THIS round.  Invariant across kernels: only launch_init_sync and k_header clear
+	                               // it (k_header whenever it leaves active = 1 for another round, decode.cc:448), so the scan kernels of a
+	                               // round may return early on it; a frame with active = 0 is never looked at again
 	int symbol_pos;                // window coordinate, decode.cc:400
 	float cfo_rad;
 	int rejects;
@@ -84,7 +86,7 @@ void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Ta
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint);
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
 void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
-	float *precision, float *llr, Result *res);
+	float *precision, float *llr, Result *res, float *esn0_rows = nullptr);   // esn0_rows (nullable): [n][ROWS_MAX] dB values, decode.cc:517-519
 // cert (nullable): per-frame verdict of the syndrome certificate (launch_syndrome): frames with 1 are skipped; retry != 0:
 // only the frames with 2 are decoded
 void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,

@@ -138,6 +138,8 @@ struct ofdmrx_handle {
 	DevBuf cert, cert2;       // syndrome certificate: verdict per frame (+ one flag), by parity
 	DevBuf soft_retry, retry_counter;   // level stores + work counter of the retry launch (frames whose certified codeword failed the CRC)
 	bool use_cert = true;     // list 8, no debug taps, not switched off
+	float *esn0_user = nullptr;   // ofdmrx_set_esn0_rows: n x OFDMRX_ROWS_MAX floats in the memory space of the results (NULL = off)
+	DevBuf esn0_dev, esn0_dev2;   // host-pointer entry: per-chunk device staging of the row values, by parity
 	DevBuf cert_log;          // per chunk of the last call: frames the certificate left to the list decoder
 	int cert_chunks = 0;
 	int *cert_of(int par) { return use_cert ? (par ? cert2 : cert).as<int>() : nullptr; }
@@ -183,6 +185,7 @@ static int upload(ofdmrx_handle *h, const std::vector<T> &v, const T **out)
 }
 
 extern "C" int ofdmrx_abi_version(void) { return OFDMRX_ABI_VERSION; }
+extern "C" int ofdmrx_abi_minor(void) { return OFDMRX_ABI_MINOR; }
 
 extern "C" const char *ofdmrx_strerror(int err)
 {
@@ -221,6 +224,18 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	// min(batch, chunk), so only a large batch pays that; cfg.chunk_frames lowers it.
 	h->chunk = cfg->chunk_frames > 0 ? cfg->chunk_frames : 8192;
 	h->max_samples = cfg->max_samples > 0 ? cfg->max_samples : ofdmrx_frame_samples(cfg->sample_rate, 6);
+	if (cfg->chunk_frames <= 0) {
+		// the DEFAULT chunk also has to fit what is free on the device right now (a second handle, a smaller part): per frame
+		// about 3.2 MB of decoder state (both parities), the resident input (two staged chunks for the host entry) and, for
+		// mono input, the analytic copy.  Halved until it fits 60 % of the free memory; an explicit cfg.chunk_frames is taken as is.
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+			const double per_frame = 3.2e6 + (double)h->max_samples * (2.0 * 4.0 + 8.0);
+			const double fixed = 4096.0 * 8.0 * CODE_LEN * 4.0 + 1.0e9;      // level stores of the resident list decoders + tables, staging
+			while (h->chunk > 1024 && fixed + per_frame * h->chunk > 0.6 * (double)free_b)
+				h->chunk /= 2;
+		}
+	}
 	if (cfg->stream) {
 		h->stream = (hipStream_t)cfg->stream;
 	} else {
@@ -303,7 +318,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2, &h->cert, &h->cert2, &h->soft_retry, &h->retry_counter, &h->cert_log })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2, &h->cert, &h->cert2, &h->soft_retry, &h->retry_counter, &h->cert_log, &h->esn0_dev, &h->esn0_dev2 })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -318,6 +333,18 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 }
 
 extern "C" int ofdmrx_chunk_frames(ofdmrx_handle *h) { return h ? h->chunk : OFDMRX_E_ARG; }
+
+// decode.cc:517-519 prints one Es/N0 value per constellation row; a batch caller gets them here: rows = n_frames x
+// OFDMRX_ROWS_MAX floats (dB; rows a frame's mode does not have, and frames without a header: 0) in the memory space of
+// the results of the decode calls that follow (device pointer for ofdmrx_decode_batch_device, host pointer for
+// ofdmrx_decode_batch).  NULL turns the output off.
+extern "C" int ofdmrx_set_esn0_rows(ofdmrx_handle *h, float *rows)
+{
+	if (!h)
+		return OFDMRX_E_ARG;
+	h->esn0_user = rows;
+	return 0;
+}
 
 // frames of the last decode call that went through the list decoder (the others were decided by the syndrome
 // certificate); -1: the certificate is off for this handle (every frame with a header is list-decoded)
@@ -366,7 +393,8 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->yint.ensure(N * ROWS_MAX * sizeof(float));
 		r = r ? r : h->precision.ensure(N * ROWS_MAX * sizeof(float));
 		r = r ? r : h->llr.ensure(N * CODE_LEN * sizeof(float));
-		r = r ? r : h->soft.ensure((N + 8) * 8 * CODE_LEN * sizeof(float));   // one 2 MiB level store per decoder; workgroups hold up to 8 decoders
+		// one 2 MiB level store per RESIDENT decoder (launches never use more than polar_grid of them), not per frame
+		r = r ? r : h->soft.ensure((size_t)(std::min<long>((long)N, h->polar_grid > 0 ? h->polar_grid : (long)N) + 8) * 8 * CODE_LEN * sizeof(float));
 		r = r ? r : h->hard.ensure(N * CODE_LEN);
 		r = r ? r : h->metric.ensure(N * LIST * sizeof(float));
 		r = r ? r : h->work_counter.ensure(256);
@@ -532,13 +560,13 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, 
 
 // The back half in two pieces, so that the pipeline can put an event between them: the LLR kernel (short, needs only the
 // Theil-Sen results) and polar + finish; *ev_polar (nullable) receives the event recorded right after the polar kernel.
-static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Result *d_res)
+static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Result *d_res, float *d_esn0 = nullptr)
 {
 	size_t e5 = mark(h, s);
 	{
 		Range r("ofdmrx:llr");
 		launch_llr(s, h->rate, n, h->st_of(sti), h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
-			h->llr_of(par), d_res);
+			h->llr_of(par), d_res, d_esn0);
 		if (h->use_cert) {
 			launch_syndrome(s, n, h->st_of(sti), h->llr_of(par), h->dev, h->hard_of(par), h->cert_of(par),
 				(h->cert_chunks < CERT_LOG_MAX && h->cert_log.p) ? h->cert_log.as<int>() + h->cert_chunks : nullptr);
@@ -600,9 +628,9 @@ static int run_polar_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, i
 }
 
 static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, uint8_t *d_payload, Result *d_res,
-	bool want_lane_mesg, size_t t_begin)
+	bool want_lane_mesg, size_t t_begin, float *d_esn0 = nullptr)
 {
-	int r = run_llr(h, s, par, sti, n, d_res);
+	int r = run_llr(h, s, par, sti, n, d_res, d_esn0);
 	return r ? r : run_polar_finish(h, s, par, sti, n, grid, d_payload, d_res, want_lane_mesg, t_begin, nullptr);
 }
 
@@ -687,6 +715,7 @@ struct PipeHooks {
 	virtual ~PipeHooks() {}
 	virtual int before_front1(size_t c, FrameBatch *fb, size_t *ready) = 0;   // fill fb.samples; ready = event index or -1
 	virtual void dst(size_t c, uint8_t **payload, Result **res) = 0;
+	virtual float *esn0(size_t) { return nullptr; }       // device destination of chunk c's per-row Es/N0 values (decode.cc:517-519), or null
 	virtual int after_front1(size_t, size_t /*event*/) { return 0; }
 	virtual int after_back(size_t, size_t /*event*/, hipStream_t /*stream the back half ran on*/) { return 0; }
 };
@@ -699,7 +728,6 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 	if (r)
 		return r;
 	auto n_of = [&](size_t c) { return (int)plan.size(c); };
-	static const bool force_grid = std::getenv("OFDMRX_POLAR_FORCE_GRID") != nullptr;   // experiments: limited grid without overlap
 	if (n_chunks == 1 || !h->stream_b || std::getenv("OFDMRX_NO_OVERLAP")) {
 		r = ensure_capacity(h, (int)chunk_max, channels == 1, (long)spf);
 		for (size_t c = 0; c < n_chunks && !r; ++c) {
@@ -716,7 +744,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 			r = run_front1(h, h->stream, 0, 0, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0);
 			r = r ? r : hooks.after_front1(c, mark(h, h->stream));
 			r = r ? r : run_front2(h, h->stream, 0, 0, n_of(c), res);
-			r = r ? r : run_back(h, h->stream, 0, 0, n_of(c), force_grid ? h->polar_grid : 0, pay, res, true, t0);
+			r = r ? r : run_back(h, h->stream, 0, 0, n_of(c), h->polar_grid, pay, res, true, t0, hooks.esn0(c));
 			r = r ? r : hooks.after_back(c, mark(h, h->stream), h->stream);
 		}
 		return r;
@@ -791,7 +819,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 				return r;
 			if (c >= 2)
 				HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_done[c - 2]], 0));
-			r = run_llr(h, sa, par, sti, n_of(c), res);
+			r = run_llr(h, sa, par, sti, n_of(c), res, hooks.esn0(c));
 			if (r)
 				return r;
 			ev_llr[c] = mark(h, sa);
@@ -824,12 +852,12 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 		HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f2[p]], 0));
 		if (ev_f1 != NONE && !llr_early)
 			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
-		int rr = run_llr(h, h->stream_b, par, sti, n_of(p), res);
+		int rr = run_llr(h, h->stream_b, par, sti, n_of(p), res, hooks.esn0(p));
 		if (rr)
 			return rr;
 		if (ev_f1 != NONE && llr_early)
 			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
-		rr = run_polar_finish(h, h->stream_b, par, sti, n_of(p), last ? 0 : h->polar_grid, pay, res, true, t0s[p], &ev_polar[p]);
+		rr = run_polar_finish(h, h->stream_b, par, sti, n_of(p), h->polar_grid, pay, res, true, t0s[p], &ev_polar[p]);
 		if (rr)
 			return rr;
 		ev_back[p] = mark(h, h->stream_b);
@@ -921,7 +949,10 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 		const ChunkPlan *plan; const char *samples; size_t stride; uint8_t *pay; Result *res;
 		int before_front1(size_t c, FrameBatch *fb, size_t *) override { fb->samples = samples + plan->first(c) * stride; return 0; }
 		void dst(size_t c, uint8_t **p, Result **r) override { *p = pay + plan->first(c) * PAYLOAD_BYTES; *r = res + plan->first(c); }
+		float *rows = nullptr;
+		float *esn0(size_t c) override { return rows ? rows + plan->first(c) * ROWS_MAX : nullptr; }
 	} hooks;
+	hooks.rows = h->esn0_user;
 	hooks.plan = &plan;
 	hooks.samples = (const char *)d_samples;
 	hooks.stride = stride;
@@ -974,7 +1005,15 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 		r = r ? r : h->skip_stage.ensure(n_frames * sizeof(int32_t));
 	if (r)
 		return r;
-	const size_t out_bytes = nc * (PAYLOAD_BYTES + sizeof(Result));
+	const size_t esn0_bytes = h->esn0_user ? nc * ROWS_MAX * sizeof(float) : 0;
+	if (esn0_bytes) {
+		r = h->esn0_dev.ensure(esn0_bytes);
+		if (!r && n_chunks > 1)
+			r = h->esn0_dev2.ensure(esn0_bytes);
+		if (r)
+			return r;
+	}
+	const size_t out_bytes = nc * (PAYLOAD_BYTES + sizeof(Result)) + esn0_bytes;
 	for (int q = 0; q < (n_chunks > 1 ? 2 : 1); ++q)
 		if (h->out_stage_cap[q] < out_bytes) {
 			if (h->out_stage[q])
@@ -1009,6 +1048,8 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 			const char *src = (const char *)h->out_stage[c & 1];
 			std::memcpy(payload_out + plan->first(c) * PAYLOAD_BYTES, src, n_of(c) * PAYLOAD_BYTES);
 			std::memcpy(results + plan->first(c), src + nc * PAYLOAD_BYTES, n_of(c) * sizeof(Result));
+			if (h->esn0_user)
+				std::memcpy(h->esn0_user + plan->first(c) * ROWS_MAX, src + nc * (PAYLOAD_BYTES + sizeof(Result)), n_of(c) * ROWS_MAX * sizeof(float));
 			return 0;
 		}
 		int before_front1(size_t c, FrameBatch *fb, size_t *ready) override
@@ -1032,6 +1073,7 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 			*p = ((c & 1) ? h->payload2 : h->payload).as<uint8_t>();
 			*r = ((c & 1) ? h->res2 : h->res).as<Result>();
 		}
+		float *esn0(size_t c) override { return h->esn0_user ? ((c & 1) ? h->esn0_dev2 : h->esn0_dev).as<float>() : nullptr; }
 		int after_back(size_t c, size_t, hipStream_t s) override
 		{
 			// out_stage[c & 1] still holds chunk c-2 until the host has copied it out
@@ -1046,6 +1088,8 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 			char *d = (char *)h->out_stage[c & 1];
 			HIP_OK(hipMemcpyAsync(d, p, n_of(c) * PAYLOAD_BYTES, hipMemcpyDeviceToHost, s));
 			HIP_OK(hipMemcpyAsync(d + nc * PAYLOAD_BYTES, rs, n_of(c) * sizeof(Result), hipMemcpyDeviceToHost, s));
+			if (h->esn0_user)
+				HIP_OK(hipMemcpyAsync(d + nc * (PAYLOAD_BYTES + sizeof(Result)), esn0(c), n_of(c) * ROWS_MAX * sizeof(float), hipMemcpyDeviceToHost, s));
 			ev_out[c] = mark(h, s);
 			return 0;
 		}
@@ -1137,7 +1181,7 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
-	launch_polar(h->stream, h->list, (int)n, 0, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(),
+	launch_polar(h->stream, h->list, (int)n, h->polar_grid, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(),
 		h->work_counter.as<int>());
 	launch_finish(h->stream, h->list, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, 0,
 		h->lane_mesg.as<uint8_t>(), h->payload.as<uint8_t>(), h->res.as<Result>());
@@ -1173,7 +1217,7 @@ extern "C" int ofdmrx_debug_decode_llr(ofdmrx_handle *h, const float *llr, size_
 	SyncState *dst = h->st.as<SyncState>();
 	if (cert)
 		launch_syndrome(h->stream, (int)n, dst, h->llr.as<float>(), h->dev, h->hard.as<uint8_t>(), cert);
-	launch_polar(h->stream, 8, (int)n, 0, dst, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(),
+	launch_polar(h->stream, 8, (int)n, h->polar_grid, dst, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(),
 		h->work_counter.as<int>(), cert, 0);
 	launch_finish(h->stream, 8, (int)n, dst, h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble, nullptr,
 		h->payload.as<uint8_t>(), h->res.as<Result>(), cert, 0);

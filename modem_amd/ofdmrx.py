@@ -19,8 +19,8 @@ STAGES = ["front", "sync", "header", "demod", "theilsen", "llr", "polar", "finis
 
 # every symbol include/ofdmrx.h declares
 EXPORTS = [
-    "ofdmrx_abi_version", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
-    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_list_decoded_frames",
+    "ofdmrx_abi_version", "ofdmrx_abi_minor", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
+    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_list_decoded_frames", "ofdmrx_set_esn0_rows",
     "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_decode_llr", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
     "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
     "ofdmrx_tx_encode_device", "ofdmrx_stream_samples", "ofdmrx_tx_encode_stream_device", "ofdmrx_tx_encode_stream",
@@ -107,6 +107,7 @@ def load_library():
     L.ofdmrx_synchronize.argtypes = [C.c_void_p]
     L.ofdmrx_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ofdmrx_chunk_frames.argtypes = [C.c_void_p]
+    L.ofdmrx_set_esn0_rows.argtypes = [C.c_void_p, C.c_void_p]
     L.ofdmrx_list_decoded_frames.argtypes = [C.c_void_p]
     L.ofdmrx_list_decoded_frames.restype = C.c_longlong
     L.ofdmrx_debug_dump.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -186,7 +187,7 @@ class Receiver:
     def _fmt(dtype):
         return {np.dtype(np.int16): FMT_S16, np.dtype(np.uint8): FMT_U8, np.dtype(np.float32): FMT_F32}[np.dtype(dtype)]
 
-    def decode(self, pcm, skip=None):
+    def decode(self, pcm, skip=None, esn0_rows=False):
         pcm = np.ascontiguousarray(pcm)
         if pcm.ndim == 2:
             pcm = pcm[None]
@@ -201,9 +202,20 @@ class Receiver:
         out = np.zeros((n, PAYLOAD_BYTES), np.uint8)
         res = np.zeros(n, RESULT_DTYPE)
         sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.int32)
-        self._check(self._lib.ofdmrx_decode_batch(self._h, _ptr(buf), self._fmt(pcm.dtype), ch, spf, stride, n,
-                                                  _ptr(sk) if sk is not None else None, _ptr(out), _ptr(res)))
-        return out, res
+        rows = np.zeros((n, 126), np.float32) if esn0_rows else None
+        if esn0_rows:
+            self._check(self._lib.ofdmrx_set_esn0_rows(self._h, _ptr(rows)))
+        try:
+            self._check(self._lib.ofdmrx_decode_batch(self._h, _ptr(buf), self._fmt(pcm.dtype), ch, spf, stride, n,
+                                                      _ptr(sk) if sk is not None else None, _ptr(out), _ptr(res)))
+        finally:
+            if esn0_rows:
+                self._lib.ofdmrx_set_esn0_rows(self._h, None)
+        return (out, res, rows) if esn0_rows else (out, res)
+
+    def set_esn0_rows(self, d_rows):
+        """device pointer (int) to n x 126 floats for the decode_device calls that follow, or None"""
+        self._check(self._lib.ofdmrx_set_esn0_rows(self._h, d_rows))
 
     def decode_device(self, d_samples, fmt, channels, spf, stride, n, d_payload, d_results, d_skip=None):
         """device pointers (ints); asynchronous on the handle's stream"""

@@ -17,6 +17,12 @@ REL = 1e-5   # north_star tolerance on fp32 intermediates
 FLIPS_SLACK = 2
 
 
+def _flips_ok(gpu, oracle):
+    """decode.cc:546-555.  Exact where the oracle counts no flip at all (clean and quiet frames: no LLR is near zero there);
+    otherwise a sign within the 1e-5 intermediate tolerance of zero may fall either way (ofdmrx.h)"""
+    return abs(int(gpu) - int(oracle)) <= (FLIPS_SLACK if int(oracle) > 0 else 0)
+
+
 @pytest.fixture(scope="module")
 def rx():
     import modem_amd
@@ -179,6 +185,45 @@ def _polar_transform_bits(u):
     return x
 
 
+def test_esn0_rows_output_for_batches():
+    """ofdmrx_set_esn0_rows: one Es/N0 value per constellation row and frame (decode.cc:506-523) for a whole batch, through the
+    host entry (three chunks, pinned staging) and the device entry, against the oracle's running precision"""
+    import modem_amd
+    import torch
+    pcms, refs = [], []
+    for i, db in enumerate((None, -30, -20, -17, -25, -22, None)):
+        pcm = O.encode_pcm(O.payload_for(300 + i), channels=2)
+        if db is not None:
+            pcm = O.impair(pcm, noise_db=db, seed=41, frame=i)
+        _, res, tb = O.decode(pcm, taps=True)
+        pcms.append(pcm)
+        refs.append(10.0 * np.log10(tb.precision[:50].astype(np.float64)))
+    batch = np.stack(pcms)
+    batch[-1] = 0                                                  # no preamble: every row 0
+    rx = modem_amd.Receiver(device=0, chunk_frames=3)
+    out, res, rows = rx.decode(batch, esn0_rows=True)
+    assert rows.shape == (7, 126)
+    for i in range(6):
+        assert res["status"][i] == 0
+        assert np.abs(rows[i, :50] - refs[i]).max() < 2e-4, (i, np.abs(rows[i, :50] - refs[i]).max())
+        assert (rows[i, 50:] == 0).all()
+        assert abs(rows[i, 49] - res["esn0_db_last"][i]) < 1e-6
+    assert res["status"][6] != 0 and (rows[6] == 0).all()
+    # device entry
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(batch).to(dev)
+    d_out = torch.zeros((7, 5380), dtype=torch.uint8, device=dev)
+    d_res = torch.zeros((7, modem_amd.ofdmrx.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    d_rows = torch.full((7, 126), -1.0, dtype=torch.float32, device=dev)
+    rx.set_esn0_rows(d_rows.data_ptr())
+    spf = batch.shape[1]
+    rx.decode_device(d_in.data_ptr(), modem_amd.ofdmrx.FMT_S16, 2, spf, spf * 4, 7, d_out.data_ptr(), d_res.data_ptr())
+    rx.synchronize()
+    rx.set_esn0_rows(None)
+    assert (d_rows.cpu().numpy() == rows).all()
+    rx.close()
+
+
 def test_syndrome_certificate_is_the_list_decoder(rx):
     """k_syndrome (k_finish.hip): a frame whose channel hard decisions already form a codeword is decided without the list
     decoder - payload, status, best lane and flip count must be what the list decoder gives (decode.cc:530-555).  Clean and
@@ -267,7 +312,7 @@ def _check_against_oracle(rx, pcm, payload, expect_ok=True):
         assert (rx.tap("LLR", 0)[64800:] == 9000).all()
         assert abs(float(r["cfo_fine"]) - ores.cfo_fine) <= REL and abs(float(r["esn0_db_last"]) - ores.esn0_db_last) < 1e-3
     if ores.status == 0:
-        assert abs(int(r["bit_flips"]) - ores.bit_flips) <= FLIPS_SLACK
+        assert _flips_ok(r["bit_flips"], ores.bit_flips)
         best = int(r["best_lane"])
         assert (rx.tap("LANE_MESG", 0)[best][:5380] ^ 0 == tb.lane_mesg[ores.best_lane][:5380]).all()
     return r, ores
@@ -499,7 +544,7 @@ def test_all_modes_of_the_mode_table(rx, mode, channels, freq):
     r = res[0]
     assert ores.status == 0 and int(r["status"]) == 0 and int(r["oper_mode"]) == mode
     assert (out[0] == p).all() and (out[0] == oout).all()
-    assert int(r["sc_start"]) == ores.sc_start and int(r["call_sign"]) == ores.call_sign and abs(int(r["bit_flips"]) - ores.bit_flips) <= FLIPS_SLACK
+    assert int(r["sc_start"]) == ores.sc_start and int(r["call_sign"]) == ores.call_sign and _flips_ok(r["bit_flips"], ores.bit_flips)
     _close(rx.tap("CONS_ROT", 0, cons_cnt=m.cons_cnt), tb.cons_rot[:m.cons_cnt], what="cons_rot")
     _close(rx.tap("PRECISION", 0, rows=m.cons_rows), tb.precision[:m.cons_rows], what="precision")
     _close(rx.tap("LLR", 0)[:m.cons_bits], tb.llr[:m.cons_bits], what="llr")
@@ -905,7 +950,7 @@ def test_chunk_pipeline_at_16k():
     assert (o3 == o16).all() and (r3["status"] == 0).all() and (r3["sc_start"] == r16["sc_start"]).all()
     assert (o3 == np.stack(pays)).all()
     o, r = O.decode(pcm[7], rate=rate)
-    assert r.status == 0 and (o == o3[7]).all() and r.sc_start == int(r3["sc_start"][7]) and abs(r.bit_flips - int(r3["bit_flips"][7])) <= FLIPS_SLACK
+    assert r.status == 0 and (o == o3[7]).all() and r.sc_start == int(r3["sc_start"][7]) and _flips_ok(r.bit_flips, r3["bit_flips"][7])
 
 
 def test_host_pointer_entry_runs_the_chunk_pipeline():
@@ -1103,7 +1148,7 @@ def test_configs_2_and_3_at_full_size(impair):
     for f, p, r in zip(frames, pays, res[pick]):
         o, orr = O.decode(f)
         assert orr.status == 0 and (o == p).all() and orr.sc_start == int(r["sc_start"]) and orr.symbol_pos == int(r["symbol_pos"])
-        assert abs(orr.cfo_rad - float(r["cfo_rad"])) <= REL and abs(orr.bit_flips - int(r["bit_flips"])) <= FLIPS_SLACK
+        assert abs(orr.cfo_rad - float(r["cfo_rad"])) <= REL and _flips_ok(r["bit_flips"], orr.bit_flips)
     rx.close()
 
 
