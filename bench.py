@@ -134,18 +134,23 @@ def cpu_baseline(pcm_sample, payload_ref, ch=2):
     for tag, L in libs.items():
         run(L, min(n, threads), threads)        # untimed: one frame per thread populates the threads' malloc arenas and tables
         variants[tag] = run(L, n, threads)
-    best = "o3_native" if "o3_native" in variants else "o2_strict"
-    one = run(libs[best], min(n, max(8, int(variants[best]["frames_per_s"] / threads * 4))), 1)
-    variants[best + "_1thread"] = one
-    v = variants[best]
+    one_tag = "o3_native" if "o3_native" in variants else "o2_strict"
+    one = run(libs[one_tag], min(n, max(8, int(variants[one_tag]["frames_per_s"] / threads * 4))), 1)
+    full = {k: v for k, v in variants.items() if v["payloads_correct"] == v["frames"]} or dict(variants)
+    best = max(full, key=lambda k: full[k]["frames_per_s"])        # the headline is the FASTEST build (round-2 verdict, weak 8)
+    v = full[best]
+    rates = sorted(x["frames_per_s"] for x in variants.values())
+    variants[one_tag + "_1thread"] = one
+    desc = {"o2_strict": "gcc -O2, strict IEEE, no contraction (the parity oracle)", "o3_native": "gcc -O3 -march=native, strict IEEE",
+            "ofast_native": "gcc -Ofast -march=native (the reference's Makefile:2 flags; speed only)"}
     return {"value": v["frames_per_s"], "unit": "frames/s", "cores": v["threads"], "kind": "port", "host_cores": host_cores,
             "value_1thread": one["frames_per_s"],
             "sample": "first %d frames of this batch; oracle = C restatement of decode.cc (the reference itself cannot be built: "
-                      "aicodix/dsp + aicodix/code absent), list 8; headline = gcc -O3 -march=native strict IEEE on %d OpenMP threads "
-                      "of %d host cores (%d/%d payloads correct, %.1f s); 1-thread %.2f frames/s; -Ofast -march=native "
-                      "(reference Makefile:2 flags) %s"
-                      % (n, v["threads"], host_cores, v["payloads_correct"], n, v["wall_s"], one["frames_per_s"],
-                         ("%.0f frames/s" % variants["ofast_native"]["frames_per_s"]) if "ofast_native" in variants else "n/a"),
+                      "aicodix/dsp + aicodix/code absent), list 8; headline = the fastest of the builds timed here: %s, on %d OpenMP "
+                      "threads of %d host cores (%d/%d payloads correct, %.1f s); the builds span %.0f - %.0f frames/s on all threads; "
+                      "1 thread (%s): %.2f frames/s"
+                      % (n, desc.get(best, best), v["threads"], host_cores, v["payloads_correct"], n, v["wall_s"], rates[0], rates[-1],
+                         one_tag, one["frames_per_s"]),
             "variants": variants}
 
 
@@ -338,7 +343,8 @@ def main():
                                      list_size=args.list, scl_always=True)
             d_out2 = torch.zeros((B, 5380), dtype=torch.uint8, device=dev)
             d_res2 = torch.zeros((B, RES), dtype=torch.uint8, device=dev)
-            rx2.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out2.data_ptr(), d_res2.data_ptr())
+            for _ in range(2):       # first call allocates, second warms the pipeline
+                rx2.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out2.data_ptr(), d_res2.data_ptr())
         fence()
         t0 = time.perf_counter()
         for s in range(scl_steps):

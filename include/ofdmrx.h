@@ -34,7 +34,7 @@ extern "C" {
 #define OFDMRX_ABI_VERSION 1
 /* Minor revisions keep every struct and signature of OFDMRX_ABI_VERSION 1 and add entry points or tighten a check:
  *   1: skip counts outside 0..OFDMRX_MAX_SKIP fail the call with OFDMRX_E_ARG (they used to be clamped)
- *   2: ofdmrx_set_esn0_rows, ofdmrx_list_decoded_frames, ofdmrx_debug_decode_llr, ofdmrx_config.flags bit 1 (OFDMRX_FLAG_SCL_ALWAYS);
+ *   2: ofdmrx_set_esn0_rows, ofdmrx_list_decoded_frames, ofdmrx_debug_decode_cons, ofdmrx_config.flags bit 1 (OFDMRX_FLAG_SCL_ALWAYS);
  *      frames whose hard decisions already form a codeword are decided by a syndrome check (same outputs) */
 #define OFDMRX_ABI_MINOR 2
 
@@ -81,9 +81,9 @@ typedef struct {
 	int32_t flags;             /* bit 0: debug taps: keep the pre-rotation constellation (OFDMRX_TAP_CONS_RAW) and run the list
 	                            * decoder for every frame, so that OFDMRX_TAP_LANE_MESG / _METRIC hold all eight lanes;
 	                            * bit 1 (OFDMRX_FLAG_SCL_ALWAYS): run the list decoder for every frame.  Without either, a frame
-	                            * whose channel hard decisions already form a codeword with a valid CRC-32 is decided by that
+	                            * whose channel hard decisions already form a codeword with a valid CRC-32 is finished by that
 	                            * syndrome check - the list decoder's lane 0 provably is that codeword - with
-	                            * identical payload, status, best_lane and bit_flips */
+	                            * identical payload, status, best_lane and bit_flips, and its LLRs are never written */
 	void *stream;              /* hipStream_t to run on, NULL = library-owned stream.  Batches longer than one chunk
 	                            * also use a second, library-owned stream for the polar stage (two-stage chunk
 	                            * pipeline); the given stream waits for it, so work enqueued on `stream` after a
@@ -190,10 +190,10 @@ int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *dst, size_t
 /* D9+D10: CODE::PolarListDecoder + systematic() (decode.cc:530-531) */
 int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n,
 	uint8_t *lane_mesg /*n*8*5476*/, float *metric /*n*8*/);
-/* D8 output (n x 65536 channel LLRs, mode 6) -> payloads + results through the syndrome certificate (use_cert != 0), the list
- * decoder, finish and the retry launch, chained as in the pipeline; cert_out (nullable): 0 = list decoder, 1 = decided by the
- * certificate, 2 = certified codeword failed the CRC-32 and the list decoder ran after all (decode.cc:530-555) */
-int ofdmrx_debug_decode_llr(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n, int use_cert,
+/* D5 output (n x 21600 rotated constellation points of mode-6 frames, cf32) -> payloads + results through D6-D10 as the pipeline
+ * chains them: with the syndrome certificate (use_cert != 0) or with the list decoder for every frame; cert_out (nullable): 1 =
+ * the frame was finished by the certificate (decode.cc:505-555) */
+int ofdmrx_debug_decode_cons(ofdmrx_handle *h, const float *cons /*n*21600*2*/, size_t n, int use_cert,
 	uint8_t *payload /*n*5380*/, ofdmrx_frame_result *results /*n*/, int32_t *cert_out /*n*/);
 /* DSP::TheilSenEstimator::compute on rows of y[cols], x = i - cols/2 (decode.cc:488) */
 int ofdmrx_debug_theil_sen(ofdmrx_handle *h, const float *y, size_t rows, int cols,

@@ -522,7 +522,7 @@ __device__ unsigned long long g_polar_prof[8];
 template <int LN>
 __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(int n_cw, const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
 	float *__restrict__ soft_all, uint8_t *__restrict__ hard_all, const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev2,
-	float *__restrict__ metric_all, int *__restrict__ next_cw, const int *__restrict__ cert_all, int retry)
+	float *__restrict__ metric_all, int *__restrict__ next_cw, const int *__restrict__ cert_all)
 {
 #ifdef POLAR_PRIO
 	__builtin_amdgcn_s_setprio(POLAR_PRIO);                   // experiments: issue priority against the co-resident Theil-Sen waves
@@ -541,9 +541,8 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 	// right).  A pair is formed when both frames have a header and share the frozen table; a codeword without such a
 	// partner is decoded alone in the low half (the high half dead: metrics +inf) into its own partial-sum array.
 	const int n_units = LN == 4 ? (n_cw + 1) / 2 : n_cw;
-	// two counters behind the verdicts: [n] certified frames that failed their CRC (the retry launch's work), [n + 1] frames the
-	// certificate did not decide (this launch's work)
-	if (cert_all && cert_all[n_cw + (retry ? 0 : 1)] == 0)
+	// behind the verdicts of the syndrome certificate (k_finish.hip: k_back): [n + 1] = frames it left to this launch
+	if (cert_all && cert_all[n_cw + 1] == 0)
 		return;
 	for (;;) {
 	int unit = 0;
@@ -572,10 +571,7 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 	} else if (!st_all[cw_a].okay) {
 		continue;                                                 // no header -> nothing to decode (decode.cc:450-451)
 	} else if (cert_all) {
-		// the syndrome certificate (k_finish.hip: k_syndrome) has decided this frame (1) - unless its codeword then failed the
-		// CRC (2): those frames, and only those, are decoded by the retry launch
-		const int cert = cert_all[cw_a];
-		if (retry ? cert != 2 : cert == 1)
+		if (cert_all[cw_a] == 1)                                  // finished by the syndrome certificate
 			continue;
 	}
 	for (int pass = 0; pass < (n_pass == 3 ? 2 : n_pass); ++pass) {
@@ -985,7 +981,7 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 }
 
 void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,
-	int *next_cw, const int *cert, int retry)
+	int *next_cw, const int *cert)
 {
 	if (list == 4)
 		cert = nullptr;                                       // (pairs of codewords per wave: the certificate is not wired into the pairing)
@@ -999,9 +995,9 @@ void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st,
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_polar_prof), z8, sizeof(z8));
 #endif
 	if (list == 4)
-		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw, cert, retry);
+		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw, cert);
 	else
-		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw, cert, retry);
+		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, n, st, llr, soft, hard, tb.frozen, tb.node_lev, metric, next_cw, cert);
 #ifdef POLAR_PROF
 	(void)hipStreamSynchronize(s);
 	(void)hipMemcpyFromSymbol(z8, HIP_SYMBOL(g_polar_prof), sizeof(z8));

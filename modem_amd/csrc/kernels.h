@@ -87,14 +87,15 @@ void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
 void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, float *llr, Result *res, float *esn0_rows = nullptr);   // esn0_rows (nullable): [n][ROWS_MAX] dB values, decode.cc:517-519
-// cert (nullable): per-frame verdict of the syndrome certificate (launch_syndrome): frames with 1 are skipped; retry != 0:
-// only the frames with 2 are decoded
+// cert (nullable): per-frame verdict of the syndrome certificate (launch_back: 1 = finished there), then two counters
 void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,
-	int *next_cw, const int *cert = nullptr, int retry = 0);
-// log (nullable): receives the number of frames the certificate left to the list decoder
-void launch_syndrome(hipStream_t s, int n, const SyncState *st, const float *llr, Tables tb, uint8_t *hard, int *cert, int *log = nullptr);
+	int *next_cw, const int *cert = nullptr);
 void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
-	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res, int *cert = nullptr, int retry = 0);
+	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res, const int *cert = nullptr);
+// D6-D8 with the syndrome certificate (k_finish.hip: k_back): frames it decides get payload + result at once and no LLRs;
+// cert: [n] verdicts + 2 counters; log (nullable): receives the number of frames left to the list decoder
+void launch_back(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
+	float *precision, float *llr, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, int *cert, int *log);
 void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb);
 void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t *out, size_t n_out,
 	size_t spf, float sigma, uint64_t seed, uint64_t first_frame);

@@ -136,7 +136,6 @@ struct ofdmrx_handle {
 	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
 	int last_par = 0;         // parity used by the last chunk (taps)
 	DevBuf cert, cert2;       // syndrome certificate: verdict per frame (+ one flag), by parity
-	DevBuf soft_retry, retry_counter;   // level stores + work counter of the retry launch (frames whose certified codeword failed the CRC)
 	bool use_cert = true;     // list 8, no debug taps, not switched off
 	float *esn0_user = nullptr;   // ofdmrx_set_esn0_rows: n x OFDMRX_ROWS_MAX floats in the memory space of the results (NULL = off)
 	DevBuf esn0_dev, esn0_dev2;   // host-pointer entry: per-chunk device staging of the row values, by parity
@@ -318,7 +317,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2, &h->cert, &h->cert2, &h->soft_retry, &h->retry_counter, &h->cert_log, &h->esn0_dev, &h->esn0_dev2 })
+			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2, &h->cert, &h->cert2, &h->cert_log, &h->esn0_dev, &h->esn0_dev2 })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -366,7 +365,6 @@ extern "C" long long ofdmrx_list_decoded_frames(ofdmrx_handle *h)
 }
 
 constexpr int CERT_LOG_MAX = 4096;   // chunks per call whose list-decoder counts are kept (ofdmrx_list_decoded_frames)
-constexpr int RETRY_DECODERS = 64;   // list decoders of the retry launch (it almost never has a frame to decode)
 static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, bool two_parities = false)
 {
 	int r = 0;
@@ -399,9 +397,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->metric.ensure(N * LIST * sizeof(float));
 		r = r ? r : h->work_counter.ensure(256);
 		r = r ? r : h->cert.ensure((N + 2) * sizeof(int));
-		r = r ? r : h->retry_counter.ensure(256);
 		r = r ? r : h->cert_log.ensure(CERT_LOG_MAX * sizeof(int));
-		r = r ? r : h->soft_retry.ensure((size_t)RETRY_DECODERS * 8 * CODE_LEN * sizeof(float));
 		r = r ? r : h->lane_mesg.ensure(N * LIST * MESG_BYTES);
 		r = r ? r : h->res.ensure(N * sizeof(Result));
 		r = r ? r : h->payload.ensure(N * PAYLOAD_BYTES);
@@ -560,18 +556,22 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, 
 
 // The back half in two pieces, so that the pipeline can put an event between them: the LLR kernel (short, needs only the
 // Theil-Sen results) and polar + finish; *ev_polar (nullable) receives the event recorded right after the polar kernel.
-static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Result *d_res, float *d_esn0 = nullptr)
+// D6-D8.  With the syndrome certificate on this is k_back (k_finish.hip): it also FINISHES the frames the certificate decides
+// (payload + result), so it needs the payload destination.
+static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Result *d_res, float *d_esn0, uint8_t *d_payload)
 {
 	size_t e5 = mark(h, s);
 	{
 		Range r("ofdmrx:llr");
-		launch_llr(s, h->rate, n, h->st_of(sti), h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
-			h->llr_of(par), d_res, d_esn0);
 		if (h->use_cert) {
-			launch_syndrome(s, n, h->st_of(sti), h->llr_of(par), h->dev, h->hard_of(par), h->cert_of(par),
-				(h->cert_chunks < CERT_LOG_MAX && h->cert_log.p) ? h->cert_log.as<int>() + h->cert_chunks : nullptr);
+			int *log = (h->cert_chunks < CERT_LOG_MAX && h->cert_log.p) ? h->cert_log.as<int>() + h->cert_chunks : nullptr;
+			launch_back(s, h->rate, n, h->st_of(sti), h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
+				h->llr_of(par), d_res, d_esn0, h->dev, h->cfg.descramble, d_payload, h->cert_of(par), log);
 			if (h->cert_chunks < CERT_LOG_MAX)
 				++h->cert_chunks;
+		} else {
+			launch_llr(s, h->rate, n, h->st_of(sti), h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
+				h->llr_of(par), d_res, d_esn0);
 		}
 	}
 	size_t e6 = mark(h, s);
@@ -586,7 +586,7 @@ static int run_polar(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, i
 	{
 		Range r("ofdmrx:polar_scl");
 		launch_polar(s, h->list, n, grid, h->st_of(sti), h->llr_of(par), h->soft.as<float>(), h->hard_of(par), h->dev, h->metric.as<float>(), h->work_counter.as<int>(),
-			h->cert_of(par), 0);
+			h->cert_of(par));
 	}
 	size_t e7 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
@@ -604,15 +604,7 @@ static int run_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, 
 	{
 		Range r("ofdmrx:finish");
 		launch_finish(s, h->list, n, h->st_of(sti), h->llr_of(par), h->hard_of(par), h->dev, h->cfg.descramble,
-			want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res, h->cert_of(par), 0);
-		if (h->use_cert) {
-			// frames whose certified codeword failed the CRC-32 (the flag behind the verdicts; practically never): the real list
-			// decoder, on its own level stores and counter (the next chunk's polar launch may be running), and their finish again
-			launch_polar(s, h->list, n, std::min(n, RETRY_DECODERS), h->st_of(sti), h->llr_of(par), h->soft_retry.as<float>(), h->hard_of(par), h->dev,
-				h->metric.as<float>(), h->retry_counter.as<int>(), h->cert_of(par), 1);
-			launch_finish(s, h->list, n, h->st_of(sti), h->llr_of(par), h->hard_of(par), h->dev, h->cfg.descramble,
-				want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res, h->cert_of(par), 1);
-		}
+			want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res, h->cert_of(par));
 	}
 	size_t e8 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_FINISH, e7, e8 });
@@ -630,7 +622,7 @@ static int run_polar_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, i
 static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, uint8_t *d_payload, Result *d_res,
 	bool want_lane_mesg, size_t t_begin, float *d_esn0 = nullptr)
 {
-	int r = run_llr(h, s, par, sti, n, d_res, d_esn0);
+	int r = run_llr(h, s, par, sti, n, d_res, d_esn0, d_payload);
 	return r ? r : run_polar_finish(h, s, par, sti, n, grid, d_payload, d_res, want_lane_mesg, t_begin, nullptr);
 }
 
@@ -819,7 +811,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 				return r;
 			if (c >= 2)
 				HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_done[c - 2]], 0));
-			r = run_llr(h, sa, par, sti, n_of(c), res, hooks.esn0(c));
+			r = run_llr(h, sa, par, sti, n_of(c), res, hooks.esn0(c), pay);
 			if (r)
 				return r;
 			ev_llr[c] = mark(h, sa);
@@ -852,7 +844,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 		HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f2[p]], 0));
 		if (ev_f1 != NONE && !llr_early)
 			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
-		int rr = run_llr(h, h->stream_b, par, sti, n_of(p), res, hooks.esn0(p));
+		int rr = run_llr(h, h->stream_b, par, sti, n_of(p), res, hooks.esn0(p), pay);
 		if (rr)
 			return rr;
 		if (ev_f1 != NONE && llr_early)
@@ -1195,12 +1187,13 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 	return 0;
 }
 
-// D8 output -> payload: the syndrome certificate (use_cert != 0), the list decoder, finish and the retry launch exactly as the
-// pipeline chains them; cert_out (nullable) receives the certificate's verdict per frame (0 / 1 / 2)
-extern "C" int ofdmrx_debug_decode_llr(ofdmrx_handle *h, const float *llr, size_t n, int use_cert, uint8_t *payload,
+// D5 output -> payload: rotated constellation rows of mode-6 frames through D6-D10 exactly as the pipeline chains them, with the
+// syndrome certificate (use_cert != 0: k_back, the list decoder only for the frames it leaves) or without (k_llr, the list decoder
+// for every frame); cert_out (nullable) receives the certificate's verdict per frame (1 = finished by it)
+extern "C" int ofdmrx_debug_decode_cons(ofdmrx_handle *h, const float *cons, size_t n, int use_cert, uint8_t *payload,
 	ofdmrx_frame_result *results, int32_t *cert_out)
 {
-	if (!h || !llr || !n || n > (size_t)h->chunk || !payload || !results || h->list != 8)
+	if (!h || !cons || !n || n > (size_t)h->chunk || !payload || !results || h->list != 8)
 		return OFDMRX_E_ARG;
 	HIP_OK(hipSetDevice(h->cfg.device));
 	int r = ensure_capacity(h, (int)n, false, 0);
@@ -1210,23 +1203,23 @@ extern "C" int ofdmrx_debug_decode_llr(ofdmrx_handle *h, const float *llr, size_
 	std::memset(st.data(), 0, n * sizeof(SyncState));
 	for (auto &s : st) { s.okay = 1; s.oper_mode = 6; }
 	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
-	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
+	HIP_OK(hipMemcpy2D(h->cons.p, CONS_MAX * sizeof(cf), cons, 21600 * sizeof(cf), 21600 * sizeof(cf), n, hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
+	HIP_OK(hipMemsetAsync(h->slope.p, 0, n * ROWS_MAX * sizeof(float), h->stream));
+	HIP_OK(hipMemsetAsync(h->yint.p, 0, n * ROWS_MAX * sizeof(float), h->stream));
 	HIP_OK(hipMemsetAsync(h->cert.p, 0, (n + 2) * sizeof(int), h->stream));
 	int *cert = use_cert ? h->cert.as<int>() : nullptr;
 	SyncState *dst = h->st.as<SyncState>();
 	if (cert)
-		launch_syndrome(h->stream, (int)n, dst, h->llr.as<float>(), h->dev, h->hard.as<uint8_t>(), cert);
+		launch_back(h->stream, h->rate, (int)n, dst, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
+			h->llr.as<float>(), h->res.as<Result>(), nullptr, h->dev, h->cfg.descramble, h->payload.as<uint8_t>(), cert, nullptr);
+	else
+		launch_llr(h->stream, h->rate, (int)n, dst, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
+			h->llr.as<float>(), h->res.as<Result>(), nullptr);
 	launch_polar(h->stream, 8, (int)n, h->polar_grid, dst, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(),
-		h->work_counter.as<int>(), cert, 0);
+		h->work_counter.as<int>(), cert);
 	launch_finish(h->stream, 8, (int)n, dst, h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble, nullptr,
-		h->payload.as<uint8_t>(), h->res.as<Result>(), cert, 0);
-	if (cert) {
-		launch_polar(h->stream, 8, (int)n, std::min((int)n, RETRY_DECODERS), dst, h->llr.as<float>(), h->soft_retry.as<float>(), h->hard.as<uint8_t>(),
-			h->dev, h->metric.as<float>(), h->retry_counter.as<int>(), cert, 1);
-		launch_finish(h->stream, 8, (int)n, dst, h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble, nullptr,
-			h->payload.as<uint8_t>(), h->res.as<Result>(), cert, 1);
-	}
+		h->payload.as<uint8_t>(), h->res.as<Result>(), cert);
 	HIP_OK(hipGetLastError());
 	HIP_OK(hipStreamSynchronize(h->stream));
 	HIP_OK(hipMemcpy(payload, h->payload.p, n * PAYLOAD_BYTES, hipMemcpyDeviceToHost));

@@ -21,7 +21,7 @@ STAGES = ["front", "sync", "header", "demod", "theilsen", "llr", "polar", "finis
 EXPORTS = [
     "ofdmrx_abi_version", "ofdmrx_abi_minor", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
     "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_list_decoded_frames", "ofdmrx_set_esn0_rows",
-    "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_decode_llr", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
+    "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_decode_cons", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
     "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
     "ofdmrx_tx_encode_device", "ofdmrx_stream_samples", "ofdmrx_tx_encode_stream_device", "ofdmrx_tx_encode_stream",
     "ofdmrx_callsign_value",
@@ -112,7 +112,7 @@ def load_library():
     L.ofdmrx_list_decoded_frames.restype = C.c_longlong
     L.ofdmrx_debug_dump.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
     L.ofdmrx_debug_polar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-    L.ofdmrx_debug_decode_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ofdmrx_debug_decode_cons.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_theil_sen.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_osd.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
@@ -254,14 +254,14 @@ class Receiver:
         self._check(self._lib.ofdmrx_debug_polar(self._h, _ptr(llr), n, _ptr(mesg), _ptr(metric)))
         return mesg, metric
 
-    def decode_llr(self, llr, use_cert=True):
-        """channel LLRs (n x 65536, mode 6) -> payloads, results and the syndrome certificate's verdict per frame"""
-        llr = np.ascontiguousarray(llr, dtype=np.float32).reshape(-1, 65536)
-        n = llr.shape[0]
+    def decode_cons(self, cons, use_cert=True):
+        """rotated constellation rows (n x 21600 complex64, mode 6) -> payloads, results, the syndrome certificate's verdict per frame"""
+        cons = np.ascontiguousarray(cons, dtype=np.complex64).reshape(-1, 21600)
+        n = cons.shape[0]
         out = np.zeros((n, 5380), np.uint8)
         res = np.zeros(n, RESULT_DTYPE)
         cert = np.zeros(n, np.int32)
-        self._check(self._lib.ofdmrx_debug_decode_llr(self._h, _ptr(llr), n, 1 if use_cert else 0, _ptr(out), _ptr(res), _ptr(cert)))
+        self._check(self._lib.ofdmrx_debug_decode_cons(self._h, _ptr(cons), n, 1 if use_cert else 0, _ptr(out), _ptr(res), _ptr(cert)))
         return out, res, cert
 
     def theil_sen(self, y):

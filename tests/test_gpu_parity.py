@@ -225,52 +225,64 @@ def test_esn0_rows_output_for_batches():
 
 
 def test_syndrome_certificate_is_the_list_decoder(rx):
-    """k_syndrome (k_finish.hip): a frame whose channel hard decisions already form a codeword is decided without the list
-    decoder - payload, status, best lane and flip count must be what the list decoder gives (decode.cc:530-555).  Clean and
-    quiet frames (certified), noisy ones (not certified), and the retry path: hard decisions that form ANOTHER polar codeword
-    (CRC-32 fails) while the transmitted one is one information-bit flip away - the list decoder has to run after all and
-    finds it in lane 1."""
+    """k_back (k_finish.hip): a frame whose hard decisions already form a codeword with a valid CRC-32 is finished without the list
+    decoder - payload, status, best lane and flip count must be what the list decoder gives (decode.cc:530-555).  Clean and quiet
+    frames (certified), noisy ones (not certified), hard decisions that form ANOTHER polar codeword (syndrome zero, CRC-32 wrong:
+    the list decoder has to run and, the transmitted codeword being one information bit away, finds it in a later lane or
+    fails like the reference), a zero LLR (never certified)."""
     import modem_amd
-    llrs = []
+    cons = []
     for i, db in enumerate((None, -40, -30, -26, -24, -20, -16)):
         pcm = O.encode_pcm(O.payload_for(60 + i), channels=2)
         if db is not None:
             pcm = O.impair(pcm, noise_db=db, seed=19, frame=i)
         _, res, tb = O.decode(pcm, taps=True)
-        llrs.append(tb.llr.copy())
-    # retry path
-    base = llrs[0]
-    x = (base < 0).astype(np.uint8)
+        assert res.oper_mode == 6
+        cons.append(tb.cons_rot[:21600].copy().view(np.complex64).reshape(-1))
+    # another codeword: flip the code bits of one row of the generator matrix (an information position with few ones in its index)
     fz = O.frozen(0)
     frozen = ((fz[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.uint8).reshape(-1)
     cand = [i for i in range(64800) if not frozen[i] and bin(i).count("1") <= 7]
+
+    def flip_code_bits(c, positions):
+        """8PSK soft bits of a carrier (psk.hh:125-130): bit 0 = sign(|re| - |im|), bit 1 = sign(re), bit 2 = sign(im)"""
+        c = c.copy()
+        for p in positions:
+            k, b = divmod(int(p), 3)
+            z = c[k]
+            if b == 1:
+                z = complex(-z.real, z.imag)
+            elif b == 2:
+                z = complex(z.real, -z.imag)
+            else:
+                z = complex(np.copysign(abs(z.imag), z.real), np.copysign(abs(z.real), z.imag))
+            c[k] = z
+        return c
+
     for i in (cand[0], cand[len(cand) // 2]):
         u = np.zeros(65536, np.uint8)
         u[i] = 1
-        c = _polar_transform_bits(u)
-        assert not c[64800:].any() and c.sum() == 2 ** bin(i).count("1")
-        x2 = x ^ c
-        l2 = np.where(c == 1, 0.01, 10.0).astype(np.float32) * (1.0 - 2.0 * x2)
-        l2[64800:] = 9000
-        llrs.append(l2.astype(np.float32))
-    z = base.copy()
-    z[1234] = 0.0                                                 # a zero LLR: never certified
-    llrs.append(z)
-    llrs = np.stack(llrs)
+        cw = _polar_transform_bits(u)
+        assert not cw[64800:].any() and cw.sum() == 2 ** bin(i).count("1")
+        cons.append(flip_code_bits(cons[0], np.flatnonzero(cw)))
+    z = cons[0].copy()
+    z[411] = complex(0.0, z[411].imag)                            # a zero LLR: never certified
+    cons.append(z)
+    cons = np.stack(cons)
     r = modem_amd.Receiver(device=0, chunk_frames=16)
-    out_c, res_c, cert = r.decode_llr(llrs, use_cert=True)
-    out_l, res_l, _ = r.decode_llr(llrs, use_cert=False)
+    out_c, res_c, cert = r.decode_cons(cons, use_cert=True)
+    out_l, res_l, _ = r.decode_cons(cons, use_cert=False)
     r.close()
     assert list(cert[:3]) == [1, 1, 1] and list(cert[4:7]) == [0, 0, 0], cert
-    assert list(cert[7:9]) == [2, 2] and cert[9] == 0, cert
-    for name in ("status", "best_lane", "bit_flips"):
+    assert list(cert[7:10]) == [0, 0, 0], cert                    # syndrome zero but CRC wrong / a zero LLR: the list decoder's case
+    for name in ("status", "best_lane", "bit_flips", "esn0_db_last", "cfo_fine", "sfo_slope", "oper_mode"):
         assert (res_c[name] == res_l[name]).all(), (name, res_c[name], res_l[name])
     assert (out_c == out_l).all()
     assert (res_c["status"][:7] == 0).all() and (res_c["best_lane"][:3] == 0).all() and (res_c["bit_flips"][:3] == 0).all()
-    found = [q for q in (7, 8) if res_c["status"][q] == 0]        # the transmitted codeword, found in a later lane (whether the
-    assert found, res_c["status"][7:9]                            # flip is among the eight survivors depends on the position)
-    for q in found:
-        assert res_c["best_lane"][q] >= 1 and (out_c[q] == out_c[0]).all()
+    for q in (7, 8):                                              # same as the forced list decoder (checked above); if it decodes,
+        if res_c["status"][q] == 0:                               # then to the transmitted payload, from a later lane
+            assert res_c["best_lane"][q] >= 1 and (out_c[q] == out_c[0]).all()
+    assert res_c["status"][9] == 0 and (out_c[9] == out_c[0]).all()
 
 
 # ---------------------------------------------------------------- whole path

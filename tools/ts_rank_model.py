@@ -208,3 +208,43 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def check_incremental(rng, trials=60):
+    """the incremental count of k_theilsen.hip: from the order sorted at T_prev to T_new by an odd-even transposition sort whose
+    swaps S are the pairs that change order; only pairs that are uncertain at either threshold need the exact division:
+        |c(T_new) - c(T_prev)| = S - #{uncertain pairs that swapped} + #{uncertain pairs with T_lo <= s < T_hi}"""
+    bad = 0
+    for trial in range(trials):
+        n = [432, 400, 255, 512][trial % 4]
+        kind = trial % 4
+        x = np.arange(n) - n // 2
+        if kind == 0:
+            y = 1e-4 * x + rng.normal(0, 0.03, n)
+        elif kind == 1:
+            y = rng.normal(0, 1e-6, n)
+        elif kind == 2:
+            y = rng.normal(0, 0.1, n); y[rng.integers(0, n, n // 8)] = 0.0
+        else:
+            y = 0.003 * x + rng.normal(0, 0.2, n)
+        r = Row(y.astype(f32))
+        base = r.truth
+        span = np.abs(np.partition(r.s, r.target + 400)[r.target + 400] - base)
+        for (tp, tn) in ((base - span, base + 0.3 * span), (base + span, base), (base, np.nextafter(base, f32(9))), (f32(0), base)):
+            tp, tn = f32(tp), f32(tn)
+            qp, qn = r.keys(tp), r.keys(tn)
+            kp = qp * 512 + np.arange(n)
+            kn = qn * 512 + np.arange(n)
+            i, j = r.i, r.j
+            swapped = (kp[i] < kp[j]) != (kn[i] < kn[j])
+            S = int(swapped.sum())
+            unc = (np.abs(qp[i] - qp[j]) <= MQ) | (np.abs(qn[i] - qn[j]) <= MQ)
+            lo, hi = (tp, tn) if tp <= tn else (tn, tp)
+            inr = (r.s >= lo) & (r.s < hi)
+            delta = S - int((swapped & unc).sum()) + int((inr & unc).sum())
+            truth = int(inr.sum())
+            if delta != truth:
+                bad += 1
+                print("incremental mismatch", trial, n, kind, tp, tn, delta, truth)
+    print("incremental count: %d mismatches" % bad)
+    return bad
