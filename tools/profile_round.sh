@@ -59,7 +59,7 @@ def calib(kern, ctr):
     m = re.search(r"^%s\s+%s\s+calls\s+(\d+)\s+sum\s+([0-9.]+)" % (re.escape(kern), ctr), txt, re.M)
     return float(m.group(2)) / int(m.group(1))
 stages = {"sync": ("cert", "k_sync", "k_sync.hip"), "header": ("cert", "k_header", "k_header.hip"), "demod": ("cert", "k_demod", "k_demod.hip"),
-          "theilsen": ("cert", "k_theil_sen", "k_theilsen.hip"), "llr": ("cert", "k_llr", "k_demod.hip"), "finish": ("cert", "k_finish", "k_finish.hip"),
+          "theilsen": ("cert", "k_theil_sen", "k_theilsen.hip"), "llr": ("cert", "k_back", "k_finish.hip"), "finish": ("cert", "k_finish", "k_finish.hip"),
           "polar": ("scl", "k_polar", "k_polar.hip")}
 out = {"frames_per_launch": 8192, "fetch_scale": 2097152.0 / calib("calib_read", "FETCH_SIZE"), "write_scale": 2097152.0 / calib("calib_write", "WRITE_SIZE"),
        "kernels": {},
@@ -68,9 +68,6 @@ out = {"frames_per_launch": 8192, "fetch_scale": 2097152.0 / calib("calib_read",
                  "bytes of tools/pmc_calib.hip (2 GiB per kernel, one dword per lane) in the same session"}
 for st, (mode, kern, src) in stages.items():
     f, w = grab(mode, kern, "FETCH_SIZE"), grab(mode, kern, "WRITE_SIZE")
-    if st == "llr":      # the stage timer spans k_llr + k_syndrome
-        f2, w2 = grab(mode, "k_syndrome", "FETCH_SIZE"), grab(mode, "k_syndrome", "WRITE_SIZE")
-        f, w = (f or 0) + (f2 or 0), (w or 0) + (w2 or 0)
     if f is not None and w is not None:
         out["kernels"][st] = {"kernel": kern, "fetch_KiB": f, "write_KiB": w, "src_sha": sha(src)}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
