@@ -965,6 +965,48 @@ def test_chunk_pipeline_at_16k():
     assert r.status == 0 and (o == o3[7]).all() and r.sc_start == int(r3["sc_start"][7]) and _flips_ok(r.bit_flips, r3["bit_flips"][7])
 
 
+def test_default_chunk_pipeline_at_48k():
+    """the DEFAULT chunk (8192 frames) three-queue pipeline at 48 kHz, two full chunks and a ragged third (round-2 verdict, weak 7):
+    16 500 mode-6 frames made on the device at a noise level of -14 dB (per carrier what -22 dB is at 8 kHz: most frames need the list decoder), all decoded to their
+    payloads; four frames re-decoded by the oracle: payload, status, sync position, header fields, flip count"""
+    import modem_amd
+    import torch
+    import modem_amd.ofdmrx as M
+    rate, n = 48000, 16500
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        rx = modem_amd.Receiver(device=0, stream=stream.cuda_stream, sample_rate=rate)
+        assert rx.chunk_frames == 8192
+        spf = rx.tx_frame_samples(6)
+        g = torch.Generator(device=dev)
+        g.manual_seed(4848)
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+        d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+        for lo in range(0, n, 4096):                               # (the transmitter's scratch is per call)
+            hi = min(lo + 4096, n)
+            rx.tx_encode(d_pay[lo:hi].data_ptr(), hi - lo, d_in[lo:hi].data_ptr(), mode=6, freq_off=2000, call_sign="ANONYMOUS", channels=2)
+        rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, -14.0, 77, 0)
+        d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+        rx.synchronize()
+        assert rx.list_decoded_frames() > n // 2
+        res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+        assert (res["status"] == 0).all()
+        assert bool((d_out == d_pay).all().item())
+        for f in (0, 8191, 8192, n - 1):                           # both sides of a chunk boundary, the ragged tail
+            pcm = d_in[f].cpu().numpy()
+            o, r = O.decode(pcm, rate=rate)
+            assert r.status == 0 and (o == d_out[f].cpu().numpy()).all()
+            assert r.sc_start == int(res["sc_start"][f]) and r.symbol_pos == int(res["symbol_pos"][f])
+            assert r.oper_mode == int(res["oper_mode"][f]) and r.call_sign == int(res["call_sign"][f])
+            assert _flips_ok(res["bit_flips"][f], r.bit_flips)
+        rx.close()
+    del d_in, d_out
+    torch.cuda.empty_cache()
+
+
 def test_host_pointer_entry_runs_the_chunk_pipeline():
     """ofdmrx_decode_batch (host pointers) goes through the same two-stream chunk pipeline as the device entry, with the
     copies hung on its events: 23 mixed frames (good, noisy, silence, truncated, SKIP) in chunks of 5 (ragged tail, both
