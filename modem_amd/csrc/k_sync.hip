@@ -23,124 +23,194 @@ namespace rx {
 
 // ---------------------------------------------------------------- D1 front end
 // Decoder::next_sample (decode.cc:294-301) for mono input: y = BlockDC(x), z = Hilbert<cmplx,21>(y).
-// One workgroup per frame walks the stream in tiles of 4096 samples (16 consecutive samples per
-// thread, 32 contiguous bytes per lane).  The DC blocker y[n] = b(x[n]-x[n-1]) + a y[n-1] is a linear
-// recurrence: each thread runs its 16 samples from a zero state, the 256 end states are combined by a
-// weighted inclusive scan (v[t] += A^d v[t-d], A = a^16) inside each wave and across the 4 waves, and
-// every sample is corrected by a^(k+1) * carry.  The tile of y (plus a 20-sample history) sits in LDS
-// for the 21-tap Hilbert FIR; z is written as 128 contiguous bytes per lane.
-// Other rates: Hilbert<cmplx, filter_len> with filter_len = 41 / 113 / 125 (decode.cc:172) - same kernel,
-// longer history and tap loop.
+// The DC blocker y[n] = b(x[n]-x[n-1]) + a y[n-1] is a linear recurrence over the whole stream.  Round 3: one workgroup per
+// (frame, TILE of 4096 samples) instead of one per frame walking its 24 tiles in turn (6.9 ms per 8192 frames, more than
+// Theil-Sen, all of it a serial chain of barriers at low occupancy).  Two passes:
+//   k_front_dc      every tile from a ZERO state: 16 consecutive samples per thread, the 256 thread-end states combined by a
+//                   weighted inclusive scan (v[t] += A^d v[t-d], A = a^16).  Kept per tile: its end state and the zero-start
+//                   values of its last FE_HIST samples (the history the next tile's Hilbert taps reach into).
+//   k_front_end     the true state at a tile's start is the fold of the earlier tiles' end states, C_t = e_{t-1} + a^4096 C_{t-1}
+//                   (<= 24 terms; 140 at 48 kHz); the tile's recurrence is run again and every sample corrected by
+//                   a^(k+1) C_t, the history samples by the same rule from the kept values and C_{t-1}; then the 21-tap
+//                   Hilbert FIR out of LDS and 128 contiguous bytes of z per lane.
+// The recurrence is evaluated in double and rounded once per sample: a parallel scan cannot reproduce the rounding sequence of
+// the serial fp32 recurrence anyway, so the GPU side is made (nearly) exact and the difference to the CPU's serial fp32 filter
+// is that filter's own rounding.  Other rates: Hilbert<cmplx, filter_len> with filter_len = 41 / 113 / 125 (decode.cc:172).
 constexpr int FE_PER = 16, FE_TILE = 256 * FE_PER;
+template <int RATE> struct FeCfg {
+	static constexpr int FL = RateCfg<RATE>::FILTER_LEN, HIST = (FL - 1 + 31) / 32 * 32, C = (FL - 1) / 2, NIM = (FL - 1) / 4;
+	static constexpr int REC = 1 + HIST;                      // doubles kept per tile: end state + the history values
+};
 
+// the tile's samples (thread tid: FE_PER consecutive ones from s0), the recurrence from a zero state per thread (y[i]), and the
+// state entering this thread when the TILE starts from zero (cin0): the pieces both passes need
 template <int RATE>
-__global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, float *__restrict__ dc_all, cf *__restrict__ z_all)
+__device__ __forceinline__ void fe_tile_local(const SampleSrc &src, const char *base, int fmt, long n, long s0, double a, double b,
+	const double (&Apow)[7], int lane, int wave, double *wave_end, double (&y)[FE_PER], double &cin0, double &tile_end)
 {
-	constexpr int FL = RateCfg<RATE>::FILTER_LEN, FE_HIST = (FL - 1 + 31) / 32 * 32, FE_C = (FL - 1) / 2, FE_NIM = (FL - 1) / 4;
-	const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const long n = fb.samples_per_frame;
-	const char *base = (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes;
-	SampleSrc src{ base, fb.fmt, 1, n, nullptr };
-	cf *z = z_all + (size_t)f * fb.samples_per_frame;
-	(void)dc_all;
-	__shared__ float ydc[FE_HIST + FE_TILE];   // [0, FE_HIST) = tail of the previous tile
-	__shared__ double wave_end[4];
-	__shared__ double tile_carry;
-	// The recurrence is evaluated in double here (chunk-local states, scan weights, carries) and rounded once per
-	// sample: a parallel scan cannot reproduce the rounding sequence of the serial fp32 recurrence anyway, so the GPU
-	// side is made (nearly) exact and the difference to the CPU's serial fp32 filter is that filter's own rounding.
-	const double a = (double)co.dc_a, b = (double)co.dc_b;
-	// powers of a: a^1..a^16 in registers, A^(2^s) = a^(16*2^s) for the scan steps
-	double apow[FE_PER];
-	apow[0] = a;
+	float x[FE_PER + 1];
+	x[0] = (s0 - 1 >= 0 && s0 - 1 < n) ? src.scalar(s0 - 1) : 0.f;
+	if (fmt == 0 && s0 + FE_PER <= n && (((size_t)base + (size_t)s0 * 2) & 15) == 0) {
+		const int4 *p = (const int4 *)((const int16_t *)base + s0);
+		int4 v0 = p[0], v1 = p[1];
+		const int w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+		#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			x[1 + 2 * q] = div_32767((float)(short)(w[q] & 0xffff));
+			x[2 + 2 * q] = div_32767((float)(short)(w[q] >> 16));
+		}
+	} else {
+		#pragma unroll
+		for (int i = 0; i < FE_PER; ++i)
+			x[1 + i] = s0 + i < n ? src.scalar(s0 + i) : 0.f;
+	}
+	double yl = 0.0;
+	#pragma unroll
+	for (int i = 0; i < FE_PER; ++i) {
+		yl = b * (double)(x[i + 1] - x[i]) + a * yl;
+		y[i] = yl;
+	}
+	// weighted inclusive scan of the thread end states over the 64 lanes of the wave
+	double v = yl;
+	#pragma unroll
+	for (int sft = 0; sft < 6; ++sft) {
+		double o = shfl_up_d(v, 1 << sft);
+		if (lane >= (1 << sft))
+			v += Apow[sft] * o;
+	}
+	if (lane == 63)
+		wave_end[wave] = v;
+	__syncthreads();
+	double st = 0.0;                                              // state at the end of the previous waves of this tile
+	for (int w2 = 0; w2 < wave; ++w2)
+		st = wave_end[w2] + Apow[6] * st;                         // A^64 decays a whole wave (1024 samples)
+	const double prev = shfl_up_d(v, 1);
+	double decay = 1.0;                                           // A^lane
+	#pragma unroll
+	for (int sft = 0; sft < 6; ++sft)
+		if (lane & (1 << sft))
+			decay *= Apow[sft];
+	cin0 = (lane ? prev : 0.0) + decay * st;
+	tile_end = ((wave_end[3] + Apow[6] * wave_end[2]) + Apow[6] * Apow[6] * wave_end[1]) + Apow[6] * Apow[6] * Apow[6] * wave_end[0];
+}
+template <int RATE>
+__device__ __forceinline__ void fe_powers(double a, double (&apow)[FE_PER], double (&Apow)[7])
+{
+	apow[0] = a;                                                  // a^1..a^16; A^(2^s) = a^(16*2^s) for the scan steps
 	#pragma unroll
 	for (int i = 1; i < FE_PER; ++i)
 		apow[i] = apow[i - 1] * a;
-	double Apow[7];   // A^1, A^2, A^4, ... A^64
 	Apow[0] = apow[FE_PER - 1];
 	#pragma unroll
 	for (int sft = 1; sft < 7; ++sft)
 		Apow[sft] = Apow[sft - 1] * Apow[sft - 1];
-	if (tid < FE_HIST)
-		ydc[tid] = 0.f;
+}
+
+template <int RATE>
+__global__ __launch_bounds__(256) void k_front_dc(FrameBatch fb, FrontCoef co, double *__restrict__ rec_all, int tiles)
+{
+	using FC = FeCfg<RATE>;
+	const int f = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const long n = fb.samples_per_frame;
+	const char *base = (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes;
+	SampleSrc src{ base, fb.fmt, 1, n, nullptr };
+	__shared__ double wave_end[4];
+	const double a = (double)co.dc_a, b = (double)co.dc_b;
+	double apow[FE_PER], Apow[7], y[FE_PER], cin0, tile_end;
+	fe_powers<RATE>(a, apow, Apow);
+	const long s0 = (long)t * FE_TILE + (long)tid * FE_PER;
+	fe_tile_local<RATE>(src, base, fb.fmt, n, s0, a, b, Apow, lane, wave, wave_end, y, cin0, tile_end);
+	double *rec = rec_all + ((size_t)f * tiles + t) * FC::REC;
 	if (tid == 0)
-		tile_carry = 0.0;
-	__syncthreads();
-	for (long t0 = 0; t0 < n; t0 += FE_TILE) {
-		const long s0 = t0 + (long)tid * FE_PER;
-		float x[FE_PER + 1];
-		double y[FE_PER];
-		x[0] = (s0 - 1 >= 0 && s0 - 1 < n) ? src.scalar(s0 - 1) : 0.f;
-		if (fb.fmt == 0 && s0 + FE_PER <= n && (((size_t)base + (size_t)s0 * 2) & 15) == 0) {
-			const int4 *p = (const int4 *)((const int16_t *)base + s0);
-			int4 v0 = p[0], v1 = p[1];
-			const int w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
-			#pragma unroll
-			for (int q = 0; q < 8; ++q) {
-				x[1 + 2 * q] = div_32767((float)(short)(w[q] & 0xffff));
-				x[2 + 2 * q] = div_32767((float)(short)(w[q] >> 16));
-			}
-		} else {
-			#pragma unroll
-			for (int i = 0; i < FE_PER; ++i)
-				x[1 + i] = s0 + i < n ? src.scalar(s0 + i) : 0.f;
-		}
-		double yl = 0.0;
-		#pragma unroll
-		for (int i = 0; i < FE_PER; ++i) {
-			yl = b * (double)(x[i + 1] - x[i]) + a * yl;
-			y[i] = yl;
-		}
-		// weighted inclusive scan of the chunk end states over the 64 lanes of the wave
-		double v = yl;
-		#pragma unroll
-		for (int sft = 0; sft < 6; ++sft) {
-			double o = shfl_up_d(v, 1 << sft);
-			if (lane >= (1 << sft))
-				v += Apow[sft] * o;
-		}
-		if (lane == 63)
-			wave_end[wave] = v;
+		rec[0] = tile_end;
+	#pragma unroll
+	for (int i = 0; i < FE_PER; ++i) {
+		const int k = tid * FE_PER + i - (FE_TILE - FC::HIST);    // index into the kept history
+		if (k >= 0)
+			rec[1 + k] = y[i] + apow[i] * cin0;
+	}
+}
+
+template <int RATE>
+__global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, const double *__restrict__ rec_all, int tiles, cf *__restrict__ z_all)
+{
+	using FC = FeCfg<RATE>;
+	constexpr int FE_HIST = FC::HIST, FE_C = FC::C, FE_NIM = FC::NIM;
+	const int f = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const long n = fb.samples_per_frame;
+	const char *base = (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes;
+	SampleSrc src{ base, fb.fmt, 1, n, nullptr };
+	cf *z = z_all + (size_t)f * fb.samples_per_frame;
+	// y of the tile, [0, FE_HIST) = tail of the previous tile.  One pad word per 32: the recurrence writes 16 consecutive samples
+	// per thread (stride 16 words across the lanes: two banks without the pad), the FIR reads consecutive samples across the lanes
+	constexpr int YN = FE_HIST + FE_TILE;
+	__shared__ float ydc[YN + YN / 32 + 1];
+	auto pad = [](int p) { return p + (p >> 5); };
+	__shared__ double wave_end[4];
+	const double a = (double)co.dc_a, b = (double)co.dc_b;
+	double apow[FE_PER], Apow[7], y[FE_PER], cin0, tile_end;
+	fe_powers<RATE>(a, apow, Apow);
+	// state at the start of the previous tile (Cp) and of this one (Ct): fold of the earlier tiles' end states
+	const double Atile = Apow[6] * Apow[6] * Apow[6] * Apow[6];   // a^4096
+	const double *rec_f = rec_all + (size_t)f * tiles * FC::REC;
+	__shared__ double ends_sh[256];
+	double Cp = 0.0, Ct = 0.0;
+	for (int q0 = 0; q0 < t; q0 += 256) {                         // (the end states through LDS: one round trip per 256 tiles, not per tile)
 		__syncthreads();
-		// carry into this thread = state after the previous thread's last sample
-		double cin = tile_carry;                      // state at the end of the previous tile
-		{
-			// state at the end of the previous waves of this tile: fold them in order
-			double st = cin;
-			for (int w2 = 0; w2 < wave; ++w2)
-				st = wave_end[w2] + Apow[6] * st;     // A^64 decays a whole wave (1024 samples)
-			// within the wave: exclusive value = inclusive of lane-1 (decayed state of lanes < lane)
-			double prev = shfl_up_d(v, 1);
-			double decay = 1.0;                       // A^lane
-			#pragma unroll
-			for (int sft = 0; sft < 6; ++sft)
-				if (lane & (1 << sft))
-					decay *= Apow[sft];
-			cin = (lane ? prev : 0.0) + decay * st;
+		if (q0 + tid < t)
+			ends_sh[tid] = rec_f[(size_t)(q0 + tid) * FC::REC];
+		__syncthreads();
+		const int m = t - q0 < 256 ? t - q0 : 256;
+		for (int q = 0; q < m; ++q) {
+			Cp = Ct;
+			Ct = ends_sh[q] + Atile * Ct;
 		}
+	}
+	if (tid < FE_HIST) {                                          // the previous tile's last samples, from their zero-start values
+		float h = 0.f;
+		if (t > 0) {
+			int e = FE_TILE - FE_HIST + tid + 1;                  // a^(position in that tile + 1)
+			double pw = 1.0, bs = a;
+			while (e) {
+				if (e & 1)
+					pw *= bs;
+				bs *= bs;
+				e >>= 1;
+			}
+			h = (float)(rec_f[(size_t)(t - 1) * FC::REC + 1 + tid] + pw * Cp);
+		}
+		ydc[pad(tid)] = h;
+	}
+	const long s0 = (long)t * FE_TILE + (long)tid * FE_PER;
+	fe_tile_local<RATE>(src, base, fb.fmt, n, s0, a, b, Apow, lane, wave, wave_end, y, cin0, tile_end);
+	{
+		double decay = 1.0;                                       // a^(16 * tid): what the tile's own entry state has decayed to at this thread
+		#pragma unroll
+		for (int sft = 0; sft < 6; ++sft)
+			if (lane & (1 << sft))
+				decay *= Apow[sft];
+		for (int w2 = 0; w2 < wave; ++w2)
+			decay *= Apow[6];
+		const double cin = cin0 + decay * Ct;
 		#pragma unroll
 		for (int i = 0; i < FE_PER; ++i)
-			ydc[FE_HIST + tid * FE_PER + i] = (float)(y[i] + apow[i] * cin);
-		__syncthreads();
-		if (tid == 255)
-			tile_carry = y[FE_PER - 1] + apow[FE_PER - 1] * cin;
-		// Hilbert<cmplx,21>: centre tap 10 back, odd taps +-1,3,5,7,9 around it
-		#pragma unroll 4
-		for (int i = 0; i < FE_PER; ++i) {
-			const int li = FE_HIST + tid * FE_PER + i;        // index of sample s0+i ; centre at li-10
-			const int c = li - FE_C;
-			float re = co.reco * ydc[c];
-			float im = co.imco[0] * (ydc[c - 1] - ydc[c + 1]);
-			#pragma unroll
-			for (int k = 1; k < FE_NIM; ++k)
-				im += co.imco[k] * (ydc[c - (2 * k + 1)] - ydc[c + (2 * k + 1)]);
-			if (s0 + i < n)
-				z[s0 + i] = mk(re, im);
-		}
-		__syncthreads();
-		if (tid < FE_HIST)
-			ydc[tid] = ydc[FE_TILE + tid];            // keep the last FE_HIST samples as history
-		__syncthreads();
+			ydc[pad(FE_HIST + tid * FE_PER + i)] = (float)(y[i] + apow[i] * cin);
+	}
+	__syncthreads();
+	// Hilbert<cmplx,21>: centre tap 10 back, odd taps +-1,3,5,7,9 around it.  Thread tid takes the samples tid + 256 i: consecutive
+	// words of LDS across the lanes, 512 contiguous bytes of z per wave instruction
+	const long t0 = (long)t * FE_TILE;
+	#pragma unroll 4
+	for (int i = 0; i < FE_PER; ++i) {
+		const int li = FE_HIST + tid + 256 * i;                   // index of sample t0 + tid + 256 i ; centre at li-10
+		const int c = li - FE_C;
+		float re = co.reco * ydc[pad(c)];
+		float im = co.imco[0] * (ydc[pad(c - 1)] - ydc[pad(c + 1)]);
+		#pragma unroll
+		for (int k = 1; k < FE_NIM; ++k)
+			im += co.imco[k] * (ydc[pad(c - (2 * k + 1))] - ydc[pad(c + (2 * k + 1))]);
+		if (t0 + tid + 256 * i < n)
+			z[t0 + tid + 256 * i] = mk(re, im);
 	}
 }
 
@@ -610,9 +680,26 @@ void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_c
 {
 	hipLaunchKernelGGL(k_init_sync, dim3((n + 255) / 256), dim3(256), 0, s, n, st, skip_counts);
 }
-void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, float *dc, cf *z)
+size_t front_end_scratch_bytes(int rate, int n, long samples_per_frame)
 {
-	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_front_end<RATE>, dim3(n), dim3(256), 0, s, fb, co, dc, z));
+	const size_t tiles = (size_t)((samples_per_frame + FE_TILE - 1) / FE_TILE);
+	size_t rec = 0;
+	RX_RATE_SWITCH(rate, rec = FeCfg<RATE>::REC);
+	return (size_t)n * tiles * rec * sizeof(double);
+}
+void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, double *scratch, cf *z)
+{
+	const int tiles = (int)((fb.samples_per_frame + FE_TILE - 1) / FE_TILE);
+	for (int f0 = 0; f0 < n; f0 += 65535) {                       // gridDim.y
+		const int nf = n - f0 < 65535 ? n - f0 : 65535;
+		FrameBatch fbq = fb;
+		fbq.samples = (const char *)fb.samples + (size_t)f0 * fb.frame_stride_bytes;
+		double *sc = scratch + (size_t)f0 * (front_end_scratch_bytes(rate, 1, fb.samples_per_frame) / sizeof(double));
+		cf *zq = z + (size_t)f0 * fb.samples_per_frame;
+		RX_RATE_SWITCH(rate,
+			hipLaunchKernelGGL(k_front_dc<RATE>, dim3(tiles, nf), dim3(256), 0, s, fbq, co, sc, tiles);
+			hipLaunchKernelGGL(k_front_end<RATE>, dim3(tiles, nf), dim3(256), 0, s, fbq, co, sc, tiles, zq));
+	}
 }
 #ifndef SYNC_SPLIT_ROUNDS
 #define SYNC_SPLIT_ROUNDS 2   // rates above 8 kHz: scan + accept pairs before the one-wave catch-all (a frame needs the catch-all only

@@ -76,7 +76,9 @@ struct Result {                    // device mirror of ofdmrx_frame_result (same
 
 // ---- launch wrappers (defined next to their kernels) ------------------------
 // `rate` selects the RateCfg instantiation (8000 / 16000 / 44100 / 48000)
-void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, float *dc, cf *z);
+// D1 (mono input): scratch = front_end_scratch_bytes() of doubles (per tile of 4096 samples: its end state + the history samples)
+size_t front_end_scratch_bytes(int rate, int n, long samples_per_frame);
+void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, double *scratch, cf *z);
 void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, cf *scratch);
 void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft);
 void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique);

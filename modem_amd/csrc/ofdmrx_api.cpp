@@ -417,6 +417,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 	if (mono) {
 		size_t need = (size_t)std::max(n, h->cap) * (size_t)samples;
 		r = r ? r : h->z.ensure(need * sizeof(cf));
+		r = r ? r : h->dc.ensure(front_end_scratch_bytes(h->rate, std::max(n, h->cap), samples));
 	}
 	return r;
 }
@@ -462,7 +463,7 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, int sti, FrameBa
 	size_t e0 = mark(h, s);
 	if (mono) {
 		Range r("ofdmrx:front_end");
-		launch_front_end(s, h->rate, n, fb, h->host.front, nullptr, h->z.as<cf>());
+		launch_front_end(s, h->rate, n, fb, h->host.front, h->dc.as<double>(), h->z.as<cf>());
 	}
 	size_t e1 = mark(h, s);
 	// sync, header and demod are short, latency-bound kernels with different shapes (1 wave x 224 VGPRs, 4 waves x 216, 4 waves
