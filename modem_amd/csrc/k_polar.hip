@@ -6,10 +6,11 @@
 // reference's SIMD lane), j = one of 8 butterflies processed per wave instruction.
 //   f(a,b)   = sign(a) sign(b) min(|a|,|b|)              left child LLRs
 //   g(a,b,u) = u ? b - a : a + b                          right child LLRs
-// Tree levels 8..15 live in HBM as soft[level m][i][k] (fp32, 2 MiB per decoder, the
-// reference's own soft[N+i] layout), levels 4..7 in LDS with the same [i][k] layout; level
-// 16 is the shared channel LLR vector; levels 3..0 (8-leaf sub-trees) never leave
-// registers: butterflies are cross-lane shuffles.
+// Tree levels 9..15 live in HBM as soft[level m][i][k] (fp32, 2 MiB per resident decoder, the
+// reference's own soft[N+i] layout); level 8 - the array of the current 256-leaf node - in LDS
+// (8 KB per decoder); levels 4..7 in registers as the arrays of the current node of each level;
+// level 16 is the shared channel LLR vector; levels 3..0 (8-leaf sub-trees) never leave
+// registers either: their butterflies are DPP / permlane exchanges ("Where the tree lives" below).
 // Lane permutations after a fork are applied lazily exactly like the reference's vshuf at
 // the g step and at the partial-sum combine: per level the composition of all leaf maps
 // since that level's node started is kept as 3-bit fields packed in two registers per
