@@ -399,6 +399,47 @@ __device__ __forceinline__ double wave_sum_d(double v)
 		v += shfl_xor_d(v, m);
 	return v;
 }
+// decode.cc:505-516 for one frame, shared by k_llr and k_back (their results must agree bit for bit): the running sp / np of
+// the SNR estimate.  Wave w reduces rows w, w + 4, ... by itself (per-lane double sums over its 7 carriers, one wave butterfly) -
+// no workgroup barrier per row; after ONE barrier thread 0 folds the row sums in order into the fp32 running sums and leaves
+// the cumulative precision of every row in prec[].  visit(j, i, c) sees every constellation point once (the caller collects
+// what it needs from it).  Returns false in every thread if a precision is not a positive finite number.
+template <typename Visit>
+__device__ __forceinline__ bool snr_rows(const cf *__restrict__ cons, int rows, int cols, int mod_bits, int tid, double (*rsum)[2], float *prec,
+	Visit visit)
+{
+	const int wave = tid >> 6, lane = tid & 63;
+	for (int j = wave; j < rows; j += 4) {
+		double dsp = 0.0, dnp = 0.0;
+		for (int i = lane; i < cols; i += 64) {
+			const cf c = cons[j * cols + i];
+			const cf h = mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c);   // decode.cc:509-511
+			const double er = (double)c.re - h.re, ei = (double)c.im - h.im;
+			dsp += (double)h.re * h.re + (double)h.im * h.im;
+			dnp += er * er + ei * ei;
+			visit(j, i, c);
+		}
+		dsp = wave_sum_d(dsp);
+		dnp = wave_sum_d(dnp);
+		if (lane == 0) { rsum[j][0] = dsp; rsum[j][1] = dnp; }
+	}
+	__syncthreads();
+	__shared__ int snr_ok;
+	if (tid == 0) {
+		float sp = 0.f, np = 0.f;
+		bool ok = true;
+		for (int j = 0; j < rows; ++j) {
+			sp = (float)((double)sp + rsum[j][0]);
+			np = (float)((double)np + rsum[j][1]);
+			const float precision = sp / np;                      // decode.cc:516
+			ok &= precision > 0.f && precision < 3.0e38f;
+			prec[j] = precision;
+		}
+		snr_ok = ok;
+	}
+	__syncthreads();
+	return snr_ok != 0;
+}
 __device__ __forceinline__ int wave_min_i(int v)
 {
 	#pragma unroll

@@ -316,63 +316,42 @@ __global__ __launch_bounds__(256) void k_llr(int sym_stride, const SyncState *__
 	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
 	float *__restrict__ llr_all, Result *__restrict__ res_all, float *__restrict__ esn0_rows)
 {
-	const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int f = blockIdx.x, tid = threadIdx.x;
 	const SyncState st = st_all[f];
 	if (esn0_rows && tid < ROWS_MAX)
 		esn0_rows[(size_t)f * ROWS_MAX + tid] = 0.f;             // rows this frame does not have (all of them without a header)
 	if (!st.okay)
 		return;
 	__syncthreads();
-	__shared__ double red[2][4];
+	__shared__ double rsum[ROWS_MAX][2];
+	__shared__ float prec[ROWS_MAX];
 	const ModeDesc md = mode_desc(st.oper_mode);
 	const cf *cons = cons_all + (size_t)f * CONS_MAX;
 	float *llr = llr_all + (size_t)f * CODE_LEN;
 	const float rcp_sqrt_2 = 0.70710678118654752440f;         // psk.hh:57,104
 	const float DIST = md.mod_bits == 3 ? 2.f * 0.38268343236508977173f : 2.f * rcp_sqrt_2;   // psk.hh:106 / psk.hh:59
-	float sp = 0.f, np = 0.f, precision = 0.f;
-	for (int j = 0; j < md.rows; ++j) {
-		double dsp = 0.0, dnp = 0.0;
-		cf c[2];
+	snr_rows(cons, md.rows, md.cols, md.mod_bits, tid, rsum, prec, [](int, int, cf) {});
+	if (tid < md.rows) {
+		precision_all[(size_t)f * ROWS_MAX + tid] = prec[tid];
+		if (esn0_rows)
+			esn0_rows[(size_t)f * ROWS_MAX + tid] = 10.f * log10f(prec[tid]);   // decode.cc:518
+	}
+	const float precision = prec[md.rows - 1];
+	for (int j = 0; j < md.rows; ++j) {                           // the row's soft bits with that row's cumulative precision
+		const float sc = DIST * prec[j];
 		#pragma unroll
 		for (int q = 0; q < 2; ++q) {
-			int i = tid + 256 * q;
-			c[q] = mk(0.f, 0.f);
-			if (i < md.cols) {
-				c[q] = cons[j * md.cols + i];
-				cf h = md.mod_bits == 3 ? psk8_hard_map(c[q]) : psk4_hard_map(c[q]);   // decode.cc:509-511
-				double er = (double)c[q].re - h.re, ei = (double)c[q].im - h.im;
-				dsp += (double)h.re * h.re + (double)h.im * h.im;
-				dnp += er * er + ei * ei;
-			}
-		}
-		dsp = wave_sum_d(dsp);
-		dnp = wave_sum_d(dnp);
-		if (lane == 0) { red[0][wave] = dsp; red[1][wave] = dnp; }
-		__syncthreads();
-		dsp = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-		dnp = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-		__syncthreads();
-		sp = (float)((double)sp + dsp);
-		np = (float)((double)np + dnp);
-		precision = sp / np;                                  // decode.cc:516
-		if (tid == 0) {
-			precision_all[(size_t)f * ROWS_MAX + j] = precision;
-			if (esn0_rows)
-				esn0_rows[(size_t)f * ROWS_MAX + j] = 10.f * log10f(precision);   // decode.cc:518
-		}
-		#pragma unroll
-		for (int q = 0; q < 2; ++q) {
-			int i = tid + 256 * q;
+			const int i = tid + 256 * q;
 			if (i < md.cols) {                                // psk.hh:76-80,125-130, decode.cc:520-521
+				const cf c = cons[j * md.cols + i];
 				float *b = llr + md.mod_bits * (j * md.cols + i);
-				float sc = DIST * precision;
 				if (md.mod_bits == 3) {
-					b[1] = c[q].re * sc;
-					b[2] = c[q].im * sc;
-					b[0] = (rcp_sqrt_2 * (fabsf(c[q].re) - fabsf(c[q].im))) * sc;
+					b[1] = c.re * sc;
+					b[2] = c.im * sc;
+					b[0] = (rcp_sqrt_2 * (fabsf(c.re) - fabsf(c.im))) * sc;
 				} else {
-					b[0] = c[q].re * sc;
-					b[1] = c[q].im * sc;
+					b[0] = c.re * sc;
+					b[1] = c.im * sc;
 				}
 			}
 		}

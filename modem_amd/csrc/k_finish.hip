@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, const SyncState *_
 	float *__restrict__ llr_all, Result *__restrict__ res_all, float *__restrict__ esn0_rows, Tables tb, int descramble,
 	uint8_t *__restrict__ payload_all, int *__restrict__ cert_all)
 {
-	const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int f = blockIdx.x, tid = threadIdx.x;
 	const SyncState st = st_all[f];
 	uint8_t *payload = payload_all + (size_t)f * PAYLOAD_BYTES;
 	if (esn0_rows && tid < ROWS_MAX)
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, const SyncState *_
 		}
 		return;
 	}
-	__shared__ double red[2][4];
+	__shared__ double rsum[ROWS_MAX][2];
 	__shared__ uint32_t bits[CODE_LEN / 32];
 	__shared__ float prec[ROWS_MAX];
 	__shared__ uint8_t mesg[MESG_BYTES_MAX];
@@ -77,54 +77,31 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, const SyncState *_
 	for (int q = 0; q < 4; ++q)
 		csh[tid + 256 * q] = tb.crc32_shift168[tid + 256 * q];
 	__syncthreads();
-	// ---- 1. decode.cc:505-523 (as k_llr) + the signs
-	float sp = 0.f, np = 0.f, precision = 0.f;
+	// ---- 1. decode.cc:505-523 (snr_rows, shared with k_llr) + the signs of the soft bits
 	bool odd = false;                                             // a zero / NaN LLR somewhere: no certificate
-	for (int j = 0; j < md.rows; ++j) {
-		double dsp = 0.0, dnp = 0.0;
-		#pragma unroll
-		for (int q = 0; q < 2; ++q) {
-			const int i = tid + 256 * q;
-			if (i < md.cols) {
-				const cf c = cons[j * md.cols + i];
-				const cf h = md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c);   // decode.cc:509-511
-				const double er = (double)c.re - h.re, ei = (double)c.im - h.im;
-				dsp += (double)h.re * h.re + (double)h.im * h.im;
-				dnp += er * er + ei * ei;
-				const float are = fabsf(c.re), aim = fabsf(c.im);
-				uint32_t v;
-				if (md.mod_bits == 3) {
-					v = (are < aim ? 1u : 0u) | (c.re < 0.f ? 2u : 0u) | (c.im < 0.f ? 4u : 0u);
-					odd |= !(are > 0.f) | !(aim > 0.f) | (are == aim);
-				} else {
-					v = (c.re < 0.f ? 1u : 0u) | (c.im < 0.f ? 2u : 0u);
-					odd |= !(are > 0.f) | !(aim > 0.f);
-				}
-				const int p0 = md.mod_bits * (j * md.cols + i), o = p0 & 31;
-				if (v) {
-					atomicOr(&bits[p0 >> 5], v << o);
-					if (o + md.mod_bits > 32)
-						atomicOr(&bits[(p0 >> 5) + 1], v >> (32 - o));
-				}
-			}
+	const int mod_bits = md.mod_bits, cols = md.cols;
+	const bool snr_ok = snr_rows(cons, md.rows, cols, mod_bits, tid, rsum, prec, [&](int j, int i, cf c) {
+		const float are = fabsf(c.re), aim = fabsf(c.im);
+		uint32_t v;
+		if (mod_bits == 3) {
+			v = (are < aim ? 1u : 0u) | (c.re < 0.f ? 2u : 0u) | (c.im < 0.f ? 4u : 0u);
+			odd |= !(are > 0.f) | !(aim > 0.f) | (are == aim);
+		} else {
+			v = (c.re < 0.f ? 1u : 0u) | (c.im < 0.f ? 2u : 0u);
+			odd |= !(are > 0.f) | !(aim > 0.f);
 		}
-		dsp = wave_sum_d(dsp);
-		dnp = wave_sum_d(dnp);
-		if (lane == 0) { red[0][wave] = dsp; red[1][wave] = dnp; }
-		__syncthreads();
-		dsp = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-		dnp = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-		__syncthreads();
-		sp = (float)((double)sp + dsp);
-		np = (float)((double)np + dnp);
-		precision = sp / np;                                  // decode.cc:516
-		odd |= !(precision > 0.f) | !(precision < 3.0e38f);   // (LLR = value * DIST * precision)
-		if (tid == 0) {
-			prec[j] = precision;
-			precision_all[(size_t)f * ROWS_MAX + j] = precision;
-			if (esn0_rows)
-				esn0_rows[(size_t)f * ROWS_MAX + j] = 10.f * log10f(precision);   // decode.cc:518
+		const int p0 = mod_bits * (j * cols + i), o = p0 & 31;
+		if (v) {
+			atomicOr(&bits[p0 >> 5], v << o);
+			if (o + mod_bits > 32)
+				atomicOr(&bits[(p0 >> 5) + 1], v >> (32 - o));
 		}
+	});
+	odd |= !snr_ok;                                               // (LLR = value * DIST * precision)
+	if (tid < md.rows) {
+		precision_all[(size_t)f * ROWS_MAX + tid] = prec[tid];
+		if (esn0_rows)
+			esn0_rows[(size_t)f * ROWS_MAX + tid] = 10.f * log10f(prec[tid]);   // decode.cc:518
 	}
 	if (tid == 0) {
 		float sum_slope = 0.f, sum_yint = 0.f;
@@ -134,9 +111,8 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, const SyncState *_
 		}
 		r.sfo_slope = sum_slope / (float)md.rows;
 		r.cfo_fine = st.cfo_rad + (sum_yint / (float)md.rows) / (float)sym_stride;   // decode.cc:501
-		r.esn0_db_last = 10.f * log10f(precision);            // decode.cc:518
+		r.esn0_db_last = 10.f * log10f(prec[md.rows - 1]);    // decode.cc:518
 	}
-	__syncthreads();
 	// ---- 3a. (before the transform overwrites the bit array) the systematic message = x at the unfrozen positions, decode.cc:254-261
 	const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
 	const int mesg_bytes = md.mesg_bits / 8;
