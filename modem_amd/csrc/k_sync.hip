@@ -650,9 +650,11 @@ __global__ __launch_bounds__(256) void k_sync_accept(FrameBatch fb, const cf *__
 
 namespace rx {
 
-__global__ void k_init_sync(int n, SyncState *st, const int32_t *skip)
+__global__ void k_init_sync(int n, SyncState *st, const int32_t *skip, int *chunk_flags)
 {
 	int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f == 0 && chunk_flags)
+		chunk_flags[0] = 0;                                       // "some frame has more rows than one Theil-Sen launch covers" (k_theilsen.hip)
 	if (f >= n)
 		return;
 	SyncState s;
@@ -676,9 +678,9 @@ __global__ void k_init_sync(int n, SyncState *st, const int32_t *skip)
 	st[f] = s;
 }
 
-void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts)
+void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts, int *chunk_flags)
 {
-	hipLaunchKernelGGL(k_init_sync, dim3((n + 255) / 256), dim3(256), 0, s, n, st, skip_counts);
+	hipLaunchKernelGGL(k_init_sync, dim3((n + 255) / 256), dim3(256), 0, s, n, st, skip_counts, chunk_flags);
 }
 size_t front_end_scratch_bytes(int rate, int n, long samples_per_frame)
 {

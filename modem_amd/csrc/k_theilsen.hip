@@ -561,7 +561,12 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 			TS_SYNC();
 			int nc = 0;
 			for (int kk = 1;; ++kk) {
-				if (kk > 8 * (TS_PS - 64)) { slow = true; TS_REASON(5); break; }
+				if (kk > 8 * (TS_PS - 64)) {
+#ifdef TS_PROBE_PRINT
+					if (lane == 0) printf("reason 5: n %d Ta %.9g Tb %.9g T %.9g ca %d cb %d target %d wq %g scale %g nc %d\n", n, Ta, Tb, T, ca, cb, target, wq, qs.scale, nc);
+#endif
+					slow = true; TS_REASON(5); break;
+				}
 				uint32_t h = 0;
 				int gmin = 0x7fffffff;
 				#pragma unroll
@@ -569,7 +574,10 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 					const uint2 o = s.sk[((t + kk) & 7) * TS_PS + lane + ((t + kk) >> 3)];
 					const int x2 = (int)o.x - km[t];              // < 0: uncertain at T
 					const int x1 = (int)o.y - kom[t];             // < 0: not clearly ascending at the other end
-					gmin = x2 < gmin ? x2 : gmin;
+					// (a slot beyond n never ends the scan late: those keys are only 8 quanta apart, and a bracket wider than
+					// the 4096 quanta between them and the real keys would walk through all of them)
+					const int x2r = o.x < (TS_QPAD0 << 9) ? x2 : 0x7fffffff;
+					gmin = x2r < gmin ? x2r : gmin;
 					h = __builtin_amdgcn_alignbit(h, (uint32_t)(x1 | x2), 31);
 				}
 				unsigned long long hm = __builtin_amdgcn_ballot_w64(h != 0);
@@ -685,25 +693,11 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 	return make_float2(slope, yint);
 }
 
-// decode.cc:479-504: one wave per (frame, row)
-// carr_all != nullptr (8 kHz): the row is formed here from the carriers of two consecutive symbols; cons_raw_all
-// (nullable) receives the unrotated row for the CONS_RAW tap
-__global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
-	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames)
+// one row: decode.cc:482-494
+__device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const ModeDesc &md, cf *__restrict__ cons_all,
+	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all)
 {
-	// grid = frames x ROWS_MAX, one row per wave; the waves of rows a frame's mode does not have leave at once (mode 6: 50 of
-	// 126 stay).  A loop over rows inside the wave costs 30 registers: everything that depends on the row length and the
-	// lane alone is hoisted out of it and stays live.
-	const int unit = (int)blockIdx.x * TS_ROWS_PER_WG + ((int)threadIdx.x >> 6);
-	const int f = unit / ROWS_MAX, j = unit % ROWS_MAX, lane = threadIdx.x & 63;
-	if (f >= n_frames || !st_all[f].okay)
-		return;
-	const ModeDesc md = mode_desc(st_all[f].oper_mode);
-	if (j >= md.rows)
-		return;
 	const int cols = md.cols;
-	__shared__ TsLds s_all[TS_ROWS_PER_WG];
-	TsLds &s = s_all[threadIdx.x >> 6];
 	cf *row = cons_all + (size_t)f * CONS_MAX + (size_t)j * cols;
 	const cf *cr = carr_all ? carr_all + (size_t)f * CARR_MAX + (size_t)j * cols : nullptr;
 	auto cons_at = [&](int i) {                                    // decode.cc:474-475
@@ -740,6 +734,57 @@ __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen(const Sync
 	}
 }
 
+// decode.cc:479-504: one wave per (frame, row)
+// carr_all != nullptr (8 kHz): the row is formed here from the carriers of two consecutive symbols; cons_raw_all
+// (nullable) receives the unrotated row for the CONS_RAW tap.
+// Rows 0 .. TS_ROWS_DIRECT-1 of every frame: one wave each (grid = frames x TS_ROWS_DIRECT; mode 6 has exactly 50 rows, mode 10 has
+// 42: its last eight waves leave at once).  The modes with more rows (7, 8, 9, 11, 12, 13: up to 126) get theirs from
+// k_theil_sen_more: TS_MORE_WAVES persistent waves that stride over the units (frame, row 50 .. R-1), R = the largest row count
+// the direct kernel met in this chunk (chunk_flags[0], an atomicMax; cleared by k_init_sync) - it leaves at once when no frame
+// has more than 50 rows.  A launch of frames x 126 one-row waves, 60 % of which leave at once for mode 6, cost 0.15 ms per
+// 8192 frames.  The loop costs registers (what depends on the row length and the lane alone is hoisted out of it; bounding it
+// to the direct kernel's 96 spills five of them), so it is its own kernel.
+#ifndef TS_MORE_WAVES_N
+#define TS_MORE_WAVES_N 20480
+#endif
+#ifndef TS_MORE_OCC
+#define TS_MORE_OCC 5
+#endif
+constexpr int TS_ROWS_DIRECT = 50, TS_MORE_WAVES = TS_MORE_WAVES_N;
+__global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
+	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames, int *__restrict__ chunk_flags)
+{
+	const int unit = (int)blockIdx.x * TS_ROWS_PER_WG + ((int)threadIdx.x >> 6);
+	const int f = unit / TS_ROWS_DIRECT, j = unit % TS_ROWS_DIRECT, lane = threadIdx.x & 63;
+	if (f >= n_frames || !st_all[f].okay)
+		return;
+	const ModeDesc md = mode_desc(st_all[f].oper_mode);
+	if (j == 0 && lane == 0 && md.rows > TS_ROWS_DIRECT)
+		atomicMax(chunk_flags, md.rows);
+	if (j >= md.rows)
+		return;
+	__shared__ TsLds s_all[TS_ROWS_PER_WG];
+	ts_row(s_all[threadIdx.x >> 6], f, j, lane, md, cons_all, carr_all, cons_raw_all, slope_all, yint_all);
+}
+__global__ __launch_bounds__(64, TS_MORE_OCC) void k_theil_sen_more(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
+	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames, const int *__restrict__ chunk_flags)
+{
+	const int more = chunk_flags[0] - TS_ROWS_DIRECT;
+	if (more <= 0)
+		return;
+	const int lane = threadIdx.x, units = n_frames * more;
+	__shared__ TsLds s;
+	for (int u = (int)blockIdx.x; u < units; u += TS_MORE_WAVES) {
+		const int f = u / more, j = TS_ROWS_DIRECT + u % more;
+		if (!st_all[f].okay)
+			continue;
+		const ModeDesc md = mode_desc(st_all[f].oper_mode);
+		if (j >= md.rows)
+			continue;
+		__syncthreads();
+		ts_row(s, f, j, lane, md, cons_all, carr_all, cons_raw_all, slope_all, yint_all);
+	}
+}
 __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen_raw(int cols, int rows, const float *__restrict__ y, float *__restrict__ slope_all,
 	float *__restrict__ yint_all)
 {
@@ -755,9 +800,12 @@ __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen_raw(int co
 	if (lane == 0) { slope_all[r] = sy.x; yint_all[r] = sy.y; }
 }
 
-void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint)
+void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint, int *chunk_flags)
 {
-	hipLaunchKernelGGL(k_theil_sen, dim3((n * ROWS_MAX + TS_ROWS_PER_WG - 1) / TS_ROWS_PER_WG), dim3(64 * TS_ROWS_PER_WG), 0, s, st, cons, carr, cons_raw, slope, yint, n);
+	hipLaunchKernelGGL(k_theil_sen, dim3((n * TS_ROWS_DIRECT + TS_ROWS_PER_WG - 1) / TS_ROWS_PER_WG), dim3(64 * TS_ROWS_PER_WG), 0, s, st, cons, carr,
+		cons_raw, slope, yint, n, chunk_flags);
+	hipLaunchKernelGGL(k_theil_sen_more, dim3(TS_MORE_WAVES), dim3(64), 0, s, st, cons, carr, cons_raw, slope, yint, n,
+		chunk_flags);
 }
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint)
 {

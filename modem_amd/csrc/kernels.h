@@ -85,7 +85,7 @@ void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_
 // 8 kHz: demod writes the carriers of every symbol (carr), the differential step happens in k_theil_sen; other rates: cons
 bool demod_writes_carriers(int rate);
 void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons, cf *carr);
-void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint);
+void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint, int *chunk_flags);
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
 void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, float *llr, Result *res, float *esn0_rows = nullptr);   // esn0_rows (nullable): [n][ROWS_MAX] dB values, decode.cc:517-519
@@ -105,6 +105,7 @@ void launch_channel(hipStream_t s, int rate, const int16_t *in, int16_t *out, si
 size_t tx_big_scratch_bytes(int rate, int n, int nsym);
 void launch_tx(hipStream_t s, int rate, int n, const uint8_t *payload, Tables tb, const void *tp, const cf *tw_sym4,
 	uint32_t *code, cf *rowsym, cf *tdom, cf *big_scratch, void *pcm);
-void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts);
+// chunk_flags (nullable): per-chunk device flags cleared here ([0]: the largest row count k_theil_sen met, when above 50)
+void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts, int *chunk_flags = nullptr);
 
 }  // namespace rx
