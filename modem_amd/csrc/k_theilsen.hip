@@ -33,6 +33,12 @@ namespace rx {
 #ifndef TS_CAP
 #define TS_CAP 56          // pairs the final bracket may hold (the list holds 64: a few candidates fall outside after the exact division)
 #endif
+#ifndef TS_OPEN_NEED
+#define TS_OPEN_NEED 30    // an open bracket (one counted end) is tried when the wanted rank is at most this far from the count
+#endif
+#ifndef TS_OPEN_MARGIN
+#define TS_OPEN_MARGIN 6   // ranks the uncounted end is placed beyond the wanted one (times 1.25 for the density estimate)
+#endif
 #ifndef TS_MARGIN
 #define TS_MARGIN 12       // a secant step aims this many ranks past the target, on the side still open
 #endif
@@ -49,6 +55,11 @@ constexpr uint32_t TS_MQ = 2;
 constexpr int TS_MQ1S = (int)((TS_MQ + 1) << 9);
 constexpr int TS_LIST = 64;                               // candidate pairs of the final bracket: one per lane
 constexpr int TS_MAX_IT = 48;
+#ifdef TS_REASON_LOG                                      // variant builds: cumulative slow-path reasons + rank counts, printed after every launch
+__device__ int g_ts_reason[8], g_ts_iters;
+#define TS_PROBE_REASON g_ts_reason
+#define TS_PROBE_ITERS (&g_ts_iters)
+#endif
 #ifdef TS_PROBE_REASON
 #define TS_REASON(r) do { if ((threadIdx.x & 63) == 0) atomicAdd(TS_PROBE_REASON + (r), 1); } while (0)
 #else
@@ -142,6 +153,9 @@ __device__ __forceinline__ int wave_sum_i(int v)
 	v += (int)dpp_u<DPP_MIRROR>((uint32_t)v);
 	return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
+// a value every lane holds alike, moved to a scalar register (fp32 arithmetic on wave-uniform values still runs on the vector
+// unit and would otherwise keep its result in a vector register for as long as it lives)
+__device__ __forceinline__ float ts_uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 template <typename Op> __device__ __forceinline__ float wave_reduce_f(float v, Op op)
 {
 	v = op(v, __uint_as_float(dpp_u<DPP_XOR1>(__float_as_uint(v))));
@@ -150,7 +164,7 @@ template <typename Op> __device__ __forceinline__ float wave_reduce_f(float v, O
 	v = op(v, __uint_as_float(dpp_u<DPP_MIRROR>(__float_as_uint(v))));
 	const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0)), b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
 	const float c = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32)), d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
-	return op(op(a, b), op(c, d));
+	return ts_uni(op(op(a, b), op(c, d)));
 }
 
 // ---------------------------------------------------------------- the sort
@@ -395,10 +409,12 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 	const int count = n * (n - 1) / 2, target = count / 2, xoff = n / 2;
 	float slope = 0.f;
 	uint32_t k[8];
-	float yv[8];
-	#pragma unroll
-	for (int t = 0; t < 8; ++t)
-		yv[t] = 8 * lane + t < n ? s.y[t * TS_YS + lane] : 0.f;
+	// the lane's eight points 8 lane .. 8 lane + 7: read again where they are needed rather than held across the search
+	auto load_y = [&](float (&yv)[8]) {
+		#pragma unroll
+		for (int t = 0; t < 8; ++t)
+			yv[t] = 8 * lane + t < n ? s.y[t * TS_YS + lane] : 0.f;
+	};
 	if (lane < TS_PS - 64) {                                      // positions past the end
 		#pragma unroll
 		for (int t = 0; t < 8; ++t)
@@ -408,6 +424,9 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 	if (count > 0) {
 		// ---- row statistics: range, least-squares slope (a starting point only: fp32)
 		float ymin = 3.0e38f, ymax = -3.0e38f, sy = 0.f, sxy = 0.f;
+		{
+		float yv[8];
+		load_y(yv);
 		#pragma unroll
 		for (int t = 0; t < 8; ++t) {
 			const int i = 8 * lane + t;
@@ -415,6 +434,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 				ymin = fminf(ymin, yv[t]); ymax = fmaxf(ymax, yv[t]);
 				sy += yv[t]; sxy += yv[t] * (float)(i - xoff);
 			}
+		}
 		}
 		ymin = wave_reduce_f(ymin, [](float a, float b) { return fminf(a, b); });
 		ymax = wave_reduce_f(ymax, [](float a, float b) { return fmaxf(a, b); });
@@ -431,6 +451,10 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 		bool hasA = false, hasB = false;
 		TsQuant qs = {0.0, 0.0};
 		const unsigned long long real_lanes = n >= 512 ? ~0ull : (1ull << ((n + 7) >> 3)) - 1ull;
+		float Tp = 0.f, irho = 0.f;                               // irho = 1 / (slopes per unit of T around the target)
+		int cp = 0, it = 0, c_at_T = 0;
+		bool hasP = false, open_end = false, open_failed = false;
+		float To_open = 0.f;
 		if (!done && !slow) {
 			{
 				const float fn = (float)n, sx = fn * (fn - 1.f) * 0.5f - fn * (float)xoff;
@@ -439,18 +463,23 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 				T = (sxy - sx * sy * rn) * __builtin_amdgcn_rcpf(sxx - sx * sx * rn);
 				if (!(fabsf(T) < 1.0e30f))
 					T = 0.f;
+				T = ts_uni(T);
 			}
-			float Tp = 0.f, irho = 0.f;                           // irho = 1 / (slopes per unit of T around the target)
-			int cp = 0;
-			bool hasP = false;
-			for (int it = 0;; ++it) {
+		}
+		for (;;) {                                                // search, then the list; again only after an open bracket that failed
+		if (!done && !slow) {
+			for (;; ++it) {
 				if (it >= TS_MAX_IT) { slow = true; TS_REASON(2); break; }
 #ifdef TS_PROBE_ITERS
 				if (lane == 0) atomicAdd(TS_PROBE_ITERS, 1);
 #endif
 				// ---- exact #{s < T}, #{s <= T}
 				qs = ts_quant(T, ymin, ymax, n);
-				ts_keys_run(k, yv, 8 * lane, n, T, qs);
+				{
+					float yv[8];
+					load_y(yv);
+					ts_keys_run(k, yv, 8 * lane, n, T, qs);
+				}
 				const int share = ts_sort(k, L, true, 6);
 				int c_lt = TS_INV_CONST + wave_sum_i(share), c_le;
 				TS_SYNC();                                  // earlier readers of sk are done
@@ -499,6 +528,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 					c_lt += dlt;
 				}
 				sorted_z = true;
+				c_at_T = c_lt;
 				if (c_lt <= target && target < c_le) { slope = T; done = true; break; }
 				if (c_lt <= target) { Ta = T; ca = c_lt; hasA = true; }
 				else { Tb = T; cb = c_lt; hasB = true; }
@@ -513,12 +543,29 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 					const float iqr = (float)(q3 > q1 ? q3 - q1 : 1u) * __builtin_amdgcn_rcpf((float)qs.scale);
 					// gaussian noise sigma = IQR / 1.349: density of slopes at their median = sum_d (n - d) d / (2 sigma sqrt(pi))
 					const float fn = (float)n;
-					irho = iqr * (2.f * 1.7724539f * 6.f / 1.349f) * __builtin_amdgcn_rcpf(fn * (fn * fn - 1.f));
+					irho = ts_uni(iqr * (2.f * 1.7724539f * 6.f / 1.349f) * __builtin_amdgcn_rcpf(fn * (fn * fn - 1.f)));
 				}
 				if (hasP && c_lt != cp && T != Tp)
-					irho = (T - Tp) * __builtin_amdgcn_rcpf((float)(c_lt - cp));
+					irho = ts_uni((T - Tp) * __builtin_amdgcn_rcpf((float)(c_lt - cp)));
+				// ---- close enough to list the pairs between T and an end that is not counted: T + / - (the ranks still missing +
+				// TS_OPEN_MARGIN) / density.  The list stage finds EVERY pair in between; with the exact count on the T side
+				// the wanted rank is the (target - ca)-th of them from below (T below the median slope) or the (cb - target)-th
+				// from above; if the list turns out too short or too long, the other end is counted after all.
+				{
+					const bool below = c_lt <= target;
+					const int need = below ? target - c_lt + 1 : c_lt - target;
+					if (!open_failed && irho > 0.f && need <= TS_OPEN_NEED) {
+						const float w = (float)(need + TS_OPEN_MARGIN) * irho * 1.25f;
+						To_open = ts_uni(below ? T + w : T - w);
+						if (fabsf(To_open) < 1.0e30f && To_open != T && (below ? (!hasB || To_open < Tb) : (!hasA || To_open > Ta))) {
+							open_end = true;
+							break;
+						}
+					}
+				}
 				int goal;
-				if (!hasA) goal = target - TS_MARGIN;
+				if (it == 0 && !open_failed) goal = target;      // the next count most likely allows an open bracket
+				else if (!hasA) goal = target - TS_MARGIN;
 				else if (!hasB) goal = target + TS_MARGIN;
 				else goal = (target - ca > cb - target) ? target - TS_MARGIN : target + TS_MARGIN;
 				float Tn = T;
@@ -536,7 +583,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 					if (Tn == T) { slow = true; TS_REASON(4); break; }
 				}
 				Tp = T; cp = c_lt; hasP = true;
-				T = Tn;
+				T = ts_uni(Tn);
 			}
 		}
 		if (!done && !slow) {
@@ -544,19 +591,17 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 			// sorted at one end (T); key the same elements at the other end and look for neighbours that are not clearly
 			// ascending there (sorted at Ta: s < Tb <=> the later key is not larger at Tb; sorted at Tb: s >= Ta <=> the same
 			// at Ta), plus the pairs that are uncertain at T itself.
-			const float To = T == Ta ? Tb : Ta;
+			const bool t_is_a = open_end ? c_at_T <= target : T == Ta;
+			const float To = open_end ? To_open : (t_is_a ? Tb : Ta);
+			const float La = t_is_a ? T : To, Lb = t_is_a ? To : T;   // the list's bracket [La, Lb)
 			const TsQuant qo = ts_quant(To, ymin, ymax, n);
-			int kom[8], km[8];
 			#pragma unroll
 			for (int t = 0; t < 8; ++t) {
 				const int i = (int)(k[t] & 511u);
-				const uint32_t ko = ts_key(i < n ? s.y[ts_yaddr(i)] : 0.f, i, n, To, qo);
-				s.sk[t * TS_PS + lane].y = ko;
-				kom[t] = (int)ko + TS_MQ1S;
-				km[t] = (int)k[t] + TS_MQ1S;
+				s.sk[t * TS_PS + lane].y = ts_key(i < n ? s.y[ts_yaddr(i)] : 0.f, i, n, To, qo);
 			}
 			// a pair inside the bracket is at most this far apart in the sorted keys (minus the margin: compared with o - km)
-			const float wq = fabsf(Tb - Ta) * (float)qs.scale * (float)(n - 1) * 1.0001f + 4.f;
+			const float wq = fabsf(Lb - La) * (float)qs.scale * (float)(n - 1) * 1.0001f + 4.f;
 			const int ws = wq < 4.0e6f ? (int)(((uint32_t)wq << 9) | 511u) : 0x7fffffff;
 			TS_SYNC();
 			int nc = 0;
@@ -571,9 +616,10 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 				int gmin = 0x7fffffff;
 				#pragma unroll
 				for (int t = 0; t < 8; ++t) {
+					// (the lane's own keys at the other end are read again per step instead of held in eight more registers)
 					const uint2 o = s.sk[((t + kk) & 7) * TS_PS + lane + ((t + kk) >> 3)];
-					const int x2 = (int)o.x - km[t];              // < 0: uncertain at T
-					const int x1 = (int)o.y - kom[t];             // < 0: not clearly ascending at the other end
+					const int x2 = (int)o.x - ((int)k[t] + TS_MQ1S);                              // < 0: uncertain at T
+					const int x1 = (int)o.y - ((int)s.sk[t * TS_PS + lane].y + TS_MQ1S);          // < 0: not clearly ascending at the other end
 					// (a slot beyond n never ends the scan late: those keys are only 8 quanta apart, and a bracket wider than
 					// the 4096 quanta between them and the real keys would walk through all of them)
 					const int x2r = o.x < (TS_QPAD0 << 9) ? x2 : 0x7fffffff;
@@ -597,26 +643,52 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 					break;
 			}
 			TS_SYNC();
+			bool retry = false;
 			if (nc > TS_LIST) {
-				slow = true; TS_REASON(6);
+				if (open_end)
+					retry = true;
+				else {
+					slow = true; TS_REASON(6);
+				}
 			}
-			if (!slow) {
+			if (!slow && !retry) {
 				bool in = false;
 				uint32_t key = 0xffffffffu;
 				if (lane < nc) {
 					const uint32_t e = s.lst[lane];
 					const float sl = ts_pair_slope(s, (int)(s.sk[ts_paddr(e & 0xffffu)].x & 511u), (int)(s.sk[ts_paddr(e >> 16)].x & 511u));
-					in = sl >= Ta && sl < Tb;
+					in = sl >= La && sl < Lb;
 					if (in)
 						key = fkey(sl);
 				}
-				if (__popcll(__builtin_amdgcn_ballot_w64(in)) != cb - ca) {
+				const int found = __popcll(__builtin_amdgcn_ballot_w64(in));
+				// rank of the wanted slope among the listed ones: counted from the side whose count is exact
+				const int idx = t_is_a ? target - c_at_T : found - (c_at_T - target);
+#ifdef TS_PROBE_PRINT
+				if (lane == 0) printf("list: n %d open %d t_is_a %d T %.9g To %.9g c_at_T %d target %d ca %d cb %d nc %d found %d idx %d it %d\n", n, (int)open_end, (int)t_is_a, T, To, c_at_T, target, ca, cb, nc, found, idx, it);
+#endif
+				if (open_end) {
+					if (idx < 0 || idx >= found)
+						retry = true;                                           // the open end was too close: count it
+				} else if (found != cb - ca) {
 					slow = true; TS_REASON(7);                                  // (cannot happen: the counts are exact)
-				} else {
+				}
+				if (!slow && !retry) {
 					key = ts_sort_lanes(key, L);
-					slope = fkey_inv(__builtin_amdgcn_readlane(key, target - ca));
+					slope = fkey_inv(__builtin_amdgcn_readlane(key, idx));
 				}
 			}
+			if (retry) {                                          // the search goes on with a count at the open end
+				TS_REASON(0);
+				open_failed = true;
+				open_end = false;
+				Tp = T; cp = c_at_T; hasP = true;
+				T = To;
+				++it;
+				continue;
+			}
+		}
+		break;
 		}
 #ifdef TS_PROBE_COUNT
 		if (slow && lane == 0) atomicAdd(TS_PROBE_COUNT, 1);
@@ -676,6 +748,8 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 		yint = fkey_inv(cand);
 	}
 	if (!have) {                                                  // one 512-key sort
+		float yv[8];
+		load_y(yv);
 		#pragma unroll
 		for (int t = 0; t < 8; ++t) {
 			const int i = 8 * lane + t;
@@ -755,7 +829,8 @@ __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen(const Sync
 	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames, int *__restrict__ chunk_flags)
 {
 	const int unit = (int)blockIdx.x * TS_ROWS_PER_WG + ((int)threadIdx.x >> 6);
-	const int f = unit / TS_ROWS_DIRECT, j = unit % TS_ROWS_DIRECT, lane = threadIdx.x & 63;
+	// (uniform per wave: said explicitly, or the row's addresses are computed per lane)
+	const int f = __builtin_amdgcn_readfirstlane(unit / TS_ROWS_DIRECT), j = __builtin_amdgcn_readfirstlane(unit % TS_ROWS_DIRECT), lane = threadIdx.x & 63;
 	if (f >= n_frames || !st_all[f].okay)
 		return;
 	const ModeDesc md = mode_desc(st_all[f].oper_mode);
@@ -788,7 +863,7 @@ __global__ __launch_bounds__(64, TS_MORE_OCC) void k_theil_sen_more(const SyncSt
 __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen_raw(int cols, int rows, const float *__restrict__ y, float *__restrict__ slope_all,
 	float *__restrict__ yint_all)
 {
-	const int r = (int)blockIdx.x * TS_ROWS_PER_WG + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const int r = __builtin_amdgcn_readfirstlane((int)blockIdx.x * TS_ROWS_PER_WG + ((int)threadIdx.x >> 6)), lane = threadIdx.x & 63;
 	if (r >= rows)
 		return;
 	__shared__ TsLds s_all[TS_ROWS_PER_WG];
@@ -800,12 +875,22 @@ __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen_raw(int co
 	if (lane == 0) { slope_all[r] = sy.x; yint_all[r] = sy.y; }
 }
 
+#ifdef TS_REASON_LOG
+__global__ void k_ts_reason_dump()
+{
+	printf("theil-sen so far: rank counts %d, open brackets that failed %d, slow path by reason 1..7: %d %d %d %d %d %d %d\n", g_ts_iters, g_ts_reason[0],
+		g_ts_reason[1], g_ts_reason[2], g_ts_reason[3], g_ts_reason[4], g_ts_reason[5], g_ts_reason[6], g_ts_reason[7]);
+}
+#endif
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint, int *chunk_flags)
 {
 	hipLaunchKernelGGL(k_theil_sen, dim3((n * TS_ROWS_DIRECT + TS_ROWS_PER_WG - 1) / TS_ROWS_PER_WG), dim3(64 * TS_ROWS_PER_WG), 0, s, st, cons, carr,
 		cons_raw, slope, yint, n, chunk_flags);
 	hipLaunchKernelGGL(k_theil_sen_more, dim3(TS_MORE_WAVES), dim3(64), 0, s, st, cons, carr, cons_raw, slope, yint, n,
 		chunk_flags);
+#ifdef TS_REASON_LOG
+	hipLaunchKernelGGL(k_ts_reason_dump, dim3(1), dim3(1), 0, s);
+#endif
 }
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint)
 {
