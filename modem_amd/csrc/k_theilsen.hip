@@ -767,6 +767,30 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 	return make_float2(slope, yint);
 }
 
+// sin and cos of the rotation angle (decode.cc:493: a row's phases are yint + slope x, a fraction of a radian).  Cody-Waite
+// reduction by pi/2 in two parts (exact enough for |a| < 1e3: n < 640, n * lo's rounding stays under 1e-10), the single-precision
+// minimax kernels of fdlibm (k_sinf / k_cosf) on |r| <= pi/4, quadrant by n & 3: <= 1 ulp on either output, 23 vector instructions
+// where the library routine (which carries the Payne-Hanek path for huge arguments) took about twice that.  Larger arguments
+// (never seen: the estimator's outputs are bounded by the row's phases) go to the library routine.
+__device__ __forceinline__ void ts_sincos(float a, float &sn, float &cs)
+{
+	if (!(fabsf(a) < 1000.f)) {
+		sincosf(a, &sn, &cs);
+		return;
+	}
+	const float n = rintf(a * 0.636619772f);
+	float r = fmaf(-n, 1.57079637f, a);
+	r = fmaf(-n, -4.37113883e-8f, r);
+	const float z = r * r;
+	const float ps = fmaf(fmaf(fmaf(2.71831149e-6f, z, -1.98393348e-4f), z, 8.33332939e-3f), z, -1.66666667e-1f);
+	const float pc = fmaf(fmaf(fmaf(2.43904488e-5f, z, -1.38867638e-3f), z, 4.16666233e-2f), z, -0.5f);
+	const float sr = fmaf(r * z, ps, r), cr = fmaf(z, pc, 1.f);
+	const int q = (int)n;
+	const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+	sn = __uint_as_float(__float_as_uint(s0) ^ ((uint32_t)(q & 2) << 30));
+	cs = __uint_as_float(__float_as_uint(c0) ^ ((uint32_t)((q + 1) & 2) << 30));
+}
+
 // one row: decode.cc:482-494
 __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const ModeDesc &md, cf *__restrict__ cons_all,
 	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all)
@@ -774,16 +798,18 @@ __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const M
 	const int cols = md.cols;
 	cf *row = cons_all + (size_t)f * CONS_MAX + (size_t)j * cols;
 	const cf *cr = carr_all ? carr_all + (size_t)f * CARR_MAX + (size_t)j * cols : nullptr;
-	auto cons_at = [&](int i) {                                    // decode.cc:474-475
-		return cr ? demod_or_erase(cr[cols + i], cr[i]) : row[i];
-	};
 	#pragma unroll 1
 	for (int q = 0; q < 8; ++q) {                                 // decode.cc:482-487
 		const int i = lane + 64 * q;
 		if (i < cols) {
-			const cf c = cons_at(i);
-			if (cr && cons_raw_all)
-				cons_raw_all[(size_t)f * CONS_MAX + (size_t)j * cols + i] = c;
+			cf c;
+			if (cr) {                                             // decode.cc:474-475
+				c = demod_or_erase(cr[cols + i], cr[i]);
+				row[i] = c;                                       // read back for the rotation below: the division is done once
+				if (cons_raw_all)
+					cons_raw_all[(size_t)f * CONS_MAX + (size_t)j * cols + i] = c;
+			} else
+				c = row[i];
 			cf d = cmul(c, cconj(md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c)));
 			s.y[ts_yaddr(i)] = atan2f(d.im, d.re);
 		}
@@ -791,15 +817,16 @@ __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const M
 	TS_SYNC();
 	const float2 sy = theil_sen_wave(s, cols, lane);
 	const float slope = sy.x, yint = sy.y;
-	// (the row is formed a second time here instead of being held in 16 registers across the search: its carriers are in L2)
+	// (the row is read a second time here instead of being held in 16 registers across the search: it is in L2 or close;
+	// each lane reads back exactly the elements it wrote)
 	#pragma unroll 1
 	for (int q = 0; q < 8; ++q) {                                 // decode.cc:493-494
 		const int i = lane + 64 * q;
 		if (i < cols) {
 			float a = -(yint + slope * (float)(i - cols / 2));
 			float sn, cs;
-			sincosf(a, &sn, &cs);
-			row[i] = cmul(cons_at(i), mk(cs, sn));
+			ts_sincos(a, sn, cs);
+			row[i] = cmul(row[i], mk(cs, sn));
 		}
 	}
 	if (lane == 0) {

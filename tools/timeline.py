@@ -6,7 +6,7 @@ import sys
 
 c = sqlite3.connect(sys.argv[1])
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-rows = c.execute("select name, start, end from kernels where name like '%rx::%' order by start").fetchall()
+rows = c.execute("select name, start, end from kernels where name like '%rx::%' or name like '%rocclr%' order by start").fetchall()
 prev = None
 for name, s, e in rows[-n:]:
     gap = (s - prev) / 1e3 if prev is not None else 0.0
