@@ -90,6 +90,9 @@ __global__ __launch_bounds__(256) void k_tx_code(const uint8_t *__restrict__ pay
 // The 4x oversampled PAPR buffer (encode.cc:50-51 fdom4/tdom4) is 5120 / 10240 points at 8 / 16 kHz and sits in
 // LDS (41 / 82 KB); at 44.1 / 48 kHz it is 28224 / 30720 points (226 / 246 KB > LDS) and lives in a per-workgroup
 // global scratch, worked on by 1024 threads so the in-place radix stages still fit the register file.
+#ifndef TX_TW_GLOBAL
+#define TX_TW_GLOBAL 0     // 1: the transforms read the root table through L1 instead of a compact copy in LDS (10 KB less per workgroup)
+#endif
 template <int RATE> struct TxCfg {
 	static constexpr bool BIG_IN_LDS = RATE <= 16000;
 #ifndef TX_NT_LDS
@@ -135,10 +138,12 @@ __global__ __launch_bounds__(256) void k_tx_rows(const uint32_t *__restrict__ co
 	}
 }
 
-template <int RATE> struct TxShared {
-	cf big[TxCfg<RATE>::BIG_IN_LDS ? 4 * RateCfg<RATE>::SL : 1];   // LDS path: four decimated sequences [r][symbol_len]
-	cf fdom[RateCfg<RATE>::SL];
-	cf twc[TxCfg<RATE>::BIG_IN_LDS ? fft_compact_size<RateCfg<RATE>::SL, RateCfg<RATE>::SL>() : 1];   // compact twiddles of the symbol_len plan
+// (8-byte alignment said out loud: `cf` alone promises 4, and the transforms then run on pairs of 32-bit LDS accesses - two-way
+// bank conflicts on every one of them, 54 % of the kernel's LDS cycles - instead of ds_read_b64 / ds_write_b64)
+template <int RATE> struct alignas(16) TxShared {
+	alignas(16) cf big[TxCfg<RATE>::BIG_IN_LDS ? 4 * RateCfg<RATE>::SL : 2];   // LDS path: four decimated sequences [r][symbol_len]
+	alignas(16) cf fdom[RateCfg<RATE>::SL];
+	alignas(16) cf twc[(TxCfg<RATE>::BIG_IN_LDS && !TX_TW_GLOBAL) ? fft_compact_size<RateCfg<RATE>::SL, RateCfg<RATE>::SL>() : 1];   // compact twiddles of the symbol_len plan
 };
 
 // symbol kinds in transmission order (encode.cc:288-313): pilot | S&C | meta | pilot | rows x data | zero
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 	const int f = blockIdx.x / tp.nsym, sidx = blockIdx.x % tp.nsym, tid = threadIdx.x;
 	const ModeDesc md = mode_desc(tp.oper_mode);
 	__shared__ TxShared<RATE> sh;
-	cf *big = TxCfg<RATE>::BIG_IN_LDS ? sh.big : big_scratch + (size_t)blockIdx.x * (4 * SYMBOL_LEN);
+	cf *big = (cf *)__builtin_assume_aligned(TxCfg<RATE>::BIG_IN_LDS ? sh.big : big_scratch + (size_t)blockIdx.x * (4 * SYMBOL_LEN), 8);
 	const int code_off = tp.offset - md.cols / 2;             // encode.cc:284
 	const int mls0_off = tp.offset - 127 + 1;                 // encode.cc:285
 	const int mls1_off = tp.offset - 255 / 2;                 // encode.cc:286
@@ -228,12 +233,13 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 		constexpr int RT = NT / 4;                            // threads per residue (64: wave-private transforms, wave barriers only)
 		static_assert(RT % 64 == 0 && RT >= 64, "whole waves per residue");
 		const int wave = tid / RT, lane = tid % RT;           // residue, thread within it
-		fft_compact_twiddles<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.twc, tb.tw_sym, tid);
+		if (!TX_TW_GLOBAL)
+			fft_compact_twiddles<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.twc, tb.tw_sym, tid);
 		const float s4 = sqrtf((float)(4 * SYMBOL_LEN)), r4 = 1.f / s4;
 		auto div_s4 = [&](float x) { const float q0 = x * r4; return __builtin_fmaf(__builtin_fmaf(-s4, q0, x), r4, q0); };   // x / s4
 		__syncthreads();
 		if (papr && sidx != last) {
-			cf *sub = big + wave * SYMBOL_LEN;
+			cf *sub = (cf *)__builtin_assume_aligned(big + wave * SYMBOL_LEN, 8);
 			auto w4 = [&](int c) {                            // w^(c * wave)
 				int t = (c * wave) % (4 * SYMBOL_LEN);
 				return tw5120[t < 0 ? t + 4 * SYMBOL_LEN : t];
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 				sub[b] = g;
 			}
 			fft_sync<RT>();
-			fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, sh.twc, lane);
+			if (TX_TW_GLOBAL) fft_fwd<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, tb.tw_sym, lane); else fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, sh.twc, lane);
 			for (int i = lane; i < SYMBOL_LEN; i += RT) {
 				cf v = cconj(sub[i]);
 				v = mk(div_s4(v.re), div_s4(v.im));
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 				sub[i] = v;
 			}
 			fft_sync<RT>();
-			fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, sh.twc, lane);
+			if (TX_TW_GLOBAL) fft_fwd<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, tb.tw_sym, lane); else fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, sh.twc, lane);
 			__syncthreads();
 			for (int i = tid; i < SYMBOL_LEN; i += NT) {
 				const int c = i - SYMBOL_LEN / 2, b = bin1280(c);
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 				sh.fdom[i] = cconj(sh.fdom[i]);
 		}
 		__syncthreads();
-		fft_fwd_compact<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fdom, sh.twc, tid);
+		if (TX_TW_GLOBAL) fft_fwd<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fdom, tb.tw_sym, tid); else fft_fwd_compact<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fdom, sh.twc, tid);
 		const float r8 = 1.f / s8;
 		for (int i = tid; i < SYMBOL_LEN; i += NT) {
 			cf v = cconj(sh.fdom[i]);

@@ -487,7 +487,7 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, int sti, FrameBa
 		SyncState *stq = st + f0;
 		const cf *zq = z ? z + (size_t)f0 * (size_t)fb.samples_per_frame : nullptr;
 		cf *scq = h->sc_scratch.p ? h->sc_scratch.as<cf>() + (size_t)f0 * sl : nullptr;
-		launch_init_sync(sq, nq, stq, d_skip ? d_skip + f0 : nullptr, h->work_counter.as<int>() + 16);
+		launch_init_sync(sq, nq, stq, d_skip ? d_skip + f0 : nullptr, h->work_counter.as<int>() + 16 + par);   // the chunk's flags, by parity
 		size_t last = e1;
 		for (int round = 0; round <= max_skip; ++round) {      // decode.cc:390-448 do { } while (skip_count--)
 			if (round == 0 && q == 0 && wait_before_sync != (size_t)-1)
@@ -547,7 +547,7 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, 
 	{
 		Range r("ofdmrx:theil_sen");
 		launch_theil_sen(s, n, st, h->cons_of(par), from_carr ? h->carr.as<cf>() : nullptr,
-			(from_carr && (h->cfg.flags & 1)) ? h->cons_raw.as<cf>() : nullptr, h->slope_of(par), h->yint_of(par), h->work_counter.as<int>() + 16);
+			(from_carr && (h->cfg.flags & 1)) ? h->cons_raw.as<cf>() : nullptr, h->slope_of(par), h->yint_of(par), h->work_counter.as<int>() + 16 + par);
 	}
 	size_t e5 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_THEILSEN, e4, e5 });
