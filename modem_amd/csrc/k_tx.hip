@@ -147,6 +147,17 @@ template <int RATE> struct alignas(16) TxShared {
 };
 
 // symbol kinds in transmission order (encode.cc:288-313): pilot | S&C | meta | pilot | rows x data | zero
+// The pilot, Schmidl-Cox, meta-data and zero symbols do not depend on the payload (one mode, offset and call sign per call):
+// they are formed once, for frame 0 / payload 0, and every other frame's cross-fade reads them from there (5 of 55 symbol
+// transforms per mode-6 frame less).
+__device__ __forceinline__ size_t tx_symbol_slot(int f, int sidx, int nsym, int rows)
+{
+	const int per = 3 + rows, last = nsym - 1;
+	if (sidx == 0 || sidx == last)
+		return (size_t)sidx;
+	const int w = (sidx - 1) % per;
+	return w < 3 ? (size_t)(1 + w) : (size_t)f * nsym + sidx;
+}
 template <int RATE>
 #ifndef TX_WAVES
 #define TX_WAVES 2        // waves per SIMD the register budget of k_tx_symbol is set for
@@ -159,6 +170,8 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 	auto bin5120 = [](int c) { return (c + 4 * SYMBOL_LEN) % (4 * SYMBOL_LEN); };     // encode.cc:72-75
 	const int f = blockIdx.x / tp.nsym, sidx = blockIdx.x % tp.nsym, tid = threadIdx.x;
 	const ModeDesc md = mode_desc(tp.oper_mode);
+	if (tx_symbol_slot(f, sidx, tp.nsym, md.rows) != (size_t)f * tp.nsym + sidx)
+		return;                                               // a payload-independent symbol: frame 0 makes it
 	__shared__ TxShared<RATE> sh;
 	cf *big = (cf *)__builtin_assume_aligned(TxCfg<RATE>::BIG_IN_LDS ? sh.big : big_scratch + (size_t)blockIdx.x * (4 * SYMBOL_LEN), 8);
 	const int code_off = tp.offset - md.cols / 2;             // encode.cc:284
@@ -378,8 +391,9 @@ __global__ __launch_bounds__(256) void k_tx_assemble(const cf *__restrict__ tdom
 			put(base + i, mk(0.f, 0.f));
 		return;
 	}
-	const cf *cur = tdom_all + ((size_t)f * tp.nsym + part) * SYMBOL_LEN;
-	const cf *prv = part ? cur - SYMBOL_LEN : nullptr;
+	const int rows = mode_desc(tp.oper_mode).rows;
+	const cf *cur = tdom_all + tx_symbol_slot(f, part, tp.nsym, rows) * SYMBOL_LEN;
+	const cf *prv = part ? tdom_all + tx_symbol_slot(f, part - 1, tp.nsym, rows) * SYMBOL_LEN : nullptr;
 	const long base = RATE + (long)part * SYM_STRIDE;
 	for (int i = tid; i < GUARD_LEN; i += 256) {              // encode.cc:110-114
 		float x = (float)i / (float)(GUARD_LEN - 1);
