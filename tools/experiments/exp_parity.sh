@@ -1,8 +1,10 @@
 #!/bin/bash
 # exp_parity.sh -- the new full-size tests, the parity sweeps (waterfall; modes / rates) on the current binary, the sweep driver with reuse
-O=$PWD/gpurun_out/parity.txt; mkdir -p gpurun_out; : > $O
+O=$PWD/gpurun_out/${OUT:-parity.txt}; mkdir -p gpurun_out; : > $O
 make -C modem_amd/csrc -q all && echo "library up to date with sources" >> $O || echo "STALE LIBRARY" >> $O
 timeout 1200 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "full_size or one_chunk or ber_sweep" 2>&1 | tail -5 >> $O
+echo "== levels where the syndrome certificate decides all / most / few frames (1024 frames per level)" >> $O
+timeout 900 python3 tests/parity_sweep.py 1024 -30 -26 -24 >> $O 2>&1
 echo "== waterfall parity sweep (tests/parity_sweep.py 1024 frames per level)" >> $O
 timeout 1500 python3 tests/parity_sweep.py 1024 -20 -17 -16 -15.5 -15 -14.5 -14 >> $O 2>&1
 echo "== modes / rates (256 frames per level)" >> $O
