@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void k_tx_code(const uint8_t *__restrict__ pay
 // LDS (41 / 82 KB); at 44.1 / 48 kHz it is 28224 / 30720 points (226 / 246 KB > LDS) and lives in a per-workgroup
 // global scratch, worked on by 1024 threads so the in-place radix stages still fit the register file.
 #ifndef TX_TW_GLOBAL
-#define TX_TW_GLOBAL 0     // 1: the transforms read the root table through L1 instead of a compact copy in LDS (10 KB less per workgroup)
+#define TX_TW_GLOBAL 2     // 0: compact stage twiddles copied to LDS per workgroup; 1: the root table read at a stride through L1;
+                           // 2: the compact table read from global memory (consecutive words, L1-resident): 10 KB of LDS less per
+                           // workgroup = three workgroups per CU, and a quarter of the transforms' LDS reads gone
 #endif
 template <int RATE> struct TxCfg {
 	static constexpr bool BIG_IN_LDS = RATE <= 16000;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 				sub[b] = g;
 			}
 			fft_sync<RT>();
-			if (TX_TW_GLOBAL) fft_fwd<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, tb.tw_sym, lane); else fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, sh.twc, lane);
+			if (TX_TW_GLOBAL == 1) fft_fwd<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, tb.tw_sym, lane); else fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, TX_TW_GLOBAL ? tb.tw_symc : sh.twc, lane);
 			for (int i = lane; i < SYMBOL_LEN; i += RT) {
 				cf v = cconj(sub[i]);
 				v = mk(div_s4(v.re), div_s4(v.im));
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 				sub[i] = v;
 			}
 			fft_sync<RT>();
-			if (TX_TW_GLOBAL) fft_fwd<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, tb.tw_sym, lane); else fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, sh.twc, lane);
+			if (TX_TW_GLOBAL == 1) fft_fwd<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, tb.tw_sym, lane); else fft_fwd_compact<SYMBOL_LEN, RT, SYMBOL_LEN>(sub, TX_TW_GLOBAL ? tb.tw_symc : sh.twc, lane);
 			__syncthreads();
 			for (int i = tid; i < SYMBOL_LEN; i += NT) {
 				const int c = i - SYMBOL_LEN / 2, b = bin1280(c);
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 				sh.fdom[i] = cconj(sh.fdom[i]);
 		}
 		__syncthreads();
-		if (TX_TW_GLOBAL) fft_fwd<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fdom, tb.tw_sym, tid); else fft_fwd_compact<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fdom, sh.twc, tid);
+		if (TX_TW_GLOBAL == 1) fft_fwd<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fdom, tb.tw_sym, tid); else fft_fwd_compact<SYMBOL_LEN, NT, SYMBOL_LEN>(sh.fdom, TX_TW_GLOBAL ? tb.tw_symc : sh.twc, tid);
 		const float r8 = 1.f / s8;
 		for (int i = tid; i < SYMBOL_LEN; i += NT) {
 			cf v = cconj(sh.fdom[i]);

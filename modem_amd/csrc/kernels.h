@@ -50,6 +50,7 @@ struct Tables {                    // device-resident constants, built once per 
 	const float *mls0_nrz;         // [127] MLS 0b10001001 (transmitter: Schmidl-Cox symbol, encode.cc:144)
 	const float *mls2_nrz;         // [512] MLS 0b100101010001 (transmitter: pilot block, encode.cc:134)
 	const cf *tw_sym4;             // e^{-j 2 pi m / (4 symbol_len)} (transmitter PAPR step)
+	const cf *tw_symc;             // compact per-stage twiddles of the symbol_len-point plan (transmitter: read through L1)
 	const uint32_t *frozen;        // [2][2048] words, bit set = frozen: frozen_64800_43072, frozen_64512_43072 (regenerated)
 	const uint16_t *info_pos;      // [2][44096] ascending unfrozen positions per table
 	const uint8_t *node_lev;       // [2][8192] per 8-leaf group: level of the largest aligned all-frozen (low nibble) /

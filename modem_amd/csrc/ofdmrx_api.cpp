@@ -287,6 +287,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.mls0_nrz, &h->dev.mls0_nrz);
 	r = r ? r : upload(h, h->host.mls2_nrz, &h->dev.mls2_nrz);
 	r = r ? r : upload(h, h->host.tw_sym4, &h->dev.tw_sym4);
+	r = r ? r : upload(h, h->host.tw_symc, &h->dev.tw_symc);
 	r = r ? r : upload(h, h->host.frozen, &h->dev.frozen);
 	r = r ? r : upload(h, h->host.info_pos, &h->dev.info_pos);
 	r = r ? r : upload(h, h->host.node_lev, &h->dev.node_lev);

@@ -123,6 +123,17 @@ void build_tables(HostTables &t, int rate)
 	};
 	roots(t.tw_sym, SL);
 	roots(t.tw_sym4, 4 * SL);
+	// the compact table of the symbol_len-point radix plan (dev_common.h FftPlan: all 5s, then 7s, 3s, 4s, a final 2):
+	// stage (P, R) owns (R - 1) P consecutive entries, entry (t - 1) P + k = w^(t k symbol_len / (P R))
+	t.tw_symc.clear();
+	for (int rem = SL, P = 1; rem > 1;) {
+		const int R = rem % 5 == 0 ? 5 : rem % 7 == 0 ? 7 : rem % 3 == 0 ? 3 : rem % 4 == 0 ? 4 : 2;
+		if (P > 1)
+			for (int i = 0; i < (R - 1) * P; ++i)
+				t.tw_symc.push_back(t.tw_sym[(size_t)((i / P + 1) * (i % P)) * (size_t)(SL / (P * R))]);
+		P *= R;
+		rem /= R;
+	}
 	// decode.cc:236-244 mls0_seq + decode.cc:80-82: kern = conj(FFT_{symbol_len/2}(seq)) / (symbol_len/2)
 	{
 		std::vector<double> seq(HS, 0.0);
