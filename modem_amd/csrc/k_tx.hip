@@ -30,21 +30,53 @@ __global__ __launch_bounds__(256) void k_tx_code(const uint8_t *__restrict__ pay
 	__shared__ uint32_t cw[2048];
 	__shared__ uint32_t crctab[256];
 	__shared__ int rank[2048];                 // unfrozen positions before word w
+	__shared__ uint32_t csh[1024], cpart[32];
 	crctab[tid] = tb.crc32_tab[tid];
+	#pragma unroll
+	for (int q = 0; q < 4; ++q)
+		csh[tid + 256 * q] = tb.crc32_shift168[tid + 256 * q];
 	for (int i = tid; i < PAYLOAD_BYTES; i += 256)
 		msg[i] = payload_all[(size_t)f * PAYLOAD_BYTES + i] ^ tb.scramble[i];   // encode.cc:417-419
 	__syncthreads();
-	if (tid == 0) {                            // CRC<uint32_t>(0xD419CC15) over the scrambled bytes, encode.cc:295-297
+	// CRC<uint32_t>(0xD419CC15) over the scrambled bytes, encode.cc:295-297: 32 threads run the byte table over 168-byte
+	// segments from a zero state, the partial states are folded in order with the "advance by 168 zero bytes" operator
+	// (k_finish.hip has the same scheme; 5380 = 32 x 168 + 4).  Unfrozen positions before each word: a wave scan.
+	constexpr int SEG = 168, NSEG = 32, TAIL = PAYLOAD_BYTES - SEG * NSEG;
+	if (tid < NSEG) {
+		const uint8_t *mp = msg + tid * SEG;
 		uint32_t crc = 0;
-		for (int i = 0; i < PAYLOAD_BYTES; ++i)
-			crc = (crc >> 8) ^ crctab[(crc ^ msg[i]) & 255];
-		for (int b = 0; b < 4; ++b)
-			msg[PAYLOAD_BYTES + b] = (uint8_t)(crc >> (8 * b));   // appended LSB first, encode.cc:298-299
-		int acc = 0;
-		for (int w = 0; w < 2048; ++w) {
+		for (int i = 0; i < SEG; ++i)
+			crc = (crc >> 8) ^ crctab[(crc ^ mp[i]) & 255];
+		cpart[tid] = crc;
+	} else if (tid >= 64 && tid < 128) {       // rank[w] = unfrozen positions before word w: 32 words per lane, then a prefix over the lanes
+		const int l = tid - 64;
+		int own = 0;
+		for (int w = 32 * l; w < 32 * l + 32; ++w)
+			own += 32 - __popc(frozen[w]);
+		int incl = own;
+		#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const int o = __shfl_up(incl, d, 64);
+			if (l >= d)
+				incl += o;
+		}
+		int acc = incl - own;
+		for (int w = 32 * l; w < 32 * l + 32; ++w) {
 			rank[w] = acc;
 			acc += 32 - __popc(frozen[w]);
 		}
+	}
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t crc = 0;
+		for (int q = 0; q < NSEG; ++q) {
+			crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
+			crc ^= cpart[q];
+		}
+		for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
+			crc = (crc >> 8) ^ crctab[(crc ^ msg[i]) & 255];
+		for (int b = 0; b < 4; ++b)
+			msg[PAYLOAD_BYTES + b] = (uint8_t)(crc >> (8 * b));   // appended LSB first, encode.cc:298-299
 	}
 	__syncthreads();
 	// u: message bit k at the k-th unfrozen position (bits >= 43072 are +1 = 0), frozen positions 0
