@@ -232,11 +232,14 @@ template <int RATE> struct SyncRing { static constexpr int N = TILE + RateCfg<RA
 #ifndef SYNC_WAVES
 #define SYNC_WAVES 2
 #endif
-template <int RATE> struct SyncShared {
+#ifndef SYNC_WAVES_SPLIT
+#define SYNC_WAVES_SPLIT 4      // register budget of the split scan (k_sync<RATE, true>): 124 VGPRs, 10 KB of LDS = 16 waves per CU
+#endif
+template <int RATE, bool SPLIT = false> struct SyncShared {   // (the split scan never runs the accept path's transforms)
 	double m[SyncRing<RATE>::N];
 	float timing[TILE];
-	cf buf[SYNC_FFT_LDS(RATE) ? RateCfg<RATE>::HS : 1];
-	cf xr[SYNC_FFT_LDS(RATE) ? RateCfg<RATE>::HS : 1];
+	cf buf[SYNC_FFT_LDS(RATE) && !SPLIT ? RateCfg<RATE>::HS : 1];
+	cf xr[SYNC_FFT_LDS(RATE) && !SPLIT ? RateCfg<RATE>::HS : 1];
 };
 
 __device__ __forceinline__ int first_index(const float *timing, int T0, int lane, int lo_t, int hi_t, bool greater, float thr)
@@ -364,12 +367,13 @@ __device__ bool sc_process(cf *buf, cf *xr, const SampleSrc &src, const cf *tw, 
 	return true;
 }
 
-// SPLIT = false: the whole of decode.cc:86-151 for one frame by one wave (8 kHz, and the catch-all at the other rates).
+// SPLIT = false: the whole of decode.cc:86-151 for one frame by one wave (the catch-all after SYNC_SPLIT_ROUNDS rejected triggers;
+// the only sync kernel at 8 kHz until round 3).
 // SPLIT = true: the scan stops at the first trigger and leaves (g, index_max, phase_max) in the frame's state; the accept
 // path runs as k_sync_accept with a whole workgroup per frame.  At 44.1 / 48 kHz the three 3528 / 3840-point transforms of
 // the accept path by ONE wave through global scratch (256 VGPRs + spills) were 60 % of this kernel's time.
 template <int RATE, bool SPLIT>
-__global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
+__global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_sync(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
 	const cf *__restrict__ kern, SyncState *__restrict__ st_all, cf *__restrict__ scratch)
 {
 	typedef RateCfg<RATE> RC;
@@ -384,9 +388,9 @@ __global__ __launch_bounds__(64, SYNC_WAVES) void k_sync(FrameBatch fb, const cf
 		return;
 	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, n,
 		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
-	__shared__ SyncShared<RATE> sh;
-	cf *fbuf = SYNC_FFT_LDS(RATE) ? sh.buf : scratch + (size_t)f * 2 * HALF_LEN;
-	cf *fxr = SYNC_FFT_LDS(RATE) ? sh.xr : scratch + (size_t)f * 2 * HALF_LEN + HALF_LEN;
+	__shared__ SyncShared<RATE, SPLIT> sh;
+	cf *fbuf = SYNC_FFT_LDS(RATE) && !SPLIT ? sh.buf : scratch + (size_t)f * 2 * HALF_LEN;
+	cf *fxr = SYNC_FFT_LDS(RATE) && !SPLIT ? sh.xr : scratch + (size_t)f * 2 * HALF_LEN + HALF_LEN;
 	for (int i = lane; i < MRING; i += 64)
 		sh.m[i] = 0.0;
 	const float thr_lo = (float)(0.17 * MATCH_LEN), thr_hi = (float)(0.19 * MATCH_LEN);   // decode.cc:76
@@ -710,7 +714,8 @@ void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef c
 void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, cf *scratch)
 {
 #ifndef SYNC_SPLIT_8K
-#define SYNC_SPLIT_8K 0
+#define SYNC_SPLIT_8K 1       // 8 kHz too since round 3: the fused one-wave kernel needs 240 VGPRs and 20 KB of LDS (8 waves per CU,
+                              // four rounds of 2048 frames per chunk); the scan alone runs at 16 per CU: 0.83 -> 0.73 ms per 8192 frames
 #endif
 	if (rate != 8000 || SYNC_SPLIT_8K) {
 		for (int r = 0; r < SYNC_SPLIT_ROUNDS; ++r) {
