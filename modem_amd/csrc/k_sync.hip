@@ -235,9 +235,12 @@ template <int RATE> struct SyncRing { static constexpr int N = TILE + RateCfg<RA
 #ifndef SYNC_WAVES_SPLIT
 #define SYNC_WAVES_SPLIT 4      // register budget of the split scan (k_sync<RATE, true>): 124 VGPRs, 10 KB of LDS = 16 waves per CU
 #endif
+// Both arrays are read and written at lane * PER + e (+ a ring offset): one pad word per eight keeps the lanes of a group on
+// distinct banks (stride 9 instead of 8).  The ring holds fp32 metric values (they are summed in double after the read).
+__device__ __forceinline__ int sync_pad(int i) { return i + (i >> 3); }
 template <int RATE, bool SPLIT = false> struct SyncShared {   // (the split scan never runs the accept path's transforms)
-	double m[SyncRing<RATE>::N];
-	float timing[TILE];
+	float m[SyncRing<RATE>::N + SyncRing<RATE>::N / 8];
+	float timing[TILE + TILE / 8];
 	cf buf[SYNC_FFT_LDS(RATE) && !SPLIT ? RateCfg<RATE>::HS : 1];
 	cf xr[SYNC_FFT_LDS(RATE) && !SPLIT ? RateCfg<RATE>::HS : 1];
 };
@@ -248,7 +251,7 @@ __device__ __forceinline__ int first_index(const float *timing, int T0, int lane
 	#pragma unroll
 	for (int e = 0; e < PER; ++e) {
 		int t = T0 + lane * PER + e;
-		float v = timing[lane * PER + e];
+		float v = timing[sync_pad(lane * PER + e)];
 		bool c = greater ? (v > thr) : (v < thr);
 		if (t >= lo_t && t < hi_t && c && best == 0x7fffffff)
 			best = t;
@@ -391,8 +394,8 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 	__shared__ SyncShared<RATE, SPLIT> sh;
 	cf *fbuf = SYNC_FFT_LDS(RATE) && !SPLIT ? sh.buf : scratch + (size_t)f * 2 * HALF_LEN;
 	cf *fxr = SYNC_FFT_LDS(RATE) && !SPLIT ? sh.xr : scratch + (size_t)f * 2 * HALF_LEN + HALF_LEN;
-	for (int i = lane; i < MRING; i += 64)
-		sh.m[i] = 0.0;
+	for (int i = lane; i < MRING + MRING / 8; i += 64)
+		sh.m[i] = 0.f;
 	const float thr_lo = (float)(0.17 * MATCH_LEN), thr_hi = (float)(0.19 * MATCH_LEN);   // decode.cc:76
 	const float min_R = 0.0001f * HALF_LEN;                                                // decode.cc:88
 	const long t_start = st.t_next;
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 			R = fmaxf(R, min_R);
 			// decode.cc:90: the fp32 expression of the reference, term by term (no contraction); only its moving sum runs in double
 			const float mf = __fdiv_rn(__fadd_rn(__fmul_rn(Pre, Pre), __fmul_rn(Pim, Pim)), __fmul_rn(R, R));
-			sh.m[(T0 + lane * PER + e) & (MRING - 1)] = (double)mf;
+			sh.m[sync_pad((int)((T0 + lane * PER + e) & (MRING - 1)))] = mf;
 		}
 		Wr = shfl_d(or_ + dr[PER - 1], 63);
 		Wi = shfl_d(oi_ + di[PER - 1], 63);
@@ -461,14 +464,14 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 		#pragma unroll
 		for (int e = 0; e < PER; ++e) {
 			long t = T0 + lane * PER + e;
-			double in = sh.m[t & (MRING - 1)];
-			double out = (t - MATCH_LEN >= 0) ? sh.m[(t - MATCH_LEN) & (MRING - 1)] : 0.0;
+			double in = (double)sh.m[sync_pad((int)(t & (MRING - 1)))];
+			double out = (t - MATCH_LEN >= 0) ? (double)sh.m[sync_pad((int)((t - MATCH_LEN) & (MRING - 1)))] : 0.0;
 			dm[e] = (e ? dm[e - 1] : 0.0) + (in - out);
 		}
 		double om = wave_scan_incl(dm[PER - 1], lane) - dm[PER - 1] + Wm;
 		#pragma unroll
 		for (int e = 0; e < PER; ++e)
-			sh.timing[lane * PER + e] = (float)(om + dm[e]);
+			sh.timing[sync_pad(lane * PER + e)] = (float)(om + dm[e]);
 		Wm = shfl_d(om + dm[PER - 1], 63);
 		__syncthreads();
 		// ---- trigger logic on the tile (decode.cc:93-108)
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 			#pragma unroll
 			for (int e = 0; e < PER; ++e) {
 				int t = (int)T0 + lane * PER + e;
-				float v = sh.timing[lane * PER + e];
+				float v = sh.timing[sync_pad(lane * PER + e)];
 				if (t >= cur && t < stop && v > bv) { bv = v; bi = t; }
 			}
 			#pragma unroll
