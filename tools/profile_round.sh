@@ -49,11 +49,12 @@ root = os.environ.get("R", ".")
 def sha(f):
     return hashlib.sha256(open(os.path.join(root, "modem_amd", "csrc", f), "rb").read()).hexdigest()[:16]
 def grab(mode, kern, ctr):
-    """average per launch of the LAST-but-warm launches: sum / calls"""
-    tot = n = 0.0
+    """per chunk: the sum over every kernel of the stage (the sync stage is several kernels, some launched twice per chunk) / the
+    number of chunks (= the calls of the kernel launched least often: each stage has one that runs once per chunk)"""
+    tot = 0.0; n = 0
     for m in re.finditer(r"^\[%s\] (\S.*?)\s+%s\s+calls\s+(\d+)\s+sum\s+([0-9.]+)" % (mode, ctr), txt, re.M):
         if kern in m.group(1):
-            tot += float(m.group(3)); n = max(n, int(m.group(2)))
+            tot += float(m.group(3)); n = int(m.group(2)) if not n else min(n, int(m.group(2)))
     return tot / n if n else None
 def calib(kern, ctr):
     m = re.search(r"^%s\s+%s\s+calls\s+(\d+)\s+sum\s+([0-9.]+)" % (re.escape(kern), ctr), txt, re.M)
