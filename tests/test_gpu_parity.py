@@ -118,6 +118,20 @@ def test_theil_sen_rank_search_rows(rx):
             assert s[r] == np.float32(os_) and yi[r] == np.float32(oy), (cols, r)
 
 
+def test_theil_sen_soak_rows(rx):
+    """1800 random rows of tests/ts_soak.py (heavy tails, clusters, quantised values, heteroscedastic noise, erased carriers:
+    the shapes that make the search's density estimate miss, so that the open bracket's retry and the closed-bracket path
+    run): slope and intercept bit-identical to the oracle"""
+    import ts_soak
+    rng = np.random.default_rng(77)
+    for cols in (432, 400, 360, 512, 384, 256):
+        rows = ts_soak.make_rows(rng, cols, 300)
+        s, yi = rx.theil_sen(rows)
+        for r in range(rows.shape[0]):
+            os_, oy = O.theil_sen(rows[r])
+            assert s[r] == np.float32(os_) and yi[r] == np.float32(oy), (cols, r, s[r], os_, yi[r], oy)
+
+
 def _bch_codeword(rng):
     data = rng.integers(0, 256, 9, dtype=np.uint8)
     data[8] &= 0xfe
