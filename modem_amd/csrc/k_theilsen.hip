@@ -18,13 +18,20 @@
 //  * pairs whose keys differ by at most TS_MQ quanta are "uncertain" (quantisation + the fp32 roundings of s_ij); they
 //    are neighbours in sorted order, found by a short scan, and get the exact fp32 division.  The count is then exact.
 //  * search: least-squares slope as the first threshold, the density of slopes from the interquartile range of z, then
-//    secant steps on EXACT counts until [Ta, Tb) holds the wanted rank and at most TS_CAP pairs (2.9 counts on
-//    average, tools/ts_rank_model.py); the pairs inside are the pairs whose order differs between the keys at Ta and
-//    at Tb - neighbours again - they get the exact division and a 128-key sort picks the rank.  Every decision rests on
-//    exact counts, so there is no probabilistic bracket to validate and no list of 2-3 % of the pairs.
-//  * the intercepts (decode.cc:488 second median) are one more 512-key sort.
+//    secant steps on EXACT counts.  As soon as a count lands within TS_OPEN_NEED ranks of the wanted one the bracket is
+//    closed by an end that is NOT counted (the missing ranks + TS_OPEN_MARGIN, over the density): the pairs inside a
+//    bracket are the pairs whose order differs between the keys at its two ends - neighbours in sorted order, a windowed
+//    scan finds ALL of them whatever the far end is - they get the exact division, and with the exact count on the
+//    counted side the wanted slope is the (target - count)-th of them from below or the (count - target)-th from above
+//    (a 64-key sort over the lanes picks it).  A list that is too short or too long has its far end counted after all
+//    and the search goes on with a closed bracket of at most TS_CAP pairs.  2.05 counts per row; every decision rests
+//    on an exact count and a complete list: no probabilistic bracket to validate, no list of 2-3 % of the pairs.
+//  * the intercepts (decode.cc:488 second median): the keys left by the last count are the row sorted by y - T x with T
+//    next to the slope, so the candidate on position n/2 is checked by an exact rank count and moved by neighbours;
+//    a full 512-key sort only if that does not settle.
 //  * rows the search cannot finish (hundreds of tied slopes, NaNs) take an exact 8-bit radix select over all pairs.
-// Bit-identical to nth_element on the CPU (tests/test_gpu_parity.py::test_theil_sen_bit_exact).
+// Bit-identical to nth_element on the CPU (tests/test_gpu_parity.py::test_theil_sen_bit_exact, ..._rank_search_rows,
+// ..._soak_rows; tests/ts_soak.py: 60 000 random rows).
 #include "dev_common.h"
 #include "kernels.h"
 
