@@ -5,13 +5,13 @@ Counts bytes per tree level under the rules of k_polar.hip (every array of a lev
 when produced, read once by the g step of its right child; a fused pass of up to three levels re-reads its lowest
 level when the next pass continues from it), and evaluates the variants DESIGN.md 4c discusses.  CPU only; the frozen
 table comes from the oracle (test infrastructure) - this is a planning tool, not product code.
-usage: python tools/polar_traffic_model.py
+usage: python tests/polar_traffic_model.py   (under tests/ because it asks the oracle for the table)
 """
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import oracle_lib as O
 
