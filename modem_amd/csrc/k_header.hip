@@ -122,6 +122,47 @@ __device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bit
 	const uint8_t *__restrict__ triples,
 	uint8_t *hard_out /* LDS or global, 32 B */, int tid)
 {
+#ifndef OSD_NO_SYNDROME_CERT
+	// ---- syndrome certificate (round 3).  The search below maximises the correlation sum_i x_i (1 - 2 c_i) over the candidate
+	// codewords c (oracle/bch_osd.c; osd.hh).  Its upper bound sum |x_i| is reached exactly by the words that equal the hard
+	// decisions h_i = [x_i < 0] wherever x_i != 0.  If h itself is a codeword it is the order-0 candidate of ANY information set
+	// (a codeword is determined by its bits on one) and therefore in the list; any other codeword with the same correlation
+	// differs from h only where x_i = 0, i.e. in at least d_min >= 59 such positions (the generator has the roots alpha^1 ..
+	// alpha^58).  So with fewer zeros than that h is the unique best: "hard = h, unique = true" is what the search returns,
+	// with no sort, no elimination and no candidate walked.  h is a codeword iff re-encoding its 71 systematic bits with the
+	// systematic generator gives back all 255 bits.
+	{
+		uint32_t *hw = (uint32_t *)s.red_best;
+		const bool neg = tid < BCH_N && s.soft[tid] < 0, zero = tid < BCH_N && s.soft[tid] == 0;
+		const unsigned long long bn = __ballot(neg), bz = __ballot(zero);
+		if ((tid & 63) == 0) {
+			hw[2 * (tid >> 6)] = (uint32_t)bn;
+			hw[2 * (tid >> 6) + 1] = (uint32_t)(bn >> 32);
+			s.red_next[tid >> 6] = __popcll(bz);
+		}
+		__syncthreads();
+		if (tid < 8) {
+			uint32_t acc = 0;
+			for (int j = 0; j < BCH_K; ++j)
+				if ((hw[j >> 5] >> (j & 31)) & 1)
+					acc ^= genmat_bits[j * 8 + tid];
+			s.red_id[tid] = acc != hw[tid];
+		}
+		__syncthreads();
+		const int zeros = s.red_next[0] + s.red_next[1] + s.red_next[2] + s.red_next[3];
+		int bad = 0;
+		#pragma unroll
+		for (int w = 0; w < 8; ++w)
+			bad |= s.red_id[w];
+		if (!bad && zeros <= 16) {                            // (16 << 59: the margin costs nothing)
+			if (tid < 32)                                         // big-endian bits: bit 7 - b of byte p = h[8 p + b]
+				hard_out[tid] = (uint8_t)(__brev((hw[tid >> 2] >> (8 * (tid & 3))) & 255u) >> 24);
+			__syncthreads();
+			return true;
+		}
+		__syncthreads();
+	}
+#endif
 	// reliabilities, stable descending sort by rank counting
 	if (tid < 256)
 		s.rel[tid] = tid < BCH_N ? (unsigned char)abs(max((int)s.soft[tid], -127)) : 0;

@@ -151,6 +151,33 @@ def test_osd_bit_exact(rx):
         softs.append(np.clip(np.rint(s), -128, 127).astype(np.int8))
     softs.append(np.zeros(255, np.int8))                          # everything ties: not unique
     softs.append(np.full(255, -128, np.int8))                     # clamp path (-128 -> -127)
+    # the syndrome certificate of k_header.hip (hard decisions already a codeword): clean words, words with a few and with
+    # very many zero soft values (the second kind must go through the search), one flipped bit (a weak and a strong one),
+    # the two extreme amplitudes
+    for t in range(12):
+        cw = _bch_codeword(rng)
+        s = (1 - 2 * cw.astype(np.int32)) * rng.integers(1, 128, 255)
+        if t == 1:
+            s[rng.choice(255, 10, replace=False)] = 0
+        elif t == 2:
+            s[rng.choice(255, 16, replace=False)] = 0
+        elif t == 3:
+            s[rng.choice(255, 17, replace=False)] = 0
+        elif t == 4:
+            s[rng.choice(255, 70, replace=False)] = 0
+        elif t == 5:
+            s[rng.choice(255, 200, replace=False)] = 0
+        elif t == 6:
+            i = int(rng.integers(0, 255)); s[i] = -np.sign(s[i]) * 1
+        elif t == 7:
+            i = int(rng.integers(0, 255)); s[i] = -np.sign(s[i]) * 127
+        elif t == 8:
+            s = (1 - 2 * cw.astype(np.int32)) * 1
+        elif t == 9:
+            s = np.where(cw == 1, -128, 127)
+        elif t == 10:
+            i = int(rng.integers(0, 71)); s[i] = 0                 # a zero on a systematic position
+        softs.append(np.clip(s, -128, 127).astype(np.int8))
     softs = np.stack(softs)
     hard, uniq = rx.osd(softs)
     for i in range(softs.shape[0]):
