@@ -451,7 +451,7 @@ def main():
         cert_note = ""
         if list_decoded >= 0:
             cert_note = ("; the syndrome certificate (hard decisions already a codeword with a valid CRC-32 => the list decoder's "
-                         "answer is known, DESIGN.md 4c) decided %d of rank 0's %d frames in the last step, the list decoder the other %d "
+                         "answer is known, DESIGN.md 4g) decided %d of rank 0's %d frames in the last step, the list decoder the other %d "
                          "- value_scl_forced is the same batch with the list decoder run for every frame" % (B - list_decoded, B, list_decoded))
         line = {
             "metric": METRIC,
