@@ -82,7 +82,7 @@ typedef struct {
 	                            * decoder for every frame, so that OFDMRX_TAP_LANE_MESG / _METRIC hold all eight lanes;
 	                            * bit 1 (OFDMRX_FLAG_SCL_ALWAYS): run the list decoder for every frame.  Without either, a frame
 	                            * whose channel hard decisions already form a codeword with a valid CRC-32 is finished by that
-	                            * syndrome check - the list decoder's lane 0 provably is that codeword (DESIGN.md 4c) - with
+	                            * syndrome check - the list decoder's lane 0 provably is that codeword (DESIGN.md 4g) - with
 	                            * identical payload, status, best_lane and bit_flips, and its LLRs are never written */
 	void *stream;              /* hipStream_t to run on, NULL = library-owned stream.  Batches longer than one chunk
 	                            * also use a second, library-owned stream for the polar stage (two-stage chunk
