@@ -205,3 +205,74 @@ def test_hilbert_is_analytic():
     re, im = C.c_float(), (C.c_float * 5)()
     O.lib().orc_hilbert_coeffs(C.byref(re), im)
     assert re.value == 1.0 and abs(im[0] - 2 / np.pi * 0.98) < 0.02 and all(im[i] > im[i + 1] > 0 for i in range(4))
+
+
+def test_osd_returns_the_hard_decisions_when_they_form_a_codeword():
+    """The rule k_header.hip's syndrome certificate rests on, checked on the oracle's exhaustive order-4 search:
+    if the hard decisions h = [soft < 0] re-encode to themselves (h is a BCH(255,71) codeword) and at most 16 soft values are
+    zero, the search returns exactly h and calls it unique - whatever the magnitudes are."""
+    rng = np.random.default_rng(20)
+
+    def codeword():
+        data = rng.integers(0, 256, 9, dtype=np.uint8)
+        data[8] &= 0xfe
+        par = np.zeros(23, np.uint8)
+        O.lib().orc_bch_encode(O.ptr(data), O.ptr(par))
+        return np.concatenate([np.unpackbits(data)[:71], np.unpackbits(par)[:184]])
+
+    def is_codeword(h):
+        data = np.packbits(np.concatenate([h[:71], [0]]))
+        par = np.zeros(23, np.uint8)
+        O.lib().orc_bch_encode(O.ptr(np.ascontiguousarray(data, dtype=np.uint8)), O.ptr(par))
+        return (np.unpackbits(par)[:184] == h[71:]).all()
+
+    held = 0
+    for t in range(120):
+        cw = codeword()
+        kind = t % 6
+        if kind == 0:                                      # clean, random magnitudes
+            s = (1 - 2 * cw.astype(np.int32)) * rng.integers(1, 128, 255)
+        elif kind == 1:                                    # the smallest magnitudes everywhere
+            s = (1 - 2 * cw.astype(np.int32)) * rng.integers(1, 3, 255)
+        elif kind == 2:                                    # up to 16 zeros anywhere
+            s = (1 - 2 * cw.astype(np.int32)) * rng.integers(1, 128, 255)
+            s[rng.choice(255, int(rng.integers(1, 17)), replace=False)] = 0
+        elif kind == 3:                                    # noisy: the hard decisions may or may not be a codeword
+            s = np.rint(20 * (1 - 2 * cw.astype(np.int32)) + rng.normal(0, 9, 255))
+        elif kind == 4:                                    # extremes of the int8 range
+            s = np.where(cw == 1, -128, 127)
+            s[rng.choice(255, 40, replace=False)] //= 64
+        else:                                              # another codeword's signs on a few weak positions: usually not a codeword
+            s = (1 - 2 * cw.astype(np.int32)) * rng.integers(1, 128, 255)
+            i = rng.choice(255, 2, replace=False)
+            s[i] = -np.sign(s[i])
+        s = np.clip(s, -128, 127).astype(np.int8)
+        h = (s < 0).astype(np.uint8)
+        if is_codeword(h) and int((s == 0).sum()) <= 16:
+            hard, uniq = O.osd(s)
+            assert uniq == 1 and (np.unpackbits(hard)[:255] == h).all(), (t, kind)
+            held += 1
+    assert held >= 60                                      # the rule applied to most of the words (all of kinds 0, 1, 2, 4)
+
+
+def test_scl_lane0_is_the_hard_decision_codeword_with_metric_zero():
+    """The rule the payload's syndrome certificate rests on, checked on the oracle's list decoder: if the hard
+    decisions of the LLRs form a codeword (here: they ARE one) and no LLR is zero, lane 0 of the list-8 decoder is that
+    codeword and its metric is exactly 0 - whatever the magnitudes are, also with magnitudes that differ by orders of magnitude."""
+    L = O.lib()
+    fr = O.frozen(0)
+    bits = np.unpackbits(fr.astype("<u4").view(np.uint8), bitorder="little")
+    rng = np.random.default_rng(8)
+    for t in range(6):
+        mesg = (1 - 2 * rng.integers(0, 2, 43808)).astype(np.int8)
+        code = np.zeros(65536, np.int8)
+        L.orc_polar_sysenc(O.ptr(code), O.ptr(mesg), O.ptr(fr), 16)
+        mag = [rng.uniform(0.5, 40.0, 65536), rng.uniform(1e-3, 1e-2, 65536), 10.0 ** rng.uniform(-4, 3, 65536),
+               np.full(65536, 1.0), rng.uniform(0.5, 40.0, 65536), rng.uniform(0.5, 40.0, 65536)][t]
+        llr = (code.astype(np.float64) * mag).astype(np.float32)
+        assert (llr != 0).all()
+        lane, metric = O.polar_lane_mesg(llr)
+        want = np.packbits((mesg < 0).astype(np.uint8), bitorder="little")
+        assert metric[0] == 0.0, (t, metric)
+        assert (lane[0] == want).all(), t
+        assert (metric[1:] > 0).all(), (t, metric)              # every other path pays a penalty somewhere
