@@ -372,7 +372,7 @@ def main():
     rx = None
     scl = None
     scl_steps = min(args.steps, 5) if args.scl_steps < 0 else args.scl_steps
-    if scl_steps > 0 and args.list == 8 and not os.environ.get("OFDMRX_NO_CERT"):     # (the same decision on every rank: barriers inside)
+    if scl_steps > 0 and not os.environ.get("OFDMRX_NO_CERT"):     # (the same decision on every rank: barriers inside)
         sm2, sl2 = {}, {}
         same = True
         if B:

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 		const int mate = f ^ 1;
 		if (mate < n_frames) {
 			const SyncState sm = st_all[mate];
-			if (sm.okay && (sm.oper_mode >= 10) == (st.oper_mode >= 10)) {
+			if (sm.okay && !(cert_all && cert_all[mate] == 1) && (sm.oper_mode >= 10) == (st.oper_mode >= 10)) {   // (k_polar's pairing rule)
 				hframe = (size_t)(f & ~1);
 				hshift = (f & 1) * 4;
 			}

@@ -556,7 +556,9 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 	if (LN == 4) {
 		cw_a = 2 * unit;
 		cw_b = cw_a + 1 < n_cw ? cw_a + 1 : -1;
-		const bool ok_a = st_all[cw_a].okay, ok_b = cw_b >= 0 && st_all[cw_b].okay;
+		// (a frame the syndrome certificate has finished counts as "nothing to decode", like one without a header)
+		const bool ok_a = st_all[cw_a].okay && !(cert_all && cert_all[cw_a] == 1);
+		const bool ok_b = cw_b >= 0 && st_all[cw_b].okay && !(cert_all && cert_all[cw_b] == 1);
 		const bool paired = ok_a && ok_b && (st_all[cw_a].oper_mode >= 10) == (st_all[cw_b].oper_mode >= 10);
 		if (!paired) {
 			n_pass = (ok_a ? 1 : 0) + (ok_b ? 1 : 0);
@@ -984,8 +986,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,
 	int *next_cw, const int *cert)
 {
-	if (list == 4)
-		cert = nullptr;                                       // (pairs of codewords per wave: the certificate is not wired into the pairing)
 	if (hipMemsetAsync(next_cw, 0, sizeof(int), s) != hipSuccess)
 		return;                                               // (the caller's hipGetLastError reports it)
 	if (grid <= 0 || grid > n)

@@ -136,7 +136,7 @@ struct ofdmrx_handle {
 	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
 	int last_par = 0;         // parity used by the last chunk (taps)
 	DevBuf cert, cert2;       // syndrome certificate: verdict per frame (+ one flag), by parity
-	bool use_cert = true;     // list 8, no debug taps, not switched off
+	bool use_cert = true;     // no debug taps, not switched off
 	float *esn0_user = nullptr;   // ofdmrx_set_esn0_rows: n x OFDMRX_ROWS_MAX floats in the memory space of the results (NULL = off)
 	DevBuf esn0_dev, esn0_dev2;   // host-pointer entry: per-chunk device staging of the row values, by parity
 	DevBuf cert_log;          // per chunk of the last call: frames the certificate left to the list decoder
@@ -215,7 +215,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	h->cfg = *cfg;
 	h->rate = cfg->sample_rate;
 	h->list = cfg->list_size == 4 ? 4 : 8;
-	h->use_cert = h->list == 8 && !(cfg->flags & (OFDMRX_FLAG_KEEP_RAW_CONS | OFDMRX_FLAG_SCL_ALWAYS)) && !std::getenv("OFDMRX_NO_CERT");
+	h->use_cert = !(cfg->flags & (OFDMRX_FLAG_KEEP_RAW_CONS | OFDMRX_FLAG_SCL_ALWAYS)) && !std::getenv("OFDMRX_NO_CERT");   // (the rule holds for any list size)
 	// default chunk: 8192 frames at every rate: the per-frame decoder state does not grow with the rate, and the two-stream
 	// schedule wants a few thousand codewords per polar launch (44.1 / 48 kHz: 121 k / 125 k frames/s against 111 k / 112 k
 	// with 4096).  What does grow is the per-chunk input: a 48 kHz frame is 4.2 MB of int16 pairs (34.6 GB per 8192 frames; the

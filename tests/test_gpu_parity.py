@@ -926,6 +926,15 @@ def test_list_size_4():
         oo, orr = O.decode(f, list_size=4)
         assert int(res[i]["status"]) == orr.status and int(res[i]["best_lane"]) == orr.best_lane and (out[i] == oo).all(), i
     assert int(res[0]["status"]) == 0 and (out[0] == pays[0]).all()
+    # the syndrome certificate with pairs of codewords per wave: a certified frame is no partner (the other one is decoded alone);
+    # pairs of (list-decoded, certified), (certified, certified), (list-decoded, list-decoded)
+    order = [1, 0, 0, 0, 2, 3, 0, 4]
+    out2, res2 = rx4.decode(np.stack([frames[q] for q in order]))
+    for i, q in enumerate(order):
+        for name in ("status", "best_lane", "bit_flips"):
+            assert int(res2[i][name]) == int(res[q][name]), (i, q, name)
+        assert (out2[i] == out[q]).all(), (i, q)
+    assert rx4.list_decoded_frames() == sum(1 for q in order if q != 0)
     rx4.close()
 
 
