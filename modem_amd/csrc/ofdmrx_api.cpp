@@ -404,7 +404,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->payload.ensure(N * PAYLOAD_BYTES);
 		if (h->cfg.flags & 1)
 			r = r ? r : h->cons_raw.ensure(N * CONS_MAX * sizeof(cf));
-		if (demod_writes_carriers(h->rate))
+		if (!demod_forms_cons(h->rate))                       // (the carriers go through HBM only when k_theil_sen forms the rows)
 			r = r ? r : h->carr.ensure(N * CARR_MAX * sizeof(cf));
 #ifndef SYNC_FFT_IN_LDS
 #define SYNC_FFT_IN_LDS 1
@@ -525,7 +525,7 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, int sti, FrameBa
 			HIP_OK(hipStreamWaitEvent(s, h->ev_pool[d], 0));
 		e3 = d;
 	}
-	if ((h->cfg.flags & 1) && !demod_writes_carriers(h->rate))
+	if ((h->cfg.flags & 1) && demod_forms_cons(h->rate))
 		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons_of(par), (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
 	(void)e3;
 	h->spans.push_back({ OFDMRX_T_FRONT, e0, e1 });
@@ -544,7 +544,7 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, 
 {
 	SyncState *st = h->st_of(sti);
 	size_t e4 = mark(h, s);
-	const bool from_carr = demod_writes_carriers(h->rate);
+	const bool from_carr = !demod_forms_cons(h->rate);
 	{
 		Range r("ofdmrx:theil_sen");
 		launch_theil_sen(s, n, st, h->cons_of(par), from_carr ? h->carr.as<cf>() : nullptr,
