@@ -36,7 +36,7 @@ template <int RATE> struct DemodSharedBlock {                // other rates: one
 #define DEMOD_WAVE_PER_SYMBOL(R) ((R) == 8000)
 #endif
 #ifndef DEMOD_CONS_OUT
-#define DEMOD_CONS_OUT 1    // 1 (since the end of round 3): the register-decimated demodulator forms cons = X_j / X_{j-1} itself, from the carriers of the
+#define DEMOD_CONS_OUT(R) ((R) != 44100)   // 1 (since the end of round 3; 44.1 kHz measured 3 % slower with it and keeps the old form): the register-decimated demodulator forms cons = X_j / X_{j-1} itself, from the carriers of the
                             // previous symbol parked in LDS (5 KB at 8 kHz) - k_theil_sen is VALU-bound and 0.42 ms per chunk shorter without the row
                             // formation, k_demod is LDS-bound and 0.16 ms longer with it; 0: the carriers go to HBM and k_theil_sen forms the rows
 #endif
@@ -107,9 +107,7 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 		__shared__ cf tw_sub[TWC];                            // compact twiddles of the NS-point plan
 		__shared__ cf tw_r[DC::TWR_LDS ? (R1 - 1) * NS : 1];  // w^(n' r), r = 1..R1-1
 		__shared__ cf rotA[R1], rotQ[NQ], symrot[ROWS_MAX + 1];
-#if DEMOD_CONS_OUT
-		__shared__ cf prevc[2][NT];                          // a thread's (at most two) carriers of the previous symbol
-#endif
+		__shared__ cf prevc[2][DEMOD_CONS_OUT(RATE) ? NT : 1];   // a thread's (at most two) carriers of the previous symbol
 		fft_compact_twiddles<NS, NT, SYMBOL_LEN>(tw_sub, tb.tw_sym, tid);
 		if (DC::TWR_LDS)
 			for (int i = tid; i < (R1 - 1) * NS; i += NT)
@@ -213,14 +211,13 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 			for (int e = 0; e < 2; ++e)
 				if (coff[e] >= 0) {
 					const cf cur = cmul(row[coff[e]], w);
-#if DEMOD_CONS_OUT
-					// decode.cc:474-475 here: the previous symbol's carrier is the one this thread parked a symbol ago (its own LDS slot)
-					if (s > 0)
-						cons[(size_t)(s - 1) * md.cols + tid + NT * e] = demod_or_erase(cur, prevc[e][tid]);
-					prevc[e][tid] = cur;
-#else
-					carr[tid + NT * e] = cur;
-#endif
+					if constexpr (DEMOD_CONS_OUT(RATE)) {
+						// decode.cc:474-475 here: the previous symbol's carrier is the one this thread parked a symbol ago (its own LDS slot)
+						if (s > 0)
+							cons[(size_t)(s - 1) * md.cols + tid + NT * e] = demod_or_erase(cur, prevc[e][tid]);
+						prevc[e][tid] = cur;
+					} else
+						carr[tid + NT * e] = cur;
 				}
 			carr += md.cols;
 			if (!DC::DOUBLE)
@@ -409,7 +406,7 @@ __global__ __launch_bounds__(256) void k_fft_debug(int len, int sign, const cf *
 }
 
 bool demod_writes_carriers(int rate) { return DEMOD_DIF || DEMOD_WAVE_PER_SYMBOL(rate); }
-bool demod_forms_cons(int rate) { return !demod_writes_carriers(rate) || (DEMOD_DIF && DEMOD_CONS_OUT); }
+bool demod_forms_cons(int rate) { return !demod_writes_carriers(rate) || (DEMOD_DIF && DEMOD_CONS_OUT(rate)); }
 void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons, cf *carr)
 {
 	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(DemodCfg<RATE>::NT), 0, s, fb, z, tb, st, cons, carr));
