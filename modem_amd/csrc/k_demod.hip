@@ -59,7 +59,7 @@ template <int RATE> struct DifCfg {
 #define DEMOD_DBL_BYTES 0
 #endif
 #ifndef DEMOD_DIF_WAVES
-#define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : 4)
+#define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : (R) == 8000 ? 7 : 4)   // 8 kHz: 72 VGPRs = five workgroups per CU (26.6 KB of LDS each); 64 spills with the swizzle
 #endif
 	static constexpr bool TWR_LDS = (R1 - 1) * NS * 8 <= DEMOD_TWR_BYTES;   // w^(n' r) table in LDS (8 / 16 kHz) or read from the global root table
 	static constexpr bool DOUBLE = 2 * SL * 8 <= DEMOD_DBL_BYTES;       // two row buffers, no third barrier per symbol: OFF by default (DEMOD_DBL_BYTES 0:
@@ -74,6 +74,35 @@ template <int RATE> struct DemodCfg {
 #endif
 	static constexpr int MINB = DIF ? DifCfg<RATE>::WAVES : DEMOD_WAVE_PER_SYMBOL(RATE) ? DEMOD_MINB : 1;        // waves per SIMD the register budget is set for
 };
+
+// Bank-conflict-free image of a wave-private 256-point buffer: element i lives at i ^ ((i >> 2) & 3) ^ (((i >> 4) & 3) << 2).  The
+// radix-4 stages read 64 consecutive elements per instruction (any bijection of the low six bits keeps that conflict-free) and
+// write at strides of 4 (P = 1) and 16 / 4 (P = 4) elements, which the plain layout puts four lanes deep on a bank; under the
+// swizzle every 16-lane store group touches 32 distinct banks (checked against the bank rules of the guide in a simulation).
+// Same operations in the same order as fft_stage<256, 4, P, 64>: only the addresses change.
+#ifndef DEMOD_SWZ
+#define DEMOD_SWZ 1     // 8 kHz (the only rate with wave-private 256-point transforms): demod 1.48 -> 1.35 ms per chunk with the seven-waves budget below
+#endif
+__device__ __forceinline__ int swz256(int i) { return i ^ ((i >> 2) & 3) ^ (((i >> 4) & 3) << 2); }
+template <int P, int TWC> __device__ __forceinline__ void fft256_stage_swz(cf *buf, const cf *tw, int lane, int sl)
+{
+	cf v[4];
+	const int k = lane % P;
+	#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		cf x = buf[sl + t * 64];                              // swz(lane + 64 t) = swz(lane) + 64 t
+		if (t && P > 1)
+			x = cmul(x, tw[TWC + (t - 1) * P + k]);
+		v[t] = x;
+	}
+	Bfly<4>::run(v);
+	fft_sync<64>();
+	const int j = (lane - k) * 4 + k;
+	#pragma unroll
+	for (int t = 0; t < 4; ++t)
+		buf[swz256(j + t * P)] = v[t];
+	fft_sync<64>();
+}
 
 template <int RATE>
 __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_demod(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
@@ -134,7 +163,7 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 		#pragma unroll
 		for (int e = 0; e < 2; ++e) {
 			const int i = tid + NT * e, k = (i + code_off + SYMBOL_LEN) % SYMBOL_LEN;
-			coff[e] = i < md.cols ? (k % R1) * NS + k / R1 : -1;
+			coff[e] = i < md.cols ? (k % R1) * NS + ((DEMOD_SWZ && NS == 256 && DC::W == 1) ? swz256(k / R1) : k / R1) : -1;
 		}
 		src.with_mode([&](auto M) {
 		constexpr int MODE = decltype(M)::value;
@@ -192,16 +221,25 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 							v[a] = cmul(pre[q][a], a ? cmul(pq, rotA[a]) : pq);
 					}
 					Bfly<R1>::run(v);
-					row[np] = v[0];
+					const int npw = (DEMOD_SWZ && NS == 256 && DC::W == 1) ? swz256(np) : np;
+					row[npw] = v[0];
 					#pragma unroll
 					for (int r = 1; r < R1; ++r)
-						row[r * NS + np] = cmul(v[r], DC::TWR_LDS ? tw_r[(r - 1) * NS + np] : tb.tw_sym[r * np]);
+						row[r * NS + npw] = cmul(v[r], DC::TWR_LDS ? tw_r[(r - 1) * NS + np] : tb.tw_sym[r * np]);
 				}
 			}
 			if (AHEAD)
 				fetch(s + 1);
 			__syncthreads();
-			fft_fwd_compact<NS, 64 * DC::W, SYMBOL_LEN>(row + (tid / (64 * DC::W)) * NS, tw_sub, tid % (64 * DC::W));
+			if constexpr (DEMOD_SWZ && NS == 256 && DC::W == 1) {
+				cf *sub = row + wave * NS;
+				const int sl = swz256(lane);
+				fft256_stage_swz<1, 0>(sub, tw_sub, lane, sl);
+				fft256_stage_swz<4, 0>(sub, tw_sub, lane, sl);
+				fft256_stage_swz<16, 12>(sub, tw_sub, lane, sl);
+				fft256_stage_swz<64, 60>(sub, tw_sub, lane, sl);
+			} else
+				fft_fwd_compact<NS, 64 * DC::W, SYMBOL_LEN>(row + (tid / (64 * DC::W)) * NS, tw_sub, tid % (64 * DC::W));
 			__syncthreads();
 			// the payload carriers of symbol s: the time-differential step cons = X_j / X_{j-1} (decode.cc:474-475) against the previous
 			// symbol's carriers (DEMOD_CONS_OUT 1; 0: the carriers go to HBM and k_theil_sen does it where it reads them).
