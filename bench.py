@@ -40,8 +40,8 @@ METRIC = "decoded frames/sec + BER, mode-6 8kHz OFDM, batch 65536, 1/2/4/8 MI355
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU per step (weak) / in total per step (strong)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--noise-db", type=float, default=-30.0)
