@@ -35,8 +35,11 @@ extern "C" {
 /* Minor revisions keep every struct and signature of OFDMRX_ABI_VERSION 1 and add entry points or tighten a check:
  *   1: skip counts outside 0..OFDMRX_MAX_SKIP fail the call with OFDMRX_E_ARG (they used to be clamped)
  *   2: ofdmrx_set_esn0_rows, ofdmrx_list_decoded_frames, ofdmrx_debug_decode_cons, ofdmrx_config.flags bit 1 (OFDMRX_FLAG_SCL_ALWAYS);
- *      frames whose hard decisions already form a codeword are decided by a syndrome check (same outputs) */
-#define OFDMRX_ABI_MINOR 2
+ *      frames whose hard decisions already form a codeword are decided by a syndrome check (same outputs)
+ *   3: ofdmrx_set_attempt_log (every preamble of a SKIP loop, decode.cc:390-448); frames the syndrome check leaves are
+ *      list-decoded from a queue in full residencies of the decoder (same outputs); OFDMRX_TAP_CONS_RAW needs no flag, and the
+ *      LLR / METRIC / LANE_MESG taps answer OFDMRX_E_UNSUPPORTED for a frame that never went through the list decoder */
+#define OFDMRX_ABI_MINOR 3
 
 #define OFDMRX_PAYLOAD_BYTES 5380     /* decode.cc:587  data_len = 43040/8 */
 #define OFDMRX_CODE_LEN 65536         /* decode.cc:309  code_order 16 */
@@ -78,15 +81,16 @@ typedef struct {
 	int32_t chunk_frames;      /* frames resident per pass (0 = default: 8192) */
 	int32_t max_samples;       /* max samples per frame (0 = ofdmrx_frame_samples(sample_rate, 6)) */
 	int32_t descramble;        /* 1 = XOR payload with Xorshift32 like main(), decode.cc:613-615 */
-	int32_t flags;             /* bit 0: debug taps: keep the pre-rotation constellation (OFDMRX_TAP_CONS_RAW) and run the list
-	                            * decoder for every frame, so that OFDMRX_TAP_LANE_MESG / _METRIC hold all eight lanes;
+	int32_t flags;             /* bit 0 (OFDMRX_FLAG_KEEP_RAW_CONS, the name is historical): debug taps: run the list decoder for
+	                            * every frame and keep its per-lane messages, so that OFDMRX_TAP_LLR / _METRIC / _LANE_MESG
+	                            * exist for every frame with a header;
 	                            * bit 1 (OFDMRX_FLAG_SCL_ALWAYS): run the list decoder for every frame.  Without either, a frame
 	                            * whose channel hard decisions already form a codeword with a valid CRC-32 is finished by that
 	                            * syndrome check - the list decoder's lane 0 provably is that codeword - with
 	                            * identical payload, status, best_lane and bit_flips, and its LLRs are never written */
 	void *stream;              /* hipStream_t to run on, NULL = library-owned stream.  Batches longer than one chunk
-	                            * also use a second, library-owned stream for the polar stage (two-stage chunk
-	                            * pipeline); the given stream waits for it, so work enqueued on `stream` after a
+	                            * also use library-owned streams for the list decoder and its finishing kernel (chunk
+	                            * pipeline); the given stream waits for them, so work enqueued on `stream` after a
 	                            * decode call sees the finished batch */
 } ofdmrx_config;
 
@@ -166,12 +170,29 @@ int ofdmrx_chunk_frames(ofdmrx_handle *h);
 #define OFDMRX_ROWS_MAX 126    /* decode.cc:181 rows_max */
 int ofdmrx_set_esn0_rows(ofdmrx_handle *h, float *rows);
 /* frames of the last decode call that went through the list decoder; the rest were decided by the syndrome certificate
- * (see ofdmrx_config.flags).  -1 if the certificate is off for this handle.  Synchronises the handle's stream. */
+ * (see ofdmrx_config.flags).  -1 if the certificate is off for this handle.  Synchronises the handle's stream.
+ * (The certificate is adaptive: after a chunk in which it finished fewer than one frame in twenty it is tried for a sample of
+ * one frame in sixteen only, until a fifth of the sample passes again - a frame it was not tried for is list-decoded, with the
+ * same outputs.  Every call starts with the certificate on.) */
 long long ofdmrx_list_decoded_frames(ofdmrx_handle *h);
+/* decode.cc:390-448 prints "symbol pos" / "coarse cfo" and the header's outcome for EVERY preamble the SKIP loop examines, not
+ * only for the last one (which ofdmrx_frame_result describes).  log = n_frames x (OFDMRX_MAX_SKIP + 1) records, counts =
+ * n_frames numbers of records written (0: the stream ended before any preamble), both in the memory space of the RESULTS of the
+ * decode calls that follow (see ofdmrx_set_esn0_rows).  NULL, NULL (the default) turns it off. */
+typedef struct {
+	int32_t status;            /* OFDMRX_OK, or OFDMRX_OSD_ERROR .. OFDMRX_BAD_CALLSIGN: what decode.cc:417-442 made of this preamble */
+	int32_t symbol_pos;        /* decode.cc:400 */
+	float cfo_rad;             /* decode.cc:401 */
+	int32_t oper_mode;         /* decode.cc:433 (valid from OFDMRX_BAD_MODE on) */
+	uint64_t call_sign;        /* decode.cc:439 */
+} ofdmrx_attempt;
+int ofdmrx_set_attempt_log(ofdmrx_handle *h, ofdmrx_attempt *log, int32_t *counts);
 
 /* ---- stage taps for parity tests (host destination buffers) --------------
  * Valid for frames of the LAST chunk processed (frame index relative to that
- * chunk's first frame). */
+ * chunk's first frame).  The rotated constellation is made on demand (the pipeline never stores it); LLR / METRIC /
+ * LANE_MESG exist for frames that went through the list decoder (every frame with a header when the handle was created with
+ * OFDMRX_FLAG_KEEP_RAW_CONS or OFDMRX_FLAG_SCL_ALWAYS; LANE_MESG needs the former), otherwise: OFDMRX_E_UNSUPPORTED. */
 enum {
 	OFDMRX_TAP_HDR_SOFT = 1,   /* int8  [255]      decode.cc:413-416 */
 	OFDMRX_TAP_CONS_RAW = 2,   /* cf32  [cons_cnt <= 32400] decode.cc:464-477 (21600 in mode 6) */

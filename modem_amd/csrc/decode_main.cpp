@@ -120,25 +120,43 @@ int main(int argc, char **argv)
 	size_t bps = w.fmt == OFDMRX_FMT_S16 ? 2 : w.fmt == OFDMRX_FMT_U8 ? 1 : 4;
 	size_t stride = (w.frames * bps * (size_t)w.channels + 3) & ~(size_t)3;
 	w.pcm.resize(stride);
+	std::vector<ofdmrx_attempt> attempts(OFDMRX_MAX_SKIP + 1);
+	int32_t n_attempts = 0;
+	ofdmrx_set_attempt_log(h, attempts.data(), &n_attempts);
 	r = ofdmrx_decode_batch(h, w.pcm.data(), w.fmt, w.channels, w.frames, stride, 1, &skip_count, out.data(), &res);
 	if (r) {
 		std::fprintf(stderr, "ofdmrx_decode_batch: %s\n", ofdmrx_strerror(r));
 		return 1;
 	}
 	const float hz = (float)w.rate / 6.28318530717958647692f;   // decode.cc:401,503
-	if (res.sc_start >= 0) {
-		std::fprintf(stderr, "symbol pos: %d\n", res.symbol_pos);
-		std::fprintf(stderr, "coarse cfo: %g Hz \n", res.cfo_rad * hz);
-	}
-	static const char *msg[] = { "", "", "OSD error.", "header CRC error.", "operation mode unsupported.",
-		"call sign unsupported.", "payload decoding error." };
-	if (res.status == OFDMRX_OK || res.status == OFDMRX_PAYLOAD_CRC) {
-		char cs[10];
-		long long v = (long long)res.call_sign;
+	auto call_sign_text = [](unsigned long long v, char *cs) {   // base37_decoder, decode.cc:155-159
 		for (int i = 8; i >= 0; --i, v /= 37)
 			cs[i] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ"[v % 37];
 		cs[9] = 0;
-		std::fprintf(stderr, "oper mode: %d\ncall sign: %s\n", res.oper_mode, cs);
+	};
+	// decode.cc:390-448: one block of lines per preamble the SKIP loop examined, the last one included
+	for (int a = 0; a < n_attempts; ++a) {
+		const ofdmrx_attempt &at = attempts[a];
+		std::fprintf(stderr, "symbol pos: %d\n", at.symbol_pos);
+		std::fprintf(stderr, "coarse cfo: %g Hz \n", at.cfo_rad * hz);
+		if (at.status == OFDMRX_OSD_ERROR) {
+			std::fprintf(stderr, "OSD error.\n");
+		} else if (at.status == OFDMRX_HEADER_CRC) {
+			std::fprintf(stderr, "header CRC error.\n");
+		} else if (at.status == OFDMRX_BAD_MODE) {
+			std::fprintf(stderr, "operation mode %d unsupported.\n", at.oper_mode);   // decode.cc:435
+		} else {
+			std::fprintf(stderr, "oper mode: %d\n", at.oper_mode);
+			if (at.status == OFDMRX_BAD_CALLSIGN) {
+				std::fprintf(stderr, "call sign unsupported.\n");
+			} else {
+				char cs[10];
+				call_sign_text(at.call_sign, cs);
+				std::fprintf(stderr, "call sign: %s\n", cs);
+			}
+		}
+	}
+	if (res.status == OFDMRX_OK || res.status == OFDMRX_PAYLOAD_CRC) {
 		// rows of the mode (decode.cc:302-374, 453): cons_bits / mod_bits / cols
 		static const int cols[14] = { 0, 0, 0, 0, 0, 0, 432, 400, 400, 360, 512, 384, 384, 256 };
 		static const int bits[14] = { 0, 0, 0, 0, 0, 0, 3, 3, 2, 2, 3, 3, 2, 2 };
@@ -162,8 +180,8 @@ int main(int argc, char **argv)
 			std::fprintf(stderr, " %g", res.esn0_db_last);
 		std::fprintf(stderr, "\n");
 	}
-	if (res.status >= OFDMRX_OSD_ERROR && res.status <= OFDMRX_PAYLOAD_CRC)
-		std::fprintf(stderr, "%s\n", msg[res.status]);
+	if (res.status == OFDMRX_PAYLOAD_CRC)
+		std::fprintf(stderr, "payload decoding error.\n");         // decode.cc:543
 	if (res.status == OFDMRX_OK)
 		std::fprintf(stderr, "bit flips: %d\n", res.bit_flips);
 	ofdmrx_destroy(h);

@@ -399,20 +399,54 @@ __device__ __forceinline__ double wave_sum_d(double v)
 		v += shfl_xor_d(v, m);
 	return v;
 }
-// decode.cc:505-516 for one frame, shared by k_llr and k_back (their results must agree bit for bit): the running sp / np of
-// the SNR estimate.  Wave w reduces rows w, w + 4, ... by itself (per-lane double sums over its 7 carriers, one wave butterfly) -
-// no workgroup barrier per row; after ONE barrier thread 0 folds the row sums in order into the fp32 running sums and leaves
-// the cumulative precision of every row in prec[].  visit(j, i, c) sees every constellation point once (the caller collects
-// what it needs from it).  Returns false in every thread if a precision is not a positive finite number.
-template <typename Visit>
-__device__ __forceinline__ bool snr_rows(const cf *__restrict__ cons, int rows, int cols, int mod_bits, int tid, double (*rsum)[2], float *prec,
-	Visit visit)
+// sin and cos of the rotation angle (decode.cc:493: a row's phases are yint + slope x, a fraction of a radian).  Cody-Waite
+// reduction by pi/2 in two parts (exact enough for |a| < 1e3: n < 640, n * lo's rounding stays under 1e-10), the single-precision
+// minimax kernels of fdlibm (k_sinf / k_cosf) on |r| <= pi/4, quadrant by n & 3: <= 1 ulp on either output, 23 vector instructions
+// where the library routine (which carries the Payne-Hanek path for huge arguments) took about twice that.  Larger arguments
+// (never seen: the estimator's outputs are bounded by the row's phases) go to the library routine.
+__device__ __forceinline__ void row_sincos(float a, float &sn, float &cs)
+{
+	if (!(fabsf(a) < 1000.f)) {
+		sincosf(a, &sn, &cs);
+		return;
+	}
+	const float n = rintf(a * 0.636619772f);
+	float r = fmaf(-n, 1.57079637f, a);
+	r = fmaf(-n, -4.37113883e-8f, r);
+	const float z = r * r;
+	const float ps = fmaf(fmaf(fmaf(2.71831149e-6f, z, -1.98393348e-4f), z, 8.33332939e-3f), z, -1.66666667e-1f);
+	const float pc = fmaf(fmaf(fmaf(2.43904488e-5f, z, -1.38867638e-3f), z, 4.16666233e-2f), z, -0.5f);
+	const float sr = fmaf(r * z, ps, r), cr = fmaf(z, pc, 1.f);
+	const int q = (int)n;
+	const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+	sn = __uint_as_float(__float_as_uint(s0) ^ ((uint32_t)(q & 2) << 30));
+	cs = __uint_as_float(__float_as_uint(c0) ^ ((uint32_t)((q + 1) & 2) << 30));
+}
+// decode.cc:493-494: cons[cons_cols * j + i] *= DSP::polar<value>(1, -tse(i + code_off)) for the point in column i of a row
+// whose Theil-Sen line is (slope, yint).  Since round 4 the rotated row is never stored: k_theil_sen leaves the line, and the
+// kernels behind it (k_back; the CONS_ROT tap) rotate each point where they use it - always through this one function.
+__device__ __forceinline__ cf rotate_point(cf c, float slope, float yint, int i, int cols)
+{
+	const float a = -(yint + slope * (float)(i - cols / 2));
+	float sn, cs;
+	row_sincos(a, sn, cs);
+	return cmul(c, mk(cs, sn));
+}
+
+// decode.cc:505-516 for one frame: the running sp / np of the SNR estimate.  Wave w reduces rows w, w + 4, ... by itself
+// (per-lane double sums over its 7 carriers, one wave butterfly) - no workgroup barrier per row; after ONE barrier thread 0
+// folds the row sums in order into the fp32 running sums and leaves the cumulative precision of every row in prec[].
+// point(j, i) delivers the constellation point (row j, column i) as decode.cc:505 sees it (rotated); visit(j, i, c) sees every
+// point once (the caller collects what it needs from it).  Returns false in every thread if a precision is not a positive
+// finite number.
+template <typename Point, typename Visit>
+__device__ __forceinline__ bool snr_rows(Point point, int rows, int cols, int mod_bits, int tid, double (*rsum)[2], float *prec, Visit visit)
 {
 	const int wave = tid >> 6, lane = tid & 63;
 	for (int j = wave; j < rows; j += 4) {
 		double dsp = 0.0, dnp = 0.0;
 		for (int i = lane; i < cols; i += 64) {
-			const cf c = cons[j * cols + i];
+			const cf c = point(j, i);
 			const cf h = mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c);   // decode.cc:509-511
 			const double er = (double)c.re - h.re, ei = (double)c.im - h.im;
 			dsp += (double)h.re * h.re + (double)h.im * h.im;

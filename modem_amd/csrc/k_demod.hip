@@ -360,70 +360,6 @@ __global__ __launch_bounds__(DemodCfg<RATE>::NT, DemodCfg<RATE>::MINB) void k_de
 	}
 }
 
-// ---------------------------------------------------------------- D6 + D7 + D8
-// decode.cc:505-529.  sp/np accumulate ACROSS rows (decode.cc:507 is outside the row loop):
-// per row the 432 terms are reduced in double and folded into the running fp32 sums once,
-// then the row's soft bits are emitted with that row's cumulative precision.
-__global__ __launch_bounds__(256) void k_llr(int sym_stride, const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
-	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
-	float *__restrict__ llr_all, Result *__restrict__ res_all, float *__restrict__ esn0_rows)
-{
-	const int f = blockIdx.x, tid = threadIdx.x;
-	const SyncState st = st_all[f];
-	if (esn0_rows && tid < ROWS_MAX)
-		esn0_rows[(size_t)f * ROWS_MAX + tid] = 0.f;             // rows this frame does not have (all of them without a header)
-	if (!st.okay)
-		return;
-	__syncthreads();
-	__shared__ double rsum[ROWS_MAX][2];
-	__shared__ float prec[ROWS_MAX];
-	const ModeDesc md = mode_desc(st.oper_mode);
-	const cf *cons = cons_all + (size_t)f * CONS_MAX;
-	float *llr = llr_all + (size_t)f * CODE_LEN;
-	const float rcp_sqrt_2 = 0.70710678118654752440f;         // psk.hh:57,104
-	const float DIST = md.mod_bits == 3 ? 2.f * 0.38268343236508977173f : 2.f * rcp_sqrt_2;   // psk.hh:106 / psk.hh:59
-	snr_rows(cons, md.rows, md.cols, md.mod_bits, tid, rsum, prec, [](int, int, cf) {});
-	if (tid < md.rows) {
-		precision_all[(size_t)f * ROWS_MAX + tid] = prec[tid];
-		if (esn0_rows)
-			esn0_rows[(size_t)f * ROWS_MAX + tid] = 10.f * log10f(prec[tid]);   // decode.cc:518
-	}
-	const float precision = prec[md.rows - 1];
-	for (int j = 0; j < md.rows; ++j) {                           // the row's soft bits with that row's cumulative precision
-		const float sc = DIST * prec[j];
-		#pragma unroll
-		for (int q = 0; q < 2; ++q) {
-			const int i = tid + 256 * q;
-			if (i < md.cols) {                                // psk.hh:76-80,125-130, decode.cc:520-521
-				const cf c = cons[j * md.cols + i];
-				float *b = llr + md.mod_bits * (j * md.cols + i);
-				if (md.mod_bits == 3) {
-					b[1] = c.re * sc;
-					b[2] = c.im * sc;
-					b[0] = (rcp_sqrt_2 * (fabsf(c.re) - fabsf(c.im))) * sc;
-				} else {
-					b[0] = c.re * sc;
-					b[1] = c.im * sc;
-				}
-			}
-		}
-	}
-	// lengthen(): the shortened positions are the index tail [cons_bits, 65536) for both tables
-	for (int i = md.cons_bits + tid; i < CODE_LEN; i += 256)
-		llr[i] = 9000.f;                                      // decode.cc:252
-	if (tid == 0) {
-		float sum_slope = 0.f, sum_yint = 0.f;
-		for (int j = 0; j < md.rows; ++j) {                   // decode.cc:491-492
-			sum_slope += slope_all[(size_t)f * ROWS_MAX + j];
-			sum_yint += yint_all[(size_t)f * ROWS_MAX + j];
-		}
-		Result &r = res_all[f];
-		r.sfo_slope = sum_slope / (float)md.rows;
-		r.cfo_fine = st.cfo_rad + (sum_yint / (float)md.rows) / (float)sym_stride;   // decode.cc:501
-		r.esn0_db_last = 10.f * log10f(precision);            // decode.cc:518
-	}
-}
-
 // ---------------------------------------------------------------- debug FFT entry
 // len = symbol_len or symbol_len/2 of the handle's rate, both directions (backward = conj . forward . conj)
 template <int RATE>
@@ -448,12 +384,6 @@ bool demod_forms_cons(int rate) { return !demod_writes_carriers(rate) || (DEMOD_
 void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons, cf *carr)
 {
 	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(DemodCfg<RATE>::NT), 0, s, fb, z, tb, st, cons, carr));
-}
-void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
-	float *precision, float *llr, Result *res, float *esn0_rows)
-{
-	const int sym_stride = rate_symbol_len(rate) + rate_symbol_len(rate) / 8;
-	hipLaunchKernelGGL(k_llr, dim3(n), dim3(256), 0, s, sym_stride, st, cons, slope, yint, precision, llr, res, esn0_rows);
 }
 void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb)
 {

@@ -1,14 +1,17 @@
-// k_finish.hip -- D10 (systematic message, CRC-32 lane selection, bit packing, descramble) for gfx950.
+// k_finish.hip -- the back end behind the Theil-Sen stage for gfx950: k_back = D5's rotation + D6-D8 (SNR estimate, soft demapper,
+// lengthen) + the syndrome certificate (+ D10 for the frames it decides); k_finish = D10 for the frames the list decoder
+// decoded; and the small kernels that run the list decoder's work queue.
 #include "dev_common.h"
 #include "kernels.h"
 
 namespace rx {
 
-// ---------------------------------------------------------------- D6-D8 + syndrome certificate + D10 for the frames it decides
-// k_back replaces k_llr (k_demod.hip) when the certificate is on.  Per frame:
-//   1. the row loop of k_llr (decode.cc:505-523: running sp / np, per-row precision) - and, beside it, the SIGN of every soft bit
-//      (psk.hh:76-80,125-130: sign(re), sign(im), sign(|re| - |im|); the precision is a positive factor) as one bit per code
-//      position in LDS.  No LLR is written yet.
+// ---------------------------------------------------------------- k_back
+// One workgroup per frame:
+//   1. decode.cc:493-494 on the fly: every point of the frame is rotated by its row's Theil-Sen line where it is used
+//      (rotate_point; k_theil_sen leaves slope / yint and no longer writes a rotated copy); decode.cc:505-523: running sp / np,
+//      per-row precision - and, beside it, the SIGN of every soft bit (psk.hh:76-80,125-130: sign(re), sign(im),
+//      sign(|re| - |im|); the precision is a positive factor) as one bit per code position in LDS.  No LLR is written yet.
 //   2. Syndrome certificate.  If those hard decisions x already ARE a codeword - u = x F^(x16) is zero on every frozen position -
 //      and no LLR is zero, the list decoder's answer is known without running it (any list size):
 //        * along the path that follows the hard decisions every node's LLR vector carries the signs of that node's sub-codeword
@@ -20,17 +23,21 @@ namespace rx {
 //      So lane 0's re-encoded codeword is x itself, its flip count (decode.cc:546-555) 0, and decode.cc:532-541 takes lane 0 if
 //      its CRC-32 is 0.
 //   3. Certified and CRC-32 of x at the unfrozen positions = 0: the frame is FINISHED here - payload bytes (descrambled) and the
-//      result record, exactly what k_polar + k_finish would have produced (best_lane 0, bit_flips 0); cert = 1, and neither of
-//      those kernels looks at the frame again.  No LLR, no partial-sum array is ever written for it.
-//   4. Otherwise (not a codeword, a zero LLR, or a codeword with the wrong CRC - then the reference goes on to lanes 1..7):
-//      cert = 0, the 65536 LLRs are written now (second pass over the row, same arithmetic as k_llr) and the list decoder and
-//      k_finish run as always.
-// At the benchmark's noise level (-30 dB) every frame is decided here; from -24 dB on almost none (tools/flips_probe.py).
-// cert_all: [n] verdicts, then [n] unused, [n + 1] = frames left to the list decoder (cleared before the launch).
-__global__ __launch_bounds__(256) void k_back(int sym_stride, const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
+//      result record, exactly what k_polar + k_finish would have produced (best_lane 0, bit_flips 0).  No LLR, no partial-sum
+//      array is ever written for it.
+//   4. Otherwise (not a codeword, a zero LLR, or a codeword with the wrong CRC - then the reference goes on to lanes 1..7, or
+//      the certificate was not tried): the frame takes the next slot of the list decoder's queue (kernels.h: ListQueue) and its
+//      65536 LLRs are written there in a second pass over the rows (decode.cc:520-529, 252).
+// At the benchmark's noise level (-30 dB) every frame is decided here; from -24 dB on almost none (tools/flips_probe.py).  So
+// the certificate is ADAPTIVE (cert_mode 1): k_queue_snap, which runs behind every launch, switches it to a probe sample (one
+// frame in sixteen) when fewer than 5 % of the frames it was tried for were finished by it, and back when a fifth of the
+// sample is.  Either way every decision is exact: the list decoder is the general path.  cert_mode 0: never tried (the
+// reference's behaviour, OFDMRX_FLAG_SCL_ALWAYS; handles with debug taps).
+// slot_of[f] (per chunk): the queue slot of the frame, -1 if it needs none (no header; finished here).
+__global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
 	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
-	float *__restrict__ llr_all, Result *__restrict__ res_all, float *__restrict__ esn0_rows, Tables tb, int descramble,
-	uint8_t *__restrict__ payload_all, int *__restrict__ cert_all)
+	Result *__restrict__ res_all, float *__restrict__ esn0_rows, Tables tb, int descramble, uint8_t *__restrict__ payload_all,
+	ListQueue *__restrict__ q, ListSlot *__restrict__ slots, float *__restrict__ llr_q, int *__restrict__ slot_of)
 {
 	const int f = blockIdx.x, tid = threadIdx.x;
 	const SyncState st = st_all[f];
@@ -47,7 +54,7 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, const SyncState *_
 	r.n_sync_rejects = st.rejects;
 	r.best_lane = -1;
 	r.bit_flips = 0;
-	if (!st.okay) {                                               // what k_finish writes for a frame without a header
+	if (!st.okay) {                                               // no header -> nothing to decode (decode.cc:450-451)
 		r.cfo_fine = st.cfo_rad;
 		r.sfo_slope = 0.f;
 		r.esn0_db_last = 0.f;
@@ -55,32 +62,42 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, const SyncState *_
 			payload[i] = 0;
 		if (tid == 0) {
 			res_all[f] = r;
-			cert_all[f] = 1;
+			slot_of[f] = -1;
 		}
 		return;
 	}
 	__shared__ double rsum[ROWS_MAX][2];
 	__shared__ uint32_t bits[CODE_LEN / 32];
-	__shared__ float prec[ROWS_MAX];
+	__shared__ float prec[ROWS_MAX], row_slope[ROWS_MAX], row_yint[ROWS_MAX];
 	__shared__ uint8_t mesg[MESG_BYTES_MAX];
 	__shared__ uint32_t ctab[256], csh[1024], cpart[32];
 	__shared__ uint32_t crc_sh;
+	__shared__ int slot_sh;
+	const bool try_cert = cert_mode && (q->cert_on || (f & 15) == 0);   // (uniform in the workgroup)
 	const ModeDesc md = mode_desc(st.oper_mode);
 	const cf *cons = cons_all + (size_t)f * CONS_MAX;
-	float *llr = llr_all + (size_t)f * CODE_LEN;
 	const float rcp_sqrt_2 = 0.70710678118654752440f;         // psk.hh:57,104
 	const float DIST = md.mod_bits == 3 ? 2.f * 0.38268343236508977173f : 2.f * rcp_sqrt_2;   // psk.hh:106 / psk.hh:59
-	for (int q = tid; q < CODE_LEN / 32; q += 256)
-		bits[q] = 0;
-	ctab[tid] = tb.crc32_tab[tid];
-	#pragma unroll
-	for (int q = 0; q < 4; ++q)
-		csh[tid + 256 * q] = tb.crc32_shift168[tid + 256 * q];
+	if (tid < md.rows) {
+		row_slope[tid] = slope_all[(size_t)f * ROWS_MAX + tid];
+		row_yint[tid] = yint_all[(size_t)f * ROWS_MAX + tid];
+	}
+	if (try_cert) {
+		for (int w = tid; w < CODE_LEN / 32; w += 256)
+			bits[w] = 0;
+		ctab[tid] = tb.crc32_tab[tid];
+		#pragma unroll
+		for (int w = 0; w < 4; ++w)
+			csh[tid + 256 * w] = tb.crc32_shift168[tid + 256 * w];
+	}
 	__syncthreads();
-	// ---- 1. decode.cc:505-523 (snr_rows, shared with k_llr) + the signs of the soft bits
-	bool odd = false;                                             // a zero / NaN LLR somewhere: no certificate
+	// ---- 1. decode.cc:493-494 + 505-523 (snr_rows) + the signs of the soft bits
 	const int mod_bits = md.mod_bits, cols = md.cols;
-	const bool snr_ok = snr_rows(cons, md.rows, cols, mod_bits, tid, rsum, prec, [&](int j, int i, cf c) {
+	auto point = [&](int j, int i) { return rotate_point(cons[j * cols + i], row_slope[j], row_yint[j], i, cols); };
+	bool odd = false;                                             // a zero / NaN LLR somewhere: no certificate
+	const bool snr_ok = snr_rows(point, md.rows, cols, mod_bits, tid, rsum, prec, [&](int j, int i, cf c) {
+		if (!try_cert)
+			return;
 		const float are = fabsf(c.re), aim = fabsf(c.im);
 		uint32_t v;
 		if (mod_bits == 3) {
@@ -106,110 +123,127 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, const SyncState *_
 	if (tid == 0) {
 		float sum_slope = 0.f, sum_yint = 0.f;
 		for (int j = 0; j < md.rows; ++j) {                   // decode.cc:491-492
-			sum_slope += slope_all[(size_t)f * ROWS_MAX + j];
-			sum_yint += yint_all[(size_t)f * ROWS_MAX + j];
+			sum_slope += row_slope[j];
+			sum_yint += row_yint[j];
 		}
 		r.sfo_slope = sum_slope / (float)md.rows;
 		r.cfo_fine = st.cfo_rad + (sum_yint / (float)md.rows) / (float)sym_stride;   // decode.cc:501
 		r.esn0_db_last = 10.f * log10f(prec[md.rows - 1]);    // decode.cc:518
 	}
-	// ---- 3a. (before the transform overwrites the bit array) the systematic message = x at the unfrozen positions, decode.cc:254-261
-	const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
-	const int mesg_bytes = md.mesg_bits / 8;
-	for (int bi = tid; bi < mesg_bytes; bi += 256) {
-		uint32_t o = 0;
-		#pragma unroll
-		for (int b = 0; b < 8; ++b) {
-			const int p = info_pos[8 * bi + b];
-			o |= ((bits[p >> 5] >> (p & 31)) & 1u) << b;
-		}
-		mesg[bi] = (uint8_t)o;
-	}
-	// ---- 2. u = x F: at every level the left half of a block takes the XOR with the right half (the involution the partial-sum
-	// combines of the decoder apply the other way round).  Word a = tid + 256 q: distances >= 256 words are inside the thread.
-	uint32_t w[8];
-	#pragma unroll
-	for (int q = 0; q < 8; ++q) {
-		uint32_t v = bits[tid + 256 * q];
-		v ^= (v >> 1) & 0x55555555u;
-		v ^= (v >> 2) & 0x33333333u;
-		v ^= (v >> 4) & 0x0f0f0f0fu;
-		v ^= (v >> 8) & 0x00ff00ffu;
-		v ^= (v >> 16) & 0x0000ffffu;
-		w[q] = v;
-	}
-	#pragma unroll
-	for (int q = 0; q < 4; ++q) w[q] ^= w[q + 4];               // 1024 words
-	w[0] ^= w[2]; w[1] ^= w[3]; w[4] ^= w[6]; w[5] ^= w[7];       // 512
-	w[0] ^= w[1]; w[2] ^= w[3]; w[4] ^= w[5]; w[6] ^= w[7];       // 256
-	for (int dw = 128; dw >= 1; dw >>= 1) {
-		__syncthreads();
-		#pragma unroll
-		for (int q = 0; q < 8; ++q)
-			bits[tid + 256 * q] = w[q];
-		__syncthreads();
-		if ((tid & dw) == 0) {
+	int bad = 1;
+	if (try_cert) {
+		// ---- 3a. (before the transform overwrites the bit array) the systematic message = x at the unfrozen positions, decode.cc:254-261
+		const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
+		const int mesg_bytes = md.mesg_bits / 8;
+		for (int bi = tid; bi < mesg_bytes; bi += 256) {
+			uint32_t o = 0;
 			#pragma unroll
-			for (int q = 0; q < 8; ++q)
-				w[q] ^= bits[tid + dw + 256 * q];
-		}
-	}
-	const uint32_t *frozen = tb.frozen + (md.table ? CODE_LEN / 32 : 0);
-	uint32_t syn = 0;
-	#pragma unroll
-	for (int q = 0; q < 8; ++q)
-		syn |= w[q] & frozen[tid + 256 * q];
-	int bad = __syncthreads_or((syn != 0) | (odd ? 1 : 0));
-	// ---- 3b. CRC<uint32_t>(0xD419CC15) over the first 43072 bits (decode.cc:533-541), as k_finish does it for a lane: 32 segments
-	// of 168 bytes from a zero state, folded in order with the "advance by 168 zero bytes" operator
-	if (!bad) {
-		constexpr int SEG = 168, NSEG = 32, TAIL = CRC_BITS / 8 - SEG * NSEG;   // 5384 = 32 * 168 + 8
-		if (tid < NSEG) {
-			const uint8_t *mp = mesg + tid * SEG;
-			uint32_t crc = 0;
-			for (int i = 0; i < SEG; ++i)
-				crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
-			cpart[tid] = crc;
-		}
-		__syncthreads();
-		if (tid == 0) {
-			uint32_t crc = 0;
-			for (int q = 0; q < NSEG; ++q) {
-				crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
-				crc ^= cpart[q];
+			for (int b = 0; b < 8; ++b) {
+				const int p = info_pos[8 * bi + b];
+				o |= ((bits[p >> 5] >> (p & 31)) & 1u) << b;
 			}
-			for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
-				crc = (crc >> 8) ^ ctab[(crc ^ mesg[i]) & 255];
-			crc_sh = crc;
+			mesg[bi] = (uint8_t)o;
 		}
-		__syncthreads();
-		bad = crc_sh != 0;
-	}
-	if (!bad) {
-		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
-			payload[i] = mesg[i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);
-		if (tid == 0) {
-			r.best_lane = 0;
-			res_all[f] = r;
-			cert_all[f] = 1;
+		// ---- 2. u = x F: at every level the left half of a block takes the XOR with the right half (the involution the partial-sum
+		// combines of the decoder apply the other way round).  Word a = tid + 256 w: distances >= 256 words are inside the thread.
+		uint32_t w[8];
+		#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			uint32_t v = bits[tid + 256 * e];
+			v ^= (v >> 1) & 0x55555555u;
+			v ^= (v >> 2) & 0x33333333u;
+			v ^= (v >> 4) & 0x0f0f0f0fu;
+			v ^= (v >> 8) & 0x00ff00ffu;
+			v ^= (v >> 16) & 0x0000ffffu;
+			w[e] = v;
 		}
-		return;
+		#pragma unroll
+		for (int e = 0; e < 4; ++e) w[e] ^= w[e + 4];               // 1024 words
+		w[0] ^= w[2]; w[1] ^= w[3]; w[4] ^= w[6]; w[5] ^= w[7];       // 512
+		w[0] ^= w[1]; w[2] ^= w[3]; w[4] ^= w[5]; w[6] ^= w[7];       // 256
+		for (int dw = 128; dw >= 1; dw >>= 1) {
+			__syncthreads();
+			#pragma unroll
+			for (int e = 0; e < 8; ++e)
+				bits[tid + 256 * e] = w[e];
+			__syncthreads();
+			if ((tid & dw) == 0) {
+				#pragma unroll
+				for (int e = 0; e < 8; ++e)
+					w[e] ^= bits[tid + dw + 256 * e];
+			}
+		}
+		const uint32_t *frozen = tb.frozen + (md.table ? CODE_LEN / 32 : 0);
+		uint32_t syn = 0;
+		#pragma unroll
+		for (int e = 0; e < 8; ++e)
+			syn |= w[e] & frozen[tid + 256 * e];
+		bad = __syncthreads_or((syn != 0) | (odd ? 1 : 0));
+		// ---- 3b. CRC<uint32_t>(0xD419CC15) over the first 43072 bits (decode.cc:533-541), as k_finish does it for a lane: 32 segments
+		// of 168 bytes from a zero state, folded in order with the "advance by 168 zero bytes" operator
+		if (!bad) {
+			constexpr int SEG = 168, NSEG = 32, TAIL = CRC_BITS / 8 - SEG * NSEG;   // 5384 = 32 * 168 + 8
+			if (tid < NSEG) {
+				const uint8_t *mp = mesg + tid * SEG;
+				uint32_t crc = 0;
+				for (int i = 0; i < SEG; ++i)
+					crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
+				cpart[tid] = crc;
+			}
+			__syncthreads();
+			if (tid == 0) {
+				uint32_t crc = 0;
+				for (int e = 0; e < NSEG; ++e) {
+					crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
+					crc ^= cpart[e];
+				}
+				for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
+					crc = (crc >> 8) ^ ctab[(crc ^ mesg[i]) & 255];
+				crc_sh = crc;
+			}
+			__syncthreads();
+			bad = crc_sh != 0;
+		}
+		if (!bad) {
+			for (int i = tid; i < PAYLOAD_BYTES; i += 256)
+				payload[i] = mesg[i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);
+			if (tid == 0) {
+				r.best_lane = 0;
+				res_all[f] = r;
+				slot_of[f] = -1;
+				atomicAdd(&q->tried, 1u);
+				atomicAdd(&q->certified, 1u);
+			}
+			return;
+		}
 	}
-	// ---- 4. the list decoder has to look: its LLRs (decode.cc:520-529), same arithmetic as k_llr
+	// ---- 4. the list decoder has to look: a queue slot and the LLRs (decode.cc:520-529)
 	if (tid == 0) {
-		res_all[f] = r;                                       // k_finish completes the record
-		cert_all[f] = 0;
-		atomicAdd(cert_all + gridDim.x + 1, 1);
+		const unsigned e = atomicAdd(&q->tail, 1u);
+		const int slot = (int)(e % q->cap);
+		ListSlot ls;
+		ls.payload = payload;
+		ls.res = res_all + f;
+		ls.oper_mode = st.oper_mode;
+		ls.frame = f;
+		slots[slot] = ls;
+		slot_of[f] = slot;
+		res_all[f] = r;                                       // k_finish completes the record (best_lane, bit_flips, status)
+		if (try_cert)
+			atomicAdd(&q->tried, 1u);
+		slot_sh = slot;
 	}
+	__syncthreads();
+	float *llr = llr_q + (size_t)slot_sh * CODE_LEN;
 	for (int j = 0; j < md.rows; ++j) {
 		const float sc = DIST * prec[j];
 		#pragma unroll
-		for (int q = 0; q < 2; ++q) {
-			const int i = tid + 256 * q;
-			if (i < md.cols) {                                // psk.hh:76-80,125-130
-				const cf c = cons[j * md.cols + i];
-				float *b = llr + md.mod_bits * (j * md.cols + i);
-				if (md.mod_bits == 3) {
+		for (int e = 0; e < 2; ++e) {
+			const int i = tid + 256 * e;
+			if (i < cols) {                                   // psk.hh:76-80,125-130
+				const cf c = point(j, i);
+				float *b = llr + mod_bits * (j * cols + i);
+				if (mod_bits == 3) {
 					b[1] = c.re * sc;
 					b[2] = c.im * sc;
 					b[0] = (rcp_sqrt_2 * (fabsf(c.re) - fabsf(c.im))) * sc;
@@ -220,69 +254,125 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, const SyncState *_
 			}
 		}
 	}
-	for (int i = md.cons_bits + tid; i < CODE_LEN; i += 256)   // lengthen(), decode.cc:252
+	for (int i = md.cons_bits + tid; i < CODE_LEN; i += 256)   // lengthen(), decode.cc:252: the shortened positions are the index tail
 		llr[i] = 9000.f;
+}
+
+// the rotated constellation of one frame (OFDMRX_TAP_CONS_ROT): what decode.cc:494 leaves in cons[]
+__global__ __launch_bounds__(256) void k_rotate_tap(const SyncState *__restrict__ st, const cf *__restrict__ cons, const float *__restrict__ slope,
+	const float *__restrict__ yint, cf *__restrict__ out)
+{
+	const ModeDesc md = mode_desc(st->oper_mode);
+	for (int p = blockIdx.x * 256 + threadIdx.x; p < CONS_MAX; p += gridDim.x * 256) {
+		const int j = p / md.cols, i = p % md.cols;
+		out[p] = (st->okay && j < md.rows) ? rotate_point(cons[p], slope[j], yint[j], i, md.cols) : mk(0.f, 0.f);
+	}
+}
+void launch_rotate_tap(hipStream_t s, const SyncState *st, const cf *cons, const float *slope, const float *yint, cf *out)
+{
+	hipLaunchKernelGGL(k_rotate_tap, dim3(32), dim3(256), 0, s, st, cons, slope, yint, out);
+}
+
+// ---------------------------------------------------------------- the list decoder's queue (kernels.h: ListQueue)
+__global__ void k_queue_reset(ListQueue *__restrict__ q, unsigned cap)
+{
+	q->tail = q->head = 0;
+	q->snap[0] = q->snap[1] = 0;
+	q->run_head[0] = q->run_head[1] = q->run_n[0] = q->run_n[1] = 0;
+	q->next_unit[0] = q->next_unit[1] = 0;
+	q->cert_on = 1;
+	q->tried = q->certified = 0;
+	q->cap = cap;
+}
+// behind k_back of a chunk: what the flush of that chunk may take, and the adaptive certificate's next state
+__global__ void k_queue_snap(ListQueue *__restrict__ q, int par)
+{
+	q->snap[par] = q->tail;
+	const unsigned tried = q->tried, cert = q->certified;
+	if (q->cert_on) {
+		if (tried >= 64 && cert * 20 < tried)
+			q->cert_on = 0;
+	} else if (tried >= 8 && cert * 5 >= tried)
+		q->cert_on = 1;
+	q->tried = q->certified = 0;
+}
+// in front of k_polar: the entries of this flush.  Nothing until `unit` entries wait (one full residency of the list decoder),
+// then whole multiples of it - the rest stays queued for the next flush; force: everything (the last flush of a call, and
+// every flush of a call whose outputs leave chunk by chunk).
+__global__ void k_queue_plan(ListQueue *__restrict__ q, int par, unsigned unit, int force)
+{
+	const unsigned head = q->head, n = q->snap[par] - head;
+	const unsigned run = force ? n : (n / unit) * unit;
+	q->run_head[par] = head;
+	q->run_n[par] = run;
+	q->head = head + run;
+	q->next_unit[par] = 0;
+}
+// debug entries: n frames in slots 0 .. n-1 in order, all to be decoded
+__global__ void k_queue_fill(ListQueue *__restrict__ q, ListSlot *__restrict__ slots, int n, uint8_t *payload, Result *res, int oper_mode)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) {
+		ListSlot ls;
+		ls.payload = payload + (size_t)i * PAYLOAD_BYTES;
+		ls.res = res + i;
+		ls.oper_mode = oper_mode;
+		ls.frame = i;
+		slots[i] = ls;
+	}
+	if (i == 0) {
+		q->tail = (unsigned)n;
+		q->snap[0] = (unsigned)n;
+	}
+}
+void launch_queue_reset(hipStream_t s, ListQueue *q, unsigned cap) { hipLaunchKernelGGL(k_queue_reset, dim3(1), dim3(1), 0, s, q, cap); }
+void launch_queue_snap(hipStream_t s, ListQueue *q, int par) { hipLaunchKernelGGL(k_queue_snap, dim3(1), dim3(1), 0, s, q, par); }
+void launch_queue_plan(hipStream_t s, ListQueue *q, int par, unsigned unit, int force) { hipLaunchKernelGGL(k_queue_plan, dim3(1), dim3(1), 0, s, q, par, unit ? unit : 1u, force); }
+void launch_queue_fill(hipStream_t s, ListQueue *q, ListSlot *slots, int n, uint8_t *payload, Result *res, int oper_mode)
+{
+	hipLaunchKernelGGL(k_queue_fill, dim3((n + 255) / 256), dim3(256), 0, s, q, slots, n, payload, res, oper_mode);
 }
 
 // ---------------------------------------------------------------- D10
 // decode.cc:254-261 (systematic message = codeword at the unfrozen positions),
 // decode.cc:532-541 (first lane whose CRC-32 over 43072 bits is 0), decode.cc:546-555
 // (LE bit packing + flip count), decode.cc:613-615 (descramble).
-__global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st_all, const float *__restrict__ llr_all,
-	const uint8_t *__restrict__ hard_all, Tables tb, int descramble, int list, int n_frames, uint8_t *__restrict__ lane_mesg_all,
-	uint8_t *__restrict__ payload_all, Result *__restrict__ res_all, const int *__restrict__ cert_all)
+// One workgroup per entry of the flush `par` of the list decoder's queue; workgroups beyond the run leave at once.
+__global__ __launch_bounds__(256) void k_finish(const ListQueue *__restrict__ q, int par, const ListSlot *__restrict__ slots,
+	const float *__restrict__ llr_q, const uint8_t *__restrict__ hard_q, Tables tb, int descramble, int list, uint8_t *__restrict__ lane_mesg_q)
 {
-	// cert_all (nullable): frames with 1 were finished by k_back (syndrome certificate)
-	const int f = blockIdx.x, tid = threadIdx.x;
-	if (cert_all && cert_all[f] == 1)
+	const int rel = blockIdx.x, tid = threadIdx.x;
+	const unsigned run_n = q->run_n[par], run_head = q->run_head[par], cap = q->cap;
+	if ((unsigned)rel >= run_n)
 		return;
-	const SyncState st = st_all[f];
-	uint8_t *payload = payload_all + (size_t)f * PAYLOAD_BYTES;
+	const int slot = (int)((run_head + (unsigned)rel) % cap);
+	const ListSlot ls = slots[slot];
+	uint8_t *payload = ls.payload;
 	__shared__ uint8_t mesg[LIST][MESG_BYTES_MAX];
 	__shared__ uint32_t crcs[LIST];
 	__shared__ int flips_red[4];
 	__shared__ uint32_t ctab[256], csh[1024], cpart[LIST][32];
 	ctab[tid] = tb.crc32_tab[tid];
 	#pragma unroll
-	for (int q = 0; q < 4; ++q)
-		csh[tid + 256 * q] = tb.crc32_shift168[tid + 256 * q];
-	Result r = res_all[f];
-	r.status = st.status;
-	r.symbol_pos = st.symbol_pos;
-	r.sc_start = st.sc_start;
-	r.cfo_rad = st.cfo_rad;
-	r.oper_mode = st.oper_mode;
-	r.call_sign = st.call_sign;
-	r.n_sync_rejects = st.rejects;
-	r.best_lane = -1;
-	r.bit_flips = 0;
-	if (!st.okay) {
-		r.cfo_fine = st.cfo_rad;
-		r.sfo_slope = 0.f;
-		r.esn0_db_last = 0.f;
-		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
-			payload[i] = 0;
-		if (tid == 0)
-			res_all[f] = r;
-		return;
-	}
-	// list 4: k_polar decodes the frames (2u, 2u+1) as a pair when both have a header and share the frozen table; the pair's
-	// partial sums are ONE byte array in the first frame's slot, bits 0..3 = first frame, bits 4..7 = second
-	int hshift = 0;
-	size_t hframe = (size_t)f;
+	for (int e = 0; e < 4; ++e)
+		csh[tid + 256 * e] = tb.crc32_shift168[tid + 256 * e];
+	// list 4: k_polar decodes the entries (2u, 2u+1) of a run as a pair when they share the frozen table; the pair's
+	// partial sums are ONE byte array in the first entry's slot, bits 0..3 = first frame, bits 4..7 = second
+	int hshift = 0, hslot = slot;
 	if (list == 4) {
-		const int mate = f ^ 1;
-		if (mate < n_frames) {
-			const SyncState sm = st_all[mate];
-			if (sm.okay && !(cert_all && cert_all[mate] == 1) && (sm.oper_mode >= 10) == (st.oper_mode >= 10)) {   // (k_polar's pairing rule)
-				hframe = (size_t)(f & ~1);
-				hshift = (f & 1) * 4;
+		const unsigned mate = (unsigned)rel ^ 1u;
+		if (mate < run_n) {
+			const int mslot = (int)((run_head + mate) % cap);
+			const bool adjacent = (rel & 1) ? mslot + 1 == slot : slot + 1 == mslot;
+			if (adjacent && (slots[mslot].oper_mode >= 10) == (ls.oper_mode >= 10)) {   // (k_polar's pairing rule)
+				hslot = (rel & 1) ? mslot : slot;
+				hshift = (rel & 1) * 4;
 			}
 		}
 	}
-	const uint8_t *hard = hard_all + hframe * CODE_LEN;
-	const float *llr = llr_all + (size_t)f * CODE_LEN;
-	const ModeDesc md = mode_desc(st.oper_mode);
+	const uint8_t *hard = hard_q + (size_t)hslot * CODE_LEN;
+	const float *llr = llr_q + (size_t)slot * CODE_LEN;
+	const ModeDesc md = mode_desc(ls.oper_mode);
 	const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
 	const int mesg_bytes = md.mesg_bits / 8;
 	// transpose: 8 code positions (one byte each, bit k = path k) -> one message byte per path
@@ -300,9 +390,9 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 			mesg[k][bi] = (uint8_t)o[k];
 	}
 	__syncthreads();
-	if (lane_mesg_all)
+	if (lane_mesg_q)
 		for (int i = tid; i < LIST * MESG_BYTES; i += 256)
-			lane_mesg_all[(size_t)f * LIST * MESG_BYTES + i] = mesg[i / MESG_BYTES][i % MESG_BYTES];
+			lane_mesg_q[(size_t)slot * LIST * MESG_BYTES + i] = mesg[i / MESG_BYTES][i % MESG_BYTES];
 	// CRC<uint32_t>(0xD419CC15) over the first 43072 bits of each lane (decode.cc:533-541), 32 threads per lane:
 	// every thread runs the byte-table CRC over its own 168-byte segment from a zero state, then the 32 partial
 	// states are folded in order with the "advance by 168 zero bytes" operator (CRC is linear: state(A|B) =
@@ -318,9 +408,9 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 		__syncthreads();
 		if (tid < LIST) {
 			crc = 0;
-			for (int q = 0; q < NSEG; ++q) {
+			for (int e = 0; e < NSEG; ++e) {
 				crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
-				crc ^= cpart[tid][q];
+				crc ^= cpart[tid][e];
 			}
 			for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
 				crc = (crc >> 8) ^ ctab[(crc ^ mesg[tid][i]) & 255];
@@ -332,13 +422,13 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 	for (int k = list - 1; k >= 0; --k)                       // decode.cc:532-541 over the list's lanes
 		if (crcs[k] == 0)
 			best = k;
-	r.best_lane = best;
 	if (best < 0) {
-		r.status = 6;                                         // decode.cc:542-545
 		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
 			payload[i] = 0;
-		if (tid == 0)
-			res_all[f] = r;
+		if (tid == 0) {
+			ls.res->status = 6;                               // decode.cc:542-545
+			ls.res->best_lane = -1;
+		}
 		return;
 	}
 	// decode.cc:546-554: received hard decision against decoded bit over the data bits.  Message bit i is x at the i-th
@@ -371,28 +461,23 @@ __global__ __launch_bounds__(256) void k_finish(const SyncState *__restrict__ st
 		payload[i] = mesg[best][i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);
 	__syncthreads();
 	if (tid == 0) {
-		r.bit_flips = flips_red[0] + flips_red[1] + flips_red[2] + flips_red[3];
-		res_all[f] = r;
+		ls.res->best_lane = best;
+		ls.res->bit_flips = flips_red[0] + flips_red[1] + flips_red[2] + flips_red[3];
 	}
 }
 
-void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
-	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res, const int *cert)
+void launch_finish(hipStream_t s, int list, int max_entries, const ListQueue *q, int par, const ListSlot *slots, const float *llr_q,
+	const uint8_t *hard_q, Tables tb, int descramble, uint8_t *lane_mesg_q)
 {
-	hipLaunchKernelGGL(k_finish, dim3(n), dim3(256), 0, s, st, llr, hard, tb, descramble, list == 4 ? 4 : 8, n, lane_mesg, payload, res, cert);
+	hipLaunchKernelGGL(k_finish, dim3(max_entries), dim3(256), 0, s, q, par, slots, llr_q, hard_q, tb, descramble, list == 4 ? 4 : 8, lane_mesg_q);
 }
-__global__ void k_cert_clear(int *__restrict__ counters) { counters[threadIdx.x] = 0; }
-__global__ void k_cert_log(const int *__restrict__ counters, int *__restrict__ log) { *log = counters[1]; }
-void launch_back(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
-	float *precision, float *llr, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, int *cert, int *log)
+void launch_back(hipStream_t s, int rate, int n, int cert_mode, const SyncState *st, const cf *cons, const float *slope, const float *yint,
+	float *precision, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, ListQueue *q, ListSlot *slots,
+	float *llr_q, int *slot_of)
 {
 	const int sym_stride = rate_symbol_len(rate) + rate_symbol_len(rate) / 8;
-	// (one-thread kernels instead of hipMemsetAsync / a 4-byte hipMemcpyAsync: the runtime's blit copy cost 0.26 ms of stream time each)
-	hipLaunchKernelGGL(k_cert_clear, dim3(1), dim3(2), 0, s, cert + n);
-	hipLaunchKernelGGL(k_back, dim3(n), dim3(256), 0, s, sym_stride, st, cons, slope, yint, precision, llr, res, esn0_rows, tb, descramble,
-		payload, cert);
-	if (log)
-		hipLaunchKernelGGL(k_cert_log, dim3(1), dim3(1), 0, s, cert + n, log);
+	hipLaunchKernelGGL(k_back, dim3(n), dim3(256), 0, s, sym_stride, cert_mode, st, cons, slope, yint, precision, res, esn0_rows, tb, descramble,
+		payload, q, slots, llr_q, slot_of);
 }
 
 }  // namespace rx

@@ -456,7 +456,7 @@ __device__ __forceinline__ unsigned crc16_u64(unsigned long long data)
 #endif
 template <int RATE>
 __global__ __launch_bounds__(256, HDR_WAVES) void k_header(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
-	SyncState *__restrict__ st_all, int8_t *__restrict__ hdr_soft)
+	SyncState *__restrict__ st_all, int8_t *__restrict__ hdr_soft, Attempt *__restrict__ attempts, int32_t *__restrict__ attempt_counts)
 {
 	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, SYM_STRIDE = RateCfg<RATE>::STRIDE;
 	const int f = blockIdx.x, tid = threadIdx.x;
@@ -522,6 +522,16 @@ __global__ __launch_bounds__(256, HDR_WAVES) void k_header(FrameBatch fb, const 
 		}
 		st.status = status;
 		st.okay = status == 0;
+		if (attempts && st.hdr_rounds < ATTEMPTS_MAX) {           // decode.cc:400-401,417-446: what the reference prints for this preamble
+			Attempt a;
+			a.status = status;
+			a.symbol_pos = st.symbol_pos;
+			a.cfo_rad = st.cfo_rad;
+			a.oper_mode = st.oper_mode;
+			a.call_sign = st.call_sign;
+			attempts[(size_t)f * ATTEMPTS_MAX + st.hdr_rounds] = a;
+			attempt_counts[f] = st.hdr_rounds + 1;
+		}
 		st.hdr_rounds += 1;
 		if (st.skip_left > 0) { st.skip_left -= 1; st.active = 1; st.found = 0; }   // decode.cc:448: the search goes on behind this preamble
 		else st.active = 0;
@@ -546,9 +556,10 @@ __global__ __launch_bounds__(256, 2) void k_osd_only(Tables tb, const int8_t *__
 		unique_out[f] = u ? 1 : 0;
 }
 
-void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft)
+void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft, Attempt *attempts,
+	int32_t *attempt_counts)
 {
-	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_header<RATE>, dim3(n), dim3(256), 0, s, fb, z, tb, st, hdr_soft));
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_header<RATE>, dim3(n), dim3(256), 0, s, fb, z, tb, st, hdr_soft, attempt_counts ? attempts : nullptr, attempt_counts));   // (both or none)
 }
 void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique)
 {

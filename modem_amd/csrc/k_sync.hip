@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void k_sync_accept(FrameBatch fb, const cf *__
 
 namespace rx {
 
-__global__ void k_init_sync(int n, SyncState *st, const int32_t *skip, int *chunk_flags)
+__global__ void k_init_sync(int n, SyncState *st, const int32_t *skip, int *chunk_flags, int32_t *attempt_counts)
 {
 	int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f == 0 && chunk_flags)
@@ -683,11 +683,13 @@ __global__ void k_init_sync(int n, SyncState *st, const int32_t *skip, int *chun
 	s.pend_phase = 0.f;
 	s.pending = 0;
 	st[f] = s;
+	if (attempt_counts)
+		attempt_counts[f] = 0;
 }
 
-void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts, int *chunk_flags)
+void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts, int *chunk_flags, int32_t *attempt_counts)
 {
-	hipLaunchKernelGGL(k_init_sync, dim3((n + 255) / 256), dim3(256), 0, s, n, st, skip_counts, chunk_flags);
+	hipLaunchKernelGGL(k_init_sync, dim3((n + 255) / 256), dim3(256), 0, s, n, st, skip_counts, chunk_flags, attempt_counts);
 }
 size_t front_end_scratch_bytes(int rate, int n, long samples_per_frame)
 {

@@ -774,33 +774,11 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 	return make_float2(slope, yint);
 }
 
-// sin and cos of the rotation angle (decode.cc:493: a row's phases are yint + slope x, a fraction of a radian).  Cody-Waite
-// reduction by pi/2 in two parts (exact enough for |a| < 1e3: n < 640, n * lo's rounding stays under 1e-10), the single-precision
-// minimax kernels of fdlibm (k_sinf / k_cosf) on |r| <= pi/4, quadrant by n & 3: <= 1 ulp on either output, 23 vector instructions
-// where the library routine (which carries the Payne-Hanek path for huge arguments) took about twice that.  Larger arguments
-// (never seen: the estimator's outputs are bounded by the row's phases) go to the library routine.
-__device__ __forceinline__ void ts_sincos(float a, float &sn, float &cs)
-{
-	if (!(fabsf(a) < 1000.f)) {
-		sincosf(a, &sn, &cs);
-		return;
-	}
-	const float n = rintf(a * 0.636619772f);
-	float r = fmaf(-n, 1.57079637f, a);
-	r = fmaf(-n, -4.37113883e-8f, r);
-	const float z = r * r;
-	const float ps = fmaf(fmaf(fmaf(2.71831149e-6f, z, -1.98393348e-4f), z, 8.33332939e-3f), z, -1.66666667e-1f);
-	const float pc = fmaf(fmaf(fmaf(2.43904488e-5f, z, -1.38867638e-3f), z, 4.16666233e-2f), z, -0.5f);
-	const float sr = fmaf(r * z, ps, r), cr = fmaf(z, pc, 1.f);
-	const int q = (int)n;
-	const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
-	sn = __uint_as_float(__float_as_uint(s0) ^ ((uint32_t)(q & 2) << 30));
-	cs = __uint_as_float(__float_as_uint(c0) ^ ((uint32_t)((q + 1) & 2) << 30));
-}
-
-// one row: decode.cc:482-494
+// one row: decode.cc:482-492.  The rotation of decode.cc:493-494 is not done here (round 4): this kernel is bound by vector
+// instruction issue, the rotated row was 176 KB per frame written and read back, and its only consumers (k_back; the CONS_ROT
+// tap) are latency-bound kernels that rotate each point where they use it (dev_common.h: rotate_point).
 __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const ModeDesc &md, cf *__restrict__ cons_all,
-	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all)
+	const cf *__restrict__ carr_all, float *__restrict__ slope_all, float *__restrict__ yint_all)
 {
 	const int cols = md.cols;
 	cf *row = cons_all + (size_t)f * CONS_MAX + (size_t)j * cols;
@@ -812,9 +790,7 @@ __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const M
 			cf c;
 			if (cr) {                                             // decode.cc:474-475
 				c = demod_or_erase(cr[cols + i], cr[i]);
-				row[i] = c;                                       // read back for the rotation below: the division is done once
-				if (cons_raw_all)
-					cons_raw_all[(size_t)f * CONS_MAX + (size_t)j * cols + i] = c;
+				row[i] = c;
 			} else
 				c = row[i];
 			cf d = cmul(c, cconj(md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c)));
@@ -823,28 +799,14 @@ __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const M
 	}
 	TS_SYNC();
 	const float2 sy = theil_sen_wave(s, cols, lane);
-	const float slope = sy.x, yint = sy.y;
-	// (the row is read a second time here instead of being held in 16 registers across the search: it is in L2 or close;
-	// each lane reads back exactly the elements it wrote)
-	#pragma unroll 1
-	for (int q = 0; q < 8; ++q) {                                 // decode.cc:493-494
-		const int i = lane + 64 * q;
-		if (i < cols) {
-			float a = -(yint + slope * (float)(i - cols / 2));
-			float sn, cs;
-			ts_sincos(a, sn, cs);
-			row[i] = cmul(row[i], mk(cs, sn));
-		}
-	}
 	if (lane == 0) {
-		slope_all[(size_t)f * ROWS_MAX + j] = slope;
-		yint_all[(size_t)f * ROWS_MAX + j] = yint;
+		slope_all[(size_t)f * ROWS_MAX + j] = sy.x;
+		yint_all[(size_t)f * ROWS_MAX + j] = sy.y;
 	}
 }
 
 // decode.cc:479-504: one wave per (frame, row)
-// carr_all != nullptr (8 kHz): the row is formed here from the carriers of two consecutive symbols; cons_raw_all
-// (nullable) receives the unrotated row for the CONS_RAW tap.
+// carr_all != nullptr: the row is formed here from the carriers of two consecutive symbols (the rates whose demodulator does not).
 // Rows 0 .. TS_ROWS_DIRECT-1 of every frame: one wave each (grid = frames x TS_ROWS_DIRECT; mode 6 has exactly 50 rows, mode 10 has
 // 42: its last eight waves leave at once).  The modes with more rows (7, 8, 9, 11, 12, 13: up to 126) get theirs from
 // k_theil_sen_more: TS_MORE_WAVES persistent waves that stride over the units (frame, row 50 .. R-1), R = the largest row count
@@ -860,7 +822,7 @@ __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const M
 #endif
 constexpr int TS_ROWS_DIRECT = 50, TS_MORE_WAVES = TS_MORE_WAVES_N;
 __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
-	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames, int *__restrict__ chunk_flags)
+	const cf *__restrict__ carr_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames, int *__restrict__ chunk_flags)
 {
 	const int unit = (int)blockIdx.x * TS_ROWS_PER_WG + ((int)threadIdx.x >> 6);
 	// (uniform per wave: said explicitly, or the row's addresses are computed per lane)
@@ -873,10 +835,10 @@ __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen(const Sync
 	if (j >= md.rows)
 		return;
 	__shared__ TsLds s_all[TS_ROWS_PER_WG];
-	ts_row(s_all[threadIdx.x >> 6], f, j, lane, md, cons_all, carr_all, cons_raw_all, slope_all, yint_all);
+	ts_row(s_all[threadIdx.x >> 6], f, j, lane, md, cons_all, carr_all, slope_all, yint_all);
 }
 __global__ __launch_bounds__(64, TS_MORE_OCC) void k_theil_sen_more(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
-	const cf *__restrict__ carr_all, cf *__restrict__ cons_raw_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames, const int *__restrict__ chunk_flags)
+	const cf *__restrict__ carr_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames, const int *__restrict__ chunk_flags)
 {
 	const int more = chunk_flags[0] - TS_ROWS_DIRECT;
 	if (more <= 0)
@@ -891,7 +853,7 @@ __global__ __launch_bounds__(64, TS_MORE_OCC) void k_theil_sen_more(const SyncSt
 		if (j >= md.rows)
 			continue;
 		__syncthreads();
-		ts_row(s, f, j, lane, md, cons_all, carr_all, cons_raw_all, slope_all, yint_all);
+		ts_row(s, f, j, lane, md, cons_all, carr_all, slope_all, yint_all);
 	}
 }
 __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen_raw(int cols, int rows, const float *__restrict__ y, float *__restrict__ slope_all,
@@ -916,11 +878,11 @@ __global__ void k_ts_reason_dump()
 		g_ts_reason[1], g_ts_reason[2], g_ts_reason[3], g_ts_reason[4], g_ts_reason[5], g_ts_reason[6], g_ts_reason[7]);
 }
 #endif
-void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint, int *chunk_flags)
+void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, float *slope, float *yint, int *chunk_flags)
 {
 	hipLaunchKernelGGL(k_theil_sen, dim3((n * TS_ROWS_DIRECT + TS_ROWS_PER_WG - 1) / TS_ROWS_PER_WG), dim3(64 * TS_ROWS_PER_WG), 0, s, st, cons, carr,
-		cons_raw, slope, yint, n, chunk_flags);
-	hipLaunchKernelGGL(k_theil_sen_more, dim3(TS_MORE_WAVES), dim3(64), 0, s, st, cons, carr, cons_raw, slope, yint, n,
+		slope, yint, n, chunk_flags);
+	hipLaunchKernelGGL(k_theil_sen_more, dim3(TS_MORE_WAVES), dim3(64), 0, s, st, cons, carr, slope, yint, n,
 		chunk_flags);
 #ifdef TS_REASON_LOG
 	hipLaunchKernelGGL(k_ts_reason_dump, dim3(1), dim3(1), 0, s);

@@ -63,6 +63,28 @@ struct Tables {                    // device-resident constants, built once per 
 	const uint8_t *scramble;       // 5380 bytes of the Xorshift32 stream (decode.cc:613-615)
 };
 
+// ---- the list decoder's work queue (round 4).  Frames the syndrome certificate cannot finish are queued by k_back with their
+// LLRs - entry e in slot e % cap of the slot arrays (LLRs, partial sums, metrics, ListSlot) - and k_polar / k_finish take
+// whole runs of entries: a flush (ofdmrx_api.cpp) is k_queue_plan | k_polar | k_finish, and it takes nothing until one full
+// residency of the list decoder waits, so a few stragglers per chunk no longer cost a decoder round each.  All counters live
+// on the device: the host never waits to learn how many frames a chunk left.
+struct ListQueue {
+	unsigned tail;                 // entries allocated since the call began (k_back: atomicAdd)
+	unsigned head;                 // entries taken by the flushes planned so far
+	unsigned snap[2];              // tail behind k_back of the chunk with parity 0 / 1 (k_queue_snap): what that chunk's flush may take
+	unsigned run_head[2], run_n[2];   // the entries of the flush of the chunk with parity 0 / 1 (k_queue_plan)
+	int next_unit[2];              // k_polar's shared work counter, per flush
+	int cert_on;                   // adaptive certificate: tried for every frame (1) or for a probe sample (0)
+	unsigned tried, certified;     // since the last snapshot: frames the certificate was tried for / that it finished
+	unsigned cap;                  // slots
+};
+struct ListSlot {                  // what k_polar / k_finish need to know about a queued frame
+	uint8_t *payload;              // where its 5380 bytes go
+	struct Result *res;            // its record (complete but for best_lane / bit_flips / a payload CRC failure)
+	int oper_mode;
+	int frame;                     // index in its chunk
+};
+
 struct Result {                    // device mirror of ofdmrx_frame_result (same layout)
 	int32_t status;
 	int32_t symbol_pos;
@@ -75,31 +97,46 @@ struct Result {                    // device mirror of ofdmrx_frame_result (same
 	int32_t n_sync_rejects;
 };
 
+struct Attempt {                   // device mirror of ofdmrx_attempt: one preamble of a frame's SKIP loop (decode.cc:390-448)
+	int32_t status, symbol_pos;
+	float cfo_rad;
+	int32_t oper_mode;
+	uint64_t call_sign;
+};
+constexpr int ATTEMPTS_MAX = 65;   // OFDMRX_MAX_SKIP + 1
+
 // ---- launch wrappers (defined next to their kernels) ------------------------
 // `rate` selects the RateCfg instantiation (8000 / 16000 / 44100 / 48000)
 // D1 (mono input): scratch = front_end_scratch_bytes() of doubles (per tile of 4096 samples: its end state + the history samples)
 size_t front_end_scratch_bytes(int rate, int n, long samples_per_frame);
 void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, double *scratch, cf *z);
 void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, cf *scratch);
-void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft);
+// attempts / attempt_counts (nullable): [n][ATTEMPTS_MAX] records of the preambles examined so far, [n] their number
+void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft, Attempt *attempts = nullptr,
+	int32_t *attempt_counts = nullptr);
 void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique);
 // 8 kHz: demod writes the carriers of every symbol (carr), the differential step happens in k_theil_sen; other rates: cons
 bool demod_writes_carriers(int rate);
 bool demod_forms_cons(int rate);   // cons is complete after k_demod (else k_theil_sen forms the rows from the carriers)
 void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons, cf *carr);
-void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, cf *cons_raw, float *slope, float *yint, int *chunk_flags);
+void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, float *slope, float *yint, int *chunk_flags);
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
-void launch_llr(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
-	float *precision, float *llr, Result *res, float *esn0_rows = nullptr);   // esn0_rows (nullable): [n][ROWS_MAX] dB values, decode.cc:517-519
-// cert (nullable): per-frame verdict of the syndrome certificate (launch_back: 1 = finished there), then two counters
-void launch_polar(hipStream_t s, int list, int n, int grid, const SyncState *st, const float *llr, float *soft, uint8_t *hard, Tables tb, float *metric,
-	int *next_cw, const int *cert = nullptr);
-void launch_finish(hipStream_t s, int list, int n, const SyncState *st, const float *llr, const uint8_t *hard, Tables tb,
-	int descramble, uint8_t *lane_mesg, uint8_t *payload, Result *res, const int *cert = nullptr);
-// D6-D8 with the syndrome certificate (k_finish.hip: k_back): frames it decides get payload + result at once and no LLRs;
-// cert: [n] verdicts + 2 counters; log (nullable): receives the number of frames left to the list decoder
-void launch_back(hipStream_t s, int rate, int n, const SyncState *st, const cf *cons, const float *slope, const float *yint,
-	float *precision, float *llr, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, int *cert, int *log);
+// D5's rotation + D6-D8 + the syndrome certificate (k_finish.hip: k_back).  cert_mode 0: every frame with a header goes to the list
+// decoder's queue; 1: the certificate is tried (adaptively) and finishes the frames it decides (payload + result).
+// esn0_rows (nullable): [n][ROWS_MAX] dB values, decode.cc:517-519; slot_of: [n] queue slot per frame, -1 = none
+void launch_back(hipStream_t s, int rate, int n, int cert_mode, const SyncState *st, const cf *cons, const float *slope, const float *yint,
+	float *precision, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, ListQueue *q, ListSlot *slots,
+	float *llr_q, int *slot_of);
+void launch_rotate_tap(hipStream_t s, const SyncState *st, const cf *cons, const float *slope, const float *yint, cf *out);   // one frame, CONS_MAX points
+void launch_queue_reset(hipStream_t s, ListQueue *q, unsigned cap);
+void launch_queue_snap(hipStream_t s, ListQueue *q, int par);
+void launch_queue_plan(hipStream_t s, ListQueue *q, int par, unsigned unit, int force);
+void launch_queue_fill(hipStream_t s, ListQueue *q, ListSlot *slots, int n, uint8_t *payload, Result *res, int oper_mode);
+// D9 / D10 for the run `par` of the queue; grid = resident decoders, max_entries = an upper bound of the run's length
+void launch_polar(hipStream_t s, int list, int grid, ListQueue *q, int par, const ListSlot *slots, const float *llr_q, float *soft, uint8_t *hard_q,
+	Tables tb, float *metric_q);
+void launch_finish(hipStream_t s, int list, int max_entries, const ListQueue *q, int par, const ListSlot *slots, const float *llr_q,
+	const uint8_t *hard_q, Tables tb, int descramble, uint8_t *lane_mesg_q);
 void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb);
 void launch_awgn_tile(hipStream_t s, const int16_t *base, size_t n_base, int16_t *out, size_t n_out,
 	size_t spf, float sigma, uint64_t seed, uint64_t first_frame);
@@ -108,6 +145,6 @@ size_t tx_big_scratch_bytes(int rate, int n, int nsym);
 void launch_tx(hipStream_t s, int rate, int n, const uint8_t *payload, Tables tb, const void *tp, const cf *tw_sym4,
 	uint32_t *code, cf *rowsym, cf *tdom, cf *big_scratch, void *pcm);
 // chunk_flags (nullable): per-chunk device flags cleared here ([0]: the largest row count k_theil_sen met, when above 50)
-void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts, int *chunk_flags = nullptr);
+void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_counts, int *chunk_flags = nullptr, int32_t *attempt_counts = nullptr);
 
 }  // namespace rx

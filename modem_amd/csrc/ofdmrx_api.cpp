@@ -22,6 +22,7 @@
 using namespace rx;
 
 static_assert(sizeof(Result) == sizeof(ofdmrx_frame_result), "Result must mirror ofdmrx_frame_result");
+static_assert(sizeof(Attempt) == sizeof(ofdmrx_attempt) && ATTEMPTS_MAX == OFDMRX_MAX_SKIP + 1, "Attempt must mirror ofdmrx_attempt");
 
 namespace {
 
@@ -120,44 +121,38 @@ struct ofdmrx_handle {
 	HostTables host;
 	Tables dev{};
 	std::vector<void *> table_allocs;
-	// per-chunk device state
+	// per-chunk device state: one buffer each - every stage from the scan to k_back runs on the handle's stream, chunk after
+	// chunk; what crosses to the list decoder's streams goes through the queue below
 	int cap = 0;              // frames the buffers below are sized for
 	long cap_samples = 0;     // samples per frame the mono buffers are sized for
-	DevBuf st, hdr_soft, cons, slope, yint, precision, llr, soft, hard, metric, lane_mesg, res, payload;
-	DevBuf st2, llr2;         // second parity of the two buffers that cross from the front stages to the polar stage
-	DevBuf cons2, slope2, yint2, precision2;   // ... and of what the LLR kernel reads: it runs on the back stream, ahead of the list decoder
+	DevBuf st, hdr_soft, cons, slope, yint, precision, slot_of, res, payload;
 	DevBuf payload2, res2;    // second parity of the device-side output staging (host-pointer entry)
-	DevBuf work_counter;      // k_polar's shared codeword counter (zeroed on the stream before every launch)
+	DevBuf chunk_flags;       // per-chunk device flags (k_theil_sen: the largest row count met)
+	DevBuf soft;              // the level stores of the resident list decoders (2 MiB each)
+	// the list decoder's work queue (kernels.h: ListQueue): control block + one slot per entry
+	DevBuf q_ctl, q_slots, q_llr, q_hard, q_metric, q_lane_mesg;
+	unsigned q_cap = 0;       // slots
+	unsigned flush_unit = 1;  // entries a flush takes at a time (one residency of the list decoder) unless it is forced
+	DevBuf rot_tap;           // OFDMRX_TAP_CONS_ROT: the rotated rows of one frame, made on demand
 	DevBuf tx_code, tx_rowsym, tx_tdom, tx_big;   // transmitter scratch, kept between calls (no allocation, no synchronisation per call)
-	hipStream_t stream_b = nullptr;   // polar + finish of chunk c run here while the front stages of chunk c+1 run on `stream`
-	hipStream_t stream_c = nullptr;   // host-pointer entry: host-to-device copies of the next chunk
-	hipStream_t stream_f[2] = { nullptr, nullptr };   // sync / header / demod of a chunk run as four sub-batches over three streams
+	hipStream_t stream_b = nullptr;     // the list decoder (k_polar) of chunk c - 1 runs here beside the front stages of chunk c
+	hipStream_t stream_fin = nullptr;   // k_finish (+ the host entry's output copies) of chunk c - 2
+	hipStream_t stream_c = nullptr;     // host-pointer entry: host-to-device copies of the next chunk
 	hipError_t sticky = hipSuccess;   // first failed hipEventRecord of the running call
-	int polar_grid = 0;       // resident polar decoders while overlapping (0 = one per codeword)
-	int last_par = 0;         // parity used by the last chunk (taps)
-	DevBuf cert, cert2;       // syndrome certificate: verdict per frame (+ one flag), by parity
-	bool use_cert = true;     // no debug taps, not switched off
+	int polar_grid = 0;       // resident list decoders
+	int cert_mode = 1;        // 1: syndrome certificate (adaptive), 0: every frame with a header is list-decoded
 	float *esn0_user = nullptr;   // ofdmrx_set_esn0_rows: n x OFDMRX_ROWS_MAX floats in the memory space of the results (NULL = off)
 	DevBuf esn0_dev, esn0_dev2;   // host-pointer entry: per-chunk device staging of the row values, by parity
-	DevBuf cert_log;          // per chunk of the last call: frames the certificate left to the list decoder
-	int cert_chunks = 0;
-	int *cert_of(int par) { return use_cert ? (par ? cert2 : cert).as<int>() : nullptr; }
-	DevBuf hard2;             // second parity of the list decoder's output: finish(c) reads its own while polar(c+1) writes
-	uint8_t *hard_of(int par) { return (par ? hard2 : hard).as<uint8_t>(); }
-	DevBuf st3;               // third SyncState array: finish(c-1) still reads its own while sync / header of chunk c+1 write theirs
-	SyncState *st_of(int i) { return (i == 0 ? st : i == 1 ? st2 : st3).as<SyncState>(); }
-	cf *cons_of(int par) { return (par ? cons2 : cons).as<cf>(); }
-	float *slope_of(int par) { return (par ? slope2 : slope).as<float>(); }
-	float *yint_of(int par) { return (par ? yint2 : yint).as<float>(); }
-	float *precision_of(int par) { return (par ? precision2 : precision).as<float>(); }
-	float *llr_of(int par) { return (par ? llr2 : llr).as<float>(); }
+	ofdmrx_attempt *att_user = nullptr;   // ofdmrx_set_attempt_log: n x (OFDMRX_MAX_SKIP + 1) records and n counts, same memory space (NULL = off)
+	int32_t *att_counts_user = nullptr;
+	DevBuf att_dev, att_dev2, attc_dev, attc_dev2;   // host-pointer entry: their device staging, by parity
+	ListQueue *queue() const { return q_ctl.as<ListQueue>(); }
 	DevBuf dc, z;             // mono front end only
-	DevBuf cons_raw;          // only with cfg.flags & 1 (keep the pre-rotation constellation for taps)
 	long last_spf = 0;
 	DevBuf in_stage, in_stage2, skip_stage;
 	void *out_stage[2] = { nullptr, nullptr };   // pinned host staging of payloads + results (host-pointer entry)
 	size_t out_stage_cap[2] = { 0, 0 };
-	DevBuf carr;                   // 8 kHz: payload carriers of every symbol (demod -> Theil-Sen)
+	DevBuf carr;                   // payload carriers of every symbol (demod -> Theil-Sen) at the rates whose demodulator does not form the rows
 	DevBuf sc_scratch;             // rates above 8 kHz: 2 x symbol_len/2 cf per frame for the S&C trigger part
 	int last_n = 0;           // frames in the last chunk (for taps)
 	bool last_mono = false;
@@ -215,7 +210,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	h->cfg = *cfg;
 	h->rate = cfg->sample_rate;
 	h->list = cfg->list_size == 4 ? 4 : 8;
-	h->use_cert = !(cfg->flags & (OFDMRX_FLAG_KEEP_RAW_CONS | OFDMRX_FLAG_SCL_ALWAYS)) && !std::getenv("OFDMRX_NO_CERT");   // (the rule holds for any list size)
+	h->cert_mode = !(cfg->flags & (OFDMRX_FLAG_KEEP_RAW_CONS | OFDMRX_FLAG_SCL_ALWAYS)) && !std::getenv("OFDMRX_NO_CERT");   // (the rule holds for any list size)
 	// default chunk: 8192 frames at every rate: the per-frame decoder state does not grow with the rate, and the two-stream
 	// schedule wants a few thousand codewords per polar launch (44.1 / 48 kHz: 121 k / 125 k frames/s against 111 k / 112 k
 	// with 4096).  What does grow is the per-chunk input: a 48 kHz frame is 4.2 MB of int16 pairs (34.6 GB per 8192 frames; the
@@ -246,38 +241,21 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		}
 		h->own_stream = true;
 	}
+	for (hipStream_t *sx : { &h->stream_b, &h->stream_fin, &h->stream_c }) {
+		hipError_t e = hipStreamCreateWithFlags(sx, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+			ofdmrx_destroy(h);
+			return OFDMRX_E_HIP;
+		}
+	}
 	{
-		// OFDMRX_POLAR_PRIO=n (experiments): stream priority of the list decoder's queue (numerically larger = lower)
-		int prio_lo = 0, prio_hi = 0;
-		(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-		const char *pe = std::getenv("OFDMRX_POLAR_PRIO");
-		hipError_t e = pe ? hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, std::max(prio_hi, std::min(prio_lo, std::atoi(pe))))
-			: hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking);
-		if (e != hipSuccess) {
-			g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-			ofdmrx_destroy(h);
-			return OFDMRX_E_HIP;
-		}
-		e = hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking);
-		if (e != hipSuccess) {
-			g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-			ofdmrx_destroy(h);
-			return OFDMRX_E_HIP;
-		}
-		for (hipStream_t &sf : h->stream_f) {
-			e = hipStreamCreateWithFlags(&sf, hipStreamNonBlocking);
-			if (e != hipSuccess) {
-				g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-				ofdmrx_destroy(h);
-				return OFDMRX_E_HIP;
-			}
-		}
 		int cus = 0;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
-		int wpc = 16;             // resident list decoders per CU (the front stages of the next chunks share the machine with them)
+		int wpc = 16;             // resident list decoders per CU: one wave each, 96 VGPRs + 8 KB of LDS (k_polar.hip)
 		if (const char *e2 = std::getenv("OFDMRX_POLAR_WPC"))
-			wpc = std::atoi(e2);
-		h->polar_grid = wpc > 0 && cus > 0 ? wpc * cus : 0;
+			wpc = std::max(1, std::atoi(e2));
+		h->polar_grid = wpc * std::max(cus, 1);
 	}
 	build_tables(h->host, h->rate);
 	int r = 0;
@@ -312,13 +290,14 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 	(void)hipSetDevice(h->cfg.device);
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
-	for (hipStream_t sx : { h->stream_b, h->stream_c, h->stream_f[0], h->stream_f[1] })
+	for (hipStream_t sx : { h->stream_b, h->stream_fin, h->stream_c })
 		if (sx) {
 			(void)hipStreamSynchronize(sx);
 			(void)hipStreamDestroy(sx);
 		}
-	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->llr, &h->soft, &h->hard,
-			&h->metric, &h->lane_mesg, &h->res, &h->payload, &h->dc, &h->z, &h->cons_raw, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->sc_scratch, &h->st2, &h->llr2, &h->carr, &h->payload2, &h->res2, &h->tx_code, &h->tx_rowsym, &h->tx_tdom, &h->tx_big, &h->work_counter, &h->cons2, &h->slope2, &h->yint2, &h->precision2, &h->st3, &h->hard2, &h->cert, &h->cert2, &h->cert_log, &h->esn0_dev, &h->esn0_dev2 })
+	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->slot_of, &h->res, &h->payload, &h->payload2, &h->res2,
+			&h->chunk_flags, &h->soft, &h->q_ctl, &h->q_slots, &h->q_llr, &h->q_hard, &h->q_metric, &h->q_lane_mesg, &h->rot_tap, &h->tx_code, &h->tx_rowsym,
+			&h->tx_tdom, &h->tx_big, &h->esn0_dev, &h->esn0_dev2, &h->att_dev, &h->att_dev2, &h->attc_dev, &h->attc_dev2, &h->dc, &h->z, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->carr, &h->sc_scratch })
 		b->release();
 	for (void *p : h->table_allocs)
 		(void)hipFree(p);
@@ -346,43 +325,38 @@ extern "C" int ofdmrx_set_esn0_rows(ofdmrx_handle *h, float *rows)
 	return 0;
 }
 
+// decode.cc:400-447 prints one block of lines per preamble of the SKIP loop; a batch caller gets them here (see ofdmrx.h)
+extern "C" int ofdmrx_set_attempt_log(ofdmrx_handle *h, ofdmrx_attempt *log, int32_t *counts)
+{
+	if (!h || (log == nullptr) != (counts == nullptr))
+		return OFDMRX_E_ARG;
+	h->att_user = log;
+	h->att_counts_user = counts;
+	return 0;
+}
+
 // frames of the last decode call that went through the list decoder (the others were decided by the syndrome
 // certificate); -1: the certificate is off for this handle (every frame with a header is list-decoded)
 extern "C" long long ofdmrx_list_decoded_frames(ofdmrx_handle *h)
 {
 	if (!h)
 		return OFDMRX_E_ARG;
-	if (!h->use_cert)
+	if (!h->cert_mode)
 		return -1;
+	if (!h->q_ctl.p)
+		return 0;
 	if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
 		return OFDMRX_E_HIP;
-	std::vector<int> v((size_t)h->cert_chunks);
-	if (!v.empty() && hipMemcpy(v.data(), h->cert_log.p, v.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+	ListQueue q;
+	if (hipMemcpy(&q, h->q_ctl.p, sizeof(q), hipMemcpyDeviceToHost) != hipSuccess)
 		return OFDMRX_E_HIP;
-	long long sum = 0;
-	for (int x : v)
-		sum += x;
-	return sum;
+	return (long long)q.tail;                                 // entries queued since the call began
 }
 
-constexpr int CERT_LOG_MAX = 4096;   // chunks per call whose list-decoder counts are kept (ofdmrx_list_decoded_frames)
-static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, bool two_parities = false)
+// device state for chunks of up to n frames; the list decoder's queue for calls whose chunks have up to n frames
+static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 {
 	int r = 0;
-	if (two_parities) {
-		const size_t N2 = (size_t)std::max(n, h->cap);
-		r = r ? r : h->st2.ensure(N2 * sizeof(SyncState));
-		r = r ? r : h->st3.ensure(N2 * sizeof(SyncState));
-		r = r ? r : h->llr2.ensure(N2 * CODE_LEN * sizeof(float));
-		r = r ? r : h->cons2.ensure(N2 * CONS_MAX * sizeof(cf));
-		r = r ? r : h->slope2.ensure(N2 * ROWS_MAX * sizeof(float));
-		r = r ? r : h->yint2.ensure(N2 * ROWS_MAX * sizeof(float));
-		r = r ? r : h->precision2.ensure(N2 * ROWS_MAX * sizeof(float));
-		r = r ? r : h->hard2.ensure(N2 * CODE_LEN);
-		r = r ? r : h->cert2.ensure((N2 + 2) * sizeof(int));
-		if (r)
-			return r;
-	}
 	if (n > h->cap) {
 		const size_t N = (size_t)n;
 		r = r ? r : h->st.ensure(N * sizeof(SyncState));
@@ -391,19 +365,25 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples, boo
 		r = r ? r : h->slope.ensure(N * ROWS_MAX * sizeof(float));
 		r = r ? r : h->yint.ensure(N * ROWS_MAX * sizeof(float));
 		r = r ? r : h->precision.ensure(N * ROWS_MAX * sizeof(float));
-		r = r ? r : h->llr.ensure(N * CODE_LEN * sizeof(float));
-		// one 2 MiB level store per RESIDENT decoder (launches never use more than polar_grid of them), not per frame
-		r = r ? r : h->soft.ensure((size_t)(std::min<long>((long)N, h->polar_grid > 0 ? h->polar_grid : (long)N) + 8) * 8 * CODE_LEN * sizeof(float));
-		r = r ? r : h->hard.ensure(N * CODE_LEN);
-		r = r ? r : h->metric.ensure(N * LIST * sizeof(float));
-		r = r ? r : h->work_counter.ensure(256);
-		r = r ? r : h->cert.ensure((N + 2) * sizeof(int));
-		r = r ? r : h->cert_log.ensure(CERT_LOG_MAX * sizeof(int));
-		r = r ? r : h->lane_mesg.ensure(N * LIST * MESG_BYTES);
+		r = r ? r : h->slot_of.ensure(N * sizeof(int));
+		r = r ? r : h->chunk_flags.ensure(256);
 		r = r ? r : h->res.ensure(N * sizeof(Result));
 		r = r ? r : h->payload.ensure(N * PAYLOAD_BYTES);
-		if (h->cfg.flags & 1)
-			r = r ? r : h->cons_raw.ensure(N * CONS_MAX * sizeof(cf));
+		r = r ? r : h->rot_tap.ensure(CONS_MAX * sizeof(cf));
+		// one 2 MiB level store per RESIDENT decoder, not per frame
+		r = r ? r : h->soft.ensure((size_t)(std::min<long>((long)N, (long)h->polar_grid) + 8) * 8 * CODE_LEN * sizeof(float));
+		// The queue: while the flush of chunk c - 1 reads its entries (fewer than flush_unit left over + one chunk) k_back of
+		// chunk c adds one chunk at most, and k_back of chunk c + 1 waits for that flush to end (run_pipeline)
+		h->flush_unit = (unsigned)std::max<long>(1, std::min<long>((long)N, (long)h->polar_grid));
+		h->q_cap = (unsigned)(2 * N + h->flush_unit + 8);
+		const size_t Q = h->q_cap;
+		r = r ? r : h->q_ctl.ensure(sizeof(ListQueue));
+		r = r ? r : h->q_slots.ensure(Q * sizeof(ListSlot));
+		r = r ? r : h->q_llr.ensure(Q * CODE_LEN * sizeof(float));
+		r = r ? r : h->q_hard.ensure(Q * CODE_LEN);
+		r = r ? r : h->q_metric.ensure(Q * LIST * sizeof(float));
+		if (h->cfg.flags & 1)                                     // (the per-lane messages are a debug tap)
+			r = r ? r : h->q_lane_mesg.ensure(Q * LIST * MESG_BYTES);
 		if (!demod_forms_cons(h->rate))                       // (the carriers go through HBM only when k_theil_sen forms the rows)
 			r = r ? r : h->carr.ensure(N * CARR_MAX * sizeof(cf));
 #ifndef SYNC_FFT_IN_LDS
@@ -448,18 +428,19 @@ static size_t mark(ofdmrx_handle *h, hipStream_t on = nullptr)
 }
 static size_t events_per_chunk(int max_skip) { return 32 + 16 * (size_t)(max_skip + 1); }
 
-// One resident chunk = every stage of SURVEY 8(a) D1..D10 as kernels, in two halves:
-//   front (D1..D8: front end, sync/header rounds, demod, Theil-Sen, LLRs) -> st[par], llr[par]
-//   back  (D9, D10: polar list decoder, systematic bits / CRC / pack)     <- st[par], llr[par]
-// A one-chunk call runs both on the handle's stream.  A longer batch is pipelined: back(c) runs on the
-// second stream while front(c+1) runs on the handle's stream.
+// One resident chunk = every stage of SURVEY 8(a) D1..D8 as kernels on ONE stream, in three pieces so that the pipeline can put
+// events between them:
+//   front1  front end (mono), rounds of sync + header/OSD (decode.cc:390-448 do { } while (skip_count--)), demod
+//   front2  Theil-Sen
+//   back    k_back: rotation, SNR, certificate / LLRs into the list decoder's queue; k_queue_snap
+// D9 + D10 for the queued frames = a flush (run_flush).
 // wait_before_sync (event index or -1): the first sync launch waits for it; *ev_after_sync (nullable) receives the event
-// recorded right after that launch - the three-queue schedule gives the scan a slot of its own between two polar launches.
-static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, int sti, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
-	size_t *t_begin, size_t wait_before_sync = (size_t)-1, size_t *ev_after_sync = nullptr, int excl_level = 1)
+// recorded right after that launch - the pipeline gives the scan a slot of its own between two list-decoder launches.
+static int run_front1(ofdmrx_handle *h, hipStream_t s, FrameBatch fb, int n, const int32_t *d_skip, int max_skip,
+	size_t *t_begin, Attempt *d_att, int32_t *d_att_counts, size_t wait_before_sync = (size_t)-1, size_t *ev_after_sync = nullptr)
 {
 	const bool mono = fb.channels == 1;
-	SyncState *st = h->st_of(sti);
+	SyncState *st = h->st.as<SyncState>();
 	const cf *z = mono ? h->z.as<cf>() : nullptr;
 	size_t e0 = mark(h, s);
 	if (mono) {
@@ -467,88 +448,50 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, int par, int sti, FrameBa
 		launch_front_end(s, h->rate, n, fb, h->host.front, h->dc.as<double>(), h->z.as<cf>());
 	}
 	size_t e1 = mark(h, s);
-	// sync, header and demod are short, latency-bound kernels with different shapes (1 wave x 224 VGPRs, 4 waves x 216, 4 waves
-	// x 128).  OFDMRX_FRONT_SPLIT=1 sends a chunk through them as four sub-batches over three streams, so that the sync of
-	// one sub-batch runs beside the header / demod of another (frames are independent; every per-frame array is offset).
-	// Measured neutral to slightly negative (147.9 k against 148.7 k frames/s), so it is off by default.
-	static const bool split_on = std::getenv("OFDMRX_FRONT_SPLIT") != nullptr;
-	const int parts = (n >= 2048 && split_on && h->stream_f[0] && h->stream_f[1]) ? 4 : 1;
-	const int per = (n + parts - 1) / parts;
-	const size_t sl = (size_t)rate_symbol_len(h->rate);
-	size_t e3 = e1;
-	for (int q = 0; q < parts; ++q) {
-		const int f0 = q * per, nq = std::min(per, n - f0);
-		if (nq <= 0)
-			break;
-		hipStream_t sq = q % 3 == 0 ? s : h->stream_f[q % 3 - 1];
-		if (sq != s)
-			HIP_OK(hipStreamWaitEvent(sq, h->ev_pool[e1], 0));
-		FrameBatch fbq = fb;
-		fbq.samples = (const char *)fb.samples + (size_t)f0 * fb.frame_stride_bytes;
-		SyncState *stq = st + f0;
-		const cf *zq = z ? z + (size_t)f0 * (size_t)fb.samples_per_frame : nullptr;
-		cf *scq = h->sc_scratch.p ? h->sc_scratch.as<cf>() + (size_t)f0 * sl : nullptr;
-		launch_init_sync(sq, nq, stq, d_skip ? d_skip + f0 : nullptr, h->work_counter.as<int>() + 16 + par);   // the chunk's flags, by parity
-		size_t last = e1;
-		for (int round = 0; round <= max_skip; ++round) {      // decode.cc:390-448 do { } while (skip_count--)
-			if (round == 0 && q == 0 && wait_before_sync != (size_t)-1)
-				HIP_OK(hipStreamWaitEvent(sq, h->ev_pool[wait_before_sync], 0));
-			size_t a = mark(h, sq);
-			{
-				Range r("ofdmrx:sync");
-				launch_sync(sq, h->rate, nq, fbq, zq, h->dev, stq, scq);
-			}
-			size_t b = mark(h, sq);
-			if (round == 0 && q == 0 && ev_after_sync && excl_level == 1)
-				*ev_after_sync = b;
-			{
-				Range r("ofdmrx:header_osd");
-				launch_header(sq, h->rate, nq, fbq, zq, h->dev, stq, h->hdr_soft.as<int8_t>() + (size_t)f0 * 256);
-			}
-			size_t c = mark(h, sq);
-			if (round == 0 && q == 0 && ev_after_sync && excl_level == 2)
-				*ev_after_sync = c;
-			h->spans.push_back({ OFDMRX_T_SYNC, a, b });
-			h->spans.push_back({ OFDMRX_T_HEADER, b, c });
-			last = c;
-		}
+	launch_init_sync(s, n, st, d_skip, h->chunk_flags.as<int>(), d_att_counts);
+	size_t last = e1;
+	for (int round = 0; round <= max_skip; ++round) {         // decode.cc:390-448
+		if (round == 0 && wait_before_sync != (size_t)-1)
+			HIP_OK(hipStreamWaitEvent(s, h->ev_pool[wait_before_sync], 0));
+		size_t a = mark(h, s);
 		{
-			Range r("ofdmrx:demod");
-			launch_demod(sq, h->rate, nq, fbq, zq, h->dev, stq, h->cons_of(par) + (size_t)f0 * CONS_MAX,
-				h->carr.p ? h->carr.as<cf>() + (size_t)f0 * CARR_MAX : nullptr);
+			Range r("ofdmrx:sync");
+			launch_sync(s, h->rate, n, fb, z, h->dev, st, h->sc_scratch.as<cf>());
 		}
-		size_t d = mark(h, sq);
-		if (q == 0 && ev_after_sync && excl_level == 3)
-			*ev_after_sync = d;
-		h->spans.push_back({ OFDMRX_T_DEMOD, last, d });
-		if (sq != s)
-			HIP_OK(hipStreamWaitEvent(s, h->ev_pool[d], 0));
-		e3 = d;
+		size_t b = mark(h, s);
+		if (round == 0 && ev_after_sync)
+			*ev_after_sync = b;
+		{
+			Range r("ofdmrx:header_osd");
+			launch_header(s, h->rate, n, fb, z, h->dev, st, h->hdr_soft.as<int8_t>(), d_att, d_att_counts);
+		}
+		size_t c = mark(h, s);
+		h->spans.push_back({ OFDMRX_T_SYNC, a, b });
+		h->spans.push_back({ OFDMRX_T_HEADER, b, c });
+		last = c;
 	}
-	if ((h->cfg.flags & 1) && demod_forms_cons(h->rate))
-		HIP_OK(hipMemcpyAsync(h->cons_raw.p, h->cons_of(par), (size_t)n * CONS_MAX * sizeof(cf), hipMemcpyDeviceToDevice, s));
-	(void)e3;
+	{
+		Range r("ofdmrx:demod");
+		launch_demod(s, h->rate, n, fb, z, h->dev, st, h->cons.as<cf>(), h->carr.as<cf>());
+	}
+	size_t d = mark(h, s);
+	h->spans.push_back({ OFDMRX_T_DEMOD, last, d });
 	h->spans.push_back({ OFDMRX_T_FRONT, e0, e1 });
 	*t_begin = e0;
 	HIP_OK(hipGetLastError());
 	h->last_n = n;
 	h->last_mono = mono;
 	h->last_spf = fb.samples_per_frame;
-	h->last_par = par;
 	return 0;
 }
 
-// front2 = the Theil-Sen stage (stream A).  The LLR kernel that follows it (D6-D8) is the first kernel of the back half:
-// it is short and HBM-bound, and every millisecond on stream A is on the critical path of a chunk.
-static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Result *)
+static int run_front2(ofdmrx_handle *h, hipStream_t s, int n)
 {
-	SyncState *st = h->st_of(sti);
 	size_t e4 = mark(h, s);
-	const bool from_carr = !demod_forms_cons(h->rate);
 	{
 		Range r("ofdmrx:theil_sen");
-		launch_theil_sen(s, n, st, h->cons_of(par), from_carr ? h->carr.as<cf>() : nullptr,
-			(from_carr && (h->cfg.flags & 1)) ? h->cons_raw.as<cf>() : nullptr, h->slope_of(par), h->yint_of(par), h->work_counter.as<int>() + 16 + par);
+		launch_theil_sen(s, n, h->st.as<SyncState>(), h->cons.as<cf>(), demod_forms_cons(h->rate) ? nullptr : h->carr.as<cf>(),
+			h->slope.as<float>(), h->yint.as<float>(), h->chunk_flags.as<int>());
 	}
 	size_t e5 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_THEILSEN, e4, e5 });
@@ -556,25 +499,16 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, 
 	return 0;
 }
 
-// The back half in two pieces, so that the pipeline can put an event between them: the LLR kernel (short, needs only the
-// Theil-Sen results) and polar + finish; *ev_polar (nullable) receives the event recorded right after the polar kernel.
-// D6-D8.  With the syndrome certificate on this is k_back (k_finish.hip): it also FINISHES the frames the certificate decides
-// (payload + result), so it needs the payload destination.
-static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Result *d_res, float *d_esn0, uint8_t *d_payload)
+// D5's rotation + D6-D8 + the certificate: frames it finishes get payload + result here, the others a queue slot and their LLRs
+static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_res, float *d_esn0, uint8_t *d_payload)
 {
 	size_t e5 = mark(h, s);
 	{
-		Range r("ofdmrx:llr");
-		if (h->use_cert) {
-			int *log = (h->cert_chunks < CERT_LOG_MAX && h->cert_log.p) ? h->cert_log.as<int>() + h->cert_chunks : nullptr;
-			launch_back(s, h->rate, n, h->st_of(sti), h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
-				h->llr_of(par), d_res, d_esn0, h->dev, h->cfg.descramble, d_payload, h->cert_of(par), log);
-			if (h->cert_chunks < CERT_LOG_MAX)
-				++h->cert_chunks;
-		} else {
-			launch_llr(s, h->rate, n, h->st_of(sti), h->cons_of(par), h->slope_of(par), h->yint_of(par), h->precision_of(par),
-				h->llr_of(par), d_res, d_esn0);
-		}
+		Range r("ofdmrx:back");
+		launch_back(s, h->rate, n, h->cert_mode, h->st.as<SyncState>(), h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(),
+			h->precision.as<float>(), d_res, d_esn0, h->dev, h->cfg.descramble, d_payload, h->queue(), h->q_slots.as<ListSlot>(),
+			h->q_llr.as<float>(), h->slot_of.as<int>());
+		launch_queue_snap(s, h->queue(), par);
 	}
 	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
@@ -582,50 +516,34 @@ static int run_llr(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, Res
 	return 0;
 }
 
-static int run_polar(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, size_t *ev_begin, size_t *ev_end)
+// A flush of the list decoder's queue: plan (what it takes: nothing until one residency waits, unless forced) | k_polar on
+// s_polar, then k_finish on s_fin.  *ev_polar receives the event behind k_polar.
+static int run_flush(ofdmrx_handle *h, hipStream_t s_polar, hipStream_t s_fin, int par, bool force, size_t t_begin, size_t *ev_polar)
 {
-	size_t e6 = mark(h, s);
+	size_t e6 = mark(h, s_polar);
 	{
 		Range r("ofdmrx:polar_scl");
-		launch_polar(s, h->list, n, grid, h->st_of(sti), h->llr_of(par), h->soft.as<float>(), h->hard_of(par), h->dev, h->metric.as<float>(), h->work_counter.as<int>(),
-			h->cert_of(par));
+		launch_queue_plan(s_polar, h->queue(), par, h->flush_unit, force ? 1 : 0);
+		launch_polar(s_polar, h->list, std::min(h->polar_grid, h->cap), h->queue(), par, h->q_slots.as<ListSlot>(), h->q_llr.as<float>(),
+			h->soft.as<float>(), h->q_hard.as<uint8_t>(), h->dev, h->q_metric.as<float>());
 	}
-	size_t e7 = mark(h, s);
+	size_t e7 = mark(h, s_polar);
 	h->spans.push_back({ OFDMRX_T_POLAR, e6, e7 });
-	if (ev_begin)
-		*ev_begin = e6;
-	if (ev_end)
-		*ev_end = e7;
-	HIP_OK(hipGetLastError());
-	return 0;
-}
-static int run_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, uint8_t *d_payload, Result *d_res, bool want_lane_mesg,
-	size_t t_begin)
-{
-	size_t e7 = mark(h, s);
+	if (ev_polar)
+		*ev_polar = e7;
+	if (s_fin != s_polar)
+		HIP_OK(hipStreamWaitEvent(s_fin, h->ev_pool[e7], 0));
+	size_t e8 = mark(h, s_fin);
 	{
 		Range r("ofdmrx:finish");
-		launch_finish(s, h->list, n, h->st_of(sti), h->llr_of(par), h->hard_of(par), h->dev, h->cfg.descramble,
-			want_lane_mesg ? h->lane_mesg.as<uint8_t>() : nullptr, d_payload, d_res, h->cert_of(par));
+		launch_finish(s_fin, h->list, (int)h->q_cap, h->queue(), par, h->q_slots.as<ListSlot>(), h->q_llr.as<float>(), h->q_hard.as<uint8_t>(),
+			h->dev, h->cfg.descramble, h->q_lane_mesg.as<uint8_t>());
 	}
-	size_t e8 = mark(h, s);
-	h->spans.push_back({ OFDMRX_T_FINISH, e7, e8 });
-	h->spans.push_back({ OFDMRX_T_TOTAL, t_begin, e8 });
+	size_t e9 = mark(h, s_fin);
+	h->spans.push_back({ OFDMRX_T_FINISH, e8, e9 });
+	h->spans.push_back({ OFDMRX_T_TOTAL, t_begin, e9 });
 	HIP_OK(hipGetLastError());
 	return 0;
-}
-static int run_polar_finish(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, uint8_t *d_payload, Result *d_res,
-	bool want_lane_mesg, size_t t_begin, size_t *ev_polar)
-{
-	int r = run_polar(h, s, par, sti, n, grid, nullptr, ev_polar);
-	return r ? r : run_finish(h, s, par, sti, n, d_payload, d_res, want_lane_mesg, t_begin);
-}
-
-static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int sti, int n, int grid, uint8_t *d_payload, Result *d_res,
-	bool want_lane_mesg, size_t t_begin, float *d_esn0 = nullptr)
-{
-	int r = run_llr(h, s, par, sti, n, d_res, d_esn0, d_payload);
-	return r ? r : run_polar_finish(h, s, par, sti, n, grid, d_payload, d_res, want_lane_mesg, t_begin, nullptr);
 }
 
 static int check_args(ofdmrx_handle *h, const void *samples, int fmt, int channels, size_t spf, size_t stride,
@@ -656,12 +574,7 @@ static int max_skip_of(const int32_t *skip, size_t n)
 	return m;
 }
 
-// How a call's frames are cut into pipeline stages: the handle's chunk, uniformly; a batch that fits one chunk runs every
-// kernel back to back on the handle's stream.  OFDMRX_SPLIT_SMALL=1 cuts such a batch (>= 2048 frames) in two halves so
-// that the two-stream overlap engages - the round-1 verdict asked for that (8192 frames per GPU when 65536 are sharded
-// over 8), but it measures SLOWER than the plain sequence: 8192 frames in one call 132.6 k frames/s back to back, 129.4 k
-// as 4096 + 4096, 123.7 k as 3328 + 4864 (one whole round of the resident polar grid, then the rest): with two chunks
-// the pipeline is all fill and drain, and each polar launch pays its own ragged tail.  So it is off by default.
+// How a call's frames are cut into pipeline stages: the handle's chunk, uniformly
 struct ChunkPlan {
 	std::vector<size_t> start;                                // n_chunks + 1 frame indices
 	size_t count() const { return start.size() - 1; }
@@ -678,22 +591,7 @@ struct ChunkPlan {
 static ChunkPlan plan_chunks(const ofdmrx_handle *h, size_t n_frames)
 {
 	ChunkPlan p;
-	const size_t chunk = (size_t)h->chunk;
-	const bool split_small = std::getenv("OFDMRX_SPLIT_SMALL") != nullptr;
-	if (split_small && n_frames <= chunk && n_frames >= 2048 && !std::getenv("OFDMRX_NO_OVERLAP")) {
-		p.start = { 0, ((n_frames + 1) / 2 + 63) & ~(size_t)63, n_frames };
-		return p;
-	}
-	// a short first chunk shortens the pipeline's fill (its sync / header / demod / Theil-Sen run with no polar stage beside them)
-	size_t first = chunk;
-	if (const char *e = std::getenv("OFDMRX_FIRST_CHUNK"))
-		first = std::min(chunk, std::max<size_t>(64, (size_t)std::atol(e)));
-	size_t f = 0;
-	if (n_frames > chunk && first < chunk) {
-		p.start.push_back(0);
-		f = first;
-	}
-	for (; f < n_frames; f += chunk)
+	for (size_t f = 0; f < n_frames; f += (size_t)h->chunk)
 		p.start.push_back(f);
 	p.start.push_back(n_frames);
 	return p;
@@ -701,210 +599,96 @@ static ChunkPlan plan_chunks(const ofdmrx_handle *h, size_t n_frames)
 
 // The chunk pipeline behind both entry points.  Chunk c's samples are at src(c) on the device when front1(c) runs
 // (`ready` = event to wait for, or -1) and its payloads / results go to dst(c) (device buffers).
-//   A (the handle's stream):  front1(c)  sync | header+OSD | demod
-//   B (second stream):                 back(c-1)  polar | finish      beside
-//   A:                                 front2(c)  Theil-Sen | LLRs
-// after_front1(c) / after_back(c) let the host-pointer entry hang its copies on the same events.
+// after_front1(c) / after_flush(c) let the host-pointer entry hang its copies on the same queues.
 struct PipeHooks {
 	virtual ~PipeHooks() {}
 	virtual int before_front1(size_t c, FrameBatch *fb, size_t *ready) = 0;   // fill fb.samples; ready = event index or -1
 	virtual void dst(size_t c, uint8_t **payload, Result **res) = 0;
 	virtual float *esn0(size_t) { return nullptr; }       // device destination of chunk c's per-row Es/N0 values (decode.cc:517-519), or null
+	virtual void attempts(size_t, Attempt **log, int32_t **counts) { *log = nullptr; *counts = nullptr; }   // ... of its attempt log
 	virtual int after_front1(size_t, size_t /*event*/) { return 0; }
-	virtual int after_back(size_t, size_t /*event*/, hipStream_t /*stream the back half ran on*/) { return 0; }
+	virtual int after_flush(size_t, hipStream_t /*the stream k_finish ran on*/) { return 0; }
+	virtual bool outputs_leave_by_chunk() { return false; }   // every flush takes everything: chunk c is complete behind flush(c)
 };
 
+// Three queues, each chunk passes through all of them:
+//   A (the handle's stream):  sync | header+OSD | demod | Theil-Sen | k_back    of chunk c, chunk after chunk
+//   B:                        flush(c - 1) = plan | k_polar                     the list decoder, for what the queue holds
+//   C:                        k_finish of flush(c - 1) (+ the host entry's output copies)
+// * A kernel launched beside the resident list decoders makes no progress until they drain, so the scan - the
+//   first kernel of a chunk - gets a slot of its own: sync(c) waits for polar(c - 2) to end and polar(c - 1) waits for sync(c).
+//   Everything else on A runs beside polar(c - 1).
+// * A flush takes nothing until one full residency of the list decoder waits in the queue, and then whole residencies; the
+//   last flush of a call takes everything (so does every flush of a call whose outputs leave chunk by chunk).  At noise levels
+//   where the certificate leaves a few frames per chunk the list decoder therefore runs once per several chunks, full.
+// * k_back(c) waits for flush(c - 2) to have ended, copies included: that bounds the queue (ensure_capacity) and frees the host
+//   entry's output staging of that parity.
+// A call of one chunk (and OFDMRX_NO_OVERLAP=1, the profiler's setting: every kernel alone on the machine) runs all of it on A.
 static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &plan, int fmt, int channels, size_t spf, size_t stride,
 	const int32_t *d_skip, int max_skip)
 {
-	const size_t n_chunks = plan.count(), chunk_max = plan.largest();
+	const size_t n_chunks = plan.count(), NONE = (size_t)-1;
 	int r = ensure_events(h, h->ev_used + n_chunks * events_per_chunk(max_skip) + 8);
+	r = r ? r : ensure_capacity(h, (int)plan.largest(), channels == 1, (long)spf);
 	if (r)
 		return r;
-	auto n_of = [&](size_t c) { return (int)plan.size(c); };
-	if (n_chunks == 1 || !h->stream_b || std::getenv("OFDMRX_NO_OVERLAP")) {
-		r = ensure_capacity(h, (int)chunk_max, channels == 1, (long)spf);
-		for (size_t c = 0; c < n_chunks && !r; ++c) {
-			FrameBatch fb{ nullptr, stride, (long)spf, fmt, channels };
-			size_t ready = (size_t)-1, t0 = 0;
-			uint8_t *pay;
-			Result *res;
-			r = hooks.before_front1(c, &fb, &ready);
-			if (r)
-				break;
-			if (ready != (size_t)-1)
-				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ready], 0));
-			hooks.dst(c, &pay, &res);
-			r = run_front1(h, h->stream, 0, 0, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0);
-			r = r ? r : hooks.after_front1(c, mark(h, h->stream));
-			r = r ? r : run_front2(h, h->stream, 0, 0, n_of(c), res);
-			r = r ? r : run_back(h, h->stream, 0, 0, n_of(c), h->polar_grid, pay, res, true, t0, hooks.esn0(c));
-			r = r ? r : hooks.after_back(c, mark(h, h->stream), h->stream);
-		}
-		return r;
-	}
-	r = ensure_capacity(h, (int)chunk_max, channels == 1, (long)spf, true);
-	if (r)
-		return r;
-	const size_t NONE = (size_t)-1;
-	static const bool sched_r2 = std::getenv("OFDMRX_SCHED_R2") != nullptr;   // the two-stream schedule of round 2 (below), for A/B runs
-	if (!sched_r2 && h->stream_f[0]) {
-		// Three queues, each chunk passes through all of them (round 3: since the Theil-Sen stage went from 15 ms to 3 ms per
-		// chunk the list decoder IS the period, so its stream should wait for nothing but its own input):
-		//   A (the handle's stream):  sync | header+OSD | demod | Theil-Sen | LLRs   of chunk c
-		//   B:                        polar(c - 1), back to back
-		//   C:                        finish(c - 2)
-		// Header, demodulator, Theil-Sen and LLR kernels run beside the resident decoders at 1.1-1.6x their time alone.  The
-		// scan does not: its 20 KB of LDS fit once per CU beside sixteen decoders and the lone wave starves (30 ms instead of
-		// 0.85).  So sync(c) gets a slot of its own: it waits for polar(c-2) to end and polar(c-1) waits for it
-		// (OFDMRX_SYNC_SHARED=1 drops both waits).
-		// Buffers: llr / cons / slope / yint / precision / hard by parity c & 1, SyncState by c mod 3.  LLRs(c) overwrite what
-		// polar(c-2) and finish(c-2) read; init_sync(c) overwrites what finish(c-3) read.
-		static const int excl = std::getenv("OFDMRX_EXCL") ? std::atoi(std::getenv("OFDMRX_EXCL")) : 1;   // 0 none, 1 sync, 2 + header, 3 + demod
-		static const bool sync_shared = excl == 0;
-		hipStream_t sa = h->stream, sb = h->stream_b, sc = h->stream_f[0];
-		std::vector<size_t> ev_done(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_llr(n_chunks, NONE), t0s(n_chunks, 0);
-		auto enqueue_polar = [&](size_t p, size_t ev_sync_next) -> int {   // polar(p) on B, finish(p) on C
-			const int par = (int)(p & 1), sti = (int)(p % 3);
-			uint8_t *pay;
-			Result *res;
-			hooks.dst(p, &pay, &res);
-			HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_llr[p]], 0));
+	const bool overlap = n_chunks > 1 && !std::getenv("OFDMRX_NO_OVERLAP");
+	hipStream_t sa = h->stream, sb = overlap ? h->stream_b : sa, sc = overlap ? h->stream_fin : sa;
+	const bool every = hooks.outputs_leave_by_chunk();
+	std::vector<size_t> ev_back(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_fin(n_chunks, NONE), t0s(n_chunks, 0);
+	launch_queue_reset(sa, h->queue(), h->q_cap);
+	auto flush = [&](size_t p, size_t ev_sync_next) -> int {
+		const int par = (int)(p & 1);
+		if (overlap) {
+			HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_back[p]], 0));
 			if (ev_sync_next != NONE)
 				HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_sync_next], 0));
 			if (p >= 2)
-				HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_done[p - 2]], 0));   // hard[par] is free
-			int rr = run_polar(h, sb, par, sti, n_of(p), h->polar_grid, nullptr, &ev_polar[p]);
-			if (rr)
-				return rr;
-			HIP_OK(hipStreamWaitEvent(sc, h->ev_pool[ev_polar[p]], 0));
-			rr = run_finish(h, sc, par, sti, n_of(p), pay, res, true, t0s[p]);
-			if (rr)
-				return rr;
-			ev_done[p] = mark(h, sc);
-			return hooks.after_back(p, ev_done[p], sc);
-		};
-		for (size_t c = 0; c < n_chunks; ++c) {
-			const int par = (int)(c & 1), sti = (int)(c % 3);
-			FrameBatch fb{ nullptr, stride, (long)spf, fmt, channels };
-			size_t ready = NONE, ev_sync = NONE;
-			uint8_t *pay;
-			Result *res;
-			r = hooks.before_front1(c, &fb, &ready);
-			if (r)
-				return r;
-			hooks.dst(c, &pay, &res);
-			if (ready != NONE)
-				HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ready], 0));
-			if (c >= 3)
-				HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_done[c - 3]], 0));
-			r = run_front1(h, sa, par, sti, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0s[c],
-				(c >= 2 && !sync_shared) ? ev_polar[c - 2] : NONE, &ev_sync, excl);
-			if (r)
-				return r;
-			if (c >= 1) {                                         // polar(c-1): its LLRs are on their way, sync(c) is in the queue
-				r = enqueue_polar(c - 1, sync_shared ? NONE : ev_sync);
-				if (r)
-					return r;
-			}
-			r = hooks.after_front1(c, mark(h, sa));
-			r = r ? r : run_front2(h, sa, par, sti, n_of(c), res);
-			if (r)
-				return r;
-			if (c >= 2)
-				HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_done[c - 2]], 0));
-			r = run_llr(h, sa, par, sti, n_of(c), res, hooks.esn0(c), pay);
-			if (r)
-				return r;
-			ev_llr[c] = mark(h, sa);
+				HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_fin[p - 2]], 0));   // k_finish(p - 2) has read the run of this parity
 		}
-		r = enqueue_polar(n_chunks - 1, NONE);
-		if (r)
-			return r;
-		for (size_t c = n_chunks >= 3 ? n_chunks - 3 : 0; c < n_chunks; ++c)   // the caller's stream sees the finished batch
-			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_done[c]], 0));
-		return 0;
-	}
-	std::vector<size_t> ev_back(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_f2(n_chunks, NONE), t0s(n_chunks, 0);
-	// Order of a period (chunk c on stream A, chunk c-1 on stream B):
-	//   A: front1(c) = sync / header / demod, alone on the device
-	//   A: front2(c) = Theil-Sen                      B: back(c-1) = llr, polar, finish
-	// back(c-1) is launched once front1(c) is through, and front1(c+1) waits for back(c-1): the three front kernels are
-	// short and latency-bound, and although each fits on a CU beside the resident polar grid (12 decoders x 96 VGPRs / 8 KB)
-	// they starve there - measured: 134 k frames/s with the whole front inside the polar phase (OFDMRX_FRONT_OVERLAP=1)
-	// against 158 k with this order.  Even the two light HBM-bound kernels of the back half disturb them: llr(c-1) beside
-	// front1(c) (OFDMRX_LLR_EARLY=1) costs sync 1.25 -> 1.9 ms: 154.6 k; front1(c+1) beside finish(c-1)
-	// (OFDMRX_FINISH_LATE=1; SyncState has three buffers, c mod 3, to allow it) is neutral: 158.7 k against 158.5 k.
-	static const bool front_exclusive = std::getenv("OFDMRX_FRONT_OVERLAP") == nullptr;
-	// experiments: the LLR kernel of chunk c-1 beside front1(c) / front1(c+1) not waiting for finish(c-1)
-	static const bool llr_early = std::getenv("OFDMRX_LLR_EARLY") != nullptr, finish_late = std::getenv("OFDMRX_FINISH_LATE") != nullptr;
-	auto enqueue_back = [&](size_t p, size_t ev_f1, bool last) -> int {
+		int rr = run_flush(h, sb, sc, par, every || p + 1 == n_chunks, t0s[p], &ev_polar[p]);
+		rr = rr ? rr : hooks.after_flush(p, sc);
+		ev_fin[p] = mark(h, sc);
+		return rr;
+	};
+	for (size_t c = 0; c < n_chunks && !r; ++c) {
+		const int n = (int)plan.size(c);
+		FrameBatch fb{ nullptr, stride, (long)spf, fmt, channels };
+		size_t ready = NONE, ev_sync = NONE;
 		uint8_t *pay;
 		Result *res;
-		hooks.dst(p, &pay, &res);
-		const int par = (int)(p & 1), sti = (int)(p % 3);
-		HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f2[p]], 0));
-		if (ev_f1 != NONE && !llr_early)
-			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
-		int rr = run_llr(h, h->stream_b, par, sti, n_of(p), res, hooks.esn0(p), pay);
-		if (rr)
-			return rr;
-		if (ev_f1 != NONE && llr_early)
-			HIP_OK(hipStreamWaitEvent(h->stream_b, h->ev_pool[ev_f1], 0));
-		rr = run_polar_finish(h, h->stream_b, par, sti, n_of(p), h->polar_grid, pay, res, true, t0s[p], &ev_polar[p]);
-		if (rr)
-			return rr;
-		ev_back[p] = mark(h, h->stream_b);
-		return hooks.after_back(p, ev_back[p], h->stream_b);
-	};
-	for (size_t c = 0; c <= n_chunks; ++c) {
-		const int par = (int)(c & 1), sti = (int)(c % 3);
-		size_t ev_f1 = NONE;
-		if (c >= 1 && !front_exclusive) {                    // nothing left to share the machine with after the last chunk: all decoders resident
-			r = enqueue_back(c - 1, NONE, c == n_chunks);
-			if (r)
-				return r;
-		}
-		if (c < n_chunks) {
-			FrameBatch fb{ nullptr, stride, (long)spf, fmt, channels };
-			size_t ready = NONE;
-			r = hooks.before_front1(c, &fb, &ready);
-			if (r)
-				return r;
-			if (ready != NONE)
-				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ready], 0));
-			// cons / slope / yint [par] are free once llr(c-2) has read them, st[sti] once finish(c-3) is done: both precede
-			// polar(c-2) on stream B
-			const std::vector<size_t> &gate = (front_exclusive && finish_late) ? ev_polar : ev_back;
-			if (c >= 2 && gate[c - 2] != NONE)
-				HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[gate[c - 2]], 0));
-			r = run_front1(h, h->stream, par, sti, fb, n_of(c), d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0s[c]);
-			if (r)
-				return r;
-			ev_f1 = mark(h, h->stream);
-			r = hooks.after_front1(c, ev_f1);
-			if (r)
-				return r;
-		}
-		if (c >= 1 && front_exclusive) {
-			r = enqueue_back(c - 1, ev_f1, c == n_chunks);
-			if (r)
-				return r;
-		}
-		if (c < n_chunks) {
-			uint8_t *pay;
-			Result *res;
-			hooks.dst(c, &pay, &res);
-			r = run_front2(h, h->stream, par, sti, n_of(c), res);
-			if (r)
-				return r;
-			ev_f2[c] = mark(h, h->stream);
-		}
+		r = hooks.before_front1(c, &fb, &ready);
+		if (r)
+			break;
+		hooks.dst(c, &pay, &res);
+		Attempt *att;
+		int32_t *att_counts;
+		hooks.attempts(c, &att, &att_counts);
+		if (ready != NONE)
+			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ready], 0));
+		if (att && overlap && c >= 2)                             // (host entry: the log's staging of this parity has left with chunk c - 2)
+			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_fin[c - 2]], 0));
+		r = run_front1(h, sa, fb, n, d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0s[c], att, att_counts,
+			(overlap && c >= 2) ? ev_polar[c - 2] : NONE, &ev_sync);
+		if (!r && overlap && c >= 1)                              // flush(c - 1): its LLRs are in the queue, sync(c) is on its way
+			r = flush(c - 1, ev_sync);
+		r = r ? r : hooks.after_front1(c, mark(h, sa));
+		r = r ? r : run_front2(h, sa, n);
+		if (r)
+			break;
+		if (overlap && c >= 2)
+			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_fin[c - 2]], 0));
+		r = run_back(h, sa, (int)(c & 1), n, res, hooks.esn0(c), pay);
+		ev_back[c] = mark(h, sa);
+		if (!r && !overlap)
+			r = flush(c, NONE);
 	}
-	for (size_t c = n_chunks >= 2 ? n_chunks - 2 : 0; c < n_chunks; ++c)   // the caller's stream sees the finished batch
-		if (ev_back[c] != NONE)
-			HIP_OK(hipStreamWaitEvent(h->stream, h->ev_pool[ev_back[c]], 0));
-	return 0;
+	if (!r && overlap) {
+		r = flush(n_chunks - 1, NONE);
+		if (!r)                                                   // the caller's stream sees the finished batch (C is in order)
+			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_fin[n_chunks - 1]], 0));
+	}
+	return r;
 }
 
 static int finish_call(ofdmrx_handle *h, int r)
@@ -936,7 +720,6 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 			return max_skip;
 	}
 	h->ev_used = 0;
-	h->cert_chunks = 0;
 	h->spans.clear();
 	const ChunkPlan plan = plan_chunks(h, n_frames);
 	struct Dev : PipeHooks {
@@ -945,8 +728,17 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 		void dst(size_t c, uint8_t **p, Result **r) override { *p = pay + plan->first(c) * PAYLOAD_BYTES; *r = res + plan->first(c); }
 		float *rows = nullptr;
 		float *esn0(size_t c) override { return rows ? rows + plan->first(c) * ROWS_MAX : nullptr; }
+		Attempt *att = nullptr;
+		int32_t *attc = nullptr;
+		void attempts(size_t c, Attempt **l, int32_t **n) override
+		{
+			*l = att ? att + plan->first(c) * ATTEMPTS_MAX : nullptr;
+			*n = att ? attc + plan->first(c) : nullptr;
+		}
 	} hooks;
 	hooks.rows = h->esn0_user;
+	hooks.att = (Attempt *)h->att_user;
+	hooks.attc = h->att_counts_user;
 	hooks.plan = &plan;
 	hooks.samples = (const char *)d_samples;
 	hooks.stride = stride;
@@ -982,7 +774,6 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 			return max_skip;
 	}
 	h->ev_used = 0;
-	h->cert_chunks = 0;
 	h->spans.clear();
 	const ChunkPlan plan = plan_chunks(h, n_frames);
 	const size_t n_chunks = plan.count(), nc = plan.largest();
@@ -1007,7 +798,18 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 		if (r)
 			return r;
 	}
-	const size_t out_bytes = nc * (PAYLOAD_BYTES + sizeof(Result)) + esn0_bytes;
+	const size_t att_bytes = h->att_user ? nc * ATTEMPTS_MAX * sizeof(Attempt) : 0, attc_bytes = h->att_user ? nc * sizeof(int32_t) : 0;
+	if (att_bytes) {
+		r = h->att_dev.ensure(att_bytes);
+		r = r ? r : h->attc_dev.ensure(attc_bytes);
+		if (!r && n_chunks > 1) {
+			r = h->att_dev2.ensure(att_bytes);
+			r = r ? r : h->attc_dev2.ensure(attc_bytes);
+		}
+		if (r)
+			return r;
+	}
+	const size_t out_bytes = nc * (PAYLOAD_BYTES + sizeof(Result)) + esn0_bytes + att_bytes + attc_bytes;
 	for (int q = 0; q < (n_chunks > 1 ? 2 : 1); ++q)
 		if (h->out_stage_cap[q] < out_bytes) {
 			if (h->out_stage[q])
@@ -1044,7 +846,17 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 			std::memcpy(results + plan->first(c), src + nc * PAYLOAD_BYTES, n_of(c) * sizeof(Result));
 			if (h->esn0_user)
 				std::memcpy(h->esn0_user + plan->first(c) * ROWS_MAX, src + nc * (PAYLOAD_BYTES + sizeof(Result)), n_of(c) * ROWS_MAX * sizeof(float));
+			if (h->att_user) {
+				std::memcpy(h->att_user + plan->first(c) * ATTEMPTS_MAX, src + att_off, n_of(c) * ATTEMPTS_MAX * sizeof(Attempt));
+				std::memcpy(h->att_counts_user + plan->first(c), src + att_off + nc * ATTEMPTS_MAX * sizeof(Attempt), n_of(c) * sizeof(int32_t));
+			}
 			return 0;
+		}
+		size_t att_off = 0;                                // where the attempt log starts in the pinned staging
+		void attempts(size_t c, Attempt **l, int32_t **n) override
+		{
+			*l = h->att_user ? ((c & 1) ? h->att_dev2 : h->att_dev).as<Attempt>() : nullptr;
+			*n = h->att_user ? ((c & 1) ? h->attc_dev2 : h->attc_dev).as<int32_t>() : nullptr;
 		}
 		int before_front1(size_t c, FrameBatch *fb, size_t *ready) override
 		{
@@ -1068,7 +880,8 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 			*r = ((c & 1) ? h->res2 : h->res).as<Result>();
 		}
 		float *esn0(size_t c) override { return h->esn0_user ? ((c & 1) ? h->esn0_dev2 : h->esn0_dev).as<float>() : nullptr; }
-		int after_back(size_t c, size_t, hipStream_t s) override
+		bool outputs_leave_by_chunk() override { return true; }
+		int after_flush(size_t c, hipStream_t s) override
 		{
 			// out_stage[c & 1] still holds chunk c-2 until the host has copied it out
 			while (copied_out + 2 <= c) {
@@ -1084,6 +897,13 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 			HIP_OK(hipMemcpyAsync(d + nc * PAYLOAD_BYTES, rs, n_of(c) * sizeof(Result), hipMemcpyDeviceToHost, s));
 			if (h->esn0_user)
 				HIP_OK(hipMemcpyAsync(d + nc * (PAYLOAD_BYTES + sizeof(Result)), esn0(c), n_of(c) * ROWS_MAX * sizeof(float), hipMemcpyDeviceToHost, s));
+			if (h->att_user) {
+				Attempt *al;
+				int32_t *an;
+				attempts(c, &al, &an);
+				HIP_OK(hipMemcpyAsync(d + att_off, al, n_of(c) * ATTEMPTS_MAX * sizeof(Attempt), hipMemcpyDeviceToHost, s));
+				HIP_OK(hipMemcpyAsync(d + att_off + nc * ATTEMPTS_MAX * sizeof(Attempt), an, n_of(c) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+			}
 			ev_out[c] = mark(h, s);
 			return 0;
 		}
@@ -1096,6 +916,7 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 	hooks.nc = nc;
 	hooks.payload_out = payload_out;
 	hooks.results = results;
+	hooks.att_off = nc * (PAYLOAD_BYTES + sizeof(Result)) + esn0_bytes;
 	hooks.ev_in.assign(n_chunks, (size_t)-1);
 	hooks.ev_f1.assign(n_chunks, (size_t)-1);
 	hooks.ev_out.assign(n_chunks, (size_t)-1);
@@ -1126,26 +947,41 @@ extern "C" int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t)
 	return 0;
 }
 
+// Stage taps of the LAST chunk the handle decoded.  CONS_RAW is the constellation as the demodulator left it (decode.cc:474-475),
+// CONS_ROT what decode.cc:494 makes of it - produced on demand, the pipeline itself never stores it.  LLR / METRIC / LANE_MESG
+// belong to frames that went through the list decoder: a frame without a queue slot (no header; finished by the syndrome
+// certificate - create the handle with OFDMRX_FLAG_KEEP_RAW_CONS or OFDMRX_FLAG_SCL_ALWAYS to list-decode every frame) has
+// none, and the call says so (OFDMRX_E_UNSUPPORTED) instead of returning stale memory; LANE_MESG needs
+// OFDMRX_FLAG_KEEP_RAW_CONS.
 extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *dst, size_t dst_bytes)
 {
 	if (!h || !dst || frame >= (size_t)h->last_n)
 		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	HIP_OK(hipStreamSynchronize(h->stream));
 	const void *src = nullptr;
-	size_t bytes = 0;
 	size_t cap = 0;   // bytes available per frame; the copy is min(dst_bytes, cap)
+	int slot = -1;
+	if (tap == OFDMRX_TAP_LLR || tap == OFDMRX_TAP_METRIC || tap == OFDMRX_TAP_LANE_MESG) {
+		HIP_OK(hipMemcpy(&slot, h->slot_of.as<int>() + frame, sizeof(int), hipMemcpyDeviceToHost));
+		if (slot < 0 || (tap == OFDMRX_TAP_LANE_MESG && !h->q_lane_mesg.p))
+			return OFDMRX_E_UNSUPPORTED;
+	}
 	switch (tap) {
 	case OFDMRX_TAP_HDR_SOFT: src = h->hdr_soft.as<int8_t>() + frame * 256; cap = 255; break;
-	case OFDMRX_TAP_CONS_RAW:   /* D5 rotates in place: the raw copy exists only with cfg.flags & 1 */
-		if (!(h->cfg.flags & 1))
-			return OFDMRX_E_ARG;
-		src = h->cons_raw.as<cf>() + frame * CONS_MAX; cap = CONS_MAX * sizeof(cf); break;
-	case OFDMRX_TAP_CONS_ROT: src = h->cons_of(h->last_par) + frame * CONS_MAX; cap = CONS_MAX * sizeof(cf); break;
-	case OFDMRX_TAP_SLOPE: src = h->slope_of(h->last_par) + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
-	case OFDMRX_TAP_YINT: src = h->yint_of(h->last_par) + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
-	case OFDMRX_TAP_PRECISION: src = h->precision_of(h->last_par) + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
-	case OFDMRX_TAP_LLR: src = h->llr_of(h->last_par) + frame * CODE_LEN; cap = CODE_LEN * 4; break;
-	case OFDMRX_TAP_METRIC: src = h->metric.as<float>() + frame * LIST; cap = LIST * 4; break;
-	case OFDMRX_TAP_LANE_MESG: src = h->lane_mesg.as<uint8_t>() + frame * LIST * MESG_BYTES; cap = LIST * MESG_BYTES; break;
+	case OFDMRX_TAP_CONS_RAW: src = h->cons.as<cf>() + frame * CONS_MAX; cap = CONS_MAX * sizeof(cf); break;
+	case OFDMRX_TAP_CONS_ROT:
+		launch_rotate_tap(h->stream, h->st.as<SyncState>() + frame, h->cons.as<cf>() + frame * CONS_MAX, h->slope.as<float>() + frame * ROWS_MAX,
+			h->yint.as<float>() + frame * ROWS_MAX, h->rot_tap.as<cf>());
+		HIP_OK(hipGetLastError());
+		HIP_OK(hipStreamSynchronize(h->stream));
+		src = h->rot_tap.p; cap = CONS_MAX * sizeof(cf); break;
+	case OFDMRX_TAP_SLOPE: src = h->slope.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
+	case OFDMRX_TAP_YINT: src = h->yint.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
+	case OFDMRX_TAP_PRECISION: src = h->precision.as<float>() + frame * ROWS_MAX; cap = ROWS_MAX * 4; break;
+	case OFDMRX_TAP_LLR: src = h->q_llr.as<float>() + (size_t)slot * CODE_LEN; cap = CODE_LEN * 4; break;
+	case OFDMRX_TAP_METRIC: src = h->q_metric.as<float>() + (size_t)slot * LIST; cap = LIST * 4; break;
+	case OFDMRX_TAP_LANE_MESG: src = h->q_lane_mesg.as<uint8_t>() + (size_t)slot * LIST * MESG_BYTES; cap = LIST * MESG_BYTES; break;
 	case OFDMRX_TAP_ANALYTIC:
 		if (!h->last_mono)
 			return OFDMRX_E_ARG;
@@ -1154,13 +990,19 @@ extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *
 		break;
 	default: return OFDMRX_E_ARG;
 	}
-	bytes = dst_bytes < cap ? dst_bytes : cap;
-	HIP_OK(hipStreamSynchronize(h->stream));
-	HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+	HIP_OK(hipMemcpy(dst, src, dst_bytes < cap ? dst_bytes : cap, hipMemcpyDeviceToHost));
 	return 0;
 }
 
 // ---- single-stage entry points ------------------------------------------------------
+// n mode-6 codewords straight into the list decoder's queue (slot i = codeword i), one forced flush
+static int queue_run_all(ofdmrx_handle *h, int list)
+{
+	launch_queue_plan(h->stream, h->queue(), 0, 1, 1);
+	launch_polar(h->stream, list, std::min(h->polar_grid, h->cap), h->queue(), 0, h->q_slots.as<ListSlot>(), h->q_llr.as<float>(), h->soft.as<float>(),
+		h->q_hard.as<uint8_t>(), h->dev, h->q_metric.as<float>());
+	return 0;
+}
 extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, uint8_t *lane_mesg, float *metric)
 {
 	if (!h || !llr || !n || n > (size_t)h->chunk)
@@ -1169,29 +1011,37 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 	int r = ensure_capacity(h, (int)n, false, 0);
 	if (r)
 		return r;
-	std::vector<SyncState> st(n);
-	std::memset(st.data(), 0, n * sizeof(SyncState));
-	for (auto &s : st) { s.okay = 1; s.oper_mode = 6; }
-	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
-	HIP_OK(hipMemcpy(h->llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
-	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
-	launch_polar(h->stream, h->list, (int)n, h->polar_grid, h->st.as<SyncState>(), h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(),
-		h->work_counter.as<int>());
-	launch_finish(h->stream, h->list, (int)n, h->st.as<SyncState>(), h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, 0,
-		h->lane_mesg.as<uint8_t>(), h->payload.as<uint8_t>(), h->res.as<Result>());
-	HIP_OK(hipGetLastError());
+	DevBuf lm;                                                // the per-lane messages: a buffer of this call's own
+	r = lm.ensure((size_t)h->q_cap * LIST * MESG_BYTES);
+	if (r)
+		return r;
 	HIP_OK(hipStreamSynchronize(h->stream));
-	if (lane_mesg)
-		HIP_OK(hipMemcpy(lane_mesg, h->lane_mesg.p, n * LIST * MESG_BYTES, hipMemcpyDeviceToHost));
-	if (metric)
-		HIP_OK(hipMemcpy(metric, h->metric.p, n * LIST * sizeof(float), hipMemcpyDeviceToHost));
-	h->last_n = (int)n;
+	HIP_OK(hipMemcpy(h->q_llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
+	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
+	launch_queue_reset(h->stream, h->queue(), h->q_cap);
+	launch_queue_fill(h->stream, h->queue(), h->q_slots.as<ListSlot>(), (int)n, h->payload.as<uint8_t>(), h->res.as<Result>(), 6);
+	queue_run_all(h, h->list);
+	launch_finish(h->stream, h->list, (int)n, h->queue(), 0, h->q_slots.as<ListSlot>(), h->q_llr.as<float>(), h->q_hard.as<uint8_t>(), h->dev, 0,
+		lm.as<uint8_t>());
+	hipError_t e = hipGetLastError();
+	e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;
+	if (e == hipSuccess && lane_mesg)
+		e = hipMemcpy(lane_mesg, lm.p, n * LIST * MESG_BYTES, hipMemcpyDeviceToHost);
+	if (e == hipSuccess && metric)
+		e = hipMemcpy(metric, h->q_metric.p, n * LIST * sizeof(float), hipMemcpyDeviceToHost);
+	lm.release();
+	if (e != hipSuccess) {
+		g_last_error = hipGetErrorString(e);
+		return OFDMRX_E_HIP;
+	}
+	h->last_n = 0;
 	return 0;
 }
 
-// D5 output -> payload: rotated constellation rows of mode-6 frames through D6-D10 exactly as the pipeline chains them, with the
-// syndrome certificate (use_cert != 0: k_back, the list decoder only for the frames it leaves) or without (k_llr, the list decoder
-// for every frame); cert_out (nullable) receives the certificate's verdict per frame (1 = finished by it)
+// D5 output -> payload: ROTATED constellation rows of mode-6 frames through D6-D10 exactly as the pipeline chains them (the rows'
+// Theil-Sen lines are set to zero, so k_back's rotation is the identity), with the syndrome certificate (use_cert != 0: tried for
+// every frame, the list decoder only for the frames it leaves) or without (the list decoder for every frame); cert_out
+// (nullable) receives the certificate's verdict per frame (1 = finished by it)
 extern "C" int ofdmrx_debug_decode_cons(ofdmrx_handle *h, const float *cons, size_t n, int use_cert, uint8_t *payload,
 	ofdmrx_frame_result *results, int32_t *cert_out)
 {
@@ -1204,30 +1054,30 @@ extern "C" int ofdmrx_debug_decode_cons(ofdmrx_handle *h, const float *cons, siz
 	std::vector<SyncState> st(n);
 	std::memset(st.data(), 0, n * sizeof(SyncState));
 	for (auto &s : st) { s.okay = 1; s.oper_mode = 6; }
+	HIP_OK(hipStreamSynchronize(h->stream));
 	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy2D(h->cons.p, CONS_MAX * sizeof(cf), cons, 21600 * sizeof(cf), 21600 * sizeof(cf), n, hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
 	HIP_OK(hipMemsetAsync(h->slope.p, 0, n * ROWS_MAX * sizeof(float), h->stream));
 	HIP_OK(hipMemsetAsync(h->yint.p, 0, n * ROWS_MAX * sizeof(float), h->stream));
-	HIP_OK(hipMemsetAsync(h->cert.p, 0, (n + 2) * sizeof(int), h->stream));
-	int *cert = use_cert ? h->cert.as<int>() : nullptr;
-	SyncState *dst = h->st.as<SyncState>();
-	if (cert)
-		launch_back(h->stream, h->rate, (int)n, dst, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
-			h->llr.as<float>(), h->res.as<Result>(), nullptr, h->dev, h->cfg.descramble, h->payload.as<uint8_t>(), cert, nullptr);
-	else
-		launch_llr(h->stream, h->rate, (int)n, dst, h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(), h->precision.as<float>(),
-			h->llr.as<float>(), h->res.as<Result>(), nullptr);
-	launch_polar(h->stream, 8, (int)n, h->polar_grid, dst, h->llr.as<float>(), h->soft.as<float>(), h->hard.as<uint8_t>(), h->dev, h->metric.as<float>(),
-		h->work_counter.as<int>(), cert);
-	launch_finish(h->stream, 8, (int)n, dst, h->llr.as<float>(), h->hard.as<uint8_t>(), h->dev, h->cfg.descramble, nullptr,
-		h->payload.as<uint8_t>(), h->res.as<Result>(), cert);
+	launch_queue_reset(h->stream, h->queue(), h->q_cap);
+	launch_back(h->stream, h->rate, (int)n, use_cert ? 1 : 0, h->st.as<SyncState>(), h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(),
+		h->precision.as<float>(), h->res.as<Result>(), nullptr, h->dev, h->cfg.descramble, h->payload.as<uint8_t>(), h->queue(),
+		h->q_slots.as<ListSlot>(), h->q_llr.as<float>(), h->slot_of.as<int>());
+	launch_queue_snap(h->stream, h->queue(), 0);
+	queue_run_all(h, 8);
+	launch_finish(h->stream, 8, (int)n, h->queue(), 0, h->q_slots.as<ListSlot>(), h->q_llr.as<float>(), h->q_hard.as<uint8_t>(), h->dev,
+		h->cfg.descramble, nullptr);
 	HIP_OK(hipGetLastError());
 	HIP_OK(hipStreamSynchronize(h->stream));
 	HIP_OK(hipMemcpy(payload, h->payload.p, n * PAYLOAD_BYTES, hipMemcpyDeviceToHost));
 	HIP_OK(hipMemcpy(results, h->res.p, n * sizeof(Result), hipMemcpyDeviceToHost));
-	if (cert_out)
-		HIP_OK(hipMemcpy(cert_out, h->cert.p, n * sizeof(int), hipMemcpyDeviceToHost));
+	if (cert_out) {
+		std::vector<int> slot(n);
+		HIP_OK(hipMemcpy(slot.data(), h->slot_of.p, n * sizeof(int), hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < n; ++i)
+			cert_out[i] = slot[i] < 0;
+	}
 	h->last_n = (int)n;
 	return 0;
 }

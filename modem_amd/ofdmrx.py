@@ -20,7 +20,7 @@ STAGES = ["front", "sync", "header", "demod", "theilsen", "llr", "polar", "finis
 # every symbol include/ofdmrx.h declares
 EXPORTS = [
     "ofdmrx_abi_version", "ofdmrx_abi_minor", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
-    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_list_decoded_frames", "ofdmrx_set_esn0_rows",
+    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_list_decoded_frames", "ofdmrx_set_esn0_rows", "ofdmrx_set_attempt_log",
     "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_decode_cons", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
     "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
     "ofdmrx_tx_encode_device", "ofdmrx_stream_samples", "ofdmrx_tx_encode_stream_device", "ofdmrx_tx_encode_stream",
@@ -50,6 +50,10 @@ RESULT_DTYPE = np.dtype([("status", "<i4"), ("symbol_pos", "<i4"), ("sc_start", 
                          ("best_lane", "<i4"), ("bit_flips", "<i4"), ("esn0_db_last", "<f4"),
                          ("n_sync_rejects", "<i4")], align=True)
 assert RESULT_DTYPE.itemsize == C.sizeof(FrameResult)
+# ofdmrx_attempt: one preamble of a frame's SKIP loop (decode.cc:390-448)
+ATTEMPT_DTYPE = np.dtype([("status", "<i4"), ("symbol_pos", "<i4"), ("cfo_rad", "<f4"), ("oper_mode", "<i4"), ("call_sign", "<u8")], align=True)
+assert ATTEMPT_DTYPE.itemsize == 24
+MAX_SKIP = 64
 
 
 class Channel(C.Structure):
@@ -108,6 +112,7 @@ def load_library():
     L.ofdmrx_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ofdmrx_chunk_frames.argtypes = [C.c_void_p]
     L.ofdmrx_set_esn0_rows.argtypes = [C.c_void_p, C.c_void_p]
+    L.ofdmrx_set_attempt_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ofdmrx_list_decoded_frames.argtypes = [C.c_void_p]
     L.ofdmrx_list_decoded_frames.restype = C.c_longlong
     L.ofdmrx_debug_dump.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -187,7 +192,8 @@ class Receiver:
     def _fmt(dtype):
         return {np.dtype(np.int16): FMT_S16, np.dtype(np.uint8): FMT_U8, np.dtype(np.float32): FMT_F32}[np.dtype(dtype)]
 
-    def decode(self, pcm, skip=None, esn0_rows=False):
+    def decode(self, pcm, skip=None, esn0_rows=False, attempts=False):
+        """-> (payload, results[, esn0 rows][, (attempt log [n, 65], counts [n])])"""
         pcm = np.ascontiguousarray(pcm)
         if pcm.ndim == 2:
             pcm = pcm[None]
@@ -205,13 +211,19 @@ class Receiver:
         rows = np.zeros((n, 126), np.float32) if esn0_rows else None
         if esn0_rows:
             self._check(self._lib.ofdmrx_set_esn0_rows(self._h, _ptr(rows)))
+        if attempts:
+            alog, acnt = np.zeros((n, MAX_SKIP + 1), ATTEMPT_DTYPE), np.zeros(n, np.int32)
+            self._check(self._lib.ofdmrx_set_attempt_log(self._h, _ptr(alog), _ptr(acnt)))
         try:
             self._check(self._lib.ofdmrx_decode_batch(self._h, _ptr(buf), self._fmt(pcm.dtype), ch, spf, stride, n,
                                                       _ptr(sk) if sk is not None else None, _ptr(out), _ptr(res)))
         finally:
             if esn0_rows:
                 self._lib.ofdmrx_set_esn0_rows(self._h, None)
-        return (out, res, rows) if esn0_rows else (out, res)
+            if attempts:
+                self._lib.ofdmrx_set_attempt_log(self._h, None, None)
+        ret = (out, res) + ((rows,) if esn0_rows else ()) + (((alog, acnt),) if attempts else ())
+        return ret
 
     def set_esn0_rows(self, d_rows):
         """device pointer (int) to n x 126 floats for the decode_device calls that follow, or None"""

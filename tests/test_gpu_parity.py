@@ -1096,50 +1096,6 @@ def test_host_pointer_entry_runs_the_chunk_pipeline():
     assert (o == o5[1]).all() and rr.sc_start == int(r5["sc_start"][1])
 
 
-def test_one_chunk_batches_can_be_split_for_the_pipeline():
-    """OFDMRX_SPLIT_SMALL=1: a batch that fits one chunk (>= 2048 frames) is cut in two so that the two-stream overlap
-    engages.  Results must not depend on it: 2200 frames as 1152 + 1048 equal the same frames decoded as one chunk.
-    (Off by default: it measures slower than the plain sequence)"""
-    import os
-    import torch
-    import modem_amd
-    import modem_amd.ofdmrx as M
-    dev = torch.device("cuda:0")
-    n = 2200
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-        rx = modem_amd.Receiver(device=0, stream=stream.cuda_stream)
-        spf = rx.tx_frame_samples(6)
-        g = torch.Generator(device=dev)
-        g.manual_seed(5)
-        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
-        d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
-        rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
-        rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, -16.0, 3, 0)
-        res = []
-        for chunk in (0, 4096):
-            r2 = rx if chunk == 0 else modem_amd.Receiver(device=0, stream=stream.cuda_stream, chunk_frames=chunk)
-            d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
-            d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-            os.environ["OFDMRX_NO_OVERLAP" if chunk else "OFDMRX_SPLIT_SMALL"] = "1"
-            try:
-                r2.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
-                r2.synchronize()
-            finally:
-                os.environ.pop("OFDMRX_NO_OVERLAP", None)
-                os.environ.pop("OFDMRX_SPLIT_SMALL", None)
-            launches = r2.timing()["polar"][1]
-            res.append((d_out.cpu().numpy(), d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1), launches))
-            if chunk:
-                r2.close()
-        rx.close()
-    (oa, ra, la), (ob, rb, lb) = res
-    assert la == 2 and lb == 1, (la, lb)
-    assert (oa == ob).all() and (oa == d_pay.cpu().numpy()).all()
-    for name in ra.dtype.names:
-        assert ((ra[name] == rb[name]) | ((ra[name] != ra[name]) & (rb[name] != rb[name]))).all(), name
-
-
 def test_argument_errors_are_reported():
     """SKIP counts outside 0..64 and channel delays outside the frame are argument errors, never silent clamps"""
     import torch

@@ -1,3 +1,9 @@
+// VARIANT of modem_amd/csrc/k_polar.hip (round 4, measured and not adopted): level 9 of the tree in 64 VGPRs instead of the HBM
+// level store - 3 waves per SIMD = 12 resident decoders per CU (run it with OFDMRX_POLAR_WPC=12).  It removes 4 MiB of level-store
+// traffic per codeword and decodes bit-identically, but 12 decoders per CU are slower than 16 whatever they move: list decoder
+// forced, 65536 frames, -30 / -20 dB: 331 / 378 ms per step against 305 / 327 for the 16-decoder kernel, and exactly the time of the
+// 16-decoder kernel held to 12 (profiles/r04_polar_level9_and_recompute_experiments.txt).  Build:
+//   SRC_k_polar=tools/experiments/variants/k_polar_level9_in_registers.hip tools/build_variant.sh l9 ""
 // k_polar.hip -- D9 (polar successive-cancellation list decoder, N = 65536, L = 8) for gfx950;
 // D10 lives in k_finish.hip.
 //
@@ -6,9 +12,10 @@
 // reference's SIMD lane), j = one of 8 butterflies processed per wave instruction.
 //   f(a,b)   = sign(a) sign(b) min(|a|,|b|)              left child LLRs
 //   g(a,b,u) = u ? b - a : a + b                          right child LLRs
-// Tree levels 9..15 live in HBM as soft[level m][i][k] (fp32, 2 MiB per resident decoder, the
-// reference's own soft[N+i] layout); level 8 - the array of the current 256-leaf node - in LDS
-// (8 KB per decoder); levels 4..7 in registers as the arrays of the current node of each level;
+// Tree levels 10..15 live in HBM as soft[level m][i][k] (fp32, 2 MiB per resident decoder, the
+// reference's own soft[N+i] layout); level 9 - the array of the current 512-leaf node - in 64 VGPRs
+// (round 4); level 8 - the array of the current 256-leaf node - in LDS (8 KB per decoder); levels 4..7
+// in registers as the arrays of the current node of each level;
 // level 16 is the shared channel LLR vector; levels 3..0 (8-leaf sub-trees) never leave
 // registers either: their butterflies are DPP / permlane exchanges ("Where the tree lives" below).
 // Lane permutations after a fork are applied lazily exactly like the reference's vshuf at
@@ -100,8 +107,15 @@ struct Maps {
 	}
 };
 
-// Where the tree lives (v11):
-//   levels 9..15  HBM level store, soft[level m][i][k] (fp32, the reference's own soft[N+i] layout)
+// Where the tree lives (round 4):
+//   levels 10..15 HBM level store, soft[level m][i][k] (fp32, the reference's own soft[N+i] layout)
+//   level  9      registers: r9a[32], r9b[32] = the array of the CURRENT 512-leaf node; position i = x*8 + j is element x
+//                 of lane (j, k), in r9a for x < 32 and in r9b[x - 32] above - so r9a[x] and r9b[x] are the two inputs of
+//                 the level-8 butterfly x.  The last pass of a descent leaves it in LDS half by half and an unrolled copy
+//                 takes it into the registers (every index a compile-time constant: 64 scalars for the register allocator);
+//                 the g step of the right child reads it 256 leaves later.  Neither the array (2 MiB written + 2 MiB read per
+//                 codeword) nor the left child's partial-sum bytes (they are still in HR) touch memory.  64 more VGPRs = 3
+//                 waves per SIMD = 12 resident decoders per CU
 //   level  8      LDS, 8 KB per decoder: the array of the current 256-leaf node, [x][lane]
 //   levels 4..7   registers: r7[16], r6[8], r5[4], r4[2] = the arrays of the CURRENT node of each level.  Position
 //                 i = x*8 + j of a level-L array is element x of lane (j, k), and the partner of x at level L+1 is
@@ -118,8 +132,10 @@ struct Maps {
 // levels are produced in registers and each level is written exactly once, never re-read.
 //   KIND 0: first step f from level m+1      KIND 1: first step g (partial sums hb, lane map gl)
 //   KIND 2: first step f from the shared channel LLRs   KIND 3: first step g from the shared channel LLRs
-// The NG highest produced levels are in global memory (gs = base of the codeword's soft array), a lower one can only
-// be level 8, in LDS (ls8).  Level L starts at element 8 << L of the level store.
+// The NG highest produced levels (all >= 10) go to global memory; a pass either ends there (D == NG) or on level 9
+// (D == NG + 1: the shapes (11,10,9), (10,9) and (9)), which is on its way into registers: such a pass covers HALF of the
+// level-9 array, local indices xlo .. xlo + 31, and leaves it in LDS (stage[(x - xlo) * 64 + lane], 8 KB) for the caller's
+// unrolled copy into r9a / r9b - a rolled loop cannot address registers.  Level L starts at element 8 << L of the level store.
 // Global accesses are raw buffer loads / stores: one per-lane byte offset in a VGPR (lane * 4, or the mapped
 // lane for the g step), everything else (level base, column, partner distance) in the scalar offset - so 16
 // loads in flight cost 16 data registers and no 64-bit address pairs.
@@ -134,8 +150,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int bytes)
                             // decoders per CU, ms per 65536 codewords: none 316, >= 13 312, >= 12 304, >= 11 300, >= 10 290, all 317
 #endif
 #ifndef POLAR_WAVES_PER_SIMD
-#define POLAR_WAVES_PER_SIMD 5     // register budget: 5 waves per SIMD = 96 VGPRs (13 dwords of scratch) so that Theil-Sen workgroups of the next
-                                   // chunk fit beside 12 resident decoders per CU; 1 = unconstrained (125 VGPRs): 2 % faster alone, 12 % slower overlapped
+#define POLAR_WAVES_PER_SIMD 3     // register budget: 3 waves per SIMD = 168 VGPRs = 12 resident decoders per CU (64 of them hold level 9)
 #endif
 template <int AUX = 0> __device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX)); }
 template <int AUX = 0> __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX); }
@@ -168,10 +183,12 @@ struct PolarBufs {
 // the sign bits of all eight paths as the node's partial-sum bytes (bit k = path k) straight to the byte array.  If
 // the test fails the caller runs the ordinary pass and walks the node; the bytes are overwritten then.
 template <int D, int KIND, int NG, bool SRC_C = false, bool DST_C = false, bool SKIP0 = false, int SRC_R = 0, bool TERM = false>
-__device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int hb_g_off, int m, int lane, int gl,
+__device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *stage, int xlo, int hb_g_off, int m, int lane, int gl,
 	uint32_t *mu_out = nullptr, uint8_t *hard_t = nullptr)
 {
 	static_assert(!TERM || (D == 1 && NG == 0), "terminal passes produce one level");
+	static_assert(TERM || D == NG || D == NG + 1, "a pass ends in the level store or on level 9");
+	constexpr bool ONCHIP = !TERM && D == NG + 1;
 	uint32_t mu = 0x7f800000u;
 	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
 #ifndef POLAR_XB3
@@ -185,6 +202,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 #endif
 	constexpr int XB = SRC_R ? (D == 3 ? 1 : (D == 2 ? 2 : 4)) : (D == 3 ? POLAR_XB3 : (D == 2 ? POLAR_XB2 : POLAR_XB1));   // columns batched: XB * 2 * NT loads in flight
 	const int S = 1 << (m - D + 1 - 3);       // local indices at the lowest produced level
+	const int x_begin = ONCHIP ? xlo : 0, x_end = ONCHIP ? xlo + 32 : S;
 	const int half = 1 << (m - 3);            // partner distance (local) at level m+1
 	const int j = lane >> 3, k = lane & 7;
 	const int src_off = (8 << (m + 1)) * 4;   // byte offset of level m+1 in the level store
@@ -211,15 +229,18 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 	else if (SRC_C || SRC_R == 1)
 		v_src += pb.half_sel << ((SRC_R ? m + 2 : m + 1) + 2);   // its compact array sits behind the first one's (2^level floats)
 	const int anc = gl & 7;
+	v_src += x_begin * XS;
+	v_dst += x_begin * (DST_C ? 32 : 256);
+	v_h += x_begin * 8;
 	#pragma unroll 1
-	for (int x0 = 0; x0 < S; x0 += XB, v_src += XB * XS, v_dst += XB * (DST_C ? 32 : 256), v_h += XB * 8) {
+	for (int x0 = x_begin; x0 < x_end; x0 += XB, v_src += XB * XS, v_dst += XB * (DST_C ? 32 : 256), v_h += XB * 8) {
 		float a[XB][NT], b[XB][NT];
 		int h[XB][NT];
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
 			#pragma unroll
 			for (int s2 = 0; s2 < NT; ++s2)
-				if (x0 + xb < S) {
+				if (x0 + xb < x_end) {
 					if (SRC_R) {
 						const float a1 = bload(C, v_src + xb * XS, so_a[s2]), a2 = bload(C, v_src + xb * XS, so_a[s2] + 2 * hx);
 						const float b1 = bload(C, v_src + xb * XS, so_a[s2] + hx), b2 = bload(C, v_src + xb * XS, so_a[s2] + 3 * hx);
@@ -242,7 +263,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 		unsigned long long mine = 0;
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
-			if (x0 + xb < S) {
+			if (x0 + xb < x_end) {
 				float v[NT];
 				#pragma unroll
 				for (int s2 = 0; s2 < NT; ++s2) {
@@ -252,11 +273,13 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 						const unsigned long long bal = __ballot(v[s2] < 0.f);
 						if (lane == xb)
 							mine = bal;
+					} else if (NG == 0) {                             // (9): on its way into registers
+						stage[(x0 + xb - xlo) * 64 + lane] = v[s2];
 					} else if (SKIP0) {
-					} else if (NG > 0) {
+					} else {
 						if (!DST_C) { if (m >= POLAR_NT_LEVEL) bstore<2>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]); else bstore<0>(pb.soft, v_dst + xb * 256, so_d[0][s2], v[s2]); }
 						else if ((k & pb.kmask) == 0) bstore(pb.soft, v_dst + xb * 32 + (pb.half_sel << (m + 2)), so_d[0][s2], v[s2]);
-					} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
+					}
 				}
 				#pragma unroll
 				for (int d = 1; d < D; ++d) {
@@ -267,7 +290,7 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 						if (NG > d) {
 							if (!DST_C) { if (m - d >= POLAR_NT_LEVEL) bstore<2>(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]); else bstore<0>(pb.soft, v_dst + xb * 256, so_d[d][s2], v[s2]); }
 							else if ((k & pb.kmask) == 0) bstore(pb.soft, v_dst + xb * 32 + (pb.half_sel << (m - d + 2)), so_d[d][s2], v[s2]);
-						} else ls8[(x0 + xb + s2 * S) * 64 + lane] = v[s2];
+						} else stage[(x0 + xb - xlo) * 64 + lane] = v[s2];   // level 9 (d == NG: s2 == 0)
 					}
 				}
 			}
@@ -495,6 +518,11 @@ template <int LN> struct Block8 {
 // workgroup barrier.  WAVE_ORDER only stops the compiler from moving memory operations across the point; a real
 // barrier would also drain every outstanding store (s_waitcnt vmcnt(0)) after each tree pass.
 #define WAVE_ORDER() __builtin_amdgcn_wave_barrier()
+// The level-9 registers are rewritten completely before they are read again, but in two halves inside a loop, which the
+// compiler's liveness analysis cannot see: without this it keeps the old array alive across the passes.
+#define R9_DEAD_16(a, o) asm volatile("" : "=v"(a[o]), "=v"(a[o + 1]), "=v"(a[o + 2]), "=v"(a[o + 3]), "=v"(a[o + 4]), "=v"(a[o + 5]), "=v"(a[o + 6]), "=v"(a[o + 7]), \
+	"=v"(a[o + 8]), "=v"(a[o + 9]), "=v"(a[o + 10]), "=v"(a[o + 11]), "=v"(a[o + 12]), "=v"(a[o + 13]), "=v"(a[o + 14]), "=v"(a[o + 15]))
+#define R9_DEAD() do { R9_DEAD_16(r9a, 0); R9_DEAD_16(r9a, 16); R9_DEAD_16(r9b, 0); R9_DEAD_16(r9b, 16); } while (0)
 
 // -DPOLAR_PROF: shader-clock cycles per phase of the decoder loop, summed over all codewords (debug builds only;
 // printed by launch_polar).  0 passes with a global source, 1 LDS passes, 2 node decisions, 3 the 8-leaf walk,
@@ -532,7 +560,8 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 	const int wave_in_block = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 	const int decoder = (int)blockIdx.x * POLAR_WPB + wave_in_block;
 	__shared__ float ls8_all[POLAR_WPB][32 * 64];              // level 8 of the current 256-leaf node: [x][lane], one per decoder
-	float *ls8 = ls8_all[wave_in_block];
+	__shared__ float ls7_all[POLAR_WPB][16 * 64];              // level 7 of the current 128-leaf node, parked between its f and g steps
+	float *ls8 = ls8_all[wave_in_block], *ls7 = ls7_all[wave_in_block];
 	// The work: the entries run_head .. run_head + run_n - 1 of the list decoder's queue (kernels.h: ListQueue; k_queue_plan
 	// decided the run - nothing at all while too few frames wait), entry e in slot e % cap.  Persistent decoders take units
 	// from a shared counter: a fixed stride would leave the fast decoders idle in the last round.
@@ -586,6 +615,8 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 	Maps A;
 	A.w0 = ID0 * (uint32_t)k;
 	A.w1 = ID1 * (uint32_t)k;
+	float r9a[32], r9b[32];                                   // level 9 of the current 512-leaf node ("Where the tree lives")
+	uint32_t HRprev = 0;                                      // partial sums of the 256-leaf node just decoded, own path
 	PROF_DECL();
 
 	// rate-1 test of a uniform node (the predicate of Block8::list_is_stable): mu = this lane's smallest |LLR| of the node
@@ -681,14 +712,30 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 		const int LtT = t ? __builtin_amdgcn_readfirstlane(nlv) >> 4 : 0;
 		int Ln = 0;
 		PROF(6);
-		// ---------------- level 8 of this 256-leaf node into LDS, through the level store
-		{
+		// ---------------- level 8 of this 256-leaf node into LDS: from the level store (and level 9 into registers on the
+		// way), or - the right child of a 512-leaf node - from the level-9 registers
+		if (t != 0 && (t256 & 1)) {
+			// g at level 8: both inputs are r9a[x], r9b[x] of the lane the path descends from (lane map since the 512-leaf node
+			// started), the left child's partial sums are still in HRprev (bit x = position x * 8 + j, own path)
+			const int glb = (j << 3) | A.get(9);
+			if (__ballot(glb != lane)) {
+				#pragma unroll
+				for (int x = 0; x < 32; ++x)
+					ls8[x * 64 + lane] = g_add(__shfl(r9a[x], glb), __shfl(r9b[x], glb), (HRprev >> x) & 1);
+			} else {
+				#pragma unroll
+				for (int x = 0; x < 32; ++x)
+					ls8[x * 64 + lane] = g_add(r9a[x], r9b[x], (HRprev >> x) & 1);
+			}
+			WAVE_ORDER();
+			PROF(1);
+		} else {
 			int cur, kind;                                    // next level to produce and how its first step works
 			int ho_g = 0, gl = lane;
 			if (t == 0) {
 				cur = 15; kind = 2;
 			} else {
-				const int z = __builtin_ctz(t);               // right child of the level-(z+1) node starts here
+				const int z = __builtin_ctz(t);               // right child of the level-(z+1) node starts here (z >= 9)
 				gl = (j << 3) | A.get(z + 1);
 				ho_g = t - (1 << z);                          // left child's partial sums (published bytes)
 				cur = z; kind = z == 15 ? 3 : 1;
@@ -696,45 +743,84 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 			bool try_big = LtT >= 9;
 			int stop = try_big ? LtT + 1 : 8;
 			for (;;) {
-				while (cur >= stop) {
-					// produced levels stay >= 8: three per pass down to 10, then (9, 8) and (8); NG = how many are above level 8
-					const int D = cur >= 10 ? 3 : (cur == 9 ? 2 : 1);
+				#define FP(...) fused_pass<__VA_ARGS__>(pb, ls8, 0, ho_g, cur, lane, gl)
+				// Passes that end in the level store: three levels each while the next one to produce is >= 12.  The first pass of a
+				// right sibling on the left spine (t = 2^cur: its source was stored compact at t = 0, its own top level is not
+				// stored - the one later reader recomputes it) and of that sibling's right child (t = 3 * 2^cur: recomputed source,
+				// SRC_R) takes (11, 10) this way too - once per codeword each.
+				for (;;) {
 					const bool spine = kind == 1 && (t & (t - 1)) == 0 && cur <= 14;
-					#define FP(...) fused_pass<__VA_ARGS__>(pb, ls8, ho_g, cur, lane, gl)
+					const bool srcr = kind == 1 && (t >> cur) == 3 && cur <= 14;
+					if (cur < stop || !(cur >= 12 || (cur == 11 && (spine || srcr))))
+						break;
 					if (t == 0) {                                     // first left descent: compact stores
 						if (cur == 15) FP(3, 2, 3, false, true);      // levels 15, 14, 13
-						else if (cur == 12) FP(3, 0, 3, true, true);  // 12, 11, 10
-						else FP(2, 0, 1, true, true);                 // 9 and 8 (LDS)
+						else FP(3, 0, 3, true, true);                 // 12, 11, 10
 					} else if (spine) {
-						// right sibling on the left spine: its source was stored compact at t = 0; its own top level
-						// (if >= 9) is not stored, the one later reader recomputes it (SRC_R below)
-						if (cur >= 11) FP(3, 1, 3, true, false, true);
-						else if (cur == 10) FP(3, 1, 2, true, false, true);
-						else if (cur == 9) FP(2, 1, 1, true, false, true);
-						else FP(1, 1, 0, true);
-					} else if (kind == 1 && (t >> cur) == 3 && cur <= 14) {
-						// t = 3 * 2^cur: right child of the right sibling on the left spine
+						if (cur >= 12) FP(3, 1, 3, true, false, true);
+						else FP(2, 1, 2, true, false, true);
+					} else if (srcr) {
 						if (cur == 14) FP(3, 1, 3, false, false, false, 2);
-						else if (cur >= 11) FP(3, 1, 3, false, false, false, 1);
-						else if (cur == 10) FP(3, 1, 2, false, false, false, 1);
-						else if (cur == 9) FP(2, 1, 1, false, false, false, 1);
-						else FP(1, 1, 0, false, false, false, 1);
+						else if (cur >= 12) FP(3, 1, 3, false, false, false, 1);
+						else FP(2, 1, 2, false, false, false, 1);
 					} else if (cur == 15) {
 						FP(3, 3, 3, false, false, true);              // t = 32768: g of the channel LLRs, level 15 itself is recomputed by its reader
 					} else if (kind == 0) {
-						if (cur >= 11) FP(3, 0, 3);
-						else if (cur == 10) FP(3, 0, 2);
-						else if (cur == 9) FP(2, 0, 1);
-						else FP(1, 0, 0);
+						FP(3, 0, 3);
 					} else {
-						if (cur >= 11) FP(3, 1, 3);
-						else if (cur == 10) FP(3, 1, 2);
-						else if (cur == 9) FP(2, 1, 1);
-						else FP(1, 1, 0);
+						FP(3, 1, 3);
 					}
-					#undef FP
 					WAVE_ORDER();
-					cur -= D;
+					cur -= cur == 11 ? 2 : 3;
+					kind = 0;
+					PROF(0);
+				}
+				#undef FP
+				// The last pass of a descent ends on level 9, which goes into registers: (11,10,9), (10,9) or (9), in two halves
+				// (r9a = local indices 0..31, r9b = 32..63) through the 8 KB of LDS that hold level 8 afterwards; then level 8 =
+				// f(r9a[x], r9b[x]).
+				if (cur >= stop) {
+					R9_DEAD();
+					const bool spine = kind == 1 && (t & (t - 1)) == 0;
+					const bool srcr = kind == 1 && (t >> cur) == 3;
+					#pragma unroll 1
+					for (int hf = 0; hf < 2; ++hf) {
+						#define FP(...) fused_pass<__VA_ARGS__>(pb, ls8, hf * 32, ho_g, cur, lane, gl)
+						if (t == 0) {
+							FP(1, 0, 0, true);                        // compact level 10 -> 9
+						} else if (spine) {
+							if (cur == 10) FP(2, 1, 1, true, false, true);
+							else FP(1, 1, 0, true);
+						} else if (srcr) {
+							if (cur == 10) FP(2, 1, 1, false, false, false, 1);
+							else FP(1, 1, 0, false, false, false, 1);
+						} else if (kind == 0) {
+							if (cur == 11) FP(3, 0, 2);
+							else if (cur == 10) FP(2, 0, 1);
+							else FP(1, 0, 0);
+						} else {
+							if (cur == 11) FP(3, 1, 2);
+							else if (cur == 10) FP(2, 1, 1);
+							else FP(1, 1, 0);
+						}
+						#undef FP
+						WAVE_ORDER();
+						if (hf == 0) {
+							#pragma unroll
+							for (int x = 0; x < 32; ++x)
+								r9a[x] = ls8[x * 64 + lane];
+						} else {
+							#pragma unroll
+							for (int x = 0; x < 32; ++x)
+								r9b[x] = ls8[x * 64 + lane];
+						}
+						WAVE_ORDER();
+					}
+					#pragma unroll
+					for (int x = 0; x < 32; ++x)
+						ls8[x * 64 + lane] = f_minsum(r9a[x], r9b[x]);
+					WAVE_ORDER();
+					cur = 7;
 					kind = 0;
 					PROF(0);
 				}
@@ -743,13 +829,13 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 				// All-information node of 512..2048 leaves that starts here: decided by a terminal pass over its SOURCE - the
 				// node's own array is never stored, none of the levels below it is computed.  (Taken when the node's level is
 				// the next one to produce - in both frozen tables every such node is a right child, so that is always; a
-				// node reached by an overshooting three-level pass is walked.)  If the list is not provably stable the
+				// node reached by an overshooting pass is walked.)  If the list is not provably stable the
 				// ordinary pass runs and the node is walked.
 				try_big = false;
 				stop = 8;
 				if (cur == LtT) {
 					uint32_t mu = 0x7f800000u;
-					#define FT(...) fused_pass<1, __VA_ARGS__, true>(pb, ls8, ho_g, cur, lane, gl, &mu, hard + t)
+					#define FT(...) fused_pass<1, __VA_ARGS__, true>(pb, ls8, 0, ho_g, cur, lane, gl, &mu, hard + t)
 					if (kind == 1 && (t & (t - 1)) == 0) FT(1, 0, true, false, false, 0);          // spine: compact source
 					else if (kind == 1 && (t >> cur) == 3) FT(1, 0, false, false, false, 1);       // its right child: recomputed source
 					else if (kind == 1) FT(1, 0, false, false, false, 0);
@@ -771,12 +857,15 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 			for (int x = 0; x < 32; ++x)
 				mu = min(mu, __float_as_uint(ls8[x * 64 + lane]) & 0x7fffffffu);
 			if (stable(mu)) {
+				HRprev = 0;
 				#pragma unroll
 				for (int x0 = 0; x0 < 32; x0 += 16) {
 					unsigned long long mine = 0;
 					#pragma unroll
 					for (int u = 0; u < 16; ++u) {
-						const unsigned long long bal = __ballot(ls8[(x0 + u) * 64 + lane] < 0.f);
+						const bool neg = ls8[(x0 + u) * 64 + lane] < 0.f;
+						const unsigned long long bal = __ballot(neg);
+						HRprev |= (neg ? 1u : 0u) << (x0 + u);
 						if (lane == u)
 							mine = bal;
 					}
@@ -792,7 +881,7 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 			adv256 = 1 << (Ln - 8);
 		} else {
 			// ---------------- the 32 8-leaf blocks of this node; levels 7..4 in registers
-			float r7[16], r6[8], r5[4], r4[2];
+			float r6[8], r5[4], r4[2];
 			uint32_t HR = 0;                                  // partial sums, own path: bit x = position x*8 + j of the node
 			for (int b = 0, adv = 1; b < 32; b += adv) {
 				const int t8 = t256 * 32 + b, tt = t8 * 8;
@@ -811,6 +900,7 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 				const bool mapped = __ballot(glb != lane) != 0;
 				const uint32_t hb = zb < 8 ? HR >> (b - (1 << (zb - 3))) : 0u;
 				PROF(6);
+				float r7[16];                                     // level 7 lives here only from its production to the f step below it
 				if (zb >= 7) {
 					if (zb == 7) {
 						#pragma unroll
@@ -823,21 +913,17 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 					}
 					if (Lt == 7 && try_node(r7, nl0 == 7, HR, b))
 						L2 = 7;
+					if (!L2) {                                        // the g step of the right child (8 blocks on) reads it back through the lane map
+						#pragma unroll
+						for (int x = 0; x < 16; ++x)
+							ls7[x * 64 + lane] = r7[x];
+					}
 				}
 				if (zb >= 6 && !L2) {
 					if (zb == 6) {
-						float p[16];
-						#pragma unroll
-						for (int x = 0; x < 16; ++x)
-							p[x] = r7[x];
-						if (mapped) {
-							#pragma unroll
-							for (int x = 0; x < 16; ++x)
-								p[x] = __shfl(p[x], glb);
-						}
 						#pragma unroll
 						for (int x = 0; x < 8; ++x)
-							r6[x] = g_add(p[x], p[x + 8], (hb >> x) & 1);
+							r6[x] = g_add(ls7[x * 64 + glb], ls7[(x + 8) * 64 + glb], (hb >> x) & 1);
 					} else {
 						#pragma unroll
 						for (int x = 0; x < 8; ++x)
@@ -950,6 +1036,7 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 				if (lane < 32)
 					*(unsigned long long *)(hard + t + lane * 8) = mine;
 			}
+			HRprev = HR;                                      // the g step of the right sibling (t + 256) takes them from here
 		}
 		const int tn = t + 256 * adv256;
 		for (int m = Ln ? Ln + 1 : 9; m <= 16 && (tn & ((1 << m) - 1)) == 0; ++m) {
