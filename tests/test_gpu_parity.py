@@ -371,6 +371,192 @@ def _check_against_oracle(rx, pcm, payload, expect_ok=True):
     return r, ores
 
 
+# ---------------------------------------------------------------- the DEFAULT product path, stage by stage
+@pytest.fixture(scope="module")
+def rxd():
+    """a DEFAULT handle - syndrome certificate on, no debug flag - i.e. what bench.py, the CLI and a binding run.  The `rx`
+    fixture above has OFDMRX_FLAG_KEEP_RAW_CONS, which list-decodes every frame"""
+    import modem_amd
+    r = modem_amd.Receiver(device=0, chunk_frames=64)
+    yield r
+    r.close()
+
+
+def _oracle_certifies(tb, ores):
+    """oracle-side restatement of the syndrome certificate for a mode-6 frame: the hard decisions of the LLRs the
+    oracle's soft demapper produced form a polar codeword (zero on every frozen position after x F), no LLR is zero, and the list
+    decoder's answer is that codeword (lane 0, no flipped bit, CRC-32 fine)"""
+    llr = np.asarray(tb.llr[:65536], np.float32)
+    if (llr == 0).any() or not np.isfinite(llr).all():
+        return False
+    x = (llr < 0).astype(np.uint8)
+    n = 65536
+    h = 1
+    while h < n:                                   # u = x F^(x16): the left half of every block takes the XOR with the right half
+        x = x.reshape(-1, 2, h)
+        x[:, 0, :] ^= x[:, 1, :]
+        x = x.reshape(-1)
+        h *= 2
+    fz = O.frozen(0)
+    frozen = ((fz[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.uint8).reshape(-1)
+    if (x & frozen).any():
+        return False
+    return ores.status == 0 and ores.best_lane == 0 and ores.bit_flips == 0
+
+
+def _check_default_path(rxd, pcm, payload, expect_ok=True):
+    """the product path against the oracle: outputs and result record, the taps that exist on it, and WHICH way the frame
+    went - finished by the certificate exactly when the oracle's own LLRs say so (one frame per call: the certificate is
+    on at the start of every call), list-decoded otherwise, and then its LLRs (written by k_back's second pass) are compared too"""
+    out, res, (alog, acnt) = rxd.decode(pcm[None], attempts=True)
+    oout, ores, tb = O.decode(pcm, taps=True)
+    r = res[0]
+    assert int(r["status"]) == ores.status
+    assert (out[0] == oout).all()
+    if expect_ok:
+        assert ores.status == 0 and (out[0] == payload).all()
+    listed = rxd.list_decoded_frames()
+    if ores.sc_start >= 0:
+        assert int(r["sc_start"]) == ores.sc_start and int(r["symbol_pos"]) == ores.symbol_pos
+        assert abs(float(r["cfo_rad"]) - ores.cfo_rad) <= REL
+        assert int(r["n_sync_rejects"]) == ores.n_sync_rejects
+        # the attempt log's last record is the preamble the result describes (decode.cc:400-401)
+        assert acnt[0] >= 1
+        last = alog[0][acnt[0] - 1]
+        assert int(last["symbol_pos"]) == ores.symbol_pos and abs(float(last["cfo_rad"]) - ores.cfo_rad) <= REL
+        assert int(last["status"]) == (0 if ores.status in (0, 6) else ores.status)
+    else:
+        assert acnt[0] == 0
+    if ores.status in (0, 6):
+        assert int(r["oper_mode"]) == ores.oper_mode and int(r["call_sign"]) == ores.call_sign
+        _close(rxd.tap("CONS_RAW", 0), tb.cons_raw[:21600], what="cons_raw")
+        assert np.abs(rxd.tap("SLOPE", 0) - tb.slope[:50]).max() <= 5e-8
+        assert np.abs(rxd.tap("YINT", 0) - tb.yint[:50]).max() <= 5e-6
+        _close(rxd.tap("CONS_ROT", 0), tb.cons_rot[:21600], what="cons_rot (made on demand)")
+        _close(rxd.tap("PRECISION", 0), tb.precision[:50], what="precision")
+        assert abs(float(r["cfo_fine"]) - ores.cfo_fine) <= REL and abs(float(r["esn0_db_last"]) - ores.esn0_db_last) < 1e-3
+        assert abs(float(r["sfo_slope"]) - ores.sfo_slope) <= 5e-8
+        want_cert = _oracle_certifies(tb, ores)
+        assert listed == (0 if want_cert else 1), (listed, want_cert)
+        if want_cert:
+            assert int(r["best_lane"]) == 0 and int(r["bit_flips"]) == 0
+            with pytest.raises(Exception):                       # no LLRs were ever written for it: the tap says so
+                rxd.tap("LLR", 0)
+        else:
+            llr = rxd.tap("LLR", 0)
+            _close(llr[:64800], tb.llr[:64800], what="llr of an uncertified frame (k_back's second pass)")
+            assert (llr[64800:] == 9000).all()
+    else:
+        assert listed == 0
+    if ores.status == 0:
+        assert _flips_ok(r["bit_flips"], ores.bit_flips) and int(r["best_lane"]) >= 0
+    return r, ores, listed
+
+
+def test_default_path_clean_frames(rxd):
+    pcms, pays = _frames([(1, None, {}), (2, None, {})])
+    for pcm, p in zip(pcms, pays):
+        r, o, listed = _check_default_path(rxd, pcm, p)
+        assert listed == 0 and int(r["bit_flips"]) == 0          # a clean frame is finished by the certificate
+
+
+@pytest.mark.parametrize("db", [-30, -26, -22, -18, -15, -14])
+def test_default_path_awgn(rxd, db):
+    """the product path over the whole operating range: all certified (-30), mixed (-26), all list-decoded, the waterfall"""
+    pcms, pays = _frames([(2, db, {}), (2, db, {}), (2, db, {})])
+    went = [_check_default_path(rxd, pcm, p, expect_ok=db <= -15)[2] for pcm, p in zip(pcms, pays)]
+    if db == -30:
+        assert went == [0, 0, 0]
+    if db >= -22:
+        assert went == [1, 1, 1]
+
+
+def test_default_path_impairment_chain(rxd):
+    extra = dict(cfo_hz=234.567, sfo_ppm=147.0, multipath=[(0, 1 + 0j), (7, 0.3 - 0.2j), (19, -0.1 + 0.15j)])
+    pcms, pays = _frames([(2, -30, extra), (2, -24, extra)])
+    for pcm, p in zip(pcms, pays):
+        _check_default_path(rxd, pcm, p)
+
+
+def test_default_path_failures(rxd):
+    silence = np.zeros((30000, 2), np.int16)
+    out, res = rxd.decode(silence[None])
+    assert int(res["status"][0]) == 1 and not out.any() and rxd.list_decoded_frames() == 0
+    p = O.payload_for(9)
+    pcm = O.encode_pcm(p, channels=2)
+    _check_default_path(rxd, O.impair(pcm, noise_db=-6, seed=2), p, expect_ok=False)
+    y = pcm.copy()
+    s = 8000 + 4 * 1440
+    y[s + 10 * 1440: s + 40 * 1440] = 0
+    r, o, listed = _check_default_path(rxd, y, p, expect_ok=False)
+    assert int(r["status"]) == 6 and int(r["best_lane"]) == -1 and listed == 1
+    _check_default_path(rxd, pcm[:40000], p, expect_ok=False)
+
+
+def test_attempt_log_of_a_skip_loop(rxd):
+    """decode.cc:390-448 prints symbol pos / coarse cfo and the header's outcome for EVERY preamble of the SKIP loop: a stream of
+    three frames whose SECOND header is destroyed, SKIP = 2 -> three records (ok, a header failure, ok), against the oracle run with
+    SKIP = 0, 1, 2 (its result describes the last preamble it examined)"""
+    p = O.payload_for(40, count=3)
+    pcm = O.encode_pcm(p, channels=2).copy()
+    ref = [O.decode(pcm, skip=k)[1] for k in range(3)]
+    hdr2 = ref[1].sc_start + 1440                               # the second frame's header symbol
+    pcm[hdr2: hdr2 + 1280] = 0
+    ref = [O.decode(pcm, skip=k)[1] for k in range(3)]
+    assert ref[0].status == 0 and ref[1].status in (2, 3, 4, 5) and ref[2].status == 0
+    out, res, (alog, acnt) = rxd.decode(np.stack([pcm, pcm, pcm]), skip=[0, 1, 2], attempts=True)
+    assert list(acnt) == [1, 2, 3]
+    for f in range(3):
+        assert int(res["status"][f]) == ref[f].status
+        for a in range(f + 1):
+            assert int(alog[f][a]["status"]) == ref[a].status
+            assert int(alog[f][a]["symbol_pos"]) == ref[a].symbol_pos and abs(float(alog[f][a]["cfo_rad"]) - ref[a].cfo_rad) <= REL
+    assert (out[2] == p[2 * 5380:]).all() and not out[1].any()
+
+
+def test_queue_defers_the_list_decoder_across_chunks():
+    """Frames the certificate leaves wait in the list decoder's queue until a full residency of it is there (here: 32 entries, the
+    chunk size) - several chunks at a noise level where a few frames per chunk need the list decoder - and the adaptive
+    certificate switches itself off after a chunk in which it finished almost nothing.  Whatever the route, the outputs equal
+    those of a handle that list-decodes every frame (OFDMRX_FLAG_SCL_ALWAYS) and the transmitted payloads"""
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    n, chunk = 32 * 9, 32
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        rx = modem_amd.Receiver(device=0, stream=stream.cuda_stream, chunk_frames=chunk)
+        rxs = modem_amd.Receiver(device=0, stream=stream.cuda_stream, chunk_frames=chunk, scl_always=True)
+        spf = rx.tx_frame_samples(6)
+        g = torch.Generator(device=dev)
+        g.manual_seed(11)
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+        d_clean = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+        rx.tx_encode(d_pay.data_ptr(), n, d_clean.data_ptr())
+        d_in = torch.empty_like(d_clean)
+        listed = {}
+        for db in (-26.0, -20.0, -30.0):
+            rx.awgn_tile(d_clean.data_ptr(), n, d_in.data_ptr(), n, spf, db, 3, 0)
+            outs = []
+            for r in (rx, rxs):
+                d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+                d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+                r.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+                r.synchronize()
+                outs.append((d_out.cpu().numpy(), d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)))
+            listed[db] = rx.list_decoded_frames()
+            (oa, ra), (ob, rb) = outs
+            assert (oa == ob).all() and (oa == d_pay.cpu().numpy()).all(), db
+            for name in ra.dtype.names:
+                assert ((ra[name] == rb[name]) | ((ra[name] != ra[name]) & (rb[name] != rb[name]))).all(), (db, name)
+        rx.close()
+        rxs.close()
+    assert 0 < listed[-26.0] < n, listed          # a few per chunk: queued across chunks
+    assert listed[-20.0] == n, listed             # nothing certifies (the adaptive switch only changes who gets tried)
+    assert listed[-30.0] == 0, listed             # every call starts with the certificate on
+
+
 def test_clean_frames_mono_and_analytic(rx):
     """config 2 flavour: clean mode-6 frames, 16-bit mono (front end D1) and 2-channel analytic"""
     pcms, pays = _frames([(1, None, {}), (2, None, {})])
@@ -513,6 +699,9 @@ def test_decode_cli_is_a_drop_in(tmp_path):
         assert "demod " + "." * 50 + " done" in r.stderr and "coarse sfo: " in r.stderr
         esn0 = [ln for ln in r.stderr.splitlines() if ln.startswith("Es/N0 (dB):")]
         assert len(esn0) == 1 and len(esn0[0].split()[2:]) == 50
+        # decode.cc:400-447 prints its block of lines for EVERY preamble of the SKIP loop
+        k = 2 if skip else 1
+        assert r.stderr.count("symbol pos: ") == k and r.stderr.count("coarse cfo: ") == k and r.stderr.count("call sign:  CALLSIGN") == k
     assert subprocess.run([exe], capture_output=True).returncode == 1            # usage
     r = subprocess.run([exe, str(out), str(tmp_path / "missing.wav")], capture_output=True)
     assert r.returncode == 1

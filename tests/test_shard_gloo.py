@@ -45,7 +45,11 @@ def _bench(args, env_extra=None, timeout=300):
     env = dict(os.environ, MODEM_AMD_NO_TORCH="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    env.update(env_extra or {})
+    for k, v in (env_extra or {}).items():
+        if v is None:
+            env.pop(k, None)
+        else:
+            env[k] = v
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     return r, [json.loads(ln) for ln in lines]
@@ -71,3 +75,23 @@ def test_world_size_mismatch_is_refused():
     """a torchrun environment whose WORLD_SIZE differs from --gpus must fail loudly, never run on fewer GPUs silently"""
     r, lines = _bench(["--gpus", "8", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and not lines and "WORLD_SIZE" in r.stderr
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_gpus_for_real():
+    """the first box with two GPUs that runs the suite proves the N = 2 path on hardware: `bench.py --gpus 2 --scaling strong` over
+    RCCL - two ranks really decoded (n_gpus is a reduced counter, not the argument), the strong-scaling split covers the batch, every
+    frame decodes.  Skipped on one-GPU boxes.  (torch.cuda.device_count() does not initialise the GPU in this image.)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    r, lines = _bench(["--gpus", "2", "--frames", "8192", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--cpu-frames", "0",
+                       "--host-frames", "0"], {"MODEM_AMD_NO_TORCH": None}, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["frames"] == 8192
+    assert d["frames_ok"] == 8192 and d["fer"] == 0.0 and d["value"] > 0

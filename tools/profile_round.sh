@@ -5,8 +5,8 @@
 #   PMC passes (FETCH_SIZE, WRITE_SIZE, instruction counters: separate runs, one 8192-frame chunk, kernels back to back), in both modes;
 #   the FETCH_SIZE / WRITE_SIZE calibration (tools/pmc_calib.hip).
 # Only text leaves the box: gpurun_out/TAG_summary.txt, TAG_bench_n1*.json, TAG_traffic.json (copy the last one to
-# profiles/r03_traffic.json: bench.py reads the per-kernel HBM bytes from it)
-TAG=${1:-r03_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
+# profiles/r04_traffic.json: bench.py reads the per-kernel HBM bytes and VALU instruction counts from it)
+TAG=${1:-r04_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
 S=$G/${TAG}_summary.txt; : > $S
 make -C modem_amd/csrc -q all && echo "# library up to date with sources" >> $S || echo "# STALE LIBRARY" >> $S
 cd /tmp; export TMPDIR=/tmp
@@ -66,11 +66,11 @@ out = {"frames_per_launch": 8192, "fetch_scale": 2097152.0 / calib("calib_read",
        "kernels": {},
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 "
                  "--host-frames 0 --scl-steps 0, kernels back to back (k_polar: with OFDMRX_NO_CERT=1); KiB per launch; scales = true bytes / counted "
-                 "bytes of tools/pmc_calib.hip (2 GiB per kernel, one dword per lane) in the same session"}
+                 "bytes of tools/pmc_calib.hip (2 GiB per kernel, one dword per lane) in the same session; valu_insts = SQ_INSTS_VALU (wave instructions) per launch"}
 for st, (mode, kern, src) in stages.items():
     f, w = grab(mode, kern, "FETCH_SIZE"), grab(mode, kern, "WRITE_SIZE")
     if f is not None and w is not None:
-        out["kernels"][st] = {"kernel": kern, "fetch_KiB": f, "write_KiB": w, "src_sha": sha(src)}
+        out["kernels"][st] = {"kernel": kern, "fetch_KiB": f, "write_KiB": w, "valu_insts": grab(mode, kern, "SQ_INSTS_VALU"), "src_sha": sha(src)}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 PY
 tail -5 $S; cat $G/${TAG}_traffic.json; cat $G/${TAG}_bench_n1.json | cut -c1-600
