@@ -118,7 +118,7 @@ __device__ bool osd_certify(OsdShared &s, const uint32_t *cwbits, int tid)
 }
 
 // soft[255] in s.soft must be valid; returns unique flag, writes hard bits (BE) to hard_out[32] (thread 0)
-__device__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bits, const uint8_t *__restrict__ pairs,
+__device__ __forceinline__ bool osd_decode(OsdShared &s, const uint32_t *__restrict__ genmat_bits, const uint8_t *__restrict__ pairs,
 	const uint8_t *__restrict__ triples,
 	uint8_t *hard_out /* LDS or global, 32 B */, int tid)
 {

@@ -115,8 +115,6 @@ void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tab
 void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft, Attempt *attempts = nullptr,
 	int32_t *attempt_counts = nullptr);
 void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique);
-// 8 kHz: demod writes the carriers of every symbol (carr), the differential step happens in k_theil_sen; other rates: cons
-bool demod_writes_carriers(int rate);
 bool demod_forms_cons(int rate);   // cons is complete after k_demod (else k_theil_sen forms the rows from the carriers)
 void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons, cf *carr);
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, float *slope, float *yint, int *chunk_flags);
