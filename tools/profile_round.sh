@@ -10,8 +10,8 @@ TAG=${1:-r04_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
 S=$G/${TAG}_summary.txt; : > $S
 make -C modem_amd/csrc -q all && echo "# library up to date with sources" >> $S || echo "# STALE LIBRARY" >> $S
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-frames 0 --host-frames 0 --scl-steps 0"
-echo "# $TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 --scl-steps 0   (default: pipeline, syndrome certificate on)" >> $S
+B="python3 $R/bench.py --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0"
+echo "# $TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0   (default: pipeline, syndrome certificate on)" >> $S
 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o trace -- $B --steps 2 --warmup 1 > $G/${TAG}_bench_n1_under_profiler.json 2>/dev/null
 python3 $R/profiles/summarize.py $(find /tmp/prof_e -name "*.db" | head -1) >> $S 2>&1
 echo "# same with OFDMRX_NO_OVERLAP=1 (every kernel alone on the device)" >> $S
@@ -26,7 +26,7 @@ python3 $R/profiles/summarize.py $(find /tmp/prof_sn -name "*.db" | head -1) >> 
 export OFDMRX_NO_OVERLAP=1
 for mode in cert scl; do
 	[ $mode = scl ] && export OFDMRX_NO_CERT=1
-	echo "# PMC passes [$mode]: rocprofv3 --pmc <counters> -- python3 bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 --host-frames 0 --scl-steps 0 (OFDMRX_NO_OVERLAP=1$([ $mode = scl ] && echo ' OFDMRX_NO_CERT=1'))" >> $S
+	echo "# PMC passes [$mode]: rocprofv3 --pmc <counters> -- python3 bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0 (OFDMRX_NO_OVERLAP=1$([ $mode = scl ] && echo ' OFDMRX_NO_CERT=1'))" >> $S
 	for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS SQ_WAIT_INST_ANY"; do
 		d=/tmp/pmc_${mode}_$(echo $c | tr ' ' '_')
 		rocprofv3 --pmc $c -d $d -o x -- $B --frames 8192 --steps 1 --warmup 0 > /dev/null 2>&1
@@ -65,7 +65,7 @@ stages = {"sync": ("cert", "k_sync", "k_sync.hip"), "header": ("cert", "k_header
 out = {"frames_per_launch": 8192, "fetch_scale": 2097152.0 / calib("calib_read", "FETCH_SIZE"), "write_scale": 2097152.0 / calib("calib_write", "WRITE_SIZE"),
        "kernels": {},
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 "
-                 "--host-frames 0 --scl-steps 0, kernels back to back (k_polar: with OFDMRX_NO_CERT=1); KiB per launch; scales = true bytes / counted "
+                 "--host-frames 0 --scl-steps 0 --leg-steps 0, kernels back to back (k_polar: with OFDMRX_NO_CERT=1); KiB per launch; scales = true bytes / counted "
                  "bytes of tools/pmc_calib.hip (2 GiB per kernel, one dword per lane) in the same session; valu_insts = SQ_INSTS_VALU (wave instructions) per launch"}
 for st, (mode, kern, src) in stages.items():
     f, w = grab(mode, kern, "FETCH_SIZE"), grab(mode, kern, "WRITE_SIZE")
