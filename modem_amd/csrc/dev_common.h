@@ -436,24 +436,52 @@ __device__ __forceinline__ cf rotate_point(cf c, float slope, float yint, int i,
 // decode.cc:505-516 for one frame: the running sp / np of the SNR estimate.  Wave w reduces rows w, w + 4, ... by itself
 // (per-lane double sums over its 7 carriers, one wave butterfly) - no workgroup barrier per row; after ONE barrier thread 0
 // folds the row sums in order into the fp32 running sums and leaves the cumulative precision of every row in prec[].
-// point(j, i) delivers the constellation point (row j, column i) as decode.cc:505 sees it (rotated); visit(j, i, c) sees every
-// point once (the caller collects what it needs from it).  Returns false in every thread if a precision is not a positive
-// finite number.
-template <typename Point, typename Visit>
-__device__ __forceinline__ bool snr_rows(Point point, int rows, int cols, int mod_bits, int tid, double (*rsum)[2], float *prec, Visit visit)
+// raw(j, i) loads the constellation point (row j, column i); begin_row(j) is called once per row and lane, then
+// rotated(j, i, c) for i = lane, lane + 64, ... in that order: it delivers the point as decode.cc:505 sees it (rotated);
+// visit(j, i, c) sees every point once (the caller collects what it needs from it).  A lane's points of a row - at most eight -
+// are loaded together, and the NEXT row's while this one is worked on: the kernel is latency-bound otherwise (one HBM round
+// trip per point and lane: k_back 0.70 ms per 8192 frames with the plain loop).
+// Returns false in every thread if a precision is not a positive finite number.
+// sp: every hard-decision point has the same norm (psk.hh:82-85,132-139: (cos, sin) of pi/8 in either order, or (r, r)) - also the
+// one an erased carrier maps to - so a lane's share of the row's sp is its point count times that constant: exactly the sum of
+// its terms (up to 8 x a 49-bit value fits a double), two conversions and two multiplications per point less.
+template <typename Raw, typename Begin, typename Rotated, typename Visit>
+__device__ __forceinline__ bool snr_rows(Raw raw, Begin begin_row, Rotated rotated, int rows, int cols, int mod_bits, int tid, double (*rsum)[2],
+	float *prec, Visit visit)
 {
 	const int wave = tid >> 6, lane = tid & 63;
+	const cf h1 = mod_bits == 3 ? psk8_hard_map(mk(1.f, 0.f)) : psk4_hard_map(mk(1.f, 0.f));
+	const double h_norm = (double)h1.re * h1.re + (double)h1.im * h1.im;
+	const double dsp_lane = (double)((cols - lane + 63) / 64) * h_norm;
+	constexpr int NP = COLS_MAX / 64;                             // points per lane and row
+	cf nxt[NP];
+	auto fetch = [&](int j) {
+		#pragma unroll
+		for (int q = 0; q < NP; ++q)
+			if (j < rows && lane + 64 * q < cols)
+				nxt[q] = raw(j, lane + 64 * q);
+	};
+	fetch(wave);
 	for (int j = wave; j < rows; j += 4) {
-		double dsp = 0.0, dnp = 0.0;
-		for (int i = lane; i < cols; i += 64) {
-			const cf c = point(j, i);
-			const cf h = mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c);   // decode.cc:509-511
-			const double er = (double)c.re - h.re, ei = (double)c.im - h.im;
-			dsp += (double)h.re * h.re + (double)h.im * h.im;
-			dnp += er * er + ei * ei;
-			visit(j, i, c);
+		cf cur[NP];
+		#pragma unroll
+		for (int q = 0; q < NP; ++q)
+			cur[q] = nxt[q];
+		fetch(j + 4);
+		double dnp = 0.0;
+		begin_row(j);
+		#pragma unroll
+		for (int q = 0; q < NP; ++q) {
+			const int i = lane + 64 * q;
+			if (i < cols) {
+				const cf c = rotated(j, i, cur[q]);
+				const cf h = mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c);   // decode.cc:509-511
+				const double er = (double)c.re - h.re, ei = (double)c.im - h.im;
+				dnp += er * er + ei * ei;
+				visit(j, i, c);
+			}
 		}
-		dsp = wave_sum_d(dsp);
+		const double dsp = wave_sum_d(dsp_lane);
 		dnp = wave_sum_d(dnp);
 		if (lane == 0) { rsum[j][0] = dsp; rsum[j][1] = dnp; }
 	}

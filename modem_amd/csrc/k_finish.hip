@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	__shared__ double rsum[ROWS_MAX][2];
 	__shared__ uint32_t bits[CODE_LEN / 32];
 	__shared__ float prec[ROWS_MAX], row_slope[ROWS_MAX], row_yint[ROWS_MAX];
+	__shared__ cf row_step[ROWS_MAX];
 	__shared__ uint8_t mesg[MESG_BYTES_MAX];
 	__shared__ uint32_t ctab[256], csh[1024], cpart[32];
 	__shared__ uint32_t crc_sh;
@@ -79,8 +80,12 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	const float rcp_sqrt_2 = 0.70710678118654752440f;         // psk.hh:57,104
 	const float DIST = md.mod_bits == 3 ? 2.f * 0.38268343236508977173f : 2.f * rcp_sqrt_2;   // psk.hh:106 / psk.hh:59
 	if (tid < md.rows) {
-		row_slope[tid] = slope_all[(size_t)f * ROWS_MAX + tid];
+		const float sl = slope_all[(size_t)f * ROWS_MAX + tid];
+		row_slope[tid] = sl;
 		row_yint[tid] = yint_all[(size_t)f * ROWS_MAX + tid];
+		float sn, cs;
+		row_sincos(-64.f * sl, sn, cs);                           // the rotation advances by this factor from column i to i + 64
+		row_step[tid] = mk(cs, sn);
 	}
 	if (try_cert) {
 		for (int w = tid; w < CODE_LEN / 32; w += 256)
@@ -93,9 +98,30 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	__syncthreads();
 	// ---- 1. decode.cc:493-494 + 505-523 (snr_rows) + the signs of the soft bits
 	const int mod_bits = md.mod_bits, cols = md.cols;
-	auto point = [&](int j, int i) { return rotate_point(cons[j * cols + i], row_slope[j], row_yint[j], i, cols); };
+	auto raw = [&](int j, int i) { return cons[j * cols + i]; };
+#ifndef BACK_WALK
+#define BACK_WALK 1
+#endif
+	// the first pass walks a row in steps of 64 columns per lane: one sin / cos for the lane's first column, then one complex
+	// multiplication per step (the phasor's error grows by an ulp per step: seven steps) - a third of the rotation's instructions
+	cf rot_cur = mk(1.f, 0.f), rot_step = mk(1.f, 0.f);
+	auto begin_row = [&](int j) {
+		if (BACK_WALK) {
+			float sn, cs;
+			row_sincos(-(row_yint[j] + row_slope[j] * (float)((tid & 63) - cols / 2)), sn, cs);
+			rot_cur = mk(cs, sn);
+			rot_step = row_step[j];
+		}
+	};
+	auto rotated = [&](int j, int i, cf c0) {
+		if (!BACK_WALK)
+			return rotate_point(c0, row_slope[j], row_yint[j], i, cols);
+		const cf c = cmul(c0, rot_cur);
+		rot_cur = cmul(rot_cur, rot_step);
+		return c;
+	};
 	bool odd = false;                                             // a zero / NaN LLR somewhere: no certificate
-	const bool snr_ok = snr_rows(point, md.rows, cols, mod_bits, tid, rsum, prec, [&](int j, int i, cf c) {
+	const bool snr_ok = snr_rows(raw, begin_row, rotated, md.rows, cols, mod_bits, tid, rsum, prec, [&](int j, int i, cf c) {
 		if (!try_cert)
 			return;
 		const float are = fabsf(c.re), aim = fabsf(c.im);
@@ -235,13 +261,23 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	}
 	__syncthreads();
 	float *llr = llr_q + (size_t)slot_sh * CODE_LEN;
+	cf nxt[2];
+	auto fetch = [&](int j) {
+		#pragma unroll
+		for (int e = 0; e < 2; ++e)
+			if (j < md.rows && tid + 256 * e < cols)
+				nxt[e] = cons[j * cols + tid + 256 * e];
+	};
+	fetch(0);
 	for (int j = 0; j < md.rows; ++j) {
 		const float sc = DIST * prec[j];
+		const cf cur[2] = { nxt[0], nxt[1] };
+		fetch(j + 1);                                             // (the next row travels while this one is written)
 		#pragma unroll
 		for (int e = 0; e < 2; ++e) {
 			const int i = tid + 256 * e;
 			if (i < cols) {                                   // psk.hh:76-80,125-130
-				const cf c = point(j, i);
+				const cf c = rotate_point(cur[e], row_slope[j], row_yint[j], i, cols);
 				float *b = llr + mod_bits * (j * cols + i);
 				if (mod_bits == 3) {
 					b[1] = c.re * sc;
