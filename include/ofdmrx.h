@@ -112,7 +112,9 @@ typedef struct {
 	                            * the HEADER (48 kHz frames with 5 % raw bit errors) one frame in 192 differed by 5: cfo_rad
 	                            * differs in its last bits (1.5e-7 rad/sample), over 440 000 samples that is 0.07 rad of
 	                            * carrier phase, which the Theil-Sen stage absorbs with different hard decisions for points
-	                            * on a decision boundary; payload, lane and every other field were identical */
+	                            * on a decision boundary; payload, lane and every other field were identical.  Round 4, 43 000
+	                            * frames against the oracle: one frame (mode 7, -17 dB) differed by 9, its coarse cfo by
+	                            * 2e-6 rad/sample - the same mechanism */
 	float esn0_db_last;        /* decode.cc:517-519, cumulative Es/N0 after the last row */
 	int32_t n_sync_rejects;    /* falling edges rejected at decode.cc:140-145 */
 } ofdmrx_frame_result;

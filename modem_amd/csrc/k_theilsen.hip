@@ -774,6 +774,47 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 	return make_float2(slope, yint);
 }
 
+// arg(d) for d = c conj(map(hard(c))) (decode.cc:486): the point turned back onto the positive real axis, so d.re > 0 and
+// |d.im| <= d.re tan(pi/8) (8PSK) or <= d.re (QPSK) - the arc tangent of a ratio of magnitude <= 0.42 / <= 1, where a minimax
+// polynomial in t^2 (6 / 10 coefficients; fitted in double, <= 1.0 / 1.4 ulp over the range in fp32 Horner form) and a division
+// refined once replace the library's atan2f (38 vector instructions, most of them quadrant and special-case handling): 11 / 15.
+// Anything else - an erased carrier (d = 0), NaN, a point exactly on a decision boundary pushed past the range by rounding -
+// takes the library routine.
+#ifndef TS_OWN_ATAN
+#define TS_OWN_ATAN 1
+#endif
+__device__ __forceinline__ float ts_phase(cf d, int mod_bits)
+{
+	const float lim = mod_bits == 3 ? 0.42f : 1.005f;               // (the fits cover 0.4225 / 1.00995)
+	if (!TS_OWN_ATAN || !(d.re > 0.f) || !(fabsf(d.im) <= lim * d.re))
+		return atan2f(d.im, d.re);
+	const float r = __builtin_amdgcn_rcpf(d.re);
+	float t = d.im * r;
+	t = fmaf(fmaf(-d.re, t, d.im), r, t);                         // the quotient, correctly rounded but for rare ties
+	const float z = t * t;
+	float p;
+	if (mod_bits == 3) {
+		p = -5.951132927e-02f;
+		p = fmaf(p, z, 1.054106507e-01f);
+		p = fmaf(p, z, -1.423576012e-01f);
+		p = fmaf(p, z, 1.999798680e-01f);
+		p = fmaf(p, z, -3.333330347e-01f);
+		p = fmaf(p, z, 9.999999993e-01f);
+	} else {
+		p = -1.718391760e-03f;
+		p = fmaf(p, z, 1.059115275e-02f);
+		p = fmaf(p, z, -3.059610274e-02f);
+		p = fmaf(p, z, 5.738879400e-02f);
+		p = fmaf(p, z, -8.370542419e-02f);
+		p = fmaf(p, z, 1.094069024e-01f);
+		p = fmaf(p, z, -1.426187097e-01f);
+		p = fmaf(p, z, 1.999827962e-01f);
+		p = fmaf(p, z, -3.333328490e-01f);
+		p = fmaf(p, z, 9.999999978e-01f);
+	}
+	return p * t;
+}
+
 // one row: decode.cc:482-492.  The rotation of decode.cc:493-494 is not done here (round 4): this kernel is bound by vector
 // instruction issue, the rotated row was 176 KB per frame written and read back, and its only consumers (k_back; the CONS_ROT
 // tap) are latency-bound kernels that rotate each point where they use it (dev_common.h: rotate_point).
@@ -794,7 +835,7 @@ __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const M
 			} else
 				c = row[i];
 			cf d = cmul(c, cconj(md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c)));
-			s.y[ts_yaddr(i)] = atan2f(d.im, d.re);
+			s.y[ts_yaddr(i)] = ts_phase(d, md.mod_bits);
 		}
 	}
 	TS_SYNC();
