@@ -36,7 +36,7 @@ def test_header_symbols_are_all_exported(lib):
 def test_header_compiles_as_plain_c(tmp_path):
     c = tmp_path / "t.c"
     c.write_text('#include "ofdmrx.h"\nint main(void){ofdmrx_config c; ofdmrx_frame_result r; (void)c; (void)r; '
-                 'return sizeof(ofdmrx_frame_result) == 56 ? 0 : 1;}\n')
+                 'ofdmrx_attempt a; (void)a; return sizeof(ofdmrx_frame_result) == 56 && sizeof(ofdmrx_attempt) == 24 ? 0 : 1;}\n')
     exe = tmp_path / "t"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
     assert subprocess.call([str(exe)]) == 0
