@@ -2,7 +2,7 @@
 //
 // DSP::TheilSenEstimator<value,512>::compute (decode.cc:488) = the median (sorted position count/2) of the n(n-1)/2
 // pairwise slopes s_ij = fl(fl(y_j - y_i) / d), then the median of the intercepts.  Round 2 classified every pair
-// against a sampled bracket (k_theilsen_pairs.hip: O(n^2), 33 k wave-instructions per row).  This kernel never walks
+// against a sampled bracket (round 2's kernel, in the history: O(n^2), 33 k wave-instructions per row).  This kernel never walks
 // the pairs.  x is the integer grid (decode.cc:485), so for a threshold T
 //
 //     s_ij < T   <=>   y_j - T x_j  <  y_i - T x_i          (up to the two fp32 roundings of s_ij)
