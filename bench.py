@@ -486,6 +486,8 @@ def main():
                 insts = tj["valu_insts"] * fpl / traffic_db["frames_per_launch"]
                 valu = {"insts_per_launch": insts, "cycles_per_inst": 4, "simds": N_SIMD, "clock_GHz": SCLK_GHZ,
                         "achieved_frac": insts * 4.0 / (N_SIMD * SCLK_GHZ * 1e9 * avg_s),
+                        "note": "1.0 = every SIMD issues a vector instruction in every slot at the nominal clock; a few per cent above "
+                                "1.0 means the counted run and this run differ by that much (clock, launch duration)",
                         "source": "profiles/%s: rocprofv3 --pmc SQ_INSTS_VALU, scaled to this run's frames per launch" % TRAFFIC_FILE}
             hbm_frac_real = (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_s > 0) else None
             bound = "valu" if (valu and hbm_frac_real is not None and valu["achieved_frac"] > hbm_frac_real) else "hbm"
