@@ -360,6 +360,17 @@ __device__ __forceinline__ void fft_fwd_compact(cf *buf, const cf *twc, int tid)
 }
 
 // ---- wave helpers ----------------------------------------------------------
+// a value every lane holds alike, moved to scalar registers (the compiler cannot know that what came out of a vector load is uniform)
+__device__ __forceinline__ long uniform_l(long v)
+{
+	const int lo = __builtin_amdgcn_readfirstlane((int)v), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+	return ((long)hi << 32) | (long)(unsigned)lo;
+}
+__device__ __forceinline__ double uniform_d(double v)
+{
+	const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+	return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double shfl_d(double v, int src)
 {
 	int lo = __double2loint(v), hi = __double2hiint(v);
@@ -381,6 +392,47 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m)
 	hi = __shfl_xor(hi, m);
 	return __hiloint2double(hi, lo);
 }
+// ---- data-parallel-primitive moves (no LDS pipe, no address registers): lanes without a source get 0
+//   0x110 + n  row_shr:n (rows of 16 lanes)     0x142 / 0x143  row_bcast:15 / :31 (lane 15 of the row before / lane 31 of the half
+//   before, for the rows ROW_MASK names)         0x138  wave_shr:1
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float dpp_f(float v)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ double dpp_d(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+// Weighted inclusive scan over the wave, v[l] = sum_{j <= l} A^(l - j) e[j] (the end states of consecutive chunks of a first-order
+// recurrence that decays by A per chunk): four shifts inside the rows of 16, then lane 15 / lane 31 broadcast to the row / half
+// behind it.  w[k] = A^(2^k), k = 0..3 (uniform); w16 = A^((lane & 15) + 1), w32 = A^((lane & 31) + 1) (per lane).
+template <class T> struct WScan;
+template <> struct WScan<float> {
+	static __device__ __forceinline__ float run(float v, const float (&w)[6], float w16, float w32)
+	{
+		v = fmaf(w[0], dpp_f<0x111>(v), v);
+		v = fmaf(w[1], dpp_f<0x112>(v), v);
+		v = fmaf(w[2], dpp_f<0x114>(v), v);
+		v = fmaf(w[3], dpp_f<0x118>(v), v);
+		v = fmaf(w16, dpp_f<0x142, 0xa>(v), v);
+		v = fmaf(w32, dpp_f<0x143, 0xc>(v), v);
+		return v;
+	}
+};
+template <> struct WScan<double> {
+	static __device__ __forceinline__ double run(double v, const double (&w)[7], double w16, double w32)
+	{
+		v = fma(w[0], dpp_d<0x111>(v), v);
+		v = fma(w[1], dpp_d<0x112>(v), v);
+		v = fma(w[2], dpp_d<0x114>(v), v);
+		v = fma(w[3], dpp_d<0x118>(v), v);
+		v = fma(w16, dpp_d<0x142, 0xa>(v), v);
+		v = fma(w32, dpp_d<0x143, 0xc>(v), v);
+		return v;
+	}
+};
 // inclusive scan of one double per lane across the wave
 __device__ __forceinline__ double wave_scan_incl(double v, int lane)
 {

@@ -4,6 +4,7 @@
 // pack - the 8 kHz demodulator is issue-bound and runs 1.75 -> 1.4 ms per 8192 frames without it.
 #include "dev_common.h"
 #include "kernels.h"
+#include "mono_front.h"
 
 namespace rx {
 
@@ -40,6 +41,9 @@ template <int RATE> struct DifCfg {
 // write at strides of 4 (P = 1) and 16 / 4 (P = 4) elements, which the plain layout puts four lanes deep on a bank; under the
 // swizzle every 16-lane store group touches 32 distinct banks (checked against the bank rules of the guide in a simulation).
 // Same operations in the same order as fft_stage<256, 4, P, 64>: only the addresses change.
+#ifndef DEMOD_PREFETCH_NQ
+#define DEMOD_PREFETCH_NQ 1   // loader points per thread up to which the NEXT symbol's samples are fetched during the transform
+#endif
 #ifndef DEMOD_SWZ
 #define DEMOD_SWZ 1     // 8 kHz (the only rate with wave-private 256-point transforms): demod 1.48 -> 1.35 ms per chunk with the seven-waves budget below
 #endif
@@ -64,11 +68,26 @@ template <int P, int TWC> __device__ __forceinline__ void fft256_stage_swz(cf *b
 	fft_sync<64>();
 }
 
-template <int RATE>
-__global__ __launch_bounds__(DifCfg<RATE>::NT, DifCfg<RATE>::WAVES) void k_demod(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
+// Mono input (mono_front.h).  MONO = 2 (8 kHz): the workgroup walks the frame's symbols in order, so it carries the DC blocker's
+// state along: a symbol's span is its guard interval and body, [t0 - guard_len, t0 + symbol_len) - 1440 samples, five per thread
+// on 288 threads - and the spans of successive symbols join without a gap.  The recurrence runs a symbol ahead in two parts that
+// hang on the transform's own barriers (thread chunks + wave scan before the barrier that follows the transform, the waves' entry
+// states + y[n] = b x[n] - s[n-1] into LDS after it), the 21-tap Hilbert filter forms a loader thread's five samples n' + 256 a
+// out of LDS where the analytic path converts five int16 pairs.  Nothing of the analytic signal is ever in memory.
+// MONO = 1 (the other rates, whose loaders take their points at the top of a symbol): the symbol's window through MonoCover into
+// the z scratch, its staging area in the (then free) row buffer.
+#ifndef DEMOD_MONO_LDS
+#define DEMOD_MONO_LDS(R) ((R) == 8000)
+#endif
+#ifndef DEMOD_MONO_WAVES
+#define DEMOD_MONO_WAVES 6    // register budget of the MONO = 2 instantiation (waves per SIMD): 6 = 80 VGPRs = four workgroups per CU.  Measured per 8192
+                              // frames: 7 (72 VGPRs, five workgroups, 84 bytes of spills) 2.46 ms, 6: 2.09, 5 (96): 2.34, 4 (128, three workgroups): 3.05
+#endif
+template <int RATE, int MONO>
+__global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : DifCfg<RATE>::WAVES) void k_demod(FrameBatch fb, cf *__restrict__ z_all, MonoArgs ma, Tables tb,
 	const SyncState *__restrict__ st_all, cf *__restrict__ cons_all, cf *__restrict__ carr_all)
 {
-	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, SYM_STRIDE = RateCfg<RATE>::STRIDE;
+	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, SYM_STRIDE = RateCfg<RATE>::STRIDE, GUARD_LEN = RateCfg<RATE>::GL;
 	const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	const SyncState st = st_all[f];
 	if (!st.okay)
@@ -96,6 +115,12 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, DifCfg<RATE>::WAVES) void k_demod
 		__shared__ cf tw_r[DC::TWR_LDS ? (R1 - 1) * NS : 1];  // w^(n' r), r = 1..R1-1
 		__shared__ cf rotA[R1], rotQ[NQ], symrot[ROWS_MAX + 1];
 		__shared__ cf prevc[2][DEMOD_CONS_OUT(RATE) ? NT : 1];   // a thread's (at most two) carriers of the previous symbol
+		// MONO = 2: y of the span from (about) 32 samples before the body on (the filter reaches 19 back), and the waves' end states
+		constexpr int MPER = 5, MTH = SYM_STRIDE / MPER, YOFF = (GUARD_LEN - 32) / MPER * MPER, YB = GUARD_LEN - YOFF;   // body sample m at ybuf[YB + m]
+		static_assert(MONO != 2 || (MTH * MPER == SYM_STRIDE && MTH <= NT && NS == 256 && NQ == 1 && MonoCfg<RATE>::REACH <= 32 && GUARD_LEN % MPER == 0
+			&& (MTH + 63) / 64 == 5 && MTH % 64 == 32), "span layout");
+		__shared__ float ybuf[MONO == 2 ? SYM_STRIDE - YOFF : 1];
+		__shared__ double mwe[5];
 		fft_compact_twiddles<NS, NT, SYMBOL_LEN>(tw_sub, tb.tw_sym, tid);
 		if (DC::TWR_LDS)
 			for (int i = tid; i < (R1 - 1) * NS; i += NT)
@@ -115,7 +140,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, DifCfg<RATE>::WAVES) void k_demod
 		if (NQ == 1) {
 			#pragma unroll
 			for (int a = 0; a < R1; ++a)
-				qa[a] = a ? cmul(p0, rotA[a]) : p0;
+				qa[a] = (a && MONO != 2) ? cmul(p0, rotA[a]) : p0;
 		}
 		// the (at most two) carriers of this thread sit at the same place of the rows in every symbol
 		int coff[2];
@@ -124,11 +149,123 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, DifCfg<RATE>::WAVES) void k_demod
 			const int i = tid + NT * e, k = (i + code_off + SYMBOL_LEN) % SYMBOL_LEN;
 			coff[e] = i < md.cols ? (k % R1) * NS + ((DEMOD_SWZ && NS == 256 && DC::W == 1) ? swz256(k / R1) : k / R1) : -1;
 		}
-		src.with_mode([&](auto M) {
+		// ---- MONO = 2: the span recurrence (see the head of the kernel)
+		const MonoFrame mfr = mono_frame(fb, ma.ck, ma.ck_per_frame, f);
+		const long span0 = MONO == 2 ? uniform_l(body0 - GUARD_LEN) : 0;   // first sample of symbol 0's span
+		double mS = 0.0, mAspan = 1.0, mAw = 1.0;                     // s before the span that is next to run; a^1440; a^(320 wave)
+		float mAlane = 1.f, mW16 = 1.f, mW32 = 1.f, mx[MPER] = {}, my0[MPER] = {};
+		auto mono_raw = [&](int sym) {                                // the span's samples (a symbol ahead of their use)
+			const long e0 = span0 + (long)sym * SYM_STRIDE;           // (uniform; a frame has fewer than 2^31 samples)
+			const int n32 = (int)mfr.n;
+			if (tid < MTH) {
+				if (mfr.fmt == 0 && e0 >= 0 && e0 + SYM_STRIDE <= mfr.n) {   // the span inside the frame, int16: the rule
+					const int16_t *q = (const int16_t *)mfr.base + e0;
+					#pragma unroll
+					for (int i = 0; i < MPER; ++i)
+						mx[i] = div_32767((float)q[tid * MPER + i]);
+				} else {                                              // any format, zeros outside the frame; straight-line code
+					#pragma unroll
+					for (int i = 0; i < MPER; ++i) {
+						const int j = (int)e0 + tid * MPER + i, jc = min(max(j, 0), n32 - 1);
+						float v;
+						if (mfr.fmt == 0) v = div_32767((float)((const int16_t *)mfr.base)[jc]);
+						else if (mfr.fmt == 1) v = div_127((float)((int)((const uint8_t *)mfr.base)[jc] - 128));
+						else v = ((const float *)mfr.base)[jc];
+						mx[i] = j == jc ? v : 0.f;
+					}
+				}
+			}
+		};
+		// y[n] = b x[n] - s[n-1] and s[n-1] = (the thread's chunk from a zero state) + a^i (the state entering the thread), which is the
+		// scan's value of the lane before + a^(5 lane) (the state entering the wave): everything but the last term is known before
+		// the barrier - my0 - and the last term is a per-thread power of a times a per-wave number that needs the other waves' ends
+		auto mono_part1 = [&]() {
+			float acc = 0.f, sl[MPER];
+			#pragma unroll
+			for (int i = 0; i < MPER; ++i) {
+				sl[i] = acc;                                          // the chunk's state BEFORE sample i
+				acc = fmaf(ma.a, acc, ma.g * mx[i]);
+			}
+			const float v = WScan<float>::run(acc, ma.astep5, mW16, mW32);   // weighted inclusive scan of the chunk ends over the wave
+			if (lane == (wave < 4 ? 63 : 31))                         // the span ends with thread 287 = lane 31 of wave 4
+				mwe[wave] = (double)v;
+			const float cw0 = dpp_f<0x138>(v);                        // the lane before (lane 0: 0)
+			my0[0] = fmaf(ma.b, mx[0], -cw0);
+			#pragma unroll
+			for (int i = 1; i < MPER; ++i)
+				my0[i] = fmaf(ma.b, mx[i], -fmaf(ma.apw[i - 1], cw0, sl[i]));
+		};
+		auto mono_part2 = [&]() {                                     // (behind a barrier) the waves' entry states, y into LDS
+			double st = 0.0, stw = 0.0;                               // the span from a zero state: at the start of wave w / of this wave
+			#pragma unroll
+			for (int w = 0; w < 4; ++w) {
+				st = mwe[w] + ma.awave5 * st;
+				if (w < wave)
+					stw = st;
+			}
+			const float cl = mAlane * (float)uniform_d(stw + mAw * mS);   // a^(5 lane) x the state entering the wave
+			mS = uniform_d((mwe[4] + (double)ma.astep5[5] * st) + mAspan * mS);   // a^160 st_4: wave 4 ends after 32 chunks
+			if (tid >= YOFF / MPER && tid < MTH) {
+				float *yo = ybuf + (tid * MPER - YOFF);
+				yo[0] = my0[0] - cl;
+				#pragma unroll
+				for (int i = 1; i < MPER; ++i)
+					yo[i] = fmaf(-ma.apw[i - 1], cl, my0[i]);
+			}
+		};
+		if constexpr (MONO == 2) {
+			// s before the first span: the kept state at or before it, then the (at most 63) samples between, one per lane
+			mAlane = (float)mono_pow((double)ma.a, MPER * lane);
+			mW16 = (float)mono_pow((double)ma.a, MPER * ((lane & 15) + 1));
+			mW32 = (float)mono_pow((double)ma.a, MPER * ((lane & 31) + 1));
+			mAspan = uniform_d(mono_pow((double)ma.a, SYM_STRIDE));
+			mAw = uniform_d(mono_pow((double)ma.a, 64 * MPER * wave));
+			if (span0 > 0) {
+				const long c0 = span0 / MONO_CK * MONO_CK;
+				const int gap = (int)(span0 - c0);
+				const double term = lane < gap ? (double)ma.g * (double)mfr.scalar(c0 + lane) * mono_pow((double)ma.a, gap - 1 - lane) : 0.0;
+				mS = uniform_d(mono_pow((double)ma.a, gap) * mfr.state_before(c0) + wave_sum_d(term));
+			}
+			mono_raw(0);
+			mono_part1();
+			__syncthreads();
+			mono_part2();
+			mono_raw(1);
+			__syncthreads();
+		}
+		MonoCover<RATE, NT> mcov;
+		if constexpr (MONO == 1) {
+			static_assert(sizeof(typename MonoCover<RATE, NT>::Shared) <= sizeof(row), "the cover's staging area lives in the row buffer");
+			mcov.init(mfr, ma, reinterpret_cast<typename MonoCover<RATE, NT>::Shared *>(row), z_all + (size_t)f * fb.samples_per_frame, tid);
+		}
+		auto symbols = [&](auto M) {
 		constexpr int MODE = decltype(M)::value;
 		cf pre[NQ][R1];
 		auto fetch = [&](int sym) {
 			const long t0 = body0 + (long)sym * SYM_STRIDE;       // wave-uniform
+			if constexpr (MONO == 2) {
+				// Hilbert<cmplx, 21> of the loader's five samples out of LDS; sample t0 + m sits at ybuf[YB + m] (outside the frame: 0,
+				// like SampleSrc::at)
+				const bool inside = t0 >= 0 && t0 + SYMBOL_LEN <= src.n;
+				if (tid < NS) {
+					#pragma unroll
+					for (int a = 0; a < R1; ++a) {
+						const int m = tid + NS * a;
+						cf zv = mono_hilbert<RATE>(ma.co, [&](int k) { return ybuf[YB + m - MonoCfg<RATE>::REACH + k]; });
+						if (!inside && (t0 + m < 0 || t0 + m >= src.n))
+							zv = mk(0.f, 0.f);
+						pre[0][a] = zv;
+						__builtin_amdgcn_sched_barrier(0);            // one sample's eleven LDS reads in flight, not five samples' (registers)
+					}
+				}
+				return;
+			}
+			if constexpr (MONO == 1) {
+				if (sym <= md.rows) {
+					mcov.any = false;                             // (the staging area was the row buffer in between)
+					mcov.cover(ma, t0, t0 + SYMBOL_LEN, tid);
+				}
+			}
 			if (MODE == 1 && sym <= md.rows && t0 >= 0 && t0 + SYMBOL_LEN <= src.n) {
 				// the whole symbol lies inside the frame (the rule): int16 pairs from a uniform base, no per-sample checks
 				const short2 *p = (const short2 *)src.base + t0;
@@ -153,10 +290,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, DifCfg<RATE>::WAVES) void k_demod
 				}
 			}
 		};
-#ifndef DEMOD_PREFETCH_NQ
-#define DEMOD_PREFETCH_NQ 1   // loader points per thread up to which the NEXT symbol's samples are fetched during the transform
-#endif
-		constexpr bool AHEAD = NQ <= DEMOD_PREFETCH_NQ;
+		constexpr bool AHEAD = NQ <= DEMOD_PREFETCH_NQ && MONO == 0;   // (mono: the points are formed at the top of the symbol)
 		if (AHEAD)
 			fetch(0);
 		cf *carr = carr_all + (size_t)f * CARR_MAX;
@@ -171,7 +305,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, DifCfg<RATE>::WAVES) void k_demod
 					if (NQ == 1) {
 						#pragma unroll
 						for (int a = 0; a < R1; ++a)
-							v[a] = cmul(pre[q][a], qa[a]);
+							v[a] = cmul(pre[q][a], (MONO == 2 && a) ? cmul(p0, rotA[a]) : qa[a]);   // (MONO = 2 is short of registers)
 					} else {
 						const cf pq = q ? cmul(p0, rotQ[q]) : p0;
 						#pragma unroll
@@ -198,6 +332,9 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, DifCfg<RATE>::WAVES) void k_demod
 				fft256_stage_swz<64, 60>(sub, tw_sub, lane, sl);
 			} else
 				fft_fwd_compact<NS, 64 * DC::W, SYMBOL_LEN>(row + (tid / (64 * DC::W)) * NS, tw_sub, tid % (64 * DC::W));
+			if constexpr (MONO == 2)
+				if (s < md.rows)
+					mono_part1();                                 // the next symbol's span (its samples arrived during the transform)
 			__syncthreads();
 			// the payload carriers of symbol s: the time-differential step cons = X_j / X_{j-1} (decode.cc:474-475) against the previous
 			// symbol's carriers (DEMOD_CONS_OUT 1; 0: the carriers go to HBM and k_theil_sen does it where it reads them).
@@ -216,9 +353,19 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, DifCfg<RATE>::WAVES) void k_demod
 						carr[tid + NT * e] = cur;
 				}
 			carr += md.cols;
+			if constexpr (MONO == 2)
+				if (s < md.rows) {
+					mono_part2();
+					if (s + 2 <= md.rows)
+						mono_raw(s + 2);
+				}
 			__syncthreads();
 		}
-		});
+		};
+		if constexpr (MONO != 0)
+			symbols(IntC<0>{});                                   // (mono: the points come out of LDS / the z scratch)
+		else
+			src.with_mode(symbols);
 	}
 }
 
@@ -242,9 +389,13 @@ __global__ __launch_bounds__(256) void k_fft_debug(int len, int sign, const cf *
 }
 
 bool demod_forms_cons(int rate) { return DEMOD_CONS_OUT(rate); }
-void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons, cf *carr)
+void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, const MonoArgs &ma, Tables tb, const SyncState *st, cf *cons, cf *carr)
 {
-	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_demod<RATE>, dim3(n), dim3(DifCfg<RATE>::NT), 0, s, fb, z, tb, st, cons, carr));
+	if (fb.channels == 1) {
+		RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_demod<RATE, DEMOD_MONO_LDS(RATE) ? 2 : 1>), dim3(n), dim3(DifCfg<RATE>::NT), 0, s, fb, z, ma, tb, st, cons, carr));
+	} else {
+		RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_demod<RATE, 0>), dim3(n), dim3(DifCfg<RATE>::NT), 0, s, fb, z, ma, tb, st, cons, carr));
+	}
 }
 void launch_fft_debug(hipStream_t s, int rate, int n, int len, int sign, const cf *in, cf *out, Tables tb)
 {

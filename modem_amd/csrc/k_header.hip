@@ -10,6 +10,7 @@
 // LDS counter; candidate metrics come from a byte-sliced LDS lookup table.
 #include "dev_common.h"
 #include "kernels.h"
+#include "mono_front.h"
 
 namespace rx {
 
@@ -454,8 +455,8 @@ __device__ __forceinline__ unsigned crc16_u64(unsigned long long data)
                            // barrier-separated steps, latency-bound: 1.48 ms per 8192 frames at 2, 0.88 at 4, 0.79 at 5; the uncertified order-3
                            // search (OSD_NO_CERTIFICATE: 30 ms) does not care
 #endif
-template <int RATE>
-__global__ __launch_bounds__(256, HDR_WAVES) void k_header(FrameBatch fb, const cf *__restrict__ z_all, Tables tb,
+template <int RATE, bool MONO>
+__global__ __launch_bounds__(256, HDR_WAVES) void k_header(FrameBatch fb, cf *__restrict__ z_all, MonoArgs ma, Tables tb,
 	SyncState *__restrict__ st_all, int8_t *__restrict__ hdr_soft, Attempt *__restrict__ attempts, int32_t *__restrict__ attempt_counts)
 {
 	constexpr int SYMBOL_LEN = RateCfg<RATE>::SL, SYM_STRIDE = RateCfg<RATE>::STRIDE;
@@ -478,6 +479,13 @@ __global__ __launch_bounds__(256, HDR_WAVES) void k_header(FrameBatch fb, const 
 	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, fb.samples_per_frame,
 		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
 	const long body = st.sc_start + SYM_STRIDE;               // decode.cc:405
+	if constexpr (MONO) {                                     // the symbol's analytic signal first (mono_front.h; its LDS is buf's)
+		typedef MonoCover<RATE, 256> MCov;
+		static_assert(sizeof(typename MCov::Shared) <= sizeof(buf), "the cover's staging area lives in the symbol buffer");
+		MCov mc;
+		mc.init(mono_frame(fb, ma.ck, ma.ck_per_frame, f), ma, reinterpret_cast<typename MCov::Shared *>(buf), z_all + (size_t)f * fb.samples_per_frame, tid);
+		mc.cover(ma, body, body + SYMBOL_LEN, tid);
+	}
 	for (int i = tid; i < SYMBOL_LEN; i += 256)
 		buf[i] = cmul(src.at(body + i), phasor(-st.cfo_rad, i));
 	__syncthreads();
@@ -556,10 +564,15 @@ __global__ __launch_bounds__(256, 2) void k_osd_only(Tables tb, const int8_t *__
 		unique_out[f] = u ? 1 : 0;
 }
 
-void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft, Attempt *attempts,
-	int32_t *attempt_counts)
+void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, const MonoArgs &ma, Tables tb, SyncState *st, int8_t *hdr_soft,
+	Attempt *attempts, int32_t *attempt_counts)
 {
-	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_header<RATE>, dim3(n), dim3(256), 0, s, fb, z, tb, st, hdr_soft, attempt_counts ? attempts : nullptr, attempt_counts));   // (both or none)
+	Attempt *att = attempt_counts ? attempts : nullptr;       // (both or none)
+	if (fb.channels == 1) {
+		RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_header<RATE, true>), dim3(n), dim3(256), 0, s, fb, z, ma, tb, st, hdr_soft, att, attempt_counts));
+	} else {
+		RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_header<RATE, false>), dim3(n), dim3(256), 0, s, fb, z, ma, tb, st, hdr_soft, att, attempt_counts));
+	}
 }
 void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique)
 {

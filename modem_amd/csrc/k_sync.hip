@@ -11,8 +11,10 @@
 //     saturating age counter) is evaluated on the tile with wave reductions.
 // D3  trigger part (decode.cc:110-151): derotate 640, FFT640, differential
 //     demod across bins, FFT640, x conj(FFT(mls0))/640, IFFT640, peak search.
+#include <type_traits>
 #include "dev_common.h"
 #include "kernels.h"
+#include "mono_front.h"
 
 // Decision-critical fp32 expressions (cfo_rad = shift*2pi/640 - frac_cfo sits at magnitude ~6 before the
 // wrap, so ONE ulp there is 5e-7 rad/sample = 7e-4 rad per symbol): no FMA contraction in this file, like
@@ -22,196 +24,97 @@
 namespace rx {
 
 // ---------------------------------------------------------------- D1 front end
-// Decoder::next_sample (decode.cc:294-301) for mono input: y = BlockDC(x), z = Hilbert<cmplx,21>(y).
-// The DC blocker y[n] = b(x[n]-x[n-1]) + a y[n-1] is a linear recurrence over the whole stream.  Round 3: one workgroup per
-// (frame, TILE of 4096 samples) instead of one per frame walking its 24 tiles in turn (6.9 ms per 8192 frames, more than
-// Theil-Sen, all of it a serial chain of barriers at low occupancy).  Two passes:
-//   k_front_dc      every tile from a ZERO state: 16 consecutive samples per thread, the 256 thread-end states combined by a
-//                   weighted inclusive scan (v[t] += A^d v[t-d], A = a^16).  Kept per tile: its end state and the zero-start
-//                   values of its last FE_HIST samples (the history the next tile's Hilbert taps reach into).
-//   k_front_end     the true state at a tile's start is the fold of the earlier tiles' end states, C_t = e_{t-1} + a^4096 C_{t-1}
-//                   (<= 24 terms; 140 at 48 kHz); the tile's recurrence is run again and every sample corrected by
-//                   a^(k+1) C_t, the history samples by the same rule from the kept values and C_{t-1}; then the 21-tap
-//                   Hilbert FIR out of LDS and 128 contiguous bytes of z per lane.
-// The recurrence is evaluated in double and rounded once per sample: a parallel scan cannot reproduce the rounding sequence of
-// the serial fp32 recurrence anyway, so the GPU side is made (nearly) exact and the difference to the CPU's serial fp32 filter
-// is that filter's own rounding.  Other rates: Hilbert<cmplx, filter_len> with filter_len = 41 / 113 / 125 (decode.cc:172).
-constexpr int FE_PER = 16, FE_TILE = 256 * FE_PER;
-template <int RATE> struct FeCfg {
-	static constexpr int FL = RateCfg<RATE>::FILTER_LEN, HIST = (FL - 1 + 31) / 32 * 32, C = (FL - 1) / 2, NIM = (FL - 1) / 4;
-	static constexpr int REC = 1 + HIST;                      // doubles kept per tile: end state + the history values
-};
-
-// the tile's samples (thread tid: FE_PER consecutive ones from s0), the recurrence from a zero state per thread (y[i]), and the
-// state entering this thread when the TILE starts from zero (cin0): the pieces both passes need
-template <int RATE>
-__device__ __forceinline__ void fe_tile_local(const SampleSrc &src, const char *base, int fmt, long n, long s0, double a, double b,
-	const double (&Apow)[7], int lane, int wave, double *wave_end, double (&y)[FE_PER], double &cin0, double &tile_end)
-{
-	float x[FE_PER + 1];
-	x[0] = (s0 - 1 >= 0 && s0 - 1 < n) ? src.scalar(s0 - 1) : 0.f;
-	if (fmt == 0 && s0 + FE_PER <= n && (((size_t)base + (size_t)s0 * 2) & 15) == 0) {
-		const int4 *p = (const int4 *)((const int16_t *)base + s0);
-		int4 v0 = p[0], v1 = p[1];
-		const int w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
-		#pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			x[1 + 2 * q] = div_32767((float)(short)(w[q] & 0xffff));
-			x[2 + 2 * q] = div_32767((float)(short)(w[q] >> 16));
-		}
-	} else {
-		#pragma unroll
-		for (int i = 0; i < FE_PER; ++i)
-			x[1 + i] = s0 + i < n ? src.scalar(s0 + i) : 0.f;
-	}
-	double yl = 0.0;
-	#pragma unroll
-	for (int i = 0; i < FE_PER; ++i) {
-		yl = b * (double)(x[i + 1] - x[i]) + a * yl;
-		y[i] = yl;
-	}
-	// weighted inclusive scan of the thread end states over the 64 lanes of the wave
-	double v = yl;
-	#pragma unroll
-	for (int sft = 0; sft < 6; ++sft) {
-		double o = shfl_up_d(v, 1 << sft);
-		if (lane >= (1 << sft))
-			v += Apow[sft] * o;
-	}
-	if (lane == 63)
-		wave_end[wave] = v;
-	__syncthreads();
-	double st = 0.0;                                              // state at the end of the previous waves of this tile
-	for (int w2 = 0; w2 < wave; ++w2)
-		st = wave_end[w2] + Apow[6] * st;                         // A^64 decays a whole wave (1024 samples)
-	const double prev = shfl_up_d(v, 1);
-	double decay = 1.0;                                           // A^lane
-	#pragma unroll
-	for (int sft = 0; sft < 6; ++sft)
-		if (lane & (1 << sft))
-			decay *= Apow[sft];
-	cin0 = (lane ? prev : 0.0) + decay * st;
-	tile_end = ((wave_end[3] + Apow[6] * wave_end[2]) + Apow[6] * Apow[6] * wave_end[1]) + Apow[6] * Apow[6] * Apow[6] * wave_end[0];
-}
-template <int RATE>
-__device__ __forceinline__ void fe_powers(double a, double (&apow)[FE_PER], double (&Apow)[7])
-{
-	apow[0] = a;                                                  // a^1..a^16; A^(2^s) = a^(16*2^s) for the scan steps
-	#pragma unroll
-	for (int i = 1; i < FE_PER; ++i)
-		apow[i] = apow[i - 1] * a;
-	Apow[0] = apow[FE_PER - 1];
-	#pragma unroll
-	for (int sft = 1; sft < 7; ++sft)
-		Apow[sft] = Apow[sft - 1] * Apow[sft - 1];
-}
+// Decoder::next_sample (decode.cc:294-301) for mono input: y = BlockDC(x), z = Hilbert<cmplx, filter_len>(y).  Round 4: the analytic
+// signal is formed by its consumers (mono_front.h); what runs over the whole stream is only this pass, which leaves the DC blocker's
+// low-pass state s[n] = a s[n-1] + g x[n] after every 64th sample - 2 bytes read and 1/8 byte written per sample where the front end
+// of rounds 1-3 wrote 8 (and k_sync / k_header / k_demod read them back).
+//   one workgroup per frame, TILE of 4096 samples = 16 consecutive samples per thread, CAR_TB tiles in flight: every tile from a ZERO
+//   state (thread recurrences, a weighted inclusive scan of the 256 thread-end states: v[t] += A^d v[t-d], A = a^16), then the
+//   tiles' true entry states C_t = e_{t-1} + a^4096 C_{t-1} in turn and s = (zero-start value) + a^(position + 1) C_t.
+// In double: a parallel scan cannot reproduce the rounding sequence of the serial fp32 recurrence anyway, so the kept states are
+// made (nearly) exact and the difference to the CPU's serial fp32 filter is that filter's own rounding.
+constexpr int FE_PER = 16, FE_TILE = 256 * FE_PER, CAR_TB = 6;
 
 template <int RATE>
-__global__ __launch_bounds__(256) void k_front_dc(FrameBatch fb, FrontCoef co, double *__restrict__ rec_all, int tiles)
+__global__ __launch_bounds__(256) void k_mono_carries(FrameBatch fb, FrontCoef co, double *__restrict__ ck_all, int ck_per_frame)
 {
-	using FC = FeCfg<RATE>;
-	const int f = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const long n = fb.samples_per_frame;
 	const char *base = (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes;
-	SampleSrc src{ base, fb.fmt, 1, n, nullptr };
-	__shared__ double wave_end[4];
-	const double a = (double)co.dc_a, b = (double)co.dc_b;
-	double apow[FE_PER], Apow[7], y[FE_PER], cin0, tile_end;
-	fe_powers<RATE>(a, apow, Apow);
-	const long s0 = (long)t * FE_TILE + (long)tid * FE_PER;
-	fe_tile_local<RATE>(src, base, fb.fmt, n, s0, a, b, Apow, lane, wave, wave_end, y, cin0, tile_end);
-	double *rec = rec_all + ((size_t)f * tiles + t) * FC::REC;
-	if (tid == 0)
-		rec[0] = tile_end;
+	MonoFrame fr{ base, fb.fmt, n, nullptr };
+	double *ck = ck_all + (size_t)f * ck_per_frame;
+	__shared__ double wave_end[CAR_TB][4];
+	const double a = (double)co.dc_a, g = (double)co.dc_b * (1.0 - a);
+	double Apow[7];                                               // a^(16 2^k): Apow[6] = a^1024 decays a whole wave
+	Apow[0] = mono_pow(a, FE_PER);
 	#pragma unroll
-	for (int i = 0; i < FE_PER; ++i) {
-		const int k = tid * FE_PER + i - (FE_TILE - FC::HIST);    // index into the kept history
-		if (k >= 0)
-			rec[1 + k] = y[i] + apow[i] * cin0;
-	}
-}
-
-template <int RATE>
-__global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, FrontCoef co, const double *__restrict__ rec_all, int tiles, cf *__restrict__ z_all)
-{
-	using FC = FeCfg<RATE>;
-	constexpr int FE_HIST = FC::HIST, FE_C = FC::C, FE_NIM = FC::NIM;
-	const int f = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const long n = fb.samples_per_frame;
-	const char *base = (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes;
-	SampleSrc src{ base, fb.fmt, 1, n, nullptr };
-	cf *z = z_all + (size_t)f * fb.samples_per_frame;
-	// y of the tile, [0, FE_HIST) = tail of the previous tile.  One pad word per 32: the recurrence writes 16 consecutive samples
-	// per thread (stride 16 words across the lanes: two banks without the pad), the FIR reads consecutive samples across the lanes
-	constexpr int YN = FE_HIST + FE_TILE;
-	__shared__ float ydc[YN + YN / 32 + 1];
-	auto pad = [](int p) { return p + (p >> 5); };
-	__shared__ double wave_end[4];
-	const double a = (double)co.dc_a, b = (double)co.dc_b;
-	double apow[FE_PER], Apow[7], y[FE_PER], cin0, tile_end;
-	fe_powers<RATE>(a, apow, Apow);
-	// state at the start of the previous tile (Cp) and of this one (Ct): fold of the earlier tiles' end states
+	for (int k = 1; k < 7; ++k)
+		Apow[k] = Apow[k - 1] * Apow[k - 1];
 	const double Atile = Apow[6] * Apow[6] * Apow[6] * Apow[6];   // a^4096
-	const double *rec_f = rec_all + (size_t)f * tiles * FC::REC;
-	__shared__ double ends_sh[256];
-	double Cp = 0.0, Ct = 0.0;
-	for (int q0 = 0; q0 < t; q0 += 256) {                         // (the end states through LDS: one round trip per 256 tiles, not per tile)
-		__syncthreads();
-		if (q0 + tid < t)
-			ends_sh[tid] = rec_f[(size_t)(q0 + tid) * FC::REC];
-		__syncthreads();
-		const int m = t - q0 < 256 ? t - q0 : 256;
-		for (int q = 0; q < m; ++q) {
-			Cp = Ct;
-			Ct = ends_sh[q] + Atile * Ct;
-		}
-	}
-	if (tid < FE_HIST) {                                          // the previous tile's last samples, from their zero-start values
-		float h = 0.f;
-		if (t > 0) {
-			int e = FE_TILE - FE_HIST + tid + 1;                  // a^(position in that tile + 1)
-			double pw = 1.0, bs = a;
-			while (e) {
-				if (e & 1)
-					pw *= bs;
-				bs *= bs;
-				e >>= 1;
+	double Dlane = 1.0;                                           // a^(16 (lane + 1))
+	#pragma unroll
+	for (int k = 0; k < 6; ++k)
+		if ((lane + 1) & (1 << k))
+			Dlane *= Apow[k];
+	if (lane == 63)
+		Dlane = Apow[6];
+	const double W16 = mono_pow(a, FE_PER * ((lane & 15) + 1)), W32 = mono_pow(a, FE_PER * ((lane & 31) + 1));
+	double Dthread = Dlane;                                       // a^(16 (tid + 1))
+	for (int w = 0; w < wave; ++w)
+		Dthread *= Apow[6];
+	const int tiles = (int)((n + FE_TILE - 1) / FE_TILE);
+	double C = 0.0;                                               // the state entering tile t0
+	for (int t0 = 0; t0 < tiles; t0 += CAR_TB) {
+		double v[CAR_TB];
+		#pragma unroll
+		for (int q = 0; q < CAR_TB; ++q) {
+			const long s0 = (long)(t0 + q) * FE_TILE + (long)tid * FE_PER;
+			float x[FE_PER];
+			{
+				float x8[8];
+				fr.load8(s0, x8);
+				#pragma unroll
+				for (int i = 0; i < 8; ++i) x[i] = x8[i];
+				fr.load8(s0 + 8, x8);
+				#pragma unroll
+				for (int i = 0; i < 8; ++i) x[8 + i] = x8[i];
 			}
-			h = (float)(rec_f[(size_t)(t - 1) * FC::REC + 1 + tid] + pw * Cp);
+			double sl = 0.0;
+			#pragma unroll
+			for (int i = 0; i < FE_PER; ++i)
+				sl = a * sl + g * (double)x[i];
+			sl = WScan<double>::run(sl, Apow, W16, W32);          // weighted inclusive scan of the thread ends over the wave
+			if (lane == 63)
+				wave_end[q][wave] = sl;
+			v[q] = sl;
 		}
-		ydc[pad(tid)] = h;
-	}
-	const long s0 = (long)t * FE_TILE + (long)tid * FE_PER;
-	fe_tile_local<RATE>(src, base, fb.fmt, n, s0, a, b, Apow, lane, wave, wave_end, y, cin0, tile_end);
-	{
-		double decay = 1.0;                                       // a^(16 * tid): what the tile's own entry state has decayed to at this thread
+		__syncthreads();
 		#pragma unroll
-		for (int sft = 0; sft < 6; ++sft)
-			if (lane & (1 << sft))
-				decay *= Apow[sft];
-		for (int w2 = 0; w2 < wave; ++w2)
-			decay *= Apow[6];
-		const double cin = cin0 + decay * Ct;
-		#pragma unroll
-		for (int i = 0; i < FE_PER; ++i)
-			ydc[pad(FE_HIST + tid * FE_PER + i)] = (float)(y[i] + apow[i] * cin);
+		for (int q = 0; q < CAR_TB; ++q) {
+			double st = 0.0;                                      // zero-start state at the end of the earlier waves of this tile
+			for (int w = 0; w < wave; ++w)
+				st = wave_end[q][w] + Apow[6] * st;
+			const double tile_end = ((wave_end[q][3] + Apow[6] * wave_end[q][2]) + Apow[6] * Apow[6] * wave_end[q][1])
+				+ Apow[6] * Apow[6] * Apow[6] * wave_end[q][0];
+			const double s_true = (v[q] + Dlane * st) + Dthread * C;
+			const long m = (long)(t0 + q) * (FE_TILE / MONO_CK) + (tid >> 2);   // this thread ends sample 16 tid + 15 of its tile
+			if ((tid & 3) == 3 && m < ck_per_frame)
+				ck[m] = s_true;
+			C = tile_end + Atile * C;
+		}
+		__syncthreads();
 	}
-	__syncthreads();
-	// Hilbert<cmplx,21>: centre tap 10 back, odd taps +-1,3,5,7,9 around it.  Thread tid takes the samples tid + 256 i: consecutive
-	// words of LDS across the lanes, 512 contiguous bytes of z per wave instruction
-	const long t0 = (long)t * FE_TILE;
-	#pragma unroll 4
-	for (int i = 0; i < FE_PER; ++i) {
-		const int li = FE_HIST + tid + 256 * i;                   // index of sample t0 + tid + 256 i ; centre at li-10
-		const int c = li - FE_C;
-		float re = co.reco * ydc[pad(c)];
-		float im = co.imco[0] * (ydc[pad(c - 1)] - ydc[pad(c + 1)]);
-		#pragma unroll
-		for (int k = 1; k < FE_NIM; ++k)
-			im += co.imco[k] * (ydc[pad(c - (2 * k + 1))] - ydc[pad(c + (2 * k + 1))]);
-		if (t0 + tid + 256 * i < n)
-			z[t0 + tid + 256 * i] = mk(re, im);
-	}
+}
+
+// the whole analytic signal of the frames (the ANALYTIC tap; the pipeline does not run this)
+template <int RATE>
+__global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, MonoArgs ma, cf *__restrict__ z_all)
+{
+	const int f = blockIdx.x, tid = threadIdx.x;
+	__shared__ typename MonoCover<RATE, 256>::Shared msh;
+	MonoCover<RATE, 256> mc;
+	mc.init(mono_frame(fb, ma.ck, ma.ck_per_frame, f), ma, &msh, z_all + (size_t)f * fb.samples_per_frame, tid);
+	mc.cover(ma, 0, fb.samples_per_frame, tid);
 }
 
 // ---------------------------------------------------------------- D2 + D3 sync
@@ -375,9 +278,14 @@ __device__ bool sc_process(cf *buf, cf *xr, const SampleSrc &src, const cf *tw, 
 // SPLIT = true: the scan stops at the first trigger and leaves (g, index_max, phase_max) in the frame's state; the accept
 // path runs as k_sync_accept with a whole workgroup per frame.  At 44.1 / 48 kHz the three 3528 / 3840-point transforms of
 // the accept path by ONE wave through global scratch (256 VGPRs + spills) were 60 % of this kernel's time.
-template <int RATE, bool SPLIT>
-__global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_sync(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
-	const cf *__restrict__ kern, SyncState *__restrict__ st_all, cf *__restrict__ scratch)
+// MONO: z_all is written here - the analytic signal of the samples the scan walks, span by span ahead of it (mono_front.h)
+struct NoShared {};
+#ifndef SYNC_WAVES_SPLIT_MONO
+#define SYNC_WAVES_SPLIT_MONO 3 // the same for mono input (the scan forms the analytic signal too): 168 VGPRs
+#endif
+template <int RATE, bool SPLIT, bool MONO>
+__global__ __launch_bounds__(64, SPLIT ? (MONO ? SYNC_WAVES_SPLIT_MONO : SYNC_WAVES_SPLIT) : SYNC_WAVES) void k_sync(FrameBatch fb, cf *__restrict__ z_all, const cf *__restrict__ tw,
+	const cf *__restrict__ kern, SyncState *__restrict__ st_all, cf *__restrict__ scratch, MonoArgs ma)
 {
 	typedef RateCfg<RATE> RC;
 	constexpr int BUFFER_LEN = RC::BUFFER_LEN, SEARCH_POS = RC::SEARCH_POS, HALF_LEN = RC::HS, GUARD_LEN = RC::GL;
@@ -392,6 +300,17 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 	SampleSrc src{ (const char *)fb.samples + (size_t)f * fb.frame_stride_bytes, fb.fmt, fb.channels, n,
 		fb.channels == 1 ? z_all + (size_t)f * fb.samples_per_frame : nullptr };
 	__shared__ SyncShared<RATE, SPLIT> sh;
+	__shared__ std::conditional_t<MONO, typename MonoCover<RATE, 64>::Shared, NoShared> msh;
+	MonoCover<RATE, 64> mc;
+	constexpr int D = BUFFER_LEN - 1 - (SEARCH_POS + HALF_LEN);   // P at time t: its newest pair is (t - D, t - D + HALF_LEN)
+	if constexpr (MONO)
+		mc.init(mono_frame(fb, ma.ck, ma.ck_per_frame, f), ma, &msh, z_all + (size_t)f * fb.samples_per_frame, lane);
+	auto need = [&](long p_lo, long p_hi) {                       // MONO: the analytic signal of [p_lo, p_hi) before it is read
+		if constexpr (MONO) {
+			mc.cover(ma, p_lo, p_hi, lane);
+			__syncthreads();
+		}
+	};
 	cf *fbuf = SYNC_FFT_LDS(RATE) && !SPLIT ? sh.buf : scratch + (size_t)f * 2 * HALF_LEN;
 	cf *fxr = SYNC_FFT_LDS(RATE) && !SPLIT ? sh.xr : scratch + (size_t)f * 2 * HALF_LEN + HALF_LEN;
 	for (int i = lane; i < MRING + MRING / 8; i += 64)
@@ -404,6 +323,7 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 	// running window sums at time T0-1
 	double Wr = 0.0, Wi = 0.0, Wp = 0.0, Wm = 0.0;
 	if (T0 > 0) {
+		need(T0 - 1 - D - (HALF_LEN - 1), T0 - D + HALF_LEN);
 		direct_P<RATE>(src, T0 - 1, lane, Wr, Wi);
 		Wp = direct_R<RATE>(src, T0 - 1, lane);
 	}
@@ -436,9 +356,13 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 			};
 			// the whole tile's sample window inside the frame and int16 pairs (the rule): no format switch, no bounds checks
 			const long w_lo = T0 - (BUFFER_LEN - 1 - (SEARCH_POS + HALF_LEN)) - HALF_LEN, w_hi = w_lo + TILE + 2 * HALF_LEN;
+			need(w_lo, w_hi);
 			if (src.mode() == 1 && w_lo >= 0 && w_hi <= n) {
 				const short2 *p = (const short2 *)src.base;
 				phase1([&](long i) { const short2 v = p[i]; return mk(div_32767((float)v.x), div_32767((float)v.y)); });
+			} else if (MONO && w_lo >= 0 && w_hi <= n) {
+				const cf *p = src.analytic;
+				phase1([&](long i) { return p[i]; });
 			} else {
 				phase1([&](long i) { return src.at(i); });
 			}
@@ -515,6 +439,7 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 				long tp = nmax - MATCH_DEL;                    // decode.cc:91 delay(arg(P))
 				if (tp >= 0) {
 					double pr, pi;
+					need(tp - D - (HALF_LEN - 1), tp - D + HALF_LEN + 1);
 					direct_P<RATE>(src, tp, lane, pr, pi);
 					phase_max = atan2f((float)pi, (float)pr);
 				}
@@ -529,6 +454,7 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 			} else {
 				int sp;
 				float cfo;
+				need((long)g - (BUFFER_LEN - 1) + (SEARCH_POS - index_max) + HALF_LEN, (long)g - (BUFFER_LEN - 1) + (SEARCH_POS - index_max) + 2 * HALF_LEN);
 				if (sc_process<RATE>(fbuf, fxr, src, tw, kern, g, index_max, phase_max, lane, sp, cfo)) {
 					found = true;
 					st.symbol_pos = sp;
@@ -554,9 +480,9 @@ __global__ __launch_bounds__(64, SPLIT ? SYNC_WAVES_SPLIT : SYNC_WAVES) void k_s
 
 // decode.cc:110-151 for a pending trigger, one workgroup per frame: the same arithmetic as sc_process (the transforms
 // are the same Stockham stages, butterfly by butterfly - only shared among 256 threads, in LDS), bit-identical results.
-template <int RATE>
-__global__ __launch_bounds__(256) void k_sync_accept(FrameBatch fb, const cf *__restrict__ z_all, const cf *__restrict__ tw,
-	const cf *__restrict__ kern, SyncState *__restrict__ st_all)
+template <int RATE, bool MONO>
+__global__ __launch_bounds__(256) void k_sync_accept(FrameBatch fb, cf *__restrict__ z_all, const cf *__restrict__ tw,
+	const cf *__restrict__ kern, SyncState *__restrict__ st_all, MonoArgs ma)
 {
 	typedef RateCfg<RATE> RC;
 	constexpr int BUFFER_LEN = RC::BUFFER_LEN, SEARCH_POS = RC::SEARCH_POS, HALF_LEN = RC::HS, GUARD_LEN = RC::GL, NT = 256;
@@ -576,6 +502,12 @@ __global__ __launch_bounds__(256) void k_sync_accept(FrameBatch fb, const cf *__
 	const float frac_cfo = phase_max / (float)HALF_LEN;       // decode.cc:110
 	int symbol_pos = SEARCH_POS - st.pend_index_max;           // decode.cc:114
 	const long base = g - (BUFFER_LEN - 1);
+	if constexpr (MONO) {                                      // the window's analytic signal (mono_front.h)
+		__shared__ typename MonoCover<RATE, 256>::Shared msh;
+		MonoCover<RATE, 256> mc;
+		mc.init(mono_frame(fb, ma.ck, ma.ck_per_frame, f), ma, &msh, z_all + (size_t)f * fb.samples_per_frame, tid);
+		mc.cover(ma, base + symbol_pos + HALF_LEN, base + symbol_pos + 2 * HALF_LEN, tid);
+	}
 	if (tid < (HALF_LEN + NT - 1) / NT)
 		rot[tid] = phasor(frac_cfo, (long)NT * tid);
 	const cf p_thread = phasor(frac_cfo, tid);
@@ -691,45 +623,40 @@ void launch_init_sync(hipStream_t s, int n, SyncState *st, const int32_t *skip_c
 {
 	hipLaunchKernelGGL(k_init_sync, dim3((n + 255) / 256), dim3(256), 0, s, n, st, skip_counts, chunk_flags, attempt_counts);
 }
-size_t front_end_scratch_bytes(int rate, int n, long samples_per_frame)
+void launch_mono_carries(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, double *ck)
 {
-	const size_t tiles = (size_t)((samples_per_frame + FE_TILE - 1) / FE_TILE);
-	size_t rec = 0;
-	RX_RATE_SWITCH(rate, rec = FeCfg<RATE>::REC);
-	return (size_t)n * tiles * rec * sizeof(double);
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_mono_carries<RATE>, dim3(n), dim3(256), 0, s, fb, co, ck, mono_ck_per_frame(fb.samples_per_frame)));
 }
-void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, double *scratch, cf *z)
+void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, MonoArgs ma, cf *z)
 {
-	const int tiles = (int)((fb.samples_per_frame + FE_TILE - 1) / FE_TILE);
-	for (int f0 = 0; f0 < n; f0 += 65535) {                       // gridDim.y
-		const int nf = n - f0 < 65535 ? n - f0 : 65535;
-		FrameBatch fbq = fb;
-		fbq.samples = (const char *)fb.samples + (size_t)f0 * fb.frame_stride_bytes;
-		double *sc = scratch + (size_t)f0 * (front_end_scratch_bytes(rate, 1, fb.samples_per_frame) / sizeof(double));
-		cf *zq = z + (size_t)f0 * fb.samples_per_frame;
-		RX_RATE_SWITCH(rate,
-			hipLaunchKernelGGL(k_front_dc<RATE>, dim3(tiles, nf), dim3(256), 0, s, fbq, co, sc, tiles);
-			hipLaunchKernelGGL(k_front_end<RATE>, dim3(tiles, nf), dim3(256), 0, s, fbq, co, sc, tiles, zq));
-	}
+	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_front_end<RATE>, dim3(n), dim3(256), 0, s, fb, ma, z));
 }
 #ifndef SYNC_SPLIT_ROUNDS
 #define SYNC_SPLIT_ROUNDS 2   // rates above 8 kHz: scan + accept pairs before the one-wave catch-all (a frame needs the catch-all only
                               // after that many rejected triggers; finished frames leave every later launch at once)
 #endif
-void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, cf *scratch)
+template <int RATE, bool MONO>
+static void sync_rounds(hipStream_t s, int n, FrameBatch fb, cf *z, Tables tb, SyncState *st, cf *scratch, const MonoArgs &ma)
 {
 #ifndef SYNC_SPLIT_8K
 #define SYNC_SPLIT_8K 1       // 8 kHz too since round 3: the fused one-wave kernel needs 240 VGPRs and 20 KB of LDS (8 waves per CU,
                               // four rounds of 2048 frames per chunk); the scan alone runs at 16 per CU: 0.83 -> 0.73 ms per 8192 frames
 #endif
-	if (rate != 8000 || SYNC_SPLIT_8K) {
+	if (RATE != 8000 || SYNC_SPLIT_8K) {
 		for (int r = 0; r < SYNC_SPLIT_ROUNDS; ++r) {
-			RX_RATE_SWITCH(rate,
-				hipLaunchKernelGGL((k_sync<RATE, true>), dim3(n), dim3(64), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, scratch);
-				hipLaunchKernelGGL(k_sync_accept<RATE>, dim3(n), dim3(256), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st));
+			hipLaunchKernelGGL((k_sync<RATE, true, MONO>), dim3(n), dim3(64), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, scratch, ma);
+			hipLaunchKernelGGL((k_sync_accept<RATE, MONO>), dim3(n), dim3(256), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, ma);
 		}
 	}
-	RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_sync<RATE, false>), dim3(n), dim3(64), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, scratch));
+	hipLaunchKernelGGL((k_sync<RATE, false, MONO>), dim3(n), dim3(64), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, scratch, ma);
+}
+void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, Tables tb, SyncState *st, cf *scratch, const MonoArgs &ma)
+{
+	if (fb.channels == 1) {
+		RX_RATE_SWITCH(rate, (sync_rounds<RATE, true>(s, n, fb, z, tb, st, scratch, ma)));
+	} else {
+		RX_RATE_SWITCH(rate, (sync_rounds<RATE, false>(s, n, fb, z, tb, st, scratch, ma)));
+	}
 }
 
 }  // namespace rx

@@ -20,6 +20,41 @@ struct FrontCoef {                 // BlockDC::samples(2*(symbol_len+guard_len))
 	float reco, imco[32];          // (filter_len-1)/4 odd-tap pairs: 5 / 10 / 28 / 31 at 8 / 16 / 44.1 / 48 kHz
 };
 
+// Mono input (round 4, mono_front.h): the DC blocker's one-pole low pass s[n] = a s[n-1] + g x[n] (y[n] = b x[n] - s[n-1]) with the
+// powers of a its blocked scans use, computed once on the host in double, and the Hilbert taps.  ck: the state after every 64th
+// sample of every frame (k_mono_carries).
+struct MonoArgs {
+	const double *ck;              // [n][ck_per_frame]
+	int ck_per_frame;
+	float a, g, b;
+	float apw[8];                  // a^1 .. a^8
+	float astep8[6], astep5[6];    // a^(8 2^k), a^(5 2^k): weights of the wave scans over thread chunks of 8 (MonoCover) / 5 (k_demod) samples
+	double awave8, awave5;         // a^512, a^320: what a whole wave of such chunks decays by
+	FrontCoef co;
+};
+inline MonoArgs mono_args(const FrontCoef &co, const double *ck, int ck_per_frame)
+{
+	MonoArgs m;
+	m.ck = ck;
+	m.ck_per_frame = ck_per_frame;
+	const double a = (double)co.dc_a, b = (double)co.dc_b;
+	m.a = (float)a; m.b = (float)b; m.g = (float)(b * (1.0 - a));
+	double p = a;
+	for (int i = 0; i < 8; ++i, p *= a)
+		m.apw[i] = (float)p;
+	double s8 = 1.0, s5 = 1.0;
+	for (int i = 0; i < 8; ++i) s8 *= a;
+	for (int i = 0; i < 5; ++i) s5 *= a;
+	for (int k = 0; k < 6; ++k) {
+		m.astep8[k] = (float)s8; m.astep5[k] = (float)s5;
+		s8 *= s8; s5 *= s5;
+	}
+	m.awave8 = s8; m.awave5 = s5;
+	m.co = co;
+	return m;
+}
+inline int mono_ck_per_frame(long samples_per_frame) { return (int)((samples_per_frame + 63) / 64); }
+
 struct SyncState {                 // per frame, across sync rounds (decode.cc:390-448 loop)
 	long t_next;                   // next sample time to examine
 	long sc_start;                 // stream index of the S&C body
@@ -107,16 +142,18 @@ constexpr int ATTEMPTS_MAX = 65;   // OFDMRX_MAX_SKIP + 1
 
 // ---- launch wrappers (defined next to their kernels) ------------------------
 // `rate` selects the RateCfg instantiation (8000 / 16000 / 44100 / 48000)
-// D1 (mono input): scratch = front_end_scratch_bytes() of doubles (per tile of 4096 samples: its end state + the history samples)
-size_t front_end_scratch_bytes(int rate, int n, long samples_per_frame);
-void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, double *scratch, cf *z);
-void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, cf *scratch);
+// D1 (mono input, mono_front.h): ck = [n][mono_ck_per_frame()] states of the DC blocker; the consumers below form the analytic
+// signal where they read it (ma.ck = ck).  z ([n][samples_per_frame]) is scratch the sync / header kernels (and k_demod above
+// 8 kHz) write the windows they read into; launch_front_end fills all of it (the ANALYTIC tap).  Analytic input: z and ma unused.
+void launch_mono_carries(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, double *ck);
+void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, MonoArgs ma, cf *z);
+void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, Tables tb, SyncState *st, cf *scratch, const MonoArgs &ma);
 // attempts / attempt_counts (nullable): [n][ATTEMPTS_MAX] records of the preambles examined so far, [n] their number
-void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, SyncState *st, int8_t *hdr_soft, Attempt *attempts = nullptr,
-	int32_t *attempt_counts = nullptr);
+void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, const MonoArgs &ma, Tables tb, SyncState *st, int8_t *hdr_soft,
+	Attempt *attempts = nullptr, int32_t *attempt_counts = nullptr);
 void launch_osd_only(hipStream_t s, int n, Tables tb, const int8_t *soft, uint8_t *hard, int32_t *unique);
 bool demod_forms_cons(int rate);   // cons is complete after k_demod (else k_theil_sen forms the rows from the carriers)
-void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, const cf *z, Tables tb, const SyncState *st, cf *cons, cf *carr);
+void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, const MonoArgs &ma, Tables tb, const SyncState *st, cf *cons, cf *carr);
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, float *slope, float *yint, int *chunk_flags);
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
 // D5's rotation + D6-D8 + the syndrome certificate (k_finish.hip: k_back).  cert_mode 0: every frame with a header goes to the list

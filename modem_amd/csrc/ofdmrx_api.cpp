@@ -156,6 +156,7 @@ struct ofdmrx_handle {
 	DevBuf sc_scratch;             // rates above 8 kHz: 2 x symbol_len/2 cf per frame for the S&C trigger part
 	int last_n = 0;           // frames in the last chunk (for taps)
 	bool last_mono = false;
+	FrameBatch last_fb{};     // the last chunk's samples (the ANALYTIC tap forms its frame's analytic signal from them)
 	// timing
 	std::vector<hipEvent_t> ev_pool;
 	size_t ev_used = 0;
@@ -397,8 +398,8 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 	}
 	if (mono) {
 		size_t need = (size_t)std::max(n, h->cap) * (size_t)samples;
-		r = r ? r : h->z.ensure(need * sizeof(cf));
-		r = r ? r : h->dc.ensure(front_end_scratch_bytes(h->rate, std::max(n, h->cap), samples));
+		r = r ? r : h->z.ensure(need * sizeof(cf));           // scratch: only the windows the sync / header kernels read are ever written
+		r = r ? r : h->dc.ensure((size_t)std::max(n, h->cap) * (size_t)mono_ck_per_frame(samples) * sizeof(double));
 	}
 	return r;
 }
@@ -441,11 +442,12 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, FrameBatch fb, int n, con
 {
 	const bool mono = fb.channels == 1;
 	SyncState *st = h->st.as<SyncState>();
-	const cf *z = mono ? h->z.as<cf>() : nullptr;
+	cf *z = mono ? h->z.as<cf>() : nullptr;
+	const MonoArgs ma = mono_args(h->host.front, mono ? h->dc.as<double>() : nullptr, mono_ck_per_frame(fb.samples_per_frame));
 	size_t e0 = mark(h, s);
-	if (mono) {
+	if (mono) {                                               // D1: the DC blocker's states; the rest of it happens in the consumers
 		Range r("ofdmrx:front_end");
-		launch_front_end(s, h->rate, n, fb, h->host.front, h->dc.as<double>(), h->z.as<cf>());
+		launch_mono_carries(s, h->rate, n, fb, h->host.front, h->dc.as<double>());
 	}
 	size_t e1 = mark(h, s);
 	launch_init_sync(s, n, st, d_skip, h->chunk_flags.as<int>(), d_att_counts);
@@ -456,14 +458,14 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, FrameBatch fb, int n, con
 		size_t a = mark(h, s);
 		{
 			Range r("ofdmrx:sync");
-			launch_sync(s, h->rate, n, fb, z, h->dev, st, h->sc_scratch.as<cf>());
+			launch_sync(s, h->rate, n, fb, z, h->dev, st, h->sc_scratch.as<cf>(), ma);
 		}
 		size_t b = mark(h, s);
 		if (round == 0 && ev_after_sync)
 			*ev_after_sync = b;
 		{
 			Range r("ofdmrx:header_osd");
-			launch_header(s, h->rate, n, fb, z, h->dev, st, h->hdr_soft.as<int8_t>(), d_att, d_att_counts);
+			launch_header(s, h->rate, n, fb, z, ma, h->dev, st, h->hdr_soft.as<int8_t>(), d_att, d_att_counts);
 		}
 		size_t c = mark(h, s);
 		h->spans.push_back({ OFDMRX_T_SYNC, a, b });
@@ -472,7 +474,7 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, FrameBatch fb, int n, con
 	}
 	{
 		Range r("ofdmrx:demod");
-		launch_demod(s, h->rate, n, fb, z, h->dev, st, h->cons.as<cf>(), h->carr.as<cf>());
+		launch_demod(s, h->rate, n, fb, z, ma, h->dev, st, h->cons.as<cf>(), h->carr.as<cf>());
 	}
 	size_t d = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_DEMOD, last, d });
@@ -482,6 +484,7 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, FrameBatch fb, int n, con
 	h->last_n = n;
 	h->last_mono = mono;
 	h->last_spf = fb.samples_per_frame;
+	h->last_fb = fb;
 	return 0;
 }
 
@@ -985,6 +988,16 @@ extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *
 	case OFDMRX_TAP_ANALYTIC:
 		if (!h->last_mono)
 			return OFDMRX_E_ARG;
+		{   // the pipeline never forms the whole analytic signal (mono_front.h): this does, for the one frame, from the last chunk's
+			// samples (the caller's buffer for the device entry: it must still be there) and kept states
+			FrameBatch fb1 = h->last_fb;
+			fb1.samples = (const char *)fb1.samples + frame * fb1.frame_stride_bytes;
+			const int ckpf = mono_ck_per_frame(fb1.samples_per_frame);
+			launch_front_end(h->stream, h->rate, 1, fb1, mono_args(h->host.front, h->dc.as<double>() + frame * (size_t)ckpf, ckpf),
+				h->z.as<cf>() + frame * (size_t)h->last_spf);
+			HIP_OK(hipGetLastError());
+			HIP_OK(hipStreamSynchronize(h->stream));
+		}
 		src = h->z.as<cf>() + frame * (size_t)h->last_spf;
 		cap = (size_t)h->last_spf * sizeof(cf);
 		break;

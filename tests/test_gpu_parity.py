@@ -576,6 +576,89 @@ def test_mono_front_end_matches_oracle(rx):
     _close(z, ref, what="analytic signal")
 
 
+# ---------------------------------------------------------------- mono input: the analytic signal formed by its consumers (mono_front.h)
+def _mono_of(pcm2, dc=0):
+    """the real part of an (impaired) analytic stream, plus a DC offset: what a sound card delivers"""
+    return np.clip(pcm2[:, :1].astype(np.int32) + dc, -32768, 32767).astype(np.int16)          # [samples, 1]
+
+
+@pytest.mark.parametrize("db,dc", [(None, 0), (None, 3000), (-30, 900), (-20, -2500), (-15, 40)])
+def test_mono_frames_noise_and_dc(rx, db, dc):
+    """D1 inside the consumers (decode.cc:294-301): 16-bit mono frames, clean / AWGN at three levels, with a DC offset for the DC
+    blocker to remove - every stage against the oracle, which runs the serial fp32 recurrence and the 21-tap Hilbert filter over
+    the whole stream"""
+    p = O.payload_for(70 + (dc & 7))
+    pcm2 = O.encode_pcm(p, channels=2)
+    if db is not None:
+        pcm2 = O.impair(pcm2, noise_db=db, seed=33, frame=abs(dc))
+    _check_against_oracle(rx, _mono_of(pcm2, dc), p, expect_ok=db != -15)     # (-15 dB on a real signal: the CRC fails in every lane)
+
+
+def test_mono_impairment_chain(rx, rxd):
+    """mono + multipath + CFO + SFO + AWGN (README.md:49's chain on a real signal), on the tap handle and on the default handle"""
+    p = O.payload_for(77)
+    extra = dict(cfo_hz=-123.4, sfo_ppm=-80.0, multipath=[(0, 1 + 0j), (9, 0.25 + 0.2j), (31, -0.1 - 0.1j)])
+    pcm = _mono_of(O.impair(O.encode_pcm(p, channels=2), noise_db=-28, seed=7, frame=3, **extra), dc=-700)
+    _check_against_oracle(rx, pcm, p)
+    out, res = rxd.decode(pcm[None])
+    oout, ores = O.decode(pcm)
+    assert int(res[0]["status"]) == ores.status == 0 and (out[0] == oout).all() and (out[0] == p).all()
+    assert int(res[0]["sc_start"]) == ores.sc_start and abs(float(res[0]["cfo_fine"]) - ores.cfo_fine) <= REL
+
+
+def test_mono_analytic_tap_anywhere(rx):
+    """the ANALYTIC tap (k_front_end: the whole frame through MonoCover) with a DC offset and noise; frame 1 of a batch of 2"""
+    p = O.payload_for(5)
+    pcm = _mono_of(O.impair(O.encode_pcm(p, channels=2), noise_db=-25, seed=2, frame=0), dc=5000)
+    rx.decode(np.stack([pcm[::-1].copy(), pcm]))
+    pcm = np.ascontiguousarray(pcm)
+    z = rx.tap("ANALYTIC", 1, samples=pcm.shape[0])
+    ref = np.zeros((pcm.shape[0], 2), np.float32)
+    O.lib().orc_front_end(O.ptr(pcm), O.FMT_S16, 1, pcm.shape[0], O.ptr(ref))
+    _close(z, ref, what="analytic signal")
+
+
+def test_mono_skip_loop_and_late_preamble(rxd):
+    """the scan forms the analytic signal as it walks (k_sync, MONO): a stream whose preamble comes after 30 000 samples of noise
+    with a DC offset, a stream of three frames with the second header destroyed (SKIP 0 / 1 / 2: the scan resumes behind a
+    rejected preamble), a frame cut inside its payload and noise only - against the oracle"""
+    p = O.payload_for(41, count=3)
+    pcm = O.encode_pcm(p, channels=1).reshape(-1).copy()
+    ref = [O.decode(pcm[:, None], skip=k)[1] for k in range(3)]
+    hdr2 = ref[1].sc_start + 1440
+    pcm[hdr2: hdr2 + 1280] = 0
+    n = pcm.shape[0]
+    rng = np.random.default_rng(4)
+    one = O.encode_pcm(p[:5380], channels=1).reshape(-1)
+    late = (rng.integers(-300, 300, size=n) + 1200).astype(np.int16)
+    late[30000: 30000 + one.shape[0]] = np.clip(one.astype(np.int32) + 1200, -32768, 32767)
+    cut = np.zeros(n, np.int16)
+    cut[:50000] = one[:50000]
+    noise = rng.integers(-200, 200, size=n).astype(np.int16)
+    batch = np.ascontiguousarray(np.stack([pcm, pcm, pcm, late, cut, noise])[:, :, None])
+    skips = [0, 1, 2, 0, 0, 0]
+    out, res, (alog, acnt) = rxd.decode(batch, skip=skips, attempts=True)
+    for f in range(6):
+        oout, ores = O.decode(batch[f], skip=skips[f])
+        assert int(res["status"][f]) == ores.status, f
+        assert (out[f] == oout).all(), f
+        if ores.sc_start >= 0:
+            assert int(res["sc_start"][f]) == ores.sc_start and int(res["n_sync_rejects"][f]) == ores.n_sync_rejects, f
+            assert abs(float(res["cfo_rad"][f]) - ores.cfo_rad) <= REL
+    assert list(acnt[:3]) == [1, 2, 3]
+    assert int(res["status"][3]) == 0 and (out[3] == p[:5380]).all() and int(res["status"][5]) == 1
+
+
+def test_mono_8bit_and_float_input(rxd):
+    """the other sample formats of mono input (u8: `make test`, Makefile:14; f32) through the same consumers"""
+    p = O.payload_for(9)
+    pcm8 = O.encode_pcm(p, bits=8, channels=1)
+    out, res = rxd.decode(pcm8[None])
+    assert int(res[0]["status"]) == 0 and (out[0] == p).all()
+    oout, ores = O.decode(pcm8)
+    assert int(res[0]["sc_start"]) == ores.sc_start and (out[0] == oout).all()
+
+
 def test_8bit_input(rx):
     p = O.payload_for(8)
     pcm = O.encode_pcm(p, bits=8, channels=1)                     # `make test` format (Makefile:14)
