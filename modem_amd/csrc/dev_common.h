@@ -366,6 +366,7 @@ __device__ __forceinline__ long uniform_l(long v)
 	const int lo = __builtin_amdgcn_readfirstlane((int)v), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
 	return ((long)hi << 32) | (long)(unsigned)lo;
 }
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ double uniform_d(double v)
 {
 	const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));

@@ -74,14 +74,11 @@ template <int P, int TWC> __device__ __forceinline__ void fft256_stage_swz(cf *b
 // hang on the transform's own barriers (thread chunks + wave scan before the barrier that follows the transform, the waves' entry
 // states + y[n] = b x[n] - s[n-1] into LDS after it), the 21-tap Hilbert filter forms a loader thread's five samples n' + 256 a
 // out of LDS where the analytic path converts five int16 pairs.  Nothing of the analytic signal is ever in memory.
-// MONO = 1 (the other rates, whose loaders take their points at the top of a symbol): the symbol's window through MonoCover into
-// the z scratch, its staging area in the (then free) row buffer.
-#ifndef DEMOD_MONO_LDS
-#define DEMOD_MONO_LDS(R) ((R) == 8000)
-#endif
+// Mono input at the other rates arrives as the analytic signal z a front pass wrote (k_front_end), MONO = 0 like 2-channel input.
 #ifndef DEMOD_MONO_WAVES
-#define DEMOD_MONO_WAVES 6    // register budget of the MONO = 2 instantiation (waves per SIMD): 6 = 80 VGPRs = four workgroups per CU.  Measured per 8192
-                              // frames: 7 (72 VGPRs, five workgroups, 84 bytes of spills) 2.46 ms, 6: 2.09, 5 (96): 2.34, 4 (128, three workgroups): 3.05
+#define DEMOD_MONO_WAVES 5    // register budget of the MONO = 2 instantiation (waves per SIMD): 5 = 96 VGPRs, four workgroups per CU (LDS + registers).
+                              // Measured per 8192 frames: 7 (72 VGPRs, five workgroups, spills) 2.46 - 2.67 ms, 6 (80) 2.04 - 2.10, 5 (96) 2.02, 4 (128, three
+                              // workgroups) 3.05
 #endif
 template <int RATE, int MONO>
 __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : DifCfg<RATE>::WAVES) void k_demod(FrameBatch fb, cf *__restrict__ z_all, MonoArgs ma, Tables tb,
@@ -120,7 +117,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 		static_assert(MONO != 2 || (MTH * MPER == SYM_STRIDE && MTH <= NT && NS == 256 && NQ == 1 && MonoCfg<RATE>::REACH <= 32 && GUARD_LEN % MPER == 0
 			&& (MTH + 63) / 64 == 5 && MTH % 64 == 32), "span layout");
 		__shared__ float ybuf[MONO == 2 ? SYM_STRIDE - YOFF : 1];
-		__shared__ double mwe[5];
+		__shared__ float mwe[5];
 		fft_compact_twiddles<NS, NT, SYMBOL_LEN>(tw_sub, tb.tw_sym, tid);
 		if (DC::TWR_LDS)
 			for (int i = tid; i < (R1 - 1) * NS; i += NT)
@@ -152,26 +149,34 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 		// ---- MONO = 2: the span recurrence (see the head of the kernel)
 		const MonoFrame mfr = mono_frame(fb, ma.ck, ma.ck_per_frame, f);
 		const long span0 = MONO == 2 ? uniform_l(body0 - GUARD_LEN) : 0;   // first sample of symbol 0's span
-		double mS = 0.0, mAspan = 1.0, mAw = 1.0;                     // s before the span that is next to run; a^1440; a^(320 wave)
-		float mAlane = 1.f, mW16 = 1.f, mW32 = 1.f, mx[MPER] = {}, my0[MPER] = {};
-		auto mono_raw = [&](int sym) {                                // the span's samples (a symbol ahead of their use)
+		float mS = 0.f, mAspan = 1.f, mAw = 1.f, mAwave = 1.f;        // s before the span that is next to run; a^1440; a^(320 wave); a^320
+		const float mg = ma.g * mfr.scale(), mb = ma.b * mfr.scale();   // (the samples are taken as the PCM's integers, mono_front.h)
+		float mAlane = 1.f, mW16 = 1.f, mW32 = 1.f, my0[MPER] = {};
+		// the span's samples, fetched a symbol ahead of their use and left as they come (the PCM's integers; f32 input: the bits) - a
+		// conversion here would wait for the loads where they are issued
+		int mxi[MPER] = {};
+		bool mpacked = false;                                         // int16 inside the frame: the five samples as 10 bytes in mxi[0..2]
+		const bool mfloat = mfr.fmt == 2;
+		auto mono_raw = [&](int sym) {
 			const long e0 = span0 + (long)sym * SYM_STRIDE;           // (uniform; a frame has fewer than 2^31 samples)
 			const int n32 = (int)mfr.n;
 			if (tid < MTH) {
-				if (mfr.fmt == 0 && e0 >= 0 && e0 + SYM_STRIDE <= mfr.n) {   // the span inside the frame, int16: the rule
-					const int16_t *q = (const int16_t *)mfr.base + e0;
-					#pragma unroll
-					for (int i = 0; i < MPER; ++i)
-						mx[i] = div_32767((float)q[tid * MPER + i]);
+				mpacked = mfr.fmt == 0 && e0 >= 0 && e0 + SYM_STRIDE <= mfr.n;   // the span inside the frame, int16: the rule
+				if (mpacked) {
+					typedef uint32_t __attribute__((aligned(2))) word_at_2;   // (10 tid bytes into the span: two-byte aligned)
+					const int16_t *q = (const int16_t *)mfr.base + e0 + tid * MPER;
+					mxi[0] = (int)((const word_at_2 *)q)[0];
+					mxi[1] = (int)((const word_at_2 *)q)[1];
+					mxi[2] = (int)((const uint16_t *)q)[4];
 				} else {                                              // any format, zeros outside the frame; straight-line code
 					#pragma unroll
 					for (int i = 0; i < MPER; ++i) {
 						const int j = (int)e0 + tid * MPER + i, jc = min(max(j, 0), n32 - 1);
-						float v;
-						if (mfr.fmt == 0) v = div_32767((float)((const int16_t *)mfr.base)[jc]);
-						else if (mfr.fmt == 1) v = div_127((float)((int)((const uint8_t *)mfr.base)[jc] - 128));
-						else v = ((const float *)mfr.base)[jc];
-						mx[i] = j == jc ? v : 0.f;
+						int v;
+						if (mfr.fmt == 0) v = ((const int16_t *)mfr.base)[jc];
+						else if (mfr.fmt == 1) v = (int)((const uint8_t *)mfr.base)[jc] - 128;
+						else v = ((const int *)mfr.base)[jc];
+						mxi[i] = j == jc ? v : 0;
 					}
 				}
 			}
@@ -180,31 +185,40 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 		// scan's value of the lane before + a^(5 lane) (the state entering the wave): everything but the last term is known before
 		// the barrier - my0 - and the last term is a per-thread power of a times a per-wave number that needs the other waves' ends
 		auto mono_part1 = [&]() {
-			float acc = 0.f, sl[MPER];
+			float acc = 0.f, sl[MPER], mx[MPER];
+			if (mpacked) {
+				mx[0] = (float)(short)(mxi[0] & 0xffff); mx[1] = (float)(mxi[0] >> 16);
+				mx[2] = (float)(short)(mxi[1] & 0xffff); mx[3] = (float)(mxi[1] >> 16);
+				mx[4] = (float)(short)mxi[2];
+			} else {
+				#pragma unroll
+				for (int i = 0; i < MPER; ++i)
+					mx[i] = mfloat ? __int_as_float(mxi[i]) : (float)mxi[i];
+			}
 			#pragma unroll
 			for (int i = 0; i < MPER; ++i) {
 				sl[i] = acc;                                          // the chunk's state BEFORE sample i
-				acc = fmaf(ma.a, acc, ma.g * mx[i]);
+				acc = fmaf(ma.a, acc, mg * mx[i]);
 			}
 			const float v = WScan<float>::run(acc, ma.astep5, mW16, mW32);   // weighted inclusive scan of the chunk ends over the wave
 			if (lane == (wave < 4 ? 63 : 31))                         // the span ends with thread 287 = lane 31 of wave 4
-				mwe[wave] = (double)v;
+				mwe[wave] = v;
 			const float cw0 = dpp_f<0x138>(v);                        // the lane before (lane 0: 0)
-			my0[0] = fmaf(ma.b, mx[0], -cw0);
+			my0[0] = fmaf(mb, mx[0], -cw0);
 			#pragma unroll
 			for (int i = 1; i < MPER; ++i)
-				my0[i] = fmaf(ma.b, mx[i], -fmaf(ma.apw[i - 1], cw0, sl[i]));
+				my0[i] = fmaf(mb, mx[i], -fmaf(ma.apw[i - 1], cw0, sl[i]));
 		};
 		auto mono_part2 = [&]() {                                     // (behind a barrier) the waves' entry states, y into LDS
-			double st = 0.0, stw = 0.0;                               // the span from a zero state: at the start of wave w / of this wave
+			float st = 0.f, stw = 0.f;                                // the span from a zero state: at the start of wave w / of this wave
 			#pragma unroll
 			for (int w = 0; w < 4; ++w) {
-				st = mwe[w] + ma.awave5 * st;
+				st = fmaf(mAwave, st, mwe[w]);
 				if (w < wave)
 					stw = st;
 			}
-			const float cl = mAlane * (float)uniform_d(stw + mAw * mS);   // a^(5 lane) x the state entering the wave
-			mS = uniform_d((mwe[4] + (double)ma.astep5[5] * st) + mAspan * mS);   // a^160 st_4: wave 4 ends after 32 chunks
+			const float cl = mAlane * uniform_f(fmaf(mAw, mS, stw));  // a^(5 lane) x the state entering the wave
+			mS = uniform_f(fmaf(mAspan, mS, fmaf(ma.astep5[5], st, mwe[4])));   // a^160 st_4: wave 4 ends after 32 chunks
 			if (tid >= YOFF / MPER && tid < MTH) {
 				float *yo = ybuf + (tid * MPER - YOFF);
 				yo[0] = my0[0] - cl;
@@ -218,13 +232,14 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 			mAlane = (float)mono_pow((double)ma.a, MPER * lane);
 			mW16 = (float)mono_pow((double)ma.a, MPER * ((lane & 15) + 1));
 			mW32 = (float)mono_pow((double)ma.a, MPER * ((lane & 31) + 1));
-			mAspan = uniform_d(mono_pow((double)ma.a, SYM_STRIDE));
-			mAw = uniform_d(mono_pow((double)ma.a, 64 * MPER * wave));
+			mAspan = uniform_f((float)mono_pow((double)ma.a, SYM_STRIDE));
+			mAw = uniform_f((float)mono_pow((double)ma.a, 64 * MPER * wave));
+			mAwave = (float)ma.awave5;
 			if (span0 > 0) {
 				const long c0 = span0 / MONO_CK * MONO_CK;
 				const int gap = (int)(span0 - c0);
-				const double term = lane < gap ? (double)ma.g * (double)mfr.scalar(c0 + lane) * mono_pow((double)ma.a, gap - 1 - lane) : 0.0;
-				mS = uniform_d(mono_pow((double)ma.a, gap) * mfr.state_before(c0) + wave_sum_d(term));
+				const double term = lane < gap ? (double)mg * (double)mfr.raw(c0 + lane) * mono_pow((double)ma.a, gap - 1 - lane) : 0.0;
+				mS = uniform_f((float)(mono_pow((double)ma.a, gap) * mfr.state_before(c0) + wave_sum_d(term)));
 			}
 			mono_raw(0);
 			mono_part1();
@@ -233,14 +248,15 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 			mono_raw(1);
 			__syncthreads();
 		}
-		MonoCover<RATE, NT> mcov;
-		if constexpr (MONO == 1) {
-			static_assert(sizeof(typename MonoCover<RATE, NT>::Shared) <= sizeof(row), "the cover's staging area lives in the row buffer");
-			mcov.init(mfr, ma, reinterpret_cast<typename MonoCover<RATE, NT>::Shared *>(row), z_all + (size_t)f * fb.samples_per_frame, tid);
-		}
 		auto symbols = [&](auto M) {
 		constexpr int MODE = decltype(M)::value;
 		cf pre[NQ][R1];
+#ifndef DEMOD_RAW_AHEAD
+#define DEMOD_RAW_AHEAD 1     // int16 pairs fetched a symbol ahead stay as they come - one register per point, no conversion (and no wait for
+                              // the load) where the load is issued - and are converted where the symbol is taken up
+#endif
+		constexpr bool RAW = DEMOD_RAW_AHEAD && MODE == 1 && MONO == 0 && NQ <= DEMOD_PREFETCH_NQ;
+		int praw[RAW ? NQ : 1][RAW ? R1 : 1];
 		auto fetch = [&](int sym) {
 			const long t0 = body0 + (long)sym * SYM_STRIDE;       // wave-uniform
 			if constexpr (MONO == 2) {
@@ -260,12 +276,6 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 				}
 				return;
 			}
-			if constexpr (MONO == 1) {
-				if (sym <= md.rows) {
-					mcov.any = false;                             // (the staging area was the row buffer in between)
-					mcov.cover(ma, t0, t0 + SYMBOL_LEN, tid);
-				}
-			}
 			if (MODE == 1 && sym <= md.rows && t0 >= 0 && t0 + SYMBOL_LEN <= src.n) {
 				// the whole symbol lies inside the frame (the rule): int16 pairs from a uniform base, no per-sample checks
 				const short2 *p = (const short2 *)src.base + t0;
@@ -275,9 +285,23 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 					if (np < NS) {
 						#pragma unroll
 						for (int a = 0; a < R1; ++a) {
-							const short2 x = p[np + NS * a];
-							pre[q][a] = mk(div_32767((float)x.x), div_32767((float)x.y));
+							if constexpr (RAW)
+								praw[q][a] = ((const int *)p)[np + NS * a];
+							else {
+								const short2 x = p[np + NS * a];
+								pre[q][a] = mk(div_32767((float)x.x), div_32767((float)x.y));
+							}
 						}
+					}
+				}
+			} else if constexpr (RAW) {                           // a symbol that leaves the frame: zeros outside (SampleSrc::at)
+				#pragma unroll
+				for (int q = 0; q < NQ; ++q) {
+					const int np = tid + NT * q;
+					#pragma unroll
+					for (int a = 0; a < R1; ++a) {
+						const long i = t0 + np + NS * a;
+						praw[q][a] = (np < NS && sym <= md.rows && i >= 0 && i < src.n) ? ((const int *)src.base)[i] : 0;
 					}
 				}
 			} else {
@@ -302,6 +326,11 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 				const int np = tid + NT * q;
 				if (np < NS) {
 					cf v[R1];
+					if constexpr (RAW) {
+						#pragma unroll
+						for (int a = 0; a < R1; ++a)
+							pre[q][a] = mk(div_32767((float)(short)(praw[q][a] & 0xffff)), div_32767((float)(praw[q][a] >> 16)));
+					}
 					if (NQ == 1) {
 						#pragma unroll
 						for (int a = 0; a < R1; ++a)
@@ -391,8 +420,8 @@ __global__ __launch_bounds__(256) void k_fft_debug(int len, int sign, const cf *
 bool demod_forms_cons(int rate) { return DEMOD_CONS_OUT(rate); }
 void launch_demod(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, const MonoArgs &ma, Tables tb, const SyncState *st, cf *cons, cf *carr)
 {
-	if (fb.channels == 1) {
-		RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_demod<RATE, DEMOD_MONO_LDS(RATE) ? 2 : 1>), dim3(n), dim3(DifCfg<RATE>::NT), 0, s, fb, z, ma, tb, st, cons, carr));
+	if (fb.channels == 1 && mono_fused(rate)) {
+		hipLaunchKernelGGL((k_demod<8000, 2>), dim3(n), dim3(DifCfg<8000>::NT), 0, s, fb, z, ma, tb, st, cons, carr);
 	} else {
 		RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_demod<RATE, 0>), dim3(n), dim3(DifCfg<RATE>::NT), 0, s, fb, z, ma, tb, st, cons, carr));
 	}

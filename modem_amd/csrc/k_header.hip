@@ -568,8 +568,8 @@ void launch_header(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, const M
 	Attempt *attempts, int32_t *attempt_counts)
 {
 	Attempt *att = attempt_counts ? attempts : nullptr;       // (both or none)
-	if (fb.channels == 1) {
-		RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_header<RATE, true>), dim3(n), dim3(256), 0, s, fb, z, ma, tb, st, hdr_soft, att, attempt_counts));
+	if (fb.channels == 1 && mono_fused(rate)) {
+		hipLaunchKernelGGL((k_header<8000, true>), dim3(n), dim3(256), 0, s, fb, z, ma, tb, st, hdr_soft, att, attempt_counts);
 	} else {
 		RX_RATE_SWITCH(rate, hipLaunchKernelGGL((k_header<RATE, false>), dim3(n), dim3(256), 0, s, fb, z, ma, tb, st, hdr_soft, att, attempt_counts));
 	}

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_mono_carries(FrameBatch fb, FrontCoef c
 	MonoFrame fr{ base, fb.fmt, n, nullptr };
 	double *ck = ck_all + (size_t)f * ck_per_frame;
 	__shared__ double wave_end[CAR_TB][4];
-	const double a = (double)co.dc_a, g = (double)co.dc_b * (1.0 - a);
+	const double a = (double)co.dc_a, g = (double)co.dc_b * (1.0 - a) * (double)fr.scale();   // (the samples come as the PCM's integers)
 	double Apow[7];                                               // a^(16 2^k): Apow[6] = a^1024 decays a whole wave
 	Apow[0] = mono_pow(a, FE_PER);
 	#pragma unroll
@@ -106,15 +106,20 @@ __global__ __launch_bounds__(256) void k_mono_carries(FrameBatch fb, FrontCoef c
 	}
 }
 
-// the whole analytic signal of the frames (the ANALYTIC tap; the pipeline does not run this)
+// the whole analytic signal of the frames (rates above 8 kHz; the ANALYTIC tap): a workgroup per stretch of FE_STRETCH samples, which
+// starts on the kept state before it - four spans of 2048 samples cover a stretch and the filter's reach + the 63 samples back to
+// that state
+constexpr int FE_STRETCH = 4 * 2048 - 256;
 template <int RATE>
 __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, MonoArgs ma, cf *__restrict__ z_all)
 {
-	const int f = blockIdx.x, tid = threadIdx.x;
+	static_assert(MonoCfg<RATE>::REACH + MONO_CK <= 256, "a stretch and its lead-in fit four spans");
+	const int f = blockIdx.y, tid = threadIdx.x;
+	const long lo = (long)blockIdx.x * FE_STRETCH;
 	__shared__ typename MonoCover<RATE, 256>::Shared msh;
 	MonoCover<RATE, 256> mc;
 	mc.init(mono_frame(fb, ma.ck, ma.ck_per_frame, f), ma, &msh, z_all + (size_t)f * fb.samples_per_frame, tid);
-	mc.cover(ma, 0, fb.samples_per_frame, tid);
+	mc.cover(ma, lo, lo + FE_STRETCH, tid);
 }
 
 // ---------------------------------------------------------------- D2 + D3 sync
@@ -356,7 +361,15 @@ __global__ __launch_bounds__(64, SPLIT ? (MONO ? SYNC_WAVES_SPLIT_MONO : SYNC_WA
 			};
 			// the whole tile's sample window inside the frame and int16 pairs (the rule): no format switch, no bounds checks
 			const long w_lo = T0 - (BUFFER_LEN - 1 - (SEARCH_POS + HALF_LEN)) - HALF_LEN, w_hi = w_lo + TILE + 2 * HALF_LEN;
-			need(w_lo, w_hi);
+			if constexpr (MONO) {
+				// this tile's window was formed a tile ago (the first tile's: here); the NEXT tile's span is formed now, so that its
+				// stores are long done when they are read - the fence at the top of the next round then costs nothing
+				if (!mc.any || mc.next < w_hi)
+					need(w_lo, w_hi);
+				else
+					__syncthreads();
+				mc.cover(ma, w_lo, w_hi + TILE, lane);
+			}
 			if (src.mode() == 1 && w_lo >= 0 && w_hi <= n) {
 				const short2 *p = (const short2 *)src.base;
 				phase1([&](long i) { const short2 v = p[i]; return mk(div_32767((float)v.x), div_32767((float)v.y)); });
@@ -629,7 +642,15 @@ void launch_mono_carries(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoe
 }
 void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, MonoArgs ma, cf *z)
 {
-	RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_front_end<RATE>, dim3(n), dim3(256), 0, s, fb, ma, z));
+	const int stretches = (int)((fb.samples_per_frame + FE_STRETCH - 1) / FE_STRETCH);
+	for (int f0 = 0; f0 < n; f0 += 65535) {                       // gridDim.y
+		const int nf = n - f0 < 65535 ? n - f0 : 65535;
+		FrameBatch fbq = fb;
+		fbq.samples = (const char *)fb.samples + (size_t)f0 * fb.frame_stride_bytes;
+		MonoArgs maq = ma;
+		maq.ck = ma.ck + (size_t)f0 * ma.ck_per_frame;
+		RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_front_end<RATE>, dim3(stretches, nf), dim3(256), 0, s, fbq, maq, z + (size_t)f0 * fb.samples_per_frame));
+	}
 }
 #ifndef SYNC_SPLIT_ROUNDS
 #define SYNC_SPLIT_ROUNDS 2   // rates above 8 kHz: scan + accept pairs before the one-wave catch-all (a frame needs the catch-all only
@@ -652,8 +673,8 @@ static void sync_rounds(hipStream_t s, int n, FrameBatch fb, cf *z, Tables tb, S
 }
 void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, Tables tb, SyncState *st, cf *scratch, const MonoArgs &ma)
 {
-	if (fb.channels == 1) {
-		RX_RATE_SWITCH(rate, (sync_rounds<RATE, true>(s, n, fb, z, tb, st, scratch, ma)));
+	if (fb.channels == 1 && mono_fused(rate)) {
+		sync_rounds<8000, true>(s, n, fb, z, tb, st, scratch, ma);
 	} else {
 		RX_RATE_SWITCH(rate, (sync_rounds<RATE, false>(s, n, fb, z, tb, st, scratch, ma)));
 	}

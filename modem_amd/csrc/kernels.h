@@ -54,6 +54,9 @@ inline MonoArgs mono_args(const FrontCoef &co, const double *ck, int ck_per_fram
 	return m;
 }
 inline int mono_ck_per_frame(long samples_per_frame) { return (int)((samples_per_frame + 63) / 64); }
+// 8 kHz: the consumers form the analytic signal (launch_sync / _header / _demod with channels = 1).  The other rates (Hilbert filters of
+// 41 - 125 taps, symbols of 2560 - 7680 samples) run launch_front_end over the whole stream first and read z like 2-channel input.
+inline bool mono_fused(int rate) { return rate == 8000; }
 
 struct SyncState {                 // per frame, across sync rounds (decode.cc:390-448 loop)
 	long t_next;                   // next sample time to examine
@@ -142,9 +145,9 @@ constexpr int ATTEMPTS_MAX = 65;   // OFDMRX_MAX_SKIP + 1
 
 // ---- launch wrappers (defined next to their kernels) ------------------------
 // `rate` selects the RateCfg instantiation (8000 / 16000 / 44100 / 48000)
-// D1 (mono input, mono_front.h): ck = [n][mono_ck_per_frame()] states of the DC blocker; the consumers below form the analytic
-// signal where they read it (ma.ck = ck).  z ([n][samples_per_frame]) is scratch the sync / header kernels (and k_demod above
-// 8 kHz) write the windows they read into; launch_front_end fills all of it (the ANALYTIC tap).  Analytic input: z and ma unused.
+// D1 (mono input, mono_front.h): ck = [n][mono_ck_per_frame()] states of the DC blocker; with mono_fused(rate) the consumers below
+// form the analytic signal where they read it (ma.ck = ck) and z ([n][samples_per_frame]) is scratch the sync / header kernels
+// write the windows they read into; launch_front_end fills all of z (the other rates; the ANALYTIC tap).  2-channel input: z, ma unused.
 void launch_mono_carries(hipStream_t s, int rate, int n, FrameBatch fb, FrontCoef co, double *ck);
 void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, MonoArgs ma, cf *z);
 void launch_sync(hipStream_t s, int rate, int n, FrameBatch fb, cf *z, Tables tb, SyncState *st, cf *scratch, const MonoArgs &ma);

@@ -39,7 +39,18 @@ struct MonoFrame {
 		if (fmt == 1) return div_127((float)((int)((const uint8_t *)base)[i] - 128));
 		return ((const float *)base)[i];
 	}
-	// eight consecutive samples from pos (pos a multiple of 8): one 16-byte load for int16 input inside the frame
+	// The PCM's integers as they are, times scale() = the sample.  The recurrences take the integers and fold the scale into their
+	// input coefficients g and b (one rounding of a coefficient instead of the three-instruction correctly rounded division per
+	// sample: the filters' outputs move by an ulp, like every other rounding of the blocked recurrence against the serial one).
+	__device__ __forceinline__ float scale() const { return fmt == 0 ? 1.0f / 32767.f : fmt == 1 ? 1.0f / 127.f : 1.f; }
+	__device__ __forceinline__ float raw(long i) const
+	{
+		if (i < 0 || i >= n) return 0.f;
+		if (fmt == 0) return (float)((const int16_t *)base)[i];
+		if (fmt == 1) return (float)((int)((const uint8_t *)base)[i] - 128);
+		return ((const float *)base)[i];
+	}
+	// eight consecutive raw samples from pos (pos a multiple of 8): one 16-byte load for int16 input inside the frame
 	__device__ __forceinline__ void load8(long pos, float (&x)[8]) const
 	{
 		if (fmt == 0 && pos >= 0 && pos + 8 <= n && (((size_t)base + (size_t)pos * 2) & 15) == 0) {
@@ -47,13 +58,13 @@ struct MonoFrame {
 			const int w[4] = { v.x, v.y, v.z, v.w };
 			#pragma unroll
 			for (int q = 0; q < 4; ++q) {
-				x[2 * q] = div_32767((float)(short)(w[q] & 0xffff));
-				x[2 * q + 1] = div_32767((float)(short)(w[q] >> 16));
+				x[2 * q] = (float)(short)(w[q] & 0xffff);
+				x[2 * q + 1] = (float)(short)(w[q] >> 16);
 			}
 		} else {
 			#pragma unroll
 			for (int i = 0; i < 8; ++i)
-				x[i] = scalar(pos + i);
+				x[i] = raw(pos + i);
 		}
 	}
 	__device__ __forceinline__ double state_before(long pos) const   // pos a multiple of MONO_CK: s[pos - 1]
@@ -145,7 +156,7 @@ template <int RATE, int NT> struct MonoCover {
 	// one more span: z[next, next + LEN) (inside the frame)
 	__device__ __forceinline__ void span(const MonoArgs &ma, int tid)
 	{
-		const float a = ma.a, g = ma.g, b = ma.b;
+		const float a = ma.a, g = ma.g * fr.scale(), b = ma.b * fr.scale();
 		const int lane = tid & 63, wave = tid >> 6;
 		float x[PER], sl[PER];
 		fr.load8(next + (long)tid * PER, x);

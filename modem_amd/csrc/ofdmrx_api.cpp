@@ -448,6 +448,8 @@ static int run_front1(ofdmrx_handle *h, hipStream_t s, FrameBatch fb, int n, con
 	if (mono) {                                               // D1: the DC blocker's states; the rest of it happens in the consumers
 		Range r("ofdmrx:front_end");
 		launch_mono_carries(s, h->rate, n, fb, h->host.front, h->dc.as<double>());
+		if (!mono_fused(h->rate))                             // (the other rates: the whole analytic signal, read like 2-channel input)
+			launch_front_end(s, h->rate, n, fb, ma, z);
 	}
 	size_t e1 = mark(h, s);
 	launch_init_sync(s, n, st, d_skip, h->chunk_flags.as<int>(), d_att_counts);

@@ -33,7 +33,16 @@ for mode in cert scl; do
 		python3 $R/tools/pmc_kernel.py $(find $d -name "*.db" | head -1) rx:: | sed "s/^/[$mode] /" >> $S 2>&1
 	done
 done
-unset OFDMRX_NO_OVERLAP OFDMRX_NO_CERT
+unset OFDMRX_NO_CERT
+echo "# mono input (--channels 1: clean 16-bit mono frames, configs[1] flavour), OFDMRX_NO_OVERLAP=1: kernel trace, then PMC passes of one 8192-frame chunk" >> $S
+rocprofv3 --kernel-trace --stats -d /tmp/prof_m -o trace -- $B --channels 1 --steps 2 --warmup 1 > $G/${TAG}_bench_mono_under_profiler.json 2>/dev/null
+python3 $R/profiles/summarize.py $(find /tmp/prof_m -name "*.db" | head -1) >> $S 2>&1
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"; do
+	d=/tmp/pmc_mono_$(echo $c | tr ' ' '_')
+	rocprofv3 --pmc $c -d $d -o x -- $B --channels 1 --frames 8192 --steps 1 --warmup 0 > /dev/null 2>&1
+	python3 $R/tools/pmc_kernel.py $(find $d -name "*.db" | head -1) rx:: | sed "s/^/[mono] /" >> $S 2>&1
+done
+unset OFDMRX_NO_OVERLAP
 echo "# calibration: tools/pmc_calib.hip, 2 GiB read / 2 GiB written / 2+2 GiB copied per kernel, one 256-byte row per wave instruction" >> $S
 hipcc -w --offload-arch=gfx950 -O3 $R/tools/pmc_calib.hip -o /tmp/pmc_calib && /tmp/pmc_calib >> $S 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
