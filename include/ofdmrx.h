@@ -39,7 +39,7 @@ extern "C" {
  *   3: ofdmrx_set_attempt_log (every preamble of a SKIP loop, decode.cc:390-448); frames the syndrome check leaves are
  *      list-decoded from a queue in full residencies of the decoder (same outputs); OFDMRX_TAP_CONS_RAW needs no flag, and the
  *      LLR / METRIC / LANE_MESG taps answer OFDMRX_E_UNSUPPORTED for a frame that never went through the list decoder */
-#define OFDMRX_ABI_MINOR 3
+#define OFDMRX_ABI_MINOR 4
 
 #define OFDMRX_PAYLOAD_BYTES 5380     /* decode.cc:587  data_len = 43040/8 */
 #define OFDMRX_CODE_LEN 65536         /* decode.cc:309  code_order 16 */
@@ -155,7 +155,10 @@ int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int sample_format
 	const int32_t *skip_counts, uint8_t *payload_out, ofdmrx_frame_result *results);
 
 /* same with DEVICE pointers (inputs already resident in HBM); asynchronous on
- * the handle's stream.  d_payload_out / d_results are device buffers.  d_skip_counts (nullable) is read back once on
+ * the handle's stream.  d_payload_out / d_results are device buffers - or, both of them, PINNED HOST memory (hipHostMalloc, a
+ * registered range; revision 1.4): then every chunk's payloads and records are copied out right behind the chunk, beside the
+ * next chunk's kernels, and the batch is on the host when the handle's stream has drained - the host-pointer entry's output
+ * half without its input half.  (Pageable host memory is refused: OFDMRX_E_ARG.)  d_skip_counts (nullable) is read back once on
  * the handle's stream before anything is enqueued (the counts steer the host loop), so it is ordered after earlier
  * work on that stream; that read-back is the call's only host synchronisation. */
 int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int sample_format, int channels,

@@ -133,11 +133,15 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 			symrot[tid] = phasor(omega, (long)tid * SYM_STRIDE);
 		const cf p0 = phasor(omega, (long)SYMBOL_LEN + tid);
 		__syncthreads();
+#ifndef DEMOD_QA_LDS
+#define DEMOD_QA_LDS 0        // 1: every instantiation forms the R1 - 1 NCO phasors per symbol from LDS (the mono one, short of registers, always does)
+#endif
+		constexpr bool QA_LDS = MONO == 2 || DEMOD_QA_LDS;
 		cf qa[NQ == 1 ? R1 : 1];                             // one point per loader: the R1 phasors stay in registers
 		if (NQ == 1) {
 			#pragma unroll
 			for (int a = 0; a < R1; ++a)
-				qa[a] = (a && MONO != 2) ? cmul(p0, rotA[a]) : p0;
+				qa[a] = (a && !QA_LDS) ? cmul(p0, rotA[a]) : p0;
 		}
 		// the (at most two) carriers of this thread sit at the same place of the rows in every symbol
 		int coff[2];
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 					if (NQ == 1) {
 						#pragma unroll
 						for (int a = 0; a < R1; ++a)
-							v[a] = cmul(pre[q][a], (MONO == 2 && a) ? cmul(p0, rotA[a]) : qa[a]);   // (MONO = 2 is short of registers)
+							v[a] = cmul(pre[q][a], (QA_LDS && a) ? cmul(p0, rotA[a]) : qa[a]);
 					} else {
 						const cf pq = q ? cmul(p0, rotQ[q]) : p0;
 						#pragma unroll

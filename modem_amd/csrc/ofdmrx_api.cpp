@@ -696,6 +696,19 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 	return r;
 }
 
+// 1: pinned host memory, 0: device (or managed) memory, -1: the runtime does not know the pointer (pageable host memory)
+static int host_pinned(const void *p)
+{
+	hipPointerAttribute_t a;
+	if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+		(void)hipGetLastError();
+		return -1;
+	}
+	if (a.type == hipMemoryTypeUnregistered)
+		return -1;
+	return a.type == hipMemoryTypeHost ? 1 : 0;
+}
+
 static int finish_call(ofdmrx_handle *h, int r)
 {
 	if (!r && h->sticky != hipSuccess) {
@@ -730,7 +743,30 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	struct Dev : PipeHooks {
 		const ChunkPlan *plan; const char *samples; size_t stride; uint8_t *pay; Result *res;
 		int before_front1(size_t c, FrameBatch *fb, size_t *) override { fb->samples = samples + plan->first(c) * stride; return 0; }
-		void dst(size_t c, uint8_t **p, Result **r) override { *p = pay + plan->first(c) * PAYLOAD_BYTES; *r = res + plan->first(c); }
+		ofdmrx_handle *h = nullptr;
+		bool host_out = false;                                    // pay / res are pinned host memory: per-chunk device buffers + copies
+		void dst(size_t c, uint8_t **p, Result **r) override
+		{
+			if (host_out) {
+				*p = ((c & 1) ? h->payload2 : h->payload).as<uint8_t>();
+				*r = ((c & 1) ? h->res2 : h->res).as<Result>();
+			} else {
+				*p = pay + plan->first(c) * PAYLOAD_BYTES;
+				*r = res + plan->first(c);
+			}
+		}
+		bool outputs_leave_by_chunk() override { return host_out; }
+		int after_flush(size_t c, hipStream_t s) override
+		{
+			if (!host_out)
+				return 0;
+			uint8_t *p;
+			Result *rs;
+			dst(c, &p, &rs);
+			HIP_OK(hipMemcpyAsync(pay + plan->first(c) * PAYLOAD_BYTES, p, plan->size(c) * PAYLOAD_BYTES, hipMemcpyDeviceToHost, s));
+			HIP_OK(hipMemcpyAsync(res + plan->first(c), rs, plan->size(c) * sizeof(Result), hipMemcpyDeviceToHost, s));
+			return 0;
+		}
 		float *rows = nullptr;
 		float *esn0(size_t c) override { return rows ? rows + plan->first(c) * ROWS_MAX : nullptr; }
 		Attempt *att = nullptr;
@@ -749,6 +785,25 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	hooks.stride = stride;
 	hooks.pay = d_payload;
 	hooks.res = (Result *)d_results;
+	// Outputs in pinned HOST memory (hipHostMalloc / a registered range): every chunk's payloads and records leave for them on the
+	// copy queue right behind the chunk's flush - beside the next chunk's kernels - instead of one copy of the whole batch that the
+	// caller hangs behind the call.  (Samples stay where they are: in HBM.)
+	const int out_kind = host_pinned(d_payload), res_kind = host_pinned(d_results);
+	if (out_kind < 0 || res_kind < 0 || out_kind != res_kind)
+		return OFDMRX_E_ARG;
+	hooks.host_out = out_kind == 1;
+	if (hooks.host_out) {
+		hooks.h = h;
+		const size_t nc = plan.largest();
+		r = h->payload.ensure(nc * PAYLOAD_BYTES);
+		r = r ? r : h->res.ensure(nc * sizeof(Result));
+		if (plan.count() > 1) {
+			r = r ? r : h->payload2.ensure(nc * PAYLOAD_BYTES);
+			r = r ? r : h->res2.ensure(nc * sizeof(Result));
+		}
+		if (r)
+			return r;
+	}
 	return finish_call(h, run_pipeline(h, hooks, plan, fmt, channels, spf, stride, d_skip, max_skip));
 }
 

@@ -1042,6 +1042,48 @@ def test_unsupported_rate_is_refused():
         modem_amd.Receiver(device=0, sample_rate=22050)
 
 
+def test_device_entry_with_pinned_host_outputs():
+    """ofdmrx_decode_batch_device takes PINNED HOST pointers for payloads + records (revision 1.4): each chunk is copied out right
+    behind its flush.  Seven chunks of 16 at a noise level where some frames need the list decoder (so the queue is flushed per
+    chunk on this route): byte-identical to the same call with device buffers; a pageable host pointer is refused"""
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    n = 16 * 6 + 5
+    rx = modem_amd.Receiver(device=0, chunk_frames=16)
+    spf = rx.tx_frame_samples(6)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+    d_clean = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+    rx.tx_encode(d_pay.data_ptr(), n, d_clean.data_ptr())
+    d_in = torch.empty_like(d_clean)
+    rx.awgn_tile(d_clean.data_ptr(), n, d_in.data_ptr(), n, spf, -25.0, 9, 0)
+    rx.synchronize()
+    d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+    d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    h_out = torch.zeros((n, 5380), dtype=torch.uint8).pin_memory()
+    h_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+    torch.cuda.synchronize()
+    rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+    rx.synchronize()
+    listed = rx.list_decoded_frames()
+    for _ in range(2):                                            # twice: the second call reuses the per-chunk buffers of the first
+        h_out.zero_()
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, h_out.data_ptr(), h_res.data_ptr())
+        rx.synchronize()
+        assert (h_out.numpy() == d_out.cpu().numpy()).all() and (h_res.numpy() == d_res.cpu().numpy()).all()
+    assert 0 < listed < n and rx.list_decoded_frames() == listed
+    assert (h_out.numpy() == d_pay.cpu().numpy()).all()
+    pageable = np.zeros((n, 5380), np.uint8)
+    with pytest.raises(modem_amd.OfdmRxError):
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, pageable.ctypes.data, h_res.data_ptr())
+    with pytest.raises(modem_amd.OfdmRxError):                    # one of each kind
+        rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, h_out.data_ptr(), d_res.data_ptr())
+    rx.close()
+
+
 def test_chunk_pipeline_matches_single_chunk():
     """the two-stream chunk pipeline (front stages of chunk c+1 beside polar/finish of chunk c, two buffer parities)
     must give exactly what one resident chunk gives: 23 frames of mixed kinds (good, noisy, silence, truncated,
