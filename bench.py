@@ -307,7 +307,10 @@ def main():
     for s in range(args.steps):
         step(s, True)
         if B:
-            t = rx.timing()      # hipEvents on the streams the kernels run on; syncs the handle's stream
+            # hipEvents on the streams the kernels run on; synchronises the handle's stream.  (Measured at the end of round 4: with the
+            # steps enqueued back to back instead - no host synchronisation inside the timed region - a step takes 38.8 ms, not 36.9:
+            # profiles/r04_v23_step_sync_and_deferred_join_ab.txt)
+            t = rx.timing()
             for k, v in t.items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v[0]
                 stage_launches[k] = stage_launches.get(k, 0) + v[1]

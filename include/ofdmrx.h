@@ -157,8 +157,9 @@ int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int sample_format
 /* same with DEVICE pointers (inputs already resident in HBM); asynchronous on
  * the handle's stream.  d_payload_out / d_results are device buffers - or, both of them, PINNED HOST memory (hipHostMalloc, a
  * registered range; revision 1.4): then every chunk's payloads and records are copied out right behind the chunk, beside the
- * next chunk's kernels, and the batch is on the host when the handle's stream has drained - the host-pointer entry's output
- * half without its input half.  (Pageable host memory is refused: OFDMRX_E_ARG.)  d_skip_counts (nullable) is read back once on
+ * next chunk's kernels (frames the list decoder finishes in a later flush are delivered by its last kernel, straight into the
+ * pinned arrays), and the batch is on the host when the handle's stream has drained - the host-pointer entry's output half
+ * without its input half.  (Pageable host memory is refused: OFDMRX_E_ARG.)  d_skip_counts (nullable) is read back once on
  * the handle's stream before anything is enqueued (the counts steer the host loop), so it is ordered after earlier
  * work on that stream; that read-back is the call's only host synchronisation. */
 int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int sample_format, int channels,

@@ -37,7 +37,8 @@ namespace rx {
 __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
 	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
 	Result *__restrict__ res_all, float *__restrict__ esn0_rows, Tables tb, int descramble, uint8_t *__restrict__ payload_all,
-	ListQueue *__restrict__ q, ListSlot *__restrict__ slots, float *__restrict__ llr_q, int *__restrict__ slot_of)
+	ListQueue *__restrict__ q, ListSlot *__restrict__ slots, float *__restrict__ llr_q, int *__restrict__ slot_of,
+	uint8_t *__restrict__ payload_later, Result *__restrict__ res_later)
 {
 	const int f = blockIdx.x, tid = threadIdx.x;
 	const SyncState st = st_all[f];
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 		const unsigned e = atomicAdd(&q->tail, 1u);
 		const int slot = (int)(e % q->cap);
 		ListSlot ls;
-		ls.payload = payload;
-		ls.res = res_all + f;
+		ls.payload = payload_later ? payload_later + (size_t)f * PAYLOAD_BYTES : payload;   // where k_finish delivers (see launch_back)
+		ls.res = (res_later ? res_later : res_all) + f;
 		ls.oper_mode = st.oper_mode;
 		ls.frame = f;
 		slots[slot] = ls;
@@ -509,11 +510,11 @@ void launch_finish(hipStream_t s, int list, int max_entries, const ListQueue *q,
 }
 void launch_back(hipStream_t s, int rate, int n, int cert_mode, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, ListQueue *q, ListSlot *slots,
-	float *llr_q, int *slot_of)
+	float *llr_q, int *slot_of, uint8_t *payload_later, Result *res_later)
 {
 	const int sym_stride = rate_symbol_len(rate) + rate_symbol_len(rate) / 8;
 	hipLaunchKernelGGL(k_back, dim3(n), dim3(256), 0, s, sym_stride, cert_mode, st, cons, slope, yint, precision, res, esn0_rows, tb, descramble,
-		payload, q, slots, llr_q, slot_of);
+		payload, q, slots, llr_q, slot_of, payload_later, res_later);
 }
 
 }  // namespace rx

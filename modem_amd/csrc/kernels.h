@@ -161,10 +161,12 @@ void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint);
 // D5's rotation + D6-D8 + the syndrome certificate (k_finish.hip: k_back).  cert_mode 0: every frame with a header goes to the list
 // decoder's queue; 1: the certificate is tried (adaptively) and finishes the frames it decides (payload + result).
-// esn0_rows (nullable): [n][ROWS_MAX] dB values, decode.cc:517-519; slot_of: [n] queue slot per frame, -1 = none
+// esn0_rows (nullable): [n][ROWS_MAX] dB values, decode.cc:517-519; slot_of: [n] queue slot per frame, -1 = none.
+// payload_later / res_later (nullable: payload / res): where k_finish delivers the frames this chunk leaves to the queue - the
+// chunk's own arrays may be a staging buffer that has been copied out and reused by the time their flush comes
 void launch_back(hipStream_t s, int rate, int n, int cert_mode, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, ListQueue *q, ListSlot *slots,
-	float *llr_q, int *slot_of);
+	float *llr_q, int *slot_of, uint8_t *payload_later = nullptr, Result *res_later = nullptr);
 void launch_rotate_tap(hipStream_t s, const SyncState *st, const cf *cons, const float *slope, const float *yint, cf *out);   // one frame, CONS_MAX points
 void launch_queue_reset(hipStream_t s, ListQueue *q, unsigned cap);
 void launch_queue_snap(hipStream_t s, ListQueue *q, int par);

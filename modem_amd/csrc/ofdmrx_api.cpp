@@ -505,14 +505,15 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int n)
 }
 
 // D5's rotation + D6-D8 + the certificate: frames it finishes get payload + result here, the others a queue slot and their LLRs
-static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_res, float *d_esn0, uint8_t *d_payload)
+static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_res, float *d_esn0, uint8_t *d_payload,
+	uint8_t *payload_later = nullptr, Result *res_later = nullptr)
 {
 	size_t e5 = mark(h, s);
 	{
 		Range r("ofdmrx:back");
 		launch_back(s, h->rate, n, h->cert_mode, h->st.as<SyncState>(), h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(),
 			h->precision.as<float>(), d_res, d_esn0, h->dev, h->cfg.descramble, d_payload, h->queue(), h->q_slots.as<ListSlot>(),
-			h->q_llr.as<float>(), h->slot_of.as<int>());
+			h->q_llr.as<float>(), h->slot_of.as<int>(), payload_later, res_later);
 		launch_queue_snap(s, h->queue(), par);
 	}
 	size_t e6 = mark(h, s);
@@ -613,6 +614,9 @@ struct PipeHooks {
 	virtual void attempts(size_t, Attempt **log, int32_t **counts) { *log = nullptr; *counts = nullptr; }   // ... of its attempt log
 	virtual int after_front1(size_t, size_t /*event*/) { return 0; }
 	virtual int after_flush(size_t, hipStream_t /*the stream k_finish ran on*/) { return 0; }
+	// dst(c) is a staging buffer that leaves before_flush(c): k_finish then delivers what the queue held back to dst_later(c) itself
+	virtual void dst_later(size_t, uint8_t **payload, Result **res) { *payload = nullptr; *res = nullptr; }
+	virtual int before_flush(size_t, hipStream_t /*the stream k_finish will run on*/, hipEvent_t /*behind k_back of that chunk*/) { return 0; }
 	virtual bool outputs_leave_by_chunk() { return false; }   // every flush takes everything: chunk c is complete behind flush(c)
 };
 
@@ -651,7 +655,8 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 			if (p >= 2)
 				HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_fin[p - 2]], 0));   // k_finish(p - 2) has read the run of this parity
 		}
-		int rr = run_flush(h, sb, sc, par, every || p + 1 == n_chunks, t0s[p], &ev_polar[p]);
+		int rr = hooks.before_flush(p, sc, h->ev_pool[ev_back[p]]);
+		rr = rr ? rr : run_flush(h, sb, sc, par, every || p + 1 == n_chunks, t0s[p], &ev_polar[p]);
 		rr = rr ? rr : hooks.after_flush(p, sc);
 		ev_fin[p] = mark(h, sc);
 		return rr;
@@ -683,7 +688,10 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 			break;
 		if (overlap && c >= 2)
 			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_fin[c - 2]], 0));
-		r = run_back(h, sa, (int)(c & 1), n, res, hooks.esn0(c), pay);
+		uint8_t *pay_later;
+		Result *res_later;
+		hooks.dst_later(c, &pay_later, &res_later);
+		r = run_back(h, sa, (int)(c & 1), n, res, hooks.esn0(c), pay, pay_later, res_later);
 		ev_back[c] = mark(h, sa);
 		if (!r && !overlap)
 			r = flush(c, NONE);
@@ -755,14 +763,22 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 				*r = res + plan->first(c);
 			}
 		}
-		bool outputs_leave_by_chunk() override { return host_out; }
-		int after_flush(size_t c, hipStream_t s) override
+		// host outputs: the chunk's staging leaves right behind its k_back (certified frames complete, queued frames with their
+		// preliminary record and a zeroed payload); what the list decoder finishes later k_finish writes into the pinned host arrays
+		// itself, over PCIe - so the queue keeps working across chunks on this route too
+		void dst_later(size_t c, uint8_t **p, Result **r) override
+		{
+			*p = host_out ? pay + plan->first(c) * PAYLOAD_BYTES : nullptr;
+			*r = host_out ? res + plan->first(c) : nullptr;
+		}
+		int before_flush(size_t c, hipStream_t s, hipEvent_t back_done) override
 		{
 			if (!host_out)
 				return 0;
 			uint8_t *p;
 			Result *rs;
 			dst(c, &p, &rs);
+			HIP_OK(hipStreamWaitEvent(s, back_done, 0));
 			HIP_OK(hipMemcpyAsync(pay + plan->first(c) * PAYLOAD_BYTES, p, plan->size(c) * PAYLOAD_BYTES, hipMemcpyDeviceToHost, s));
 			HIP_OK(hipMemcpyAsync(res + plan->first(c), rs, plan->size(c) * sizeof(Result), hipMemcpyDeviceToHost, s));
 			return 0;
@@ -807,12 +823,17 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	return finish_call(h, run_pipeline(h, hooks, plan, fmt, channels, spf, stride, d_skip, max_skip));
 }
 
+// the host waits for everything the handle has enqueued
+static int host_wait(ofdmrx_handle *h)
+{
+	HIP_OK(hipStreamSynchronize(h->stream));
+	return 0;
+}
 extern "C" int ofdmrx_synchronize(ofdmrx_handle *h)
 {
 	if (!h)
 		return OFDMRX_E_ARG;
-	HIP_OK(hipStreamSynchronize(h->stream));
-	return 0;
+	return host_wait(h);
 }
 
 // Host-pointer entry: the same chunk pipeline with three copies hung on its events.  Chunk c+1 is copied in on a copy
@@ -992,7 +1013,8 @@ extern "C" int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t)
 {
 	if (!h || !t)
 		return OFDMRX_E_ARG;
-	HIP_OK(hipStreamSynchronize(h->stream));
+	if (int r = host_wait(h))
+		return r;
 	std::memset(&h->timing, 0, sizeof(h->timing));
 	for (const auto &sp : h->spans) {
 		if (sp.a == (size_t)-1 || sp.b == (size_t)-1)
@@ -1018,7 +1040,8 @@ extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *
 	if (!h || !dst || frame >= (size_t)h->last_n)
 		return OFDMRX_E_ARG;
 	HIP_OK(hipSetDevice(h->cfg.device));
-	HIP_OK(hipStreamSynchronize(h->stream));
+	if (int r = host_wait(h))
+		return r;
 	const void *src = nullptr;
 	size_t cap = 0;   // bytes available per frame; the copy is min(dst_bytes, cap)
 	int slot = -1;
@@ -1085,7 +1108,8 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 	r = lm.ensure((size_t)h->q_cap * LIST * MESG_BYTES);
 	if (r)
 		return r;
-	HIP_OK(hipStreamSynchronize(h->stream));
+	if ((r = host_wait(h)))
+		return r;
 	HIP_OK(hipMemcpy(h->q_llr.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));
 	launch_queue_reset(h->stream, h->queue(), h->q_cap);
@@ -1124,7 +1148,8 @@ extern "C" int ofdmrx_debug_decode_cons(ofdmrx_handle *h, const float *cons, siz
 	std::vector<SyncState> st(n);
 	std::memset(st.data(), 0, n * sizeof(SyncState));
 	for (auto &s : st) { s.okay = 1; s.oper_mode = 6; }
-	HIP_OK(hipStreamSynchronize(h->stream));
+	if ((r = host_wait(h)))
+		return r;
 	HIP_OK(hipMemcpy(h->st.p, st.data(), n * sizeof(SyncState), hipMemcpyHostToDevice));
 	HIP_OK(hipMemcpy2D(h->cons.p, CONS_MAX * sizeof(cf), cons, 21600 * sizeof(cf), 21600 * sizeof(cf), n, hipMemcpyHostToDevice));
 	HIP_OK(hipMemsetAsync(h->res.p, 0, n * sizeof(Result), h->stream));

@@ -1043,9 +1043,10 @@ def test_unsupported_rate_is_refused():
 
 
 def test_device_entry_with_pinned_host_outputs():
-    """ofdmrx_decode_batch_device takes PINNED HOST pointers for payloads + records (revision 1.4): each chunk is copied out right
-    behind its flush.  Seven chunks of 16 at a noise level where some frames need the list decoder (so the queue is flushed per
-    chunk on this route): byte-identical to the same call with device buffers; a pageable host pointer is refused"""
+    """ofdmrx_decode_batch_device takes PINNED HOST pointers for payloads + records (revision 1.4): each chunk's staging is copied
+    out right behind its k_back, and what the list decoder finishes in a LATER flush (the queue works across chunks on this route
+    too) k_finish writes into the pinned arrays itself.  Seven chunks of 16 at a noise level where a few frames per chunk need the
+    list decoder: byte-identical to the same call with device buffers; a pageable host pointer is refused"""
     import torch
     import modem_amd
     import modem_amd.ofdmrx as M
