@@ -15,6 +15,8 @@ import modem_amd.ofdmrx as M
 
 mode = int(os.environ.get("SWEEP_MODE", "6"))
 rate = int(os.environ.get("SWEEP_RATE", "8000"))
+channels = int(os.environ.get("SWEEP_CHANNELS", "2"))   # 1: the real part of the noisy analytic stream + a DC offset (SWEEP_DC, LSB): mono input
+dc = int(os.environ.get("SWEEP_DC", "700"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 levels = [float(x) for x in sys.argv[2:]] or [-17.0, -15.5, -15.0, -14.5]
 dev = torch.device("cuda:0")
@@ -23,7 +25,7 @@ torch.cuda.set_stream(stream)
 rx = modem_amd.Receiver(device=0, chunk_frames=96, stream=stream.cuda_stream, sample_rate=rate)
 spf = rx.tx_frame_samples(mode)
 O.lib().orc_decode_rate   # (loads the library)
-print("mode %d, %d Hz" % (mode, rate), flush=True)
+print("mode %d, %d Hz, %d channel%s" % (mode, rate, channels, "s" if channels == 2 else " (DC offset %d LSB)" % dc), flush=True)
 threads = min(os.cpu_count() or 1, 32)
 bad = 0
 for li, db in enumerate(levels):
@@ -33,9 +35,13 @@ for li, db in enumerate(levels):
     d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
     rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr(), mode=mode)
     rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, db, 99, li * n)
+    rx.synchronize()
+    if channels == 1:
+        d_in = torch.clamp(d_in[:, :, 0].to(torch.int32) + dc, -32768, 32767).to(torch.int16).contiguous()
+        torch.cuda.synchronize()
     d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
     d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+    rx.decode_device(d_in.data_ptr(), M.FMT_S16, channels, spf, spf * 2 * channels, n, d_out.data_ptr(), d_res.data_ptr())
     rx.synchronize()
     out = d_out.cpu().numpy()
     res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
@@ -44,11 +50,11 @@ for li, db in enumerate(levels):
     ores = np.zeros(n * 56, np.uint8)
     t = time.perf_counter()
     if rate == 8000:
-        O.lib().orc_decode_batch(O.ptr(pcm), O.FMT_S16, 2, spf, spf * 4, n, 8, O.ptr(oout), O.ptr(ores), threads)
+        O.lib().orc_decode_batch(O.ptr(pcm), O.FMT_S16, channels, spf, spf * 2 * channels, n, 8, O.ptr(oout), O.ptr(ores), threads)
     else:   # the batch helper is the 8 kHz instantiation: other rates frame by frame
         ov = ores.view(M.RESULT_DTYPE).reshape(-1)
         for f in range(n):
-            o, r = O.decode(pcm[f], rate=rate)
+            o, r = O.decode(pcm[f] if channels == 2 else pcm[f][:, None], rate=rate)
             oout[f] = o
             for name in ov.dtype.names:
                 ov[name][f] = getattr(r, name)

@@ -12,6 +12,10 @@ echo "== noisy headers, 2048 frames each" >> $O
 timeout 1500 python3 tests/parity_sweep.py 2048 -15 -14.5 -14 -13 >> $O 2>&1
 echo "== the many-row modes, 1024 frames each" >> $O
 for m in 13 9 7 11; do SWEEP_MODE=$m timeout 900 python3 tests/parity_sweep.py 1024 -19 -17 >> $O 2>&1; done
+echo "== mono input (the real part of the noisy stream + a DC offset of 700 LSB), 4096 / 2048 frames each, and 16 kHz mono, 192 each" >> $O
+SWEEP_CHANNELS=1 timeout 1500 python3 tests/parity_sweep.py 4096 -30 -26 >> $O 2>&1
+SWEEP_CHANNELS=1 SWEEP_DC=-4000 timeout 1500 python3 tests/parity_sweep.py 2048 -22 -18 -17 -16 >> $O 2>&1
+SWEEP_CHANNELS=1 SWEEP_RATE=16000 timeout 900 python3 tests/parity_sweep.py 192 -24 -18 >> $O 2>&1
 echo "== 16 kHz mode 6, 256 frames each" >> $O
 SWEEP_RATE=16000 timeout 900 python3 tests/parity_sweep.py 256 -20 -16 -15 >> $O 2>&1
 echo "== all eight modes, bench line" >> $O
