@@ -114,7 +114,8 @@ typedef struct {
 	                            * carrier phase, which the Theil-Sen stage absorbs with different hard decisions for points
 	                            * on a decision boundary; payload, lane and every other field were identical.  Round 4, 43 000
 	                            * frames against the oracle: one frame (mode 7, -17 dB) differed by 9, its coarse cfo by
-	                            * 2e-6 rad/sample - the same mechanism */
+	                            * 2e-6 rad/sample - the same mechanism; mono input (its front end is a blocked scan, the
+	                            * reference's a serial fp32 recurrence), 16 384 frames: two frames at -18 dB by 10 */
 	float esn0_db_last;        /* decode.cc:517-519, cumulative Es/N0 after the last row */
 	int32_t n_sync_rejects;    /* falling edges rejected at decode.cc:140-145 */
 } ofdmrx_frame_result;

@@ -659,6 +659,26 @@ def test_mono_8bit_and_float_input(rxd):
     assert int(res[0]["sc_start"]) == ores.sc_start and (out[0] == oout).all()
 
 
+def test_float32_input_equals_int16_input(rxd):
+    """OFDMRX_FMT_F32 (pcm.hh's float WAV): the samples x / 32767 as float32 decode like the int16 they came from - bit-identical for
+    2-channel input (the same float values enter the same kernels), the same decisions for mono (the mono path takes the PCM's
+    integers as they are and folds the scale into its filter coefficients: an ulp apart inside the front end)"""
+    p = O.payload_for(12)
+    for ch in (1, 2):
+        pcm = O.encode_pcm(p, channels=2)
+        pcm = O.impair(pcm, noise_db=-24, seed=3, frame=ch)
+        if ch == 1:
+            pcm = _mono_of(pcm, dc=250)
+        f32 = (pcm.astype(np.float32) / np.float32(32767)).astype(np.float32)
+        out_i, res_i = rxd.decode(pcm[None])
+        out_f, res_f = rxd.decode(f32[None])
+        assert int(res_i[0]["status"]) == 0 and (out_i[0] == p).all()
+        assert (out_i == out_f).all()
+        for name in ("status", "sc_start", "symbol_pos", "oper_mode", "call_sign", "best_lane", "n_sync_rejects"):
+            assert res_i[0][name] == res_f[0][name], name
+        assert abs(float(res_i[0]["cfo_fine"]) - float(res_f[0]["cfo_fine"])) <= (0 if ch == 2 else REL)
+
+
 def test_8bit_input(rx):
     p = O.payload_for(8)
     pcm = O.encode_pcm(p, bits=8, channels=1)                     # `make test` format (Makefile:14)
