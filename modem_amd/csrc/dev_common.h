@@ -367,11 +367,6 @@ __device__ __forceinline__ long uniform_l(long v)
 	return ((long)hi << 32) | (long)(unsigned)lo;
 }
 __device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ double uniform_d(double v)
-{
-	const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-	return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double shfl_d(double v, int src)
 {
 	int lo = __double2loint(v), hi = __double2hiint(v);

@@ -32,13 +32,6 @@ struct MonoFrame {
 	int fmt;
 	long n;
 	const double *ck;                                         // s after sample 64 (m + 1) - 1, m = 0 ..
-	__device__ __forceinline__ float scalar(long i) const
-	{
-		if (i < 0 || i >= n) return 0.f;
-		if (fmt == 0) return div_32767((float)((const int16_t *)base)[i]);
-		if (fmt == 1) return div_127((float)((int)((const uint8_t *)base)[i] - 128));
-		return ((const float *)base)[i];
-	}
 	// The PCM's integers as they are, times scale() = the sample.  The recurrences take the integers and fold the scale into their
 	// input coefficients g and b (one rounding of a coefficient instead of the three-instruction correctly rounded division per
 	// sample: the filters' outputs move by an ulp, like every other rounding of the blocked recurrence against the serial one).
@@ -139,7 +132,8 @@ template <int RATE, int NT> struct MonoCover {
 		long q = p - MC::REACH;
 		q = q <= 0 ? 0 : q / MONO_CK * MONO_CK;
 		next = q;
-		lo = q == 0 ? 0 : q + MC::REACH;                      // the first outputs of the first span lack their history
+		lo = p < 0 ? 0 : p;                                   // (the outputs before q + REACH lack their history; nothing before p is written,
+		                                                      // so that two workgroups never write the same sample - k_front_end's stretches)
 		S = fr.state_before(q);
 		sync();
 		for (int i = tid; i < HIST; i += NT)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# bench_cmp.sh -- the bench line with the default flags, without the CPU / host legs and with the suite flags, twice each on one box (box-to-box spread of `value`: 1.71 - 1.77 M)
 O=$PWD/gpurun_out/bench_cmp.txt; : > $O
 pick='import json,sys
 d=json.loads(sys.stdin.readline()); print("value", round(d["value"]), "kernel_only", round(d["value_kernel_only"]), "ms_per_step", round(d["ms_per_step"],2), "steps", d["steps"], "warmup", d["warmup"])'
