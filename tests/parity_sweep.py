@@ -26,7 +26,7 @@ rx = modem_amd.Receiver(device=0, chunk_frames=96, stream=stream.cuda_stream, sa
 spf = rx.tx_frame_samples(mode)
 O.lib().orc_decode_rate   # (loads the library)
 print("mode %d, %d Hz, %d channel%s" % (mode, rate, channels, "s" if channels == 2 else " (DC offset %d LSB)" % dc), flush=True)
-threads = min(os.cpu_count() or 1, 32)
+threads = min(os.cpu_count() or 1, int(os.environ.get("SWEEP_THREADS", "32")))
 bad = 0
 for li, db in enumerate(levels):
     g = torch.Generator(device=dev)
