@@ -564,6 +564,8 @@ static int check_args(ofdmrx_handle *h, const void *samples, int fmt, int channe
 		return OFDMRX_E_ARG;
 	if (fmt == OFDMRX_FMT_S16 && channels == 2 && (stride & 3))
 		return OFDMRX_E_ARG;
+	if ((stride % bps) || ((size_t)samples % bps))             // whole samples between the frames, frames on a sample boundary
+		return OFDMRX_E_ARG;
 	return 0;
 }
 

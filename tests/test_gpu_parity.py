@@ -679,6 +679,25 @@ def test_float32_input_equals_int16_input(rxd):
         assert abs(float(res_i[0]["cfo_fine"]) - float(res_f[0]["cfo_fine"])) <= (0 if ch == 2 else REL)
 
 
+def test_misaligned_samples_are_refused(rxd):
+    """frames on a sample boundary, whole samples between them (include/ofdmrx.h): anything else is OFDMRX_E_ARG, not a slow path"""
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    spf = 95200
+    d = torch.zeros(spf * 2 + 8, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros((1, 5380), dtype=torch.uint8, device=dev)
+    d_res = torch.zeros((1, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for ptr, stride in ((d.data_ptr() + 1, spf * 2), (d.data_ptr(), spf * 2 + 1)):
+        with pytest.raises(modem_amd.OfdmRxError):
+            rxd.decode_device(ptr, M.FMT_S16, 1, spf, stride, 1, d_out.data_ptr(), d_res.data_ptr())
+    rxd.decode_device(d.data_ptr() + 2, M.FMT_S16, 1, spf, spf * 2, 1, d_out.data_ptr(), d_res.data_ptr())   # (two-byte aligned: fine)
+    rxd.synchronize()
+    assert int(d_res.cpu().numpy().view(M.RESULT_DTYPE)["status"][0]) == 1                                       # silence: no preamble
+
+
 def test_8bit_input(rx):
     p = O.payload_for(8)
     pcm = O.encode_pcm(p, bits=8, channels=1)                     # `make test` format (Makefile:14)
