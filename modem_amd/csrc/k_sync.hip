@@ -324,10 +324,15 @@ __global__ __launch_bounds__(64, SPLIT ? (MONO ? SYNC_WAVES_SPLIT_MONO : SYNC_WA
 	const float min_R = 0.0001f * HALF_LEN;                                                // decode.cc:88
 	const long t_start = st.t_next;
 	long T0 = t_start - (MATCH_LEN - 1);
-	if (T0 < 0) T0 = 0;
+	// The correlator looks at the samples up to t - FIRST at time t (decode.cc:86: the delay lines in front of it are BUFFER_LEN long):
+	// before t = FIRST it sees none of the stream, P = R = 0, the metric and its moving sum are exactly 0 and nothing can trigger.
+	// A scan from the start of a stream - every frame of a batch, first round - therefore starts there instead of walking eight
+	// tiles of zeros (round 4: the scan was 0.48 ms per 8192 frames, 60 % of it those tiles).
+	constexpr long FIRST = D - HALF_LEN;
+	if (T0 < FIRST - (MATCH_LEN - 1)) T0 = FIRST - (MATCH_LEN - 1);
 	// running window sums at time T0-1
 	double Wr = 0.0, Wi = 0.0, Wp = 0.0, Wm = 0.0;
-	if (T0 > 0) {
+	if (T0 > FIRST) {
 		need(T0 - 1 - D - (HALF_LEN - 1), T0 - D + HALF_LEN);
 		direct_P<RATE>(src, T0 - 1, lane, Wr, Wi);
 		Wp = direct_R<RATE>(src, T0 - 1, lane);
@@ -376,6 +381,16 @@ __global__ __launch_bounds__(64, SPLIT ? (MONO ? SYNC_WAVES_SPLIT_MONO : SYNC_WA
 			} else if (MONO && w_lo >= 0 && w_hi <= n) {
 				const cf *p = src.analytic;
 				phase1([&](long i) { return p[i]; });
+			} else if (src.mode() == 1 && w_hi <= n) {
+				// the head of the stream (the three tiles behind FIRST): zeros in front of sample 0, no branches per sample
+				const short2 *p = (const short2 *)src.base;
+				phase1([&](long i) {
+					const short2 v = p[i < 0 ? 0 : i];
+					return i < 0 ? mk(0.f, 0.f) : mk(div_32767((float)v.x), div_32767((float)v.y));
+				});
+			} else if (MONO && w_hi <= n) {
+				const cf *p = src.analytic;
+				phase1([&](long i) { const cf v = p[i < 0 ? 0 : i]; return i < 0 ? mk(0.f, 0.f) : v; });
 			} else {
 				phase1([&](long i) { return src.at(i); });
 			}
