@@ -596,10 +596,17 @@ struct ChunkPlan {
 		return m;
 	}
 };
-static ChunkPlan plan_chunks(const ofdmrx_handle *h, size_t n_frames)
+// host_side: the call's outputs (and, for the host entry, its samples) cross PCIe.  A batch that fits one chunk then runs as two
+// halves when it is large enough for half-sized kernels to fill the machine: the second half's kernels run beside the first half's
+// copies (8192 frames: 1.49 -> 1.57 M frames/s; four quarters: 1.40 M, profiles/r04_v25_one_chunk_split.txt).  With the outputs
+// left in HBM one chunk is the faster form (1.86 against 1.77 M).
+static ChunkPlan plan_chunks(const ofdmrx_handle *h, size_t n_frames, bool host_side = false)
 {
 	ChunkPlan p;
-	for (size_t f = 0; f < n_frames; f += (size_t)h->chunk)
+	size_t step = (size_t)h->chunk;
+	if (host_side && n_frames <= step && n_frames >= 6144)
+		step = (n_frames + 1) / 2;
+	for (size_t f = 0; f < n_frames; f += step)
 		p.start.push_back(f);
 	p.start.push_back(n_frames);
 	return p;
@@ -749,7 +756,10 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	}
 	h->ev_used = 0;
 	h->spans.clear();
-	const ChunkPlan plan = plan_chunks(h, n_frames);
+	const int out_kind = host_pinned(d_payload), res_kind = host_pinned(d_results);
+	if (out_kind < 0 || res_kind < 0 || out_kind != res_kind)
+		return OFDMRX_E_ARG;
+	const ChunkPlan plan = plan_chunks(h, n_frames, out_kind == 1);
 	struct Dev : PipeHooks {
 		const ChunkPlan *plan; const char *samples; size_t stride; uint8_t *pay; Result *res;
 		int before_front1(size_t c, FrameBatch *fb, size_t *) override { fb->samples = samples + plan->first(c) * stride; return 0; }
@@ -806,9 +816,6 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	// Outputs in pinned HOST memory (hipHostMalloc / a registered range): every chunk's payloads and records leave for them on the
 	// copy queue right behind the chunk's flush - beside the next chunk's kernels - instead of one copy of the whole batch that the
 	// caller hangs behind the call.  (Samples stay where they are: in HBM.)
-	const int out_kind = host_pinned(d_payload), res_kind = host_pinned(d_results);
-	if (out_kind < 0 || res_kind < 0 || out_kind != res_kind)
-		return OFDMRX_E_ARG;
 	hooks.host_out = out_kind == 1;
 	if (hooks.host_out) {
 		hooks.h = h;
@@ -858,7 +865,7 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 	}
 	h->ev_used = 0;
 	h->spans.clear();
-	const ChunkPlan plan = plan_chunks(h, n_frames);
+	const ChunkPlan plan = plan_chunks(h, n_frames, true);
 	const size_t n_chunks = plan.count(), nc = plan.largest();
 	r = ensure_events(h, n_chunks * (events_per_chunk(max_skip) + 4) + 8);
 	r = r ? r : h->in_stage.ensure(nc * stride);
