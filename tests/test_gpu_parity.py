@@ -695,7 +695,7 @@ def test_misaligned_samples_are_refused(rxd):
             rxd.decode_device(ptr, M.FMT_S16, 1, spf, stride, 1, d_out.data_ptr(), d_res.data_ptr())
     rxd.decode_device(d.data_ptr() + 2, M.FMT_S16, 1, spf, spf * 2, 1, d_out.data_ptr(), d_res.data_ptr())   # (two-byte aligned: fine)
     rxd.synchronize()
-    assert int(d_res.cpu().numpy().view(M.RESULT_DTYPE)["status"][0]) == 1                                       # silence: no preamble
+    assert int(d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)["status"][0]) == 1                           # silence: no preamble
 
 
 def test_8bit_input(rx):
