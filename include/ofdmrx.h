@@ -120,7 +120,8 @@ typedef struct {
 	                            * nothing that is decided differed in any frame.  AT the waterfall (-15 / -14.5 dB, where
 	                            * 38 % of the frames are lost) 4 of 65 536 frames differed from the scalar restatement in
 	                            * something decided: sync position one sample apart (decode.cc:143's nearbyint on a
-	                            * boundary), or the list decoder keeping / losing the right path an ulp apart */
+	                            * boundary), or the list decoder keeping / losing the right path an ulp apart.  The timing
+	                            * tie also occurred once in 230 000 mono frames above the waterfall (same payload) */
 	float esn0_db_last;        /* decode.cc:517-519, cumulative Es/N0 after the last row */
 	int32_t n_sync_rejects;    /* falling edges rejected at decode.cc:140-145 */
 } ofdmrx_frame_result;
