@@ -38,8 +38,12 @@ extern "C" {
  *      frames whose hard decisions already form a codeword are decided by a syndrome check (same outputs)
  *   3: ofdmrx_set_attempt_log (every preamble of a SKIP loop, decode.cc:390-448); frames the syndrome check leaves are
  *      list-decoded from a queue in full residencies of the decoder (same outputs); OFDMRX_TAP_CONS_RAW needs no flag, and the
- *      LLR / METRIC / LANE_MESG taps answer OFDMRX_E_UNSUPPORTED for a frame that never went through the list decoder */
-#define OFDMRX_ABI_MINOR 4
+ *      LLR / METRIC / LANE_MESG taps answer OFDMRX_E_UNSUPPORTED for a frame that never went through the list decoder
+ *   4: ofdmrx_decode_batch_device delivers to pinned host memory when both output pointers are pinned host memory
+ *   5: ofdmrx_sc_decided_frames, ofdmrx_get_sc_timing, ofdmrx_debug_sc_path, ofdmrx_config.flags bit 2 (OFDMRX_FLAG_NO_SC); frames
+ *      with raw bit errors whose sign-following path provably is the list decoder's lane 0 are finished by a list-1 decode of
+ *      that path (same outputs) */
+#define OFDMRX_ABI_MINOR 5
 
 #define OFDMRX_PAYLOAD_BYTES 5380     /* decode.cc:587  data_len = 43040/8 */
 #define OFDMRX_CODE_LEN 65536         /* decode.cc:309  code_order 16 */
@@ -68,6 +72,7 @@ enum {
 
 #define OFDMRX_FLAG_KEEP_RAW_CONS 1
 #define OFDMRX_FLAG_SCL_ALWAYS 2
+#define OFDMRX_FLAG_NO_SC 4
 
 typedef struct ofdmrx_handle ofdmrx_handle;
 
@@ -87,7 +92,12 @@ typedef struct {
 	                            * bit 1 (OFDMRX_FLAG_SCL_ALWAYS): run the list decoder for every frame.  Without either, a frame
 	                            * whose channel hard decisions already form a codeword with a valid CRC-32 is finished by that
 	                            * syndrome check - the list decoder's lane 0 provably is that codeword - with
-	                            * identical payload, status, best_lane and bit_flips, and its LLRs are never written */
+	                            * identical payload, status, best_lane and bit_flips, and its LLRs are never written; a frame the
+	                            * syndrome check leaves is decoded along its sign-following path alone (list size 1) and finished
+	                            * there when that path provably is the list decoder's lane 0 (min over the information leaves of
+	                            * fl(metric so far + |llr|) > the path's final metric) and its CRC-32 is zero - again
+	                            * with identical payload, status, best_lane (0) and bit_flips; every other frame is list-decoded;
+	                            * bit 2 (OFDMRX_FLAG_NO_SC): without that list-1 pass (syndrome check, then the list decoder) */
 	void *stream;              /* hipStream_t to run on, NULL = library-owned stream.  Batches longer than one chunk
 	                            * also use library-owned streams for the list decoder and its finishing kernel (chunk
 	                            * pipeline); the given stream waits for them, so work enqueued on `stream` after a
@@ -189,6 +199,14 @@ int ofdmrx_set_esn0_rows(ofdmrx_handle *h, float *rows);
  * one frame in sixteen only, until a fifth of the sample passes again - a frame it was not tried for is list-decoded, with the
  * same outputs.  Every call starts with the certificate on.) */
 long long ofdmrx_list_decoded_frames(ofdmrx_handle *h);
+/* frames of the last decode call that the list-1 pass finished (neither the syndrome check nor the list decoder); -1 if that
+ * pass is off for this handle (OFDMRX_FLAG_KEEP_RAW_CONS / _SCL_ALWAYS / _NO_SC).  Synchronises the handle's stream.  The pass is
+ * adaptive like the syndrome check: after a chunk in which it finished fewer than an eighth of its frames only a sample of one
+ * frame in sixteen goes through it, until an eighth of the sample is finished again; the others go straight to the list decoder. */
+long long ofdmrx_sc_decided_frames(ofdmrx_handle *h);
+/* hipEvent time and launches of that pass (k_sc + k_sc_finish) in the last decode call, like ofdmrx_timing's stages (which keep
+ * their layout); either pointer may be NULL */
+int ofdmrx_get_sc_timing(ofdmrx_handle *h, float *ms, int32_t *launches);
 /* decode.cc:390-448 prints "symbol pos" / "coarse cfo" and the header's outcome for EVERY preamble the SKIP loop examines, not
  * only for the last one (which ofdmrx_frame_result describes).  log = n_frames x (OFDMRX_MAX_SKIP + 1) records, counts =
  * n_frames numbers of records written (0: the stream ended before any preamble), both in the memory space of the RESULTS of the
@@ -225,6 +243,11 @@ int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *dst, size_t
 /* D9+D10: CODE::PolarListDecoder + systematic() (decode.cc:530-531) */
 int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n,
 	uint8_t *lane_mesg /*n*8*5476*/, float *metric /*n*8*/);
+/* the sign-following path of the list decoder alone (k_sc): n LLR vectors of `oper_mode`'s code -> its re-encoded codeword
+ * (bit i = bit i % 8 of byte i / 8), the hard decisions of the LLRs packed alike, its path metric, min over the information
+ * leaves of fl(metric so far + |llr|), and whether the rule "min_fork > metric, every |llr| < 6e29" holds.  Any output may be NULL. */
+int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n, int oper_mode, uint8_t *codeword /*n*8192*/,
+	uint8_t *hard /*n*8192*/, float *metric /*n*/, float *min_fork /*n*/, int32_t *rule_ok /*n*/);
 /* D5 output (n x 21600 rotated constellation points of mode-6 frames, cf32) -> payloads + results through D6-D10 as the pipeline
  * chains them: with the syndrome certificate (use_cert != 0) or with the list decoder for every frame; cert_out (nullable): 1 =
  * the frame was finished by the certificate (decode.cc:505-555) */

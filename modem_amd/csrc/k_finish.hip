@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
 	Result *__restrict__ res_all, float *__restrict__ esn0_rows, Tables tb, int descramble, uint8_t *__restrict__ payload_all,
 	ListQueue *__restrict__ q, ListSlot *__restrict__ slots, float *__restrict__ llr_q, int *__restrict__ slot_of,
-	uint8_t *__restrict__ payload_later, Result *__restrict__ res_later)
+	uint8_t *__restrict__ payload_later, Result *__restrict__ res_later, ScRing sc)
 {
 	const int f = blockIdx.x, tid = threadIdx.x;
 	const SyncState st = st_all[f];
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	__shared__ uint32_t ctab[256], csh[1024], cpart[32];
 	__shared__ uint32_t crc_sh;
 	__shared__ int slot_sh;
+	ListQueue *const q_cert = q;                                      // the syndrome certificate's switch and counters (the list queue's block)
 	const bool try_cert = cert_mode && (q->cert_on || (f & 15) == 0);   // (uniform in the workgroup)
 	const ModeDesc md = mode_desc(st.oper_mode);
 	const cf *cons = cons_all + (size_t)f * CONS_MAX;
@@ -244,20 +245,29 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 			return;
 		}
 	}
-	// ---- 4. the list decoder has to look: a queue slot and the LLRs (decode.cc:520-529)
+	// ---- 4. a decoder has to look: a slot and the LLRs (decode.cc:520-529) - in the SC ring when that pass is on (all frames, or its
+	// probe sample: k_sc.hip), else in the list decoder's queue
+	const bool to_sc = sc.q && (sc.q->cert_on || (f & 15) == 8);      // (uniform in the workgroup)
+	if (to_sc) {
+		q = sc.q;
+		slots = sc.slots;
+		llr_q = sc.llr;
+	}
 	if (tid == 0) {
 		const unsigned e = atomicAdd(&q->tail, 1u);
 		const int slot = (int)(e % q->cap);
 		ListSlot ls;
 		ls.payload = payload_later ? payload_later + (size_t)f * PAYLOAD_BYTES : payload;   // where k_finish delivers (see launch_back)
 		ls.res = (res_later ? res_later : res_all) + f;
+		ls.payload_now = payload;
+		ls.res_now = res_all + f;
 		ls.oper_mode = st.oper_mode;
 		ls.frame = f;
 		slots[slot] = ls;
-		slot_of[f] = slot;
-		res_all[f] = r;                                       // k_finish completes the record (best_lane, bit_flips, status)
+		slot_of[f] = to_sc ? -2 - slot : slot;
+		res_all[f] = r;                                       // k_sc_finish / k_finish completes the record (best_lane, bit_flips, status)
 		if (try_cert)
-			atomicAdd(&q->tried, 1u);
+			atomicAdd(&q_cert->tried, 1u);
 		slot_sh = slot;
 	}
 	__syncthreads();
@@ -320,6 +330,7 @@ __global__ void k_queue_reset(ListQueue *__restrict__ q, unsigned cap)
 	q->cert_on = 1;
 	q->tried = q->certified = 0;
 	q->cap = cap;
+	q->done_total = 0;
 }
 // behind k_back of a chunk: what the flush of that chunk may take, and the adaptive certificate's next state
 __global__ void k_queue_snap(ListQueue *__restrict__ q, int par)
@@ -353,6 +364,8 @@ __global__ void k_queue_fill(ListQueue *__restrict__ q, ListSlot *__restrict__ s
 		ListSlot ls;
 		ls.payload = payload + (size_t)i * PAYLOAD_BYTES;
 		ls.res = res + i;
+		ls.payload_now = ls.payload;
+		ls.res_now = ls.res;
 		ls.oper_mode = oper_mode;
 		ls.frame = i;
 		slots[i] = ls;
@@ -510,11 +523,11 @@ void launch_finish(hipStream_t s, int list, int max_entries, const ListQueue *q,
 }
 void launch_back(hipStream_t s, int rate, int n, int cert_mode, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, ListQueue *q, ListSlot *slots,
-	float *llr_q, int *slot_of, uint8_t *payload_later, Result *res_later)
+	float *llr_q, int *slot_of, uint8_t *payload_later, Result *res_later, ScRing sc)
 {
 	const int sym_stride = rate_symbol_len(rate) + rate_symbol_len(rate) / 8;
 	hipLaunchKernelGGL(k_back, dim3(n), dim3(256), 0, s, sym_stride, cert_mode, st, cons, slope, yint, precision, res, esn0_rows, tb, descramble,
-		payload, q, slots, llr_q, slot_of, payload_later, res_later);
+		payload, q, slots, llr_q, slot_of, payload_later, res_later, sc);
 }
 
 }  // namespace rx

@@ -23,19 +23,10 @@
 // candidate index 2k+u); survivors are stored in rank order (same rule as the CPU oracle).
 #include "dev_common.h"
 #include "kernels.h"
+#include "polar_common.h"
 #include <cstdio>
 
 namespace rx {
-
-// three VALU: v_xor, v_med3_f32 with |.| modifiers (median of (|a|, |b|, 0) = the smaller magnitude; unlike
-// fminf no canonicalising v_max is emitted), v_and_or.  A zero result may carry a minus sign; no consumer can tell.
-__device__ __forceinline__ float f_minsum(float a, float b)
-{
-	const uint32_t sgn = (__float_as_uint(a) ^ __float_as_uint(b)) & 0x80000000u;
-	const float m = __builtin_amdgcn_fmed3f(fabsf(a), fabsf(b), 0.f);
-	return __uint_as_float(sgn | __float_as_uint(m));
-}
-__device__ __forceinline__ float g_add(float a, float b, int u) { return u ? b - a : a + b; }
 
 // ---- cheap cross-lane exchanges (no LDS crossbar): lane ^ 8 (DPP row_ror:8), lane ^ 16 and
 // lane ^ 32 (gfx950 v_permlane16_swap / v_permlane32_swap)
@@ -123,11 +114,6 @@ struct Maps {
 // Global accesses are raw buffer loads / stores: one per-lane byte offset in a VGPR (lane * 4, or the mapped
 // lane for the g step), everything else (level base, column, partner distance) in the scalar offset - so 16
 // loads in flight cost 16 data registers and no 64-bit address pairs.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void *p, int bytes)
-{
-	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
-}
 #ifndef POLAR_NT_LEVEL
 #define POLAR_NT_LEVEL 10   // level-store accesses of levels >= this are non-temporal (written once, read once a long time later: keeping
                             // them out of the caches leaves room for level 9, which is re-read soon).  r02 sweep, k_polar alone at 16
@@ -137,10 +123,6 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int bytes)
 #define POLAR_WAVES_PER_SIMD 5     // register budget: 5 waves per SIMD = 96 VGPRs (13 dwords of scratch) so that Theil-Sen workgroups of the next
                                    // chunk fit beside 12 resident decoders per CU; 1 = unconstrained (125 VGPRs): 2 % faster alone, 12 % slower overlapped
 #endif
-template <int AUX = 0> __device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX)); }
-template <int AUX = 0> __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX); }
-__device__ __forceinline__ int bload_u8(rsrc_t r, int voff, int soff) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0); }
-
 struct PolarBufs {
 	rsrc_t soft, llr, hard;    // this decoder's 2 MiB level store, the channel LLRs, the partial-sum bytes of what it decodes
 	// List 4 decodes TWO codewords per wave (paths 0..3 = the first, 4..7 = the second, see k_polar): everything that is

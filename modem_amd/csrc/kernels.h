@@ -91,6 +91,7 @@ struct Tables {                    // device-resident constants, built once per 
 	const cf *tw_symc;             // compact per-stage twiddles of the symbol_len-point plan (transmitter: read through L1)
 	const uint32_t *frozen;        // [2][2048] words, bit set = frozen: frozen_64800_43072, frozen_64512_43072 (regenerated)
 	const uint16_t *info_pos;      // [2][44096] ascending unfrozen positions per table
+	const uint8_t *node_lev64;     // [2][1024] the same per 64-leaf block, for k_sc (frozen: 64 or 128 leaves, information: 64 .. 2048)
 	const uint8_t *node_lev;       // [2][8192] per 8-leaf group: level of the largest aligned all-frozen (low nibble) /
 	                               // all-information (high nibble) node that starts there (frozen: <= 128 leaves, information: <= 2048), 0 = none
 	const uint32_t *genmat_bits;   // BCH(255,71) systematic generator, [71][8] words, bit i of row j
@@ -115,13 +116,21 @@ struct ListQueue {
 	int cert_on;                   // adaptive certificate: tried for every frame (1) or for a probe sample (0)
 	unsigned tried, certified;     // since the last snapshot: frames the certificate was tried for / that it finished
 	unsigned cap;                  // slots
+	unsigned done_total;           // SC ring only: frames k_sc_finish has finished since the call began
 };
+// The SC ring (k_sc.hip) is a second queue of the same shape in front of this one: k_back puts a frame there when the SC pass is
+// on (its cert_on; tried / certified count the last run's entries / decided frames), k_sc | k_sc_finish drain it right behind
+// k_back of the same chunk on the same stream, and what they cannot decide moves on to the list decoder's queue.
+struct ScStat { float metric, min_fork; int32_t ok, pad; };   // per SC-ring slot: P*'s metric, min_fork, rule holds
 struct ListSlot {                  // what k_polar / k_finish need to know about a queued frame
-	uint8_t *payload;              // where its 5380 bytes go
+	uint8_t *payload;              // where its 5380 bytes go when the list decoder's flush delivers them (k_finish)
 	struct Result *res;            // its record (complete but for best_lane / bit_flips / a payload CRC failure)
+	uint8_t *payload_now;          // the same in the chunk's own arrays: where k_sc_finish delivers, which runs right behind k_back -
+	struct Result *res_now;        // before a staging buffer of the chunk leaves (launch_back: payload_later)
 	int oper_mode;
 	int frame;                     // index in its chunk
 };
+struct ScRing { ListQueue *q; ListSlot *slots; float *llr; };  // what k_back needs of the SC ring (q = nullptr: the pass is off)
 
 struct Result {                    // device mirror of ofdmrx_frame_result (same layout)
 	int32_t status;
@@ -166,12 +175,20 @@ void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, flo
 // chunk's own arrays may be a staging buffer that has been copied out and reused by the time their flush comes
 void launch_back(hipStream_t s, int rate, int n, int cert_mode, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, ListQueue *q, ListSlot *slots,
-	float *llr_q, int *slot_of, uint8_t *payload_later = nullptr, Result *res_later = nullptr);
+	float *llr_q, int *slot_of, uint8_t *payload_later = nullptr, Result *res_later = nullptr, ScRing sc = ScRing{ nullptr, nullptr, nullptr });
 void launch_rotate_tap(hipStream_t s, const SyncState *st, const cf *cons, const float *slope, const float *yint, cf *out);   // one frame, CONS_MAX points
 void launch_queue_reset(hipStream_t s, ListQueue *q, unsigned cap);
 void launch_queue_snap(hipStream_t s, ListQueue *q, int par);
 void launch_queue_plan(hipStream_t s, ListQueue *q, int par, unsigned unit, int force);
 void launch_queue_fill(hipStream_t s, ListQueue *q, ListSlot *slots, int n, uint8_t *payload, Result *res, int oper_mode);
+// the sign-following path alone + its certificate (k_sc.hip): grid = resident decoders (sc_store_bytes() of level store each)
+void launch_sc_plan(hipStream_t s, ListQueue *qs);
+void launch_sc(hipStream_t s, int grid, ListQueue *qs, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
+	unsigned long long *xw_q, ScStat *stat_q, Tables tb);
+void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
+	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of);
+void launch_sc_adapt(hipStream_t s, ListQueue *qs);
+size_t sc_store_bytes();
 // D9 / D10 for the run `par` of the queue; grid = resident decoders, max_entries = an upper bound of the run's length
 void launch_polar(hipStream_t s, int list, int grid, ListQueue *q, int par, const ListSlot *slots, const float *llr_q, float *soft, uint8_t *hard_q,
 	Tables tb, float *metric_q);

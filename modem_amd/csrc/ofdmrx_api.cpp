@@ -110,6 +110,8 @@ long long callsign_value(const char *str)
 
 }  // namespace
 
+static constexpr int T_SC = OFDMRX_T_COUNT;   // internal stage index of the list-1 pass
+
 struct ofdmrx_handle {
 	ofdmrx_config cfg;
 	hipStream_t stream = nullptr;
@@ -132,6 +134,14 @@ struct ofdmrx_handle {
 	// the list decoder's work queue (kernels.h: ListQueue): control block + one slot per entry
 	DevBuf q_ctl, q_slots, q_llr, q_hard, q_metric, q_lane_mesg;
 	unsigned q_cap = 0;       // slots
+	// the SC ring in front of it (k_sc.hip): control block, one slot per frame of a chunk (LLRs, P*'s codeword, the channel's hard
+	// decisions, ScStat), one level store per resident decoder
+	DevBuf s_ctl, s_slots, s_llr, s_cw, s_xw, s_stat, sc_soft;
+	unsigned s_cap = 0;
+	int sc_mode = 1;          // 1: the list-1 pass (adaptive) in front of the list decoder, 0: off
+	int sc_grid = 0;          // resident SC decoders
+	ListQueue *sc_queue() const { return s_ctl.as<ListQueue>(); }
+	ScRing sc_ring() const { return sc_mode ? ScRing{ s_ctl.as<ListQueue>(), s_slots.as<ListSlot>(), s_llr.as<float>() } : ScRing{ nullptr, nullptr, nullptr }; }
 	unsigned flush_unit = 1;  // entries a flush takes at a time (one residency of the list decoder) unless it is forced
 	DevBuf rot_tap;           // OFDMRX_TAP_CONS_ROT: the rotated rows of one frame, made on demand
 	DevBuf tx_code, tx_rowsym, tx_tdom, tx_big;   // transmitter scratch, kept between calls (no allocation, no synchronisation per call)
@@ -163,6 +173,8 @@ struct ofdmrx_handle {
 	struct Span { int stage; size_t a, b; };
 	std::vector<Span> spans;
 	ofdmrx_timing timing{};
+	float sc_ms = 0.f;        // the list-1 pass (stage T_SC: ofdmrx_timing keeps its layout, ofdmrx_get_sc_timing reports it)
+	int sc_launches = 0;
 };
 
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -212,6 +224,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	h->rate = cfg->sample_rate;
 	h->list = cfg->list_size == 4 ? 4 : 8;
 	h->cert_mode = !(cfg->flags & (OFDMRX_FLAG_KEEP_RAW_CONS | OFDMRX_FLAG_SCL_ALWAYS)) && !std::getenv("OFDMRX_NO_CERT");   // (the rule holds for any list size)
+	h->sc_mode = !(cfg->flags & (OFDMRX_FLAG_KEEP_RAW_CONS | OFDMRX_FLAG_SCL_ALWAYS | OFDMRX_FLAG_NO_SC)) && !std::getenv("OFDMRX_NO_SC");   // (so does this one)
 	// default chunk: 8192 frames at every rate: the per-frame decoder state does not grow with the rate, and the two-stream
 	// schedule wants a few thousand codewords per polar launch (44.1 / 48 kHz: 121 k / 125 k frames/s against 111 k / 112 k
 	// with 4096).  What does grow is the per-chunk input: a 48 kHz frame is 4.2 MB of int16 pairs (34.6 GB per 8192 frames; the
@@ -257,6 +270,10 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		if (const char *e2 = std::getenv("OFDMRX_POLAR_WPC"))
 			wpc = std::max(1, std::atoi(e2));
 		h->polar_grid = wpc * std::max(cus, 1);
+		int swpc = 8;             // resident SC decoders per CU: one wave each, two per SIMD (239 VGPRs) + 16 KB of LDS (k_sc.hip)
+		if (const char *e3 = std::getenv("OFDMRX_SC_WPC"))
+			swpc = std::max(1, std::atoi(e3));
+		h->sc_grid = swpc * std::max(cus, 1);
 	}
 	build_tables(h->host, h->rate);
 	int r = 0;
@@ -270,6 +287,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.frozen, &h->dev.frozen);
 	r = r ? r : upload(h, h->host.info_pos, &h->dev.info_pos);
 	r = r ? r : upload(h, h->host.node_lev, &h->dev.node_lev);
+	r = r ? r : upload(h, h->host.node_lev64, &h->dev.node_lev64);
 	r = r ? r : upload(h, h->host.genmat_bits, &h->dev.genmat_bits);
 	r = r ? r : upload(h, h->host.osd_pairs, &h->dev.osd_pairs);
 	r = r ? r : upload(h, h->host.osd_triples, &h->dev.osd_triples);
@@ -297,7 +315,7 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 			(void)hipStreamDestroy(sx);
 		}
 	for (DevBuf *b : { &h->st, &h->hdr_soft, &h->cons, &h->slope, &h->yint, &h->precision, &h->slot_of, &h->res, &h->payload, &h->payload2, &h->res2,
-			&h->chunk_flags, &h->soft, &h->q_ctl, &h->q_slots, &h->q_llr, &h->q_hard, &h->q_metric, &h->q_lane_mesg, &h->rot_tap, &h->tx_code, &h->tx_rowsym,
+			&h->chunk_flags, &h->soft, &h->s_ctl, &h->s_slots, &h->s_llr, &h->s_cw, &h->s_xw, &h->s_stat, &h->sc_soft, &h->q_ctl, &h->q_slots, &h->q_llr, &h->q_hard, &h->q_metric, &h->q_lane_mesg, &h->rot_tap, &h->tx_code, &h->tx_rowsym,
 			&h->tx_tdom, &h->tx_big, &h->esn0_dev, &h->esn0_dev2, &h->att_dev, &h->att_dev2, &h->attc_dev, &h->attc_dev2, &h->dc, &h->z, &h->in_stage, &h->in_stage2, &h->skip_stage, &h->carr, &h->sc_scratch })
 		b->release();
 	for (void *p : h->table_allocs)
@@ -354,6 +372,23 @@ extern "C" long long ofdmrx_list_decoded_frames(ofdmrx_handle *h)
 	return (long long)q.tail;                                 // entries queued since the call began
 }
 
+// frames of the last decode call that the list-1 pass finished; -1: that pass is off for this handle
+extern "C" long long ofdmrx_sc_decided_frames(ofdmrx_handle *h)
+{
+	if (!h)
+		return OFDMRX_E_ARG;
+	if (!h->sc_mode)
+		return -1;
+	if (!h->s_ctl.p)
+		return 0;
+	if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+		return OFDMRX_E_HIP;
+	ListQueue q;
+	if (hipMemcpy(&q, h->s_ctl.p, sizeof(q), hipMemcpyDeviceToHost) != hipSuccess)
+		return OFDMRX_E_HIP;
+	return (long long)q.done_total;
+}
+
 // device state for chunks of up to n frames; the list decoder's queue for calls whose chunks have up to n frames
 static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 {
@@ -385,6 +420,17 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 		r = r ? r : h->q_metric.ensure(Q * LIST * sizeof(float));
 		if (h->cfg.flags & 1)                                     // (the per-lane messages are a debug tap)
 			r = r ? r : h->q_lane_mesg.ensure(Q * LIST * MESG_BYTES);
+		if (h->sc_mode) {                                         // the SC ring is drained right behind k_back of every chunk: one chunk of slots
+			h->s_cap = (unsigned)(N + 8);
+			const size_t S = h->s_cap;
+			r = r ? r : h->s_ctl.ensure(sizeof(ListQueue));
+			r = r ? r : h->s_slots.ensure(S * sizeof(ListSlot));
+			r = r ? r : h->s_llr.ensure(S * CODE_LEN * sizeof(float));
+			r = r ? r : h->s_cw.ensure(S * (CODE_LEN / 8));
+			r = r ? r : h->s_xw.ensure(S * (CODE_LEN / 8));
+			r = r ? r : h->s_stat.ensure(S * sizeof(ScStat));
+			r = r ? r : h->sc_soft.ensure((size_t)(std::min<long>((long)N, (long)h->sc_grid) + 1) * sc_store_bytes());
+		}
 		if (!demod_forms_cons(h->rate))                       // (the carriers go through HBM only when k_theil_sen forms the rows)
 			r = r ? r : h->carr.ensure(N * CARR_MAX * sizeof(cf));
 #ifndef SYNC_FFT_IN_LDS
@@ -513,11 +559,25 @@ static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_r
 		Range r("ofdmrx:back");
 		launch_back(s, h->rate, n, h->cert_mode, h->st.as<SyncState>(), h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(),
 			h->precision.as<float>(), d_res, d_esn0, h->dev, h->cfg.descramble, d_payload, h->queue(), h->q_slots.as<ListSlot>(),
-			h->q_llr.as<float>(), h->slot_of.as<int>(), payload_later, res_later);
-		launch_queue_snap(s, h->queue(), par);
+			h->q_llr.as<float>(), h->slot_of.as<int>(), payload_later, res_later, h->sc_ring());
 	}
 	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
+	if (h->sc_mode) {
+		// the list-1 pass on what k_back put into the SC ring (k_sc.hip): frames it decides are finished, the rest move on to the
+		// list decoder's queue - all in stream order with k_back's own entries there, so the snapshot below sees complete entries only
+		Range r("ofdmrx:sc_path");
+		launch_sc_plan(s, h->sc_queue());
+		launch_sc(s, std::min(h->sc_grid, n), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->sc_soft.as<float>(),
+			h->s_cw.as<unsigned long long>(), h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev);
+		launch_sc_finish(s, n, h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->s_cw.as<unsigned long long>(),
+			h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev, h->cfg.descramble, h->queue(), h->q_slots.as<ListSlot>(),
+			h->q_llr.as<float>(), h->slot_of.as<int>());
+		launch_sc_adapt(s, h->sc_queue());
+		size_t e7 = mark(h, s);
+		h->spans.push_back({ T_SC, e6, e7 });
+	}
+	launch_queue_snap(s, h->queue(), par);
 	HIP_OK(hipGetLastError());
 	return 0;
 }
@@ -655,6 +715,8 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 	const bool every = hooks.outputs_leave_by_chunk();
 	std::vector<size_t> ev_back(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_fin(n_chunks, NONE), t0s(n_chunks, 0);
 	launch_queue_reset(sa, h->queue(), h->q_cap);
+	if (h->sc_mode)
+		launch_queue_reset(sa, h->sc_queue(), h->s_cap);
 	auto flush = [&](size_t p, size_t ev_sync_next) -> int {
 		const int par = (int)(p & 1);
 		if (overlap) {
@@ -1025,16 +1087,35 @@ extern "C" int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t)
 	if (int r = host_wait(h))
 		return r;
 	std::memset(&h->timing, 0, sizeof(h->timing));
+	h->sc_ms = 0.f;
+	h->sc_launches = 0;
 	for (const auto &sp : h->spans) {
 		if (sp.a == (size_t)-1 || sp.b == (size_t)-1)
 			continue;
 		float ms = 0.f;
 		if (hipEventElapsedTime(&ms, h->ev_pool[sp.a], h->ev_pool[sp.b]) == hipSuccess) {
-			h->timing.ms[sp.stage] += ms;
-			h->timing.launches[sp.stage] += 1;
+			if (sp.stage == T_SC) {
+				h->sc_ms += ms;
+				h->sc_launches += 1;
+			} else {
+				h->timing.ms[sp.stage] += ms;
+				h->timing.launches[sp.stage] += 1;
+			}
 		}
 	}
 	*t = h->timing;
+	return 0;
+}
+
+extern "C" int ofdmrx_get_sc_timing(ofdmrx_handle *h, float *ms, int32_t *launches)
+{
+	ofdmrx_timing t;
+	if (int r = ofdmrx_get_timing(h, &t))
+		return r;
+	if (ms)
+		*ms = h->sc_ms;
+	if (launches)
+		*launches = h->sc_launches;
 	return 0;
 }
 
@@ -1056,6 +1137,10 @@ extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *
 	int slot = -1;
 	if (tap == OFDMRX_TAP_LLR || tap == OFDMRX_TAP_METRIC || tap == OFDMRX_TAP_LANE_MESG) {
 		HIP_OK(hipMemcpy(&slot, h->slot_of.as<int>() + frame, sizeof(int), hipMemcpyDeviceToHost));
+		if (slot <= -2 && tap == OFDMRX_TAP_LLR) {                // finished by the list-1 pass: its LLRs are still in the SC ring
+			HIP_OK(hipMemcpy(dst, h->s_llr.as<float>() + (size_t)(-2 - slot) * CODE_LEN, std::min<size_t>(dst_bytes, CODE_LEN * 4), hipMemcpyDeviceToHost));
+			return 0;
+		}
 		if (slot < 0 || (tap == OFDMRX_TAP_LANE_MESG && !h->q_lane_mesg.p))
 			return OFDMRX_E_UNSUPPORTED;
 	}
@@ -1139,6 +1224,58 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 	}
 	h->last_n = 0;
 	return 0;
+}
+
+// the sign-following path alone: n LLR vectors -> k_sc's outputs (codeword, hard decisions, metric, min_fork, rule)
+extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n, int oper_mode, uint8_t *codeword, uint8_t *hard, float *metric,
+	float *min_fork, int32_t *rule_ok)
+{
+	if (!h || !llr || !n || n > (size_t)h->chunk || oper_mode < 6 || oper_mode > 13)
+		return OFDMRX_E_ARG;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	int r = ensure_capacity(h, (int)n, false, 0);
+	if (r)
+		return r;
+	// buffers of this call's own: the handle may have been created without the pass
+	DevBuf ctl, slots, dl, cw, xw, stat, soft;
+	const int grid = (int)std::min<size_t>(n, (size_t)h->sc_grid);
+	r = r ? r : ctl.ensure(sizeof(ListQueue));
+	r = r ? r : slots.ensure(n * sizeof(ListSlot));
+	r = r ? r : dl.ensure(n * CODE_LEN * sizeof(float));
+	r = r ? r : cw.ensure(n * (CODE_LEN / 8));
+	r = r ? r : xw.ensure(n * (CODE_LEN / 8));
+	r = r ? r : stat.ensure(n * sizeof(ScStat));
+	r = r ? r : soft.ensure((size_t)(grid + 1) * sc_store_bytes());
+	if (!r && (r = host_wait(h)) == 0) {
+		hipError_t e = hipMemcpy(dl.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice);
+		launch_queue_reset(h->stream, ctl.as<ListQueue>(), (unsigned)n);
+		launch_queue_fill(h->stream, ctl.as<ListQueue>(), slots.as<ListSlot>(), (int)n, h->payload.as<uint8_t>(), h->res.as<Result>(), oper_mode);
+		launch_sc_plan(h->stream, ctl.as<ListQueue>());
+		launch_sc(h->stream, grid, ctl.as<ListQueue>(), slots.as<ListSlot>(), dl.as<float>(), soft.as<float>(), cw.as<unsigned long long>(),
+			xw.as<unsigned long long>(), stat.as<ScStat>(), h->dev);
+		e = e == hipSuccess ? hipGetLastError() : e;
+		e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;
+		if (e == hipSuccess && codeword)
+			e = hipMemcpy(codeword, cw.p, n * (CODE_LEN / 8), hipMemcpyDeviceToHost);
+		if (e == hipSuccess && hard)
+			e = hipMemcpy(hard, xw.p, n * (CODE_LEN / 8), hipMemcpyDeviceToHost);
+		std::vector<ScStat> st(n);
+		if (e == hipSuccess)
+			e = hipMemcpy(st.data(), stat.p, n * sizeof(ScStat), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) {
+			g_last_error = hipGetErrorString(e);
+			r = OFDMRX_E_HIP;
+		} else
+			for (size_t i = 0; i < n; ++i) {
+				if (metric) metric[i] = st[i].metric;
+				if (min_fork) min_fork[i] = st[i].min_fork;
+				if (rule_ok) rule_ok[i] = st[i].ok;
+			}
+	}
+	for (DevBuf *b : { &ctl, &slots, &dl, &cw, &xw, &stat, &soft })
+		b->release();
+	h->last_n = 0;
+	return r;
 }
 
 // D5 output -> payload: ROTATED constellation rows of mode-6 frames through D6-D10 exactly as the pipeline chains them (the rows'

@@ -20,8 +20,8 @@ STAGES = ["front", "sync", "header", "demod", "theilsen", "llr", "polar", "finis
 # every symbol include/ofdmrx.h declares
 EXPORTS = [
     "ofdmrx_abi_version", "ofdmrx_abi_minor", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
-    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_list_decoded_frames", "ofdmrx_set_esn0_rows", "ofdmrx_set_attempt_log",
-    "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_decode_cons", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
+    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_list_decoded_frames", "ofdmrx_sc_decided_frames", "ofdmrx_get_sc_timing", "ofdmrx_set_esn0_rows", "ofdmrx_set_attempt_log",
+    "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_sc_path", "ofdmrx_debug_decode_cons", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
     "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
     "ofdmrx_tx_encode_device", "ofdmrx_stream_samples", "ofdmrx_tx_encode_stream_device", "ofdmrx_tx_encode_stream",
     "ofdmrx_callsign_value",
@@ -115,6 +115,10 @@ def load_library():
     L.ofdmrx_set_attempt_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ofdmrx_list_decoded_frames.argtypes = [C.c_void_p]
     L.ofdmrx_list_decoded_frames.restype = C.c_longlong
+    L.ofdmrx_sc_decided_frames.argtypes = [C.c_void_p]
+    L.ofdmrx_sc_decided_frames.restype = C.c_longlong
+    L.ofdmrx_get_sc_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.ofdmrx_debug_sc_path.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_dump.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
     L.ofdmrx_debug_polar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_decode_cons.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -159,13 +163,13 @@ class Receiver:
     """
 
     def __init__(self, device=0, chunk_frames=0, max_samples=0, descramble=True, keep_raw_cons=False, stream=None,
-                 sample_rate=8000, list_size=8, scl_always=False):
+                 sample_rate=8000, list_size=8, scl_always=False, no_sc=False):
         self._lib = load_library()
         if self._lib.ofdmrx_abi_version() != 1:
             raise OfdmRxError("ABI mismatch")
         self.sample_rate = int(sample_rate)
         cfg = Config(1, self.sample_rate, int(list_size), device, chunk_frames, max_samples, 1 if descramble else 0,
-                     (1 if keep_raw_cons else 0) | (2 if scl_always else 0), stream)
+                     (1 if keep_raw_cons else 0) | (2 if scl_always else 0) | (4 if no_sc else 0), stream)
         self._h = C.c_void_p()
         self._check(self._lib.ofdmrx_create(C.byref(cfg), C.byref(self._h)))
 
@@ -238,6 +242,15 @@ class Receiver:
         """frames of the last decode call the syndrome certificate left to the list decoder (-1: certificate off)"""
         return int(self._lib.ofdmrx_list_decoded_frames(self._h))
 
+    def sc_decided_frames(self):
+        """frames of the last decode call finished by the list-1 pass (-1: that pass is off)"""
+        return int(self._lib.ofdmrx_sc_decided_frames(self._h))
+
+    def sc_timing(self):
+        ms, n = C.c_float(), C.c_int32()
+        self._check(self._lib.ofdmrx_get_sc_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def synchronize(self):
         self._check(self._lib.ofdmrx_synchronize(self._h))
 
@@ -265,6 +278,16 @@ class Receiver:
         metric = np.zeros((n, 8), np.float32)
         self._check(self._lib.ofdmrx_debug_polar(self._h, _ptr(llr), n, _ptr(mesg), _ptr(metric)))
         return mesg, metric
+
+    def sc_path(self, llr, mode=6):
+        """k_sc alone: codeword bits [n, 65536], hard decisions of the LLRs [n, 65536], metric, min_fork, rule [n]"""
+        llr = np.ascontiguousarray(llr, dtype=np.float32).reshape(-1, CODE_LEN)
+        n = llr.shape[0]
+        cw = np.zeros((n, CODE_LEN // 8), np.uint8)
+        hd = np.zeros((n, CODE_LEN // 8), np.uint8)
+        metric, fork, ok = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        self._check(self._lib.ofdmrx_debug_sc_path(self._h, _ptr(llr), n, mode, _ptr(cw), _ptr(hd), _ptr(metric), _ptr(fork), _ptr(ok)))
+        return np.unpackbits(cw, axis=1, bitorder="little"), np.unpackbits(hd, axis=1, bitorder="little"), metric, fork, ok
 
     def decode_cons(self, cons, use_cert=True):
         """rotated constellation rows (n x 21600 complex64, mode 6) -> payloads, results, the syndrome certificate's verdict per frame"""

@@ -146,6 +146,12 @@ int orc_polar_list_decode(float *metric_out, int8_t *mesg_out, const float *llr,
 
 int orc_polar_lane_mesg(const float *llr, const uint32_t *frozen, int level, int L,
 	uint8_t *lane_mesg, int mesg_bytes, float *metric);
+/* NOT reference code: the checker of the build's "SC dominance" certificate (polar.c).  The sign-following
+ * path of the list decoder alone, with one lane's arithmetic of orc_polar_list_decode: hard[1<<level] = its re-encoded
+ * codeword (+1/-1), *metric = its path metric, *min_fork = min over the information leaves of fl(metric so far + |llr|).
+ * min_fork > metric  =>  that path is lane 0 of orc_polar_list_decode for every list size.  Returns the number of
+ * information leaves. */
+int orc_polar_sc_path(const float *llr, const uint32_t *frozen, int level, int8_t *hard, float *metric, float *min_fork);
 
 /* ---- BCH(255,71) + OSD --------------------------------------------------- */
 void orc_bch_encode(const uint8_t *data /*9 B*/, uint8_t *parity /*23 B*/); /* encode.cc:164 */

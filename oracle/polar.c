@@ -333,3 +333,86 @@ int orc_polar_lane_mesg(const float *llr, const uint32_t *frozen, int level, int
 	free(x);
 	return count;
 }
+
+/* ---- the sign-following path of the list decoder, alone (list size 1) -----------------------------------------
+ * NOT a restatement of reference code: the checker of the build's own "SC dominance" certificate.
+ * The path P* that takes the sign of its LLR at every information leaf, decoded with exactly the arithmetic
+ * scl_node runs for one lane (same prod / g, same order of the penalty sums incl. the rate-0 grouping and the
+ * numerics switches), carrying
+ *   metric    = P*'s path metric M* (its frozen-leaf penalties)
+ *   min_fork  = min over the information leaves i of fl(M*(i) + |llr_i|): what the sibling candidate at i costs
+ * Claim checked by tests/test_oracle_kat.py: if min_fork > metric (final), orc_polar_list_decode ends with P* as
+ * lane 0 - same message, same metric - for any list size.
+ * hard[N]: P*'s re-encoded codeword (+1 / -1), i.e. the root's partial sums.  Returns the number of information leaves. */
+typedef struct {
+	float *soft;       /* 2N */
+	int8_t *hard;      /* N */
+	float metric, min_fork;
+	int count;
+	const uint32_t *frozen;
+} sc1_t;
+
+static void sc1_node(sc1_t *s, int m, int index)
+{
+	if (m == 0) {
+		float v = s->soft[1];
+		if (is_frozen(s->frozen, index)) {
+			if (v < 0.f)
+				s->metric -= v;
+			s->hard[index] = 1;
+			return;
+		}
+		float fork = s->metric + fabsf(v);            /* scl_leaf: the candidate that does NOT follow the sign */
+		if (!(fork >= s->min_fork))                   /* (a NaN sticks) */
+			s->min_fork = fork;
+		s->hard[index] = (int8_t)(v < 0.f ? -1 : 1);
+		++s->count;
+		return;
+	}
+	if (m >= ORC_RATE0_MIN && m <= ORC_RATE0_MAX && !(g_numerics & ORC_NUM_RATE0_LEAFWALK) && all_frozen(s->frozen, index, m)) {
+		const int n = 1 << m;
+		float p[1 << ORC_RATE0_MAX];
+		for (int i = 0; i < n; ++i) {
+			float v = s->soft[n + i];
+			p[i] = v < 0.f ? -v : 0.f;
+		}
+		for (int h = n / 2; h >= 1; h /= 2)
+			for (int i = 0; i < h; ++i)
+				p[i] = p[i] + p[i + h];
+		s->metric += p[0];
+		for (int i = 0; i < n; ++i)
+			s->hard[index + i] = 1;
+		return;
+	}
+	const int n = 1 << m, h = n / 2;
+	float *soft = s->soft;
+	int8_t *hard = s->hard + index;
+	for (int i = 0; i < h; ++i)
+		soft[h + i] = prod(soft[n + i], soft[n + h + i]);
+	sc1_node(s, m - 1, index);
+	for (int i = 0; i < h; ++i)
+		soft[h + i] = (float)hard[i] * soft[n + i] + soft[n + h + i];
+	sc1_node(s, m - 1, index + h);
+	for (int i = 0; i < h; ++i)
+		hard[i] = (int8_t)(hard[i] * hard[h + i]);
+}
+
+int orc_polar_sc_path(const float *llr, const uint32_t *frozen, int level, int8_t *hard, float *metric, float *min_fork)
+{
+	const int N = 1 << level;
+	sc1_t s;
+	s.soft = (float *)malloc(sizeof(float) * 2 * (size_t)N);
+	s.hard = hard;
+	s.metric = 0.f;
+	s.min_fork = INFINITY;
+	s.count = 0;
+	s.frozen = frozen;
+	memcpy(s.soft + N, llr, sizeof(float) * (size_t)N);
+	sc1_node(&s, level, 0);
+	if (metric)
+		*metric = s.metric;
+	if (min_fork)
+		*min_fork = s.min_fork;
+	free(s.soft);
+	return s.count;
+}

@@ -80,6 +80,8 @@ def lib():
         L.orc_polar_list_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_polar_lane_mesg.restype = C.c_int
         L.orc_polar_lane_mesg.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_polar_sc_path.restype = C.c_int
+        L.orc_polar_sc_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_frozen_get.restype = C.POINTER(C.c_uint32)
         L.orc_frozen_get.argtypes = [C.c_int]
         L.orc_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -219,6 +221,31 @@ def polar_lane_mesg(llr, L=8, table=0):
     metric = np.zeros(L, np.float32)
     lib().orc_polar_lane_mesg(ptr(llr), ptr(fr), 16, L, ptr(mesg), 5476, ptr(metric))
     return mesg, metric
+
+
+def polar_sc_path(llr, fr=None, level=16):
+    """the sign-following path alone (oracle/polar.c: orc_polar_sc_path): codeword bits [N] (1 = -1), metric, min_fork"""
+    llr = np.ascontiguousarray(llr, dtype=np.float32)
+    fr = frozen(0) if fr is None else np.ascontiguousarray(fr, dtype=np.uint32)
+    hard = np.zeros(1 << level, np.int8)
+    metric, fork = C.c_float(), C.c_float()
+    lib().orc_polar_sc_path(ptr(llr), ptr(fr), level, ptr(hard), C.byref(metric), C.byref(fork))
+    return (hard < 0).astype(np.uint8), np.float32(metric.value), np.float32(fork.value)
+
+
+def polar_list_decode(llr, fr, level, L):
+    """orc_polar_list_decode on any code length: per-lane re-encoded codewords [L, N] (1 = -1) and metrics [L]"""
+    llr = np.ascontiguousarray(llr, dtype=np.float32)
+    fr = np.ascontiguousarray(fr, dtype=np.uint32)
+    N = 1 << level
+    mesg = np.zeros((N, L), np.int8)
+    metric = np.zeros(L, np.float32)
+    count = lib().orc_polar_list_decode(ptr(metric), ptr(mesg), ptr(llr), ptr(fr), level, L)
+    code = np.zeros((L, N), np.int8)
+    for k in range(L):
+        u = np.ascontiguousarray(mesg[:count, k])
+        lib().orc_polar_enc(ptr(code[k]), ptr(u), ptr(fr), level)
+    return (code < 0).astype(np.uint8), metric
 
 
 def theil_sen(y):

@@ -276,3 +276,105 @@ def test_scl_lane0_is_the_hard_decision_codeword_with_metric_zero():
         assert metric[0] == 0.0, (t, metric)
         assert (lane[0] == want).all(), t
         assert (metric[1:] > 0).all(), (t, metric)              # every other path pays a penalty somewhere
+
+
+# ---------------------------------------------------------------- the SC-dominance certificate
+def _awgn_llr(rng, code_nrz, sigma):
+    y = code_nrz + sigma * rng.standard_normal(code_nrz.size)
+    return (2.0 * y / sigma ** 2).astype(np.float32)
+
+
+def test_sc_dominance_rule_on_small_codes():
+    """The rule k_sc's certificate rests on, checked on the oracle's list decoder for codes of 32 .. 1024 bits, frozen sets of
+    the usual shape and arbitrary ones, list sizes 2 / 4 / 8, LLRs from clean to hopeless incl. exact zeros: whenever
+    min_fork > M* (tests/sc_model.py), lane 0 of the list decoder is the sign-following path P* - same codeword, metric M*
+    bit for bit - and every other lane ends strictly above it.  The C checker of the large tests (orc_polar_sc_path) is
+    compared with the numpy model on every vector.  When the rule does NOT hold, lane 0 often is another path: the rule is no
+    formality."""
+    import sc_model as S
+    rng = np.random.default_rng(5)
+    held = failed = other = 0
+    for level in (5, 6, 7, 8, 9, 10):
+        N = 1 << level
+        for trial in range(40):
+            if trial % 2 == 0:
+                fz = S.bec_frozen(level, int(N * rng.uniform(0.3, 0.8)))
+            else:
+                fz = rng.random(N) < rng.uniform(0.2, 0.7)
+                fz[0] = True
+            fw = S.pack_frozen(fz)
+            u = np.where(fz, 1, 1 - 2 * rng.integers(0, 2, N)).astype(np.int8)
+            mesg = np.ascontiguousarray(u[~fz])
+            code = np.zeros(N, np.int8)
+            O.lib().orc_polar_enc(O.ptr(code), O.ptr(mesg), O.ptr(fw), level)
+            llr = _awgn_llr(rng, code, rng.choice([0.3, 0.5, 0.7, 0.9, 1.2]))
+            if trial % 7 == 3:
+                llr[rng.integers(0, N, 3)] = 0
+            c1, M1, F1 = O.polar_sc_path(llr, fw, level)
+            c2, M2, F2 = S.sc_path(llr, fz)
+            assert (c1 == c2).all() and M1 == M2 and F1 == F2, (level, trial, M1, M2, F1, F2)
+            for L in (2, 4, 8):
+                codes, metric = O.polar_list_decode(llr, fw, level, L)
+                if F1 > M1:
+                    held += 1
+                    assert (codes[0] == c1).all() and metric[0] == M1 and (metric[1:] > M1).all(), (level, trial, L, M1, F1, metric)
+                else:
+                    failed += 1
+                    other += int((codes[0] != c1).any())
+    assert held >= 200 and failed >= 200 and other >= 50, (held, failed, other)
+
+
+def test_sc_dominance_rule_on_the_payload_code():
+    """The same on the (65536, 43808) code of mode 6 with the LLRs the oracle's own soft demapper makes of noisy frames: the rule
+    holds from -24 dB (where the syndrome certificate has already given up) down to -19 dB and lane 0 of the list-8 decoder is
+    P* with P*'s metric; at -17 dB P*'s metric has outgrown min_fork, the rule says nothing (and the frame is list-decoded).
+    Two constructed vectors: P* is ANOTHER codeword than the transmitted one (rule holds, metric 0, lane 0 = P*, its CRC fails,
+    a later lane carries the transmitted message: the certificate must leave such a frame to the list decoder), and an
+    information leaf with |llr| = 0 (min_fork = M* at that leaf: the rule can never hold)."""
+    fr = O.frozen(0)
+    base = O.encode_pcm(O.payload_for(3), channels=2)
+    seen = {}
+    for db in (-24, -20, -19, -17):
+        pcm = O.impair(base, noise_db=db, seed=7, frame=int(-db * 10))
+        out, r, tb = O.decode(pcm, taps=True)
+        c, M, F = O.polar_sc_path(tb.llr, fr)
+        seen[db] = bool(F > M)
+        if F > M:
+            lane, metric = O.polar_lane_mesg(tb.llr)
+            fz = ((fr[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1).astype(bool)
+            want = np.packbits(c[~fz], bitorder="little")
+            assert metric[0] == M and (lane[0] == want).all() and (metric[1:] > M).all(), (db, M, F, metric)
+            assert r.status == 0 and r.best_lane == 0
+            flips = int(((tb.llr < 0)[~fz][:43040] != c[~fz][:43040]).sum())
+            assert flips == r.bit_flips, (db, flips, r.bit_flips)         # decode.cc:546-555 from P*'s codeword
+    assert seen[-24] and seen[-20] and seen[-19] and not seen[-17], seen
+    # another codeword as P*
+    rng = np.random.default_rng(12)
+    mesg = (1 - 2 * rng.integers(0, 2, 43808)).astype(np.int8)
+    code = np.zeros(65536, np.int8)
+    O.lib().orc_polar_sysenc(O.ptr(code), O.ptr(mesg), O.ptr(fr), 16)
+    fzb = ((fr[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1).astype(bool)
+    info = np.flatnonzero(~fzb)
+    row = int(info[np.argmin([bin(int(i)).count("1") for i in info])])    # a lightest generator row of an information position
+    e = np.zeros(65536, np.int8) + 1
+    ue = np.ones(65536, np.int8)
+    ue[row] = -1
+    uu = np.ascontiguousarray(ue[~fzb])
+    O.lib().orc_polar_enc(O.ptr(e), O.ptr(uu), O.ptr(fr), 16)             # the codeword of that single message bit
+    other = (code * e).astype(np.int8)                                    # = code with that row's code bits flipped
+    mag = np.where(e < 0, 0.25, 8.0)                                      # weak where the two codewords differ
+    llr = (other.astype(np.float64) * mag).astype(np.float32)
+    c, M, F = O.polar_sc_path(llr, fr)
+    assert M == 0 and F > 0 and (c == (other < 0)).all()
+    lane, metric = O.polar_lane_mesg(llr)
+    assert metric[0] == 0 and (lane[0] == np.packbits(c[~fzb], bitorder="little")).all()
+    sent = np.packbits((code < 0)[~fzb], bitorder="little")
+    assert any((lane[k] == sent).all() for k in range(1, 8))              # the transmitted message is in a LATER lane
+    # a zero at an information leaf
+    llr2 = (code.astype(np.float64) * 8.0).astype(np.float32)
+    llr2[65535] = 0.0                                                     # the last leaf's LLR is a sum that this zero does not cancel ...
+    c, M, F = O.polar_sc_path(llr2, fr)
+    assert F > M                                                          # ... so the rule still holds
+    llr2[:] = 0.0
+    c, M, F = O.polar_sc_path(llr2, fr)
+    assert not F > M                                                      # all zero: every fork is a tie
