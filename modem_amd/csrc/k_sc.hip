@@ -33,9 +33,24 @@ namespace rx {
 
 #define SC_WAVE_ORDER() __builtin_amdgcn_wave_barrier()
 
-// ---- positions and lanes.  Lane l holds position q = l ^ ((l & 4) ? 3 : 0) of a 64-leaf block: then "the lane whose position
-// differs in bit 2" is row_half_mirror (l ^ 7), and all six butterfly exchanges are single DPP / permlane instructions.
-__device__ __forceinline__ int sc_pos(int lane) { return lane ^ ((lane & 4) ? 3 : 0); }
+// ---- how a wave is cut: LB = log2 of the lanes that work on one codeword (6: one codeword per wave, 5: two).  The decoder has
+// NO data-dependent control flow - what it does at every node follows from the frozen table alone - so codewords of the same
+// table run in lock-step in one wave, and whatever a 2^LB-leaf block costs is shared by 64 >> LB codewords.
+template <int LB> struct ScCfg {
+	static constexpr int J = 1 << LB, C = 64 >> LB;
+	static constexpr int LL = LB + 6;                         // the level whose array lives in LDS: 64 elements per lane
+	static constexpr int NSUB = 1 << (16 - LL);               // sub-trees of that size per codeword
+	static constexpr int SUB_BYTES = 64 * J * 4;              // one of them in a level array
+	static constexpr int STORE_FLOATS = 65536 - (2 << LL);    // levels LL+1 .. 15 of one codeword
+	static constexpr int SPARE_WORDS = 2 * (CODE_LEN / 32);   // behind a decoder's level stores: where the second lane group of an unpaired
+	                                                          // codeword publishes its (identical) words instead of the codeword's own
+	static constexpr int DECODER_FLOATS = C * STORE_FLOATS + SPARE_WORDS;
+};
+__host__ __device__ constexpr int sc_off(int m) { return (65536 - (2 << m)) * 4; }   // level m <= 15 in a codeword's level store, bytes
+
+// ---- positions and lanes.  Lane l holds position q = j ^ ((j & 4) ? 3 : 0), j = l mod 2^LB, of its codeword's block: then "the
+// lane whose position differs in bit 2" is row_half_mirror (l ^ 7), and every butterfly exchange is one DPP / permlane instruction.
+__device__ __forceinline__ int sc_pos(int j) { return j ^ ((j & 4) ? 3 : 0); }
 template <int H> __device__ __forceinline__ int xpos_i(int v, int lane)
 {
 	if constexpr (H == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
@@ -53,6 +68,12 @@ template <int H> __device__ __forceinline__ int xpos_i(int v, int lane)
 template <int H> __device__ __forceinline__ float xpos(float v, int lane) { return __int_as_float(xpos_i<H>(__float_as_int(v), lane)); }
 template <int H> __device__ __forceinline__ uint32_t xpos(uint32_t v, int lane) { return (uint32_t)xpos_i<H>((int)v, lane); }
 
+constexpr uint32_t SC_SIGN = 0x80000000u;
+// what a lane knows about itself: lowsel[L] = the sign bit if its position lies in the LOW half of its level-L node, else 0
+struct ScLane {
+	int lane, q;
+	uint32_t lowsel[7];
+};
 // the decoder's running figures: M* and min_fork (as its bit pattern: non-negative floats order like unsigned integers)
 struct ScAcc {
 	float M;
@@ -86,173 +107,171 @@ template <int LV> __device__ __forceinline__ uint32_t sc_min_mag(uint32_t mu, in
 	if constexpr (LV >= 1) mu = min(mu, xpos<1>(mu, lane));
 	return mu;
 }
-__device__ __forceinline__ float sc_pen(float v) { return v < 0.f ? -v : 0.f; }
+// max(0, -llr): what a frozen leaf adds when its LLR is negative (oracle/polar.c: scl_leaf; adding +0 changes nothing)
+__device__ __forceinline__ float sc_pen(float v) { return __builtin_fmaxf(-v, 0.f); }
 __device__ __forceinline__ uint32_t sc_mag(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 
-// g step inside a 64-leaf block: the level-LV node's own value and its partner's (position bit LV-1), the left child's partial sum
-template <int LV> __device__ __forceinline__ float sc_g_cross(float own, int ub, int lane, int q)
+// Partial sums inside a block are kept in SIGN-BIT FORM, one register per level: beta = 0x80000000 if the partial sum of the
+// level's current node AT THE LANE'S OWN POSITION (mod the node size) is 1, else 0.  Then
+//   g step     t = beta_left & lowsel[L];  r' = r ^ t;  child = r' + partner(r')      (b + a or b - a: the low half carries a and
+//                                                                                     flips its sign, the sum is the same on both sides)
+//   combine    beta_L = beta_right ^ t                                                (low half: left ^ right, high half: right)
+//   leaf / all-information node   beta = the sign bit of the LLR;  frozen: 0.
+// (A zero LLR at an information leaf carries either sign bit; min_fork then equals M* and the rule cannot hold, see ScAcc.)
+template <int LV> __device__ __forceinline__ float sc_f_cross(float r, const ScLane &L) { return f_minsum(r, xpos<(1 << (LV - 1))>(r, L.lane)); }
+template <int LV> __device__ __forceinline__ float sc_g_cross(float r, uint32_t t, const ScLane &L)
 {
-	const float oth = xpos<(1 << (LV - 1))>(own, lane);
-	const bool hi = (q >> (LV - 1)) & 1;
-	return g_add(hi ? oth : own, hi ? own : oth, ub);
+	const float rp = __uint_as_float(__float_as_uint(r) ^ t);
+	return rp + xpos<(1 << (LV - 1))>(rp, L.lane);
 }
 
-// ---- the 8-leaf sub-tree (levels 3..0): a top-down walk that decides every uniform node it meets.  r[L] = this lane's LLR at
-// level L (position = the low L bits of q, duplicated over the others); H = partial sums, one bit per leaf: only the bit of the
-// lane's own position (mod the node size) is ever consumed, and the combines keep exactly that bit right.
-struct ScBlock8 {
-	ScAcc &acc;
-	int &H;
-	float r[4];
-	const uint32_t fz;
-	const int lane, q;
-
-	template <int LV, int P0> __device__ __forceinline__ void node()
-	{
-		if constexpr (LV == 0) {
-			const float r0 = r[0];
-			if ((fz >> P0) & 1) {
-				if (r0 < 0.f)
-					acc.M -= r0;
-			} else {
-				acc.info(sc_mag(r0));
-				H |= (r0 < 0.f ? 1 : 0) << P0;
-			}
-		} else {
-			constexpr int N = 1 << LV, HALF = N / 2;
-			constexpr uint32_t MASK = ((1u << N) - 1u) << P0;
-			const uint32_t pat = fz & MASK;
-			if (pat == MASK) {
-				acc.M += sc_pen_sum<LV>(sc_pen(r[LV]), lane);
-				return;
-			}
-			if (pat == 0) {
-				acc.info(sc_min_mag<LV>(sc_mag(r[LV]), lane));
-				H |= r[LV] < 0.f ? (int)MASK : 0;
-				return;
-			}
-			r[LV - 1] = f_minsum(r[LV], xpos<HALF>(r[LV], lane));
-			node<LV - 1, P0>();
-			r[LV - 1] = sc_g_cross<LV>(r[LV], (H >> (P0 + (q & (HALF - 1)))) & 1, lane, q);
-			node<LV - 1, P0 + HALF>();
-			constexpr int lmask = ((1 << HALF) - 1) << P0;
-			H = (H & ~lmask) | ((H ^ (H >> HALF)) & lmask);
-		}
-	}
-};
-
-// ---- the 64-leaf block: levels 6..4 as a loop over its eight 8-leaf sub-trees (the step pattern of the loops above it), the
-// rest in ScBlock8.  fz0 / fz1: frozen bits of leaves 0..31 / 32..63.  Returns the partial sum of the lane's own position.
-__device__ __forceinline__ int sc_walk64(float r6, uint32_t fz0, uint32_t fz1, ScAcc &acc, int lane, int q)
+// ---- a sub-tree of 2^LV <= 16 leaves whose frozen pattern FZ is known at compile time: straight-line code, every uniform node
+// decided in one step (all frozen: the penalty sum; all information: signs + smallest magnitude), nothing scalar left
+template <uint32_t FZ, int LV, int P0> __device__ __forceinline__ uint32_t sc_node_ct(float r, ScAcc &acc, const ScLane &L)
 {
-	unsigned long long H = 0;
-	float r5 = 0.f, r4 = 0.f;
-	#pragma unroll 1
-	for (int b8 = 0, adv8 = 1; b8 < 8; b8 += adv8) {
-		adv8 = 1;
-		const int z8 = b8 ? __builtin_ctz(b8) + 3 : 6;            // the level whose array a g step produces here (6: none, all f)
-		const uint32_t fzw = b8 < 4 ? fz0 : fz1;
-		const int sh = (b8 & 3) * 8;
-		int L8 = 0;
-		float rn = 0.f;                                           // the uniform node's own value
-		if (z8 >= 5) {
-			r5 = z8 == 5 ? sc_g_cross<6>(r6, (int)((uint32_t)H >> (q & 31)) & 1, lane, q) : f_minsum(r6, xpos<32>(r6, lane));
-			if (fzw == 0xffffffffu) {
-				acc.M += sc_pen_sum<5>(sc_pen(r5), lane);
-				L8 = 5;
-			} else if (fzw == 0u) {
-				acc.info(sc_min_mag<5>(sc_mag(r5), lane));
-				L8 = 5;
-				rn = r5;
-			}
-		}
-		if (z8 >= 4 && !L8) {
-			r4 = z8 == 4 ? sc_g_cross<5>(r5, (int)(H >> ((b8 - 2) * 8 + (q & 15))) & 1, lane, q) : f_minsum(r5, xpos<16>(r5, lane));
-			const uint32_t pat = (fzw >> sh) & 0xffffu;
-			if (pat == 0xffffu) {
-				acc.M += sc_pen_sum<4>(sc_pen(r4), lane);
-				L8 = 4;
-			} else if (pat == 0u) {
-				acc.info(sc_min_mag<4>(sc_mag(r4), lane));
-				L8 = 4;
-				rn = r4;
-			}
-		}
-		if (!L8) {
-			const float r3 = z8 == 3 ? sc_g_cross<4>(r4, (int)(H >> ((b8 - 1) * 8 + (q & 7))) & 1, lane, q) : f_minsum(r4, xpos<8>(r4, lane));
-			int H8 = 0;
-			ScBlock8 blk{ acc, H8, { 0.f, 0.f, 0.f, r3 }, (fzw >> sh) & 0xffu, lane, q };
-			blk.node<3, 0>();
-			H |= (unsigned long long)(uint32_t)H8 << (b8 * 8);
-		} else {
-			adv8 = 1 << (L8 - 3);
-			if (rn < 0.f)                                         // all-information: the node's partial sums are its sign bits (own position)
-				H |= (L8 == 5 ? 0xffffffffull : 0xffffull) << (b8 * 8);
-		}
-		const int bn8 = b8 + adv8;
-		for (int m = L8 ? L8 + 1 : 4; m <= 6 && (bn8 & ((1 << (m - 3)) - 1)) == 0; ++m) {
-			const int half = 1 << (m - 1), st = bn8 * 8 - 2 * half;
-			const unsigned long long lmask = ((1ull << half) - 1ull) << st;
-			H = (H & ~lmask) | ((H ^ (H >> half)) & lmask);
-		}
+	constexpr int N = 1 << LV;
+	constexpr uint32_t MASK = (N == 32 ? 0xffffffffu : ((1u << N) - 1u)) << P0, pat = FZ & MASK;
+	if constexpr (pat == MASK) {
+		acc.M += sc_pen_sum<LV>(sc_pen(r), L.lane);
+		return 0u;
+	} else if constexpr (pat == 0u) {
+		acc.info(sc_min_mag<LV>(sc_mag(r), L.lane));
+		return __float_as_uint(r) & SC_SIGN;
+	} else {
+		const uint32_t bl = sc_node_ct<FZ, LV - 1, P0>(sc_f_cross<LV>(r, L), acc, L);
+		const uint32_t t = bl & L.lowsel[LV];
+		const uint32_t br = sc_node_ct<FZ, LV - 1, P0 + N / 2>(sc_g_cross<LV>(r, t, L), acc, L);
+		return br ^ t;
 	}
-	return (int)(H >> q) & 1;
+}
+// the same for a pattern only known at run time (wave-uniform): the general walk
+template <int LV, int P0> __device__ __forceinline__ uint32_t sc_node_rt(float r, uint32_t fz, ScAcc &acc, const ScLane &L)
+{
+	constexpr int N = 1 << LV;
+	constexpr uint32_t MASK = ((1u << N) - 1u) << P0;
+	const uint32_t pat = fz & MASK;
+	if (pat == MASK) {
+		acc.M += sc_pen_sum<LV>(sc_pen(r), L.lane);
+		return 0u;
+	}
+	if (pat == 0u) {
+		acc.info(sc_min_mag<LV>(sc_mag(r), L.lane));
+		return __float_as_uint(r) & SC_SIGN;
+	}
+	if constexpr (LV > 0) {
+		const uint32_t bl = sc_node_rt<LV - 1, P0>(sc_f_cross<LV>(r, L), fz, acc, L);
+		const uint32_t t = bl & L.lowsel[LV];
+		const uint32_t br = sc_node_rt<LV - 1, P0 + N / 2>(sc_g_cross<LV>(r, t, L), fz, acc, L);
+		return br ^ t;
+	} else
+		return 0u;                                                // (a leaf is always uniform)
+}
+// The mixed 16-leaf patterns of both frozen tables (frozen_64800_43072, frozen_64512_43072: fifteen, the same in both; leaf 0 =
+// bit 0) as straight-line code; anything else takes the general walk.  tests/test_abi_cpu.py checks the list against the tables.
+#define SC_PATTERNS16(X) \
+	X(0x0001u) X(0x0117u) X(0x177fu) X(0x7fffu) X(0x17ffu) X(0x011fu) X(0x0017u) X(0x0003u) \
+	X(0x017fu) X(0x037fu) X(0x0007u) X(0x077fu) X(0x3fffu) X(0x1fffu) X(0x013fu)
+__device__ __forceinline__ uint32_t sc_block16(float r4, uint32_t pat, ScAcc &acc, const ScLane &L)
+{
+	switch (pat) {
+#define SC_CASE16(P) case P: return sc_node_ct<P, 4, 0>(r4, acc, L);
+	SC_PATTERNS16(SC_CASE16)
+#undef SC_CASE16
+	default: return sc_node_rt<4, 0>(r4, pat, acc, L);
+	}
 }
 
-// ---- the level store: input arrays of the current nodes of 2^15 | 2^14 | 2^13 leaves
-constexpr int SC_STORE_FLOATS = 32768 + 16384 + 8192;
-__host__ __device__ constexpr int sc_off(int m) { return m == 15 ? 0 : (m == 14 ? 32768 * 4 : (32768 + 16384) * 4); }   // bytes
+// ---- the block of 2^LB leaves one lane group holds: its 16-leaf quarters / halves in turn.  fz0 / fz1: frozen bits of its leaves
+// 0..31 / 32..63.  Returns beta of the whole block (the partial sum of the lane's own position, sign-bit form).
+template <int LB> __device__ __forceinline__ uint32_t sc_walk_block(float rb, uint32_t fz0, uint32_t fz1, ScAcc &acc, const ScLane &L)
+{
+	static_assert(LB == 5 || LB == 6, "blocks of 32 or 64 leaves");
+	uint32_t beta6 = 0;
+	float r5 = rb;
+	uint32_t t6 = 0;
+	#pragma unroll
+	for (int h = 0; h < (LB == 6 ? 2 : 1); ++h) {                 // the 32-leaf halves
+		const uint32_t fzw = h ? fz1 : fz0;
+		if constexpr (LB == 6) {
+			if (h == 0)
+				r5 = sc_f_cross<6>(rb, L);
+			else {
+				t6 = beta6 & L.lowsel[6];                         // (beta6 holds the left half's beta5 here)
+				r5 = sc_g_cross<6>(rb, t6, L);
+			}
+		}
+		uint32_t beta5;
+		if (fzw == 0xffffffffu) {
+			acc.M += sc_pen_sum<5>(sc_pen(r5), L.lane);
+			beta5 = 0u;
+		} else if (fzw == 0u) {
+			acc.info(sc_min_mag<5>(sc_mag(r5), L.lane));
+			beta5 = __float_as_uint(r5) & SC_SIGN;
+		} else {
+			const uint32_t bl = sc_block16(sc_f_cross<5>(r5, L), fzw & 0xffffu, acc, L);
+			const uint32_t t5 = bl & L.lowsel[5];
+			const uint32_t br = sc_block16(sc_g_cross<5>(r5, t5, L), fzw >> 16, acc, L);
+			beta5 = br ^ t5;
+		}
+		beta6 = (LB == 6 && h == 1) ? (beta5 ^ t6) : beta5;
+	}
+	return beta6;
+}
 
-// One pass over the top of the tree: the array of the 4096-leaf node that starts at sub-tree s, from the level D above it.
-//   KIND 0: f chain from the channel LLRs (s = 0, D = 4)   KIND 1: g of the channel LLRs, then f (s = 8, D = 4)
-//   KIND 2: g of level 12 + D of the level store, then f (s = 4, 12: D = 3; s = 2 mod 4: D = 2; odd s: D = 1)
-// A lane owns the columns x * 64 + lane (x = 0..63) of EVERY level: the chain below the first step is lane-local, each level
-// between is written once (levels >= 13 to the store, level 12 to LDS).  g takes the left child's partial sums from the
-// published words: lane l fetches word l of each of its sub-trees once, the loop picks word x with v_readlane.
-// KIND 0 also leaves the hard decisions of the channel LLRs (xw, bit-packed like the codeword) for the flip count, and
+// One pass over the top of the tree: the array of the sub-tree s (64 * 2^LB leaves per codeword) from the level D above it.
+//   KIND 0: f chain from the channel LLRs (s = 0)   KIND 1: g of the channel LLRs, then f (s = NSUB / 2)
+//   KIND 2: g of level LL + D of the level store, then f
+// A lane owns the columns x * J + j (x = 0..63) of its codeword at EVERY level: the chain below the first step is lane-local,
+// each level between is written once (levels > LL to the store, level LL to LDS).  g takes the left child's partial sums from
+// the published words (pa / pb: the two 32-bit halves a wave publishes per 64 lanes - the halves of a 64-bit word of one
+// codeword, or one word of each of two): lane l fetches word l of each sub-tree once, the loop picks word x with v_readlane.
+// KIND 0 also leaves the hard decisions of the channel LLRs (xa / xb, bit-packed like the codeword) for the flip count, and
 // checks that every LLR is finite and small enough that no sum of 65536 of them overflows.
-template <int LEV, int N> __device__ __forceinline__ void sc_emit(rsrc_t soft, float *a12, int voff, int idx, float (&t)[N])
+template <int LB> struct ScIo {                                   // where the wave's 32-bit half-words live: half h, word w
+	uint32_t *cwa, *cwb, *xwa, *xwb;
+	__device__ __forceinline__ static int idx(int w) { return LB == 6 ? 2 * w : w; }
+};
+template <int LB, int LEV, int N> __device__ __forceinline__ void sc_emit(rsrc_t soft, float *lds, int v_dst, int lidx, float (&t)[N])
 {
-	if constexpr (LEV >= 13) {
+	if constexpr (LEV > ScCfg<LB>::LL) {
 		#pragma unroll
 		for (int k = 0; k < N; ++k)
-			bstore<2>(soft, voff, sc_off(LEV) + k * 16384, t[k]);
+			bstore<2>(soft, v_dst, sc_off(LEV) + k * ScCfg<LB>::SUB_BYTES, t[k]);
 		float u[N / 2];
 		#pragma unroll
 		for (int k = 0; k < N / 2; ++k)
 			u[k] = f_minsum(t[k], t[k + N / 2]);
-		sc_emit<LEV - 1, N / 2>(soft, a12, voff, idx, u);
+		sc_emit<LB, LEV - 1, N / 2>(soft, lds, v_dst, lidx, u);
 	} else
-		a12[idx] = t[0];
+		lds[lidx] = t[0];
 }
-template <int D, int KIND>
-__device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *a12, const unsigned long long *cw, unsigned long long *xw, int s, int lane,
-	bool &finite)
+template <int LB, int D, int KIND>
+__device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds, const ScIo<LB> &io, int s, int lane, int v_llr0, int v_soft0, bool &finite)
 {
-	constexpr int NS = 1 << D, NH = NS / 2, XB = NS >= 16 ? 1 : 16 / NS;
+	using Cf = ScCfg<LB>;
+	constexpr int NS = 1 << D, NH = NS / 2, XB = NS >= 16 ? 1 : 16 / NS, XSTEP = Cf::J * 4;
 	const rsrc_t src = KIND == 2 ? soft : llr;
-	constexpr int src_off = KIND == 2 ? sc_off(12 + D) : 0;
-	uint32_t wl[NH], wh[NH];
+	constexpr int src_off = KIND == 2 ? sc_off(Cf::LL + D) : 0;
+	uint32_t wa[NH], wb[NH];
 	if (KIND) {
 		#pragma unroll
 		for (int k = 0; k < NH; ++k) {
-			const unsigned long long w = cw[(s - NH + k) * 64 + lane];
-			wl[k] = (uint32_t)w;
-			wh[k] = (uint32_t)(w >> 32);
+			const int w = ScIo<LB>::idx((s - NH + k) * 64 + lane);
+			wa[k] = io.cwa[w];
+			wb[k] = io.cwb[w];
 		}
 	}
-	unsigned long long X[KIND == 0 ? NS : 1];
-	const int sh = lane & 31;
+	const int sh = 31 - (lane & 31);
 	const bool up = lane >= 32;
-	int voff = lane * 4;
+	int v_src = KIND == 2 ? v_soft0 : v_llr0, v_dst = v_soft0, lidx = (lane >> LB) * (64 * Cf::J) + (lane & (Cf::J - 1));
 	#pragma unroll 1
-	for (int x0 = 0; x0 < 64; x0 += XB, voff += XB * 256) {
+	for (int x0 = 0; x0 < 64; x0 += XB, v_src += XB * XSTEP, v_dst += XB * XSTEP, lidx += XB * Cf::J) {
 		float v[XB][NS];
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
 			#pragma unroll
 			for (int k = 0; k < NS; ++k)
-				v[xb][k] = KIND == 0 ? bload<0>(src, voff + xb * 256, src_off + k * 16384) : bload<2>(src, voff + xb * 256, src_off + k * 16384);
+				v[xb][k] = KIND == 0 ? bload<0>(src, v_src + xb * XSTEP, src_off + k * Cf::SUB_BYTES) : bload<2>(src, v_src + xb * XSTEP, src_off + k * Cf::SUB_BYTES);
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb) {
 			const int x = x0 + xb;
@@ -262,31 +281,36 @@ __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *a12,
 				if (KIND == 0)
 					t[k] = f_minsum(v[xb][k], v[xb][k + NH]);
 				else {
-					const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)wl[k], x), hi = (uint32_t)__builtin_amdgcn_readlane((int)wh[k], x);
-					t[k] = g_add(v[xb][k], v[xb][k + NH], (int)(((up ? hi : lo) >> sh) & 1u));
+					const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)wa[k], x), b = (uint32_t)__builtin_amdgcn_readlane((int)wb[k], x);
+					const uint32_t sg = ((up ? b : a) << sh) & SC_SIGN;
+					t[k] = __uint_as_float(__float_as_uint(v[xb][k]) ^ sg) + v[xb][k + NH];
 				}
 			}
 			if (KIND == 0) {
+				// the hard decisions of this column's NS elements: word x of sub-tree k, gathered on lane k and stored from there
+				int ma = 0, mb = 0;
 				#pragma unroll
 				for (int k = 0; k < NS; ++k) {
 					const unsigned long long bal = __ballot(v[xb][k] < 0.f);
-					if (lane == x)
-						X[k] = bal;
+					if (lane == k) {
+						ma = (int)(uint32_t)bal;
+						mb = (int)(uint32_t)(bal >> 32);
+					}
 					finite &= sc_mag(v[xb][k]) < 0x71000000u;         // |llr| < 6e29 (and not a NaN)
 				}
+				if (lane < NS) {
+					const int w = ScIo<LB>::idx(lane * 64 + x);
+					io.xwa[w] = (uint32_t)ma;
+					io.xwb[w] = (uint32_t)mb;
+				}
 			}
-			sc_emit<11 + D, NH>(soft, a12, voff + xb * 256, x * 64 + lane, t);
+			sc_emit<LB, Cf::LL + D - 1, NH>(soft, lds, v_dst + xb * XSTEP, lidx + xb * Cf::J, t);
 		}
-	}
-	if (KIND == 0) {
-		#pragma unroll
-		for (int k = 0; k < NS; ++k)
-			xw[k * 64 + lane] = X[k];
 	}
 }
 
-// a uniform node of 64 * CNT leaves on its register array (element x = position x * 64 + q)
-template <int CNT> __device__ __forceinline__ void sc_rate0(const float (&r)[CNT], ScAcc &acc, int lane)
+// a uniform node of J * CNT leaves on its register array (element x = position x * J + q)
+template <int LB, int CNT> __device__ __forceinline__ void sc_rate0(const float (&r)[CNT], ScAcc &acc, int lane)
 {
 	float pz[CNT];
 	#pragma unroll
@@ -297,17 +321,17 @@ template <int CNT> __device__ __forceinline__ void sc_rate0(const float (&r)[CNT
 		#pragma unroll
 		for (int x = 0; x < hx; ++x)
 			pz[x] = pz[x] + pz[x + hx];
-	acc.M += sc_pen_sum<6>(pz[0], lane);
+	acc.M += sc_pen_sum<LB>(pz[0], lane);
 }
-template <int CNT> __device__ __forceinline__ uint32_t sc_rate1(const float (&r)[CNT], ScAcc &acc, int lane)
+template <int LB, int CNT> __device__ __forceinline__ uint32_t sc_rate1(const float (&r)[CNT], ScAcc &acc, int lane)
 {
 	uint32_t mu = 0x7f800000u, bits = 0;
 	#pragma unroll
 	for (int x = 0; x < CNT; ++x) {
 		mu = min(mu, sc_mag(r[x]));
-		bits |= (r[x] < 0.f ? 1u : 0u) << x;
+		bits |= (__float_as_uint(r[x]) >> 31) << x;
 	}
-	acc.info(sc_min_mag<6>(mu, lane));
+	acc.info(sc_min_mag<LB>(mu, lane));
 	return bits;
 }
 template <int CNT> __device__ __forceinline__ void sc_f_half(float (&dst)[CNT], const float (&src)[2 * CNT])
@@ -320,116 +344,178 @@ template <int CNT> __device__ __forceinline__ void sc_g_half(float (&dst)[CNT], 
 {
 	#pragma unroll
 	for (int x = 0; x < CNT; ++x)
-		dst[x] = g_add(src[x], src[x + CNT], (int)((hb >> x) & 1u));
+		dst[x] = __uint_as_float(__float_as_uint(src[x]) ^ ((hb << (31 - x)) & SC_SIGN)) + src[x + CNT];
 }
 
-// Persistent grid: workgroup = one wave = one decoder with its own level store; decoders take codewords from the run's counter.
+// Persistent grid: workgroup = one wave = one decoder (of 64 >> LB codewords) with its own level stores; decoders take units of
+// 64 >> LB consecutive entries from the run's counter.  Entries of a unit that share the frozen table are decoded side by side;
+// a unit whose entries do not (a mixed-mode batch), or whose second entry does not exist, is decoded one entry at a time with
+// the lanes of the other codeword doing the same work on the same data.
+template <int LB>
 __global__ __launch_bounds__(64) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
-	float *__restrict__ soft_all, unsigned long long *__restrict__ cw_q, unsigned long long *__restrict__ xw_q, ScStat *__restrict__ stat_q,
-	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev64)
+	float *__restrict__ soft_all, uint32_t *__restrict__ cw_q, uint32_t *__restrict__ xw_q, ScStat *__restrict__ stat_q,
+	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev_blk)
 {
-	const int lane = threadIdx.x, qp = sc_pos(lane);
-	__shared__ float a12[4096];                                   // the array of the current 4096-leaf node, [x][position]
+	using Cf = ScCfg<LB>;
+	constexpr int J = Cf::J, C = Cf::C, NBLK = CODE_LEN / J;
+	const int lane = threadIdx.x, c = lane >> LB, j = lane & (J - 1);
+	ScLane L;
+	L.lane = lane;
+	L.q = sc_pos(j);
+	L.lowsel[0] = 0;
+	#pragma unroll
+	for (int lv = 1; lv <= 6; ++lv)
+		L.lowsel[lv] = ((L.q >> (lv - 1)) & 1) ? 0u : SC_SIGN;
+	__shared__ float lds[C * 64 * J];                             // the array of the current sub-tree of each codeword, [c][x][position]
 	const int par = 0;
 	const int run_n = (int)q->run_n[par];
 	const unsigned run_head = q->run_head[par], cap = q->cap;
 	if (run_n == 0)
 		return;
-	const rsrc_t soft = make_rsrc(soft_all + (size_t)blockIdx.x * SC_STORE_FLOATS, SC_STORE_FLOATS * 4);
+	const int n_units = (run_n + C - 1) / C;
+	float *const my_store = soft_all + (size_t)blockIdx.x * Cf::DECODER_FLOATS;
+	const rsrc_t soft = make_rsrc(my_store, C * Cf::STORE_FLOATS * 4);
+	const int v_soft0 = c * (Cf::STORE_FLOATS * 4) + j * 4;
 	for (;;) {
 		int unit = 0;
 		if (lane == 0)
 			unit = atomicAdd(&q->next_unit[par], 1);
 		unit = __builtin_amdgcn_readfirstlane(unit);
-		if (unit >= run_n)
+		if (unit >= n_units)
 			break;
-		const int slot = (int)((run_head + (unsigned)unit) % cap);
-		const int tab = slots[slot].oper_mode >= 10;                   // decode.cc:312,344
+		// the unit's entries; which of them go side by side
+		int slot_of_c[2], n_pass = 1;
+		slot_of_c[0] = (int)((run_head + (unsigned)(unit * C)) % cap);
+		slot_of_c[1] = slot_of_c[0];
+		if (C == 2 && unit * C + 1 < run_n) {
+			slot_of_c[1] = (int)((run_head + (unsigned)(unit * C + 1)) % cap);
+			const long dist = ((long)slot_of_c[1] - (long)slot_of_c[0]) * CODE_LEN * 4;
+			if ((slots[slot_of_c[0]].oper_mode >= 10) != (slots[slot_of_c[1]].oper_mode >= 10) || dist < 0 || dist >= (1l << 31))
+				n_pass = 2;                                       // different tables (or slots a ring's wrap apart): one after the other
+		}
+		for (int pass = 0; pass < n_pass; ++pass) {
+		const int sa = n_pass == 2 ? slot_of_c[pass] : slot_of_c[0], sb = n_pass == 2 ? slot_of_c[pass] : slot_of_c[1];
+		const int my_slot = c ? sb : sa;
+		const int tab = slots[sa].oper_mode >= 10;                     // decode.cc:312,344
 		const uint32_t *frozen = frozen2 + (tab ? 2048 : 0);
-		const uint8_t *nlev = node_lev64 + (tab ? 1024 : 0);
-		const rsrc_t llr = make_rsrc(llr_q + (size_t)slot * CODE_LEN, CODE_LEN * 4);
-		unsigned long long *cw = cw_q + (size_t)slot * (CODE_LEN / 64), *xw = xw_q + (size_t)slot * (CODE_LEN / 64);
+		const uint8_t *nlev = node_lev_blk + (tab ? NBLK : 0);
+		const rsrc_t llr = make_rsrc(llr_q + (size_t)sa * CODE_LEN, (sb - sa + 1) * CODE_LEN * 4);
+		const int v_llr0 = (my_slot - sa) * (CODE_LEN * 4) + j * 4;
+		ScIo<LB> io;
+		if (LB == 6) {                                                // halves of one codeword's 64-bit words
+			io.cwa = cw_q + (size_t)sa * (CODE_LEN / 32);
+			io.cwb = io.cwa + 1;
+			io.xwa = xw_q + (size_t)sa * (CODE_LEN / 32);
+			io.xwb = io.xwa + 1;
+		} else {                                                      // 32-bit words of two codewords
+			io.cwa = cw_q + (size_t)sa * (CODE_LEN / 32);
+			io.xwa = xw_q + (size_t)sa * (CODE_LEN / 32);
+			if (sb != sa) {
+				io.cwb = cw_q + (size_t)sb * (CODE_LEN / 32);
+				io.xwb = xw_q + (size_t)sb * (CODE_LEN / 32);
+			} else {                                                  // alone: both lane groups decode it; the second one's words go aside
+				io.cwb = (uint32_t *)(my_store + C * Cf::STORE_FLOATS);
+				io.xwb = io.cwb + CODE_LEN / 32;
+			}
+		}
 		ScAcc acc{ 0.f, 0x7f800000u };
 		bool finite = true;
 		#pragma unroll 1
-		for (int s = 0; s < 16; ++s) {
-			// ---------------- the array of this 4096-leaf node into LDS, through the level store
-			if (s == 0) sc_top_pass<4, 0>(soft, llr, a12, cw, xw, s, lane, finite);
-			else if (s == 8) sc_top_pass<4, 1>(soft, llr, a12, cw, xw, s, lane, finite);
-			else if ((s & 3) == 0) sc_top_pass<3, 2>(soft, llr, a12, cw, xw, s, lane, finite);
-			else if ((s & 1) == 0) sc_top_pass<2, 2>(soft, llr, a12, cw, xw, s, lane, finite);
-			else sc_top_pass<1, 2>(soft, llr, a12, cw, xw, s, lane, finite);
+		for (int s = 0; s < Cf::NSUB; ++s) {
+			// ---------------- the array of this sub-tree into LDS, through the level store
+			{
+				const int D = s ? __builtin_ctz(s) + 1 : 16 - Cf::LL;
+				#define SC_PASS(DD, KK) sc_top_pass<LB, DD, KK>(soft, llr, lds, io, s, lane, v_llr0, v_soft0, finite)
+				if (s == 0) SC_PASS(16 - Cf::LL, 0);
+				else if (s == Cf::NSUB / 2) SC_PASS(16 - Cf::LL, 1);
+				else if (D == 1) SC_PASS(1, 2);
+				else if (D == 2) SC_PASS(2, 2);
+				else if (D == 3) SC_PASS(3, 2);
+				else if constexpr (16 - Cf::LL > 4) SC_PASS(4, 2);
+				#undef SC_PASS
+			}
 			SC_WAVE_ORDER();
-			// this node's 64 table bytes and frozen words, one block per lane; the block loop reads them with v_readlane
-			const int nlv = nlev[s * 64 + lane];
-			const uint32_t fzl = frozen[(s * 64 + lane) * 2], fzh = frozen[(s * 64 + lane) * 2 + 1];
-			unsigned long long HR = 0;                                // partial sums: bit x = position x * 64 + qp
-			float R11[32], R10[16], R9[8], R8[4], R7[2], R6[1];
+			// this sub-tree's 64 table bytes and frozen words, one block per lane; the block loop reads them with v_readlane
+			const int blk0 = s * 64;
+			const int nlv = nlev[blk0 + lane];
+			uint32_t fzl, fzh = 0;
+			if (LB == 6) {
+				fzl = frozen[(blk0 + lane) * 2];
+				fzh = frozen[(blk0 + lane) * 2 + 1];
+			} else
+				fzl = frozen[blk0 + lane];
+			const float *my = lds + c * (64 * J) + L.q;
+			unsigned long long HR = 0;                                // partial sums: bit x = position x * J + q
+			float R5[32], R4[16], R3[8], R2[4], R1[2], R0[1];
 			#pragma unroll 1
 			for (int b = 0, adv = 1; b < 64; b += adv) {
 				adv = 1;
-				const int zb = b ? __builtin_ctz(b) + 6 : 12;         // the level whose array the one g step of this block produces (12: none)
+				const int zb = b ? __builtin_ctz(b) : 6;              // the one g step of this block produces the array of J << zb leaves (6: none)
 				const int nl = __builtin_amdgcn_readlane(nlv, b), nl0 = nl & 15, nl1 = nl >> 4;
-				const int Lt = nl0 > nl1 ? nl0 : nl1;                 // the largest uniform node that starts here (0: none)
+				const int Lt = (nl0 > nl1 ? nl0 : nl1) - LB;          // the largest uniform node that starts here: J << Lt leaves (< 0: none)
 				const bool frz = nl0 > nl1;
-				const uint32_t hb = zb < 12 ? (uint32_t)(HR >> (b - (1 << (zb - 6)))) : 0u;
-				int L2 = 0;
+				const uint32_t hb = zb < 6 ? (uint32_t)(HR >> (b - (1 << zb))) : 0u;
+				int L2 = -1;
 				uint32_t bits = 0;
-				if (zb >= 11) {
-					if (zb == 11) {
+				if (zb >= 5) {
+					if (zb == 5) {
 						#pragma unroll
 						for (int x = 0; x < 32; ++x)
-							R11[x] = g_add(a12[x * 64 + qp], a12[(x + 32) * 64 + qp], (int)((hb >> x) & 1u));
+							R5[x] = __uint_as_float(__float_as_uint(my[x * J]) ^ ((hb << (31 - x)) & SC_SIGN)) + my[(x + 32) * J];
 					} else {
 						#pragma unroll
 						for (int x = 0; x < 32; ++x)
-							R11[x] = f_minsum(a12[x * 64 + qp], a12[(x + 32) * 64 + qp]);
+							R5[x] = f_minsum(my[x * J], my[(x + 32) * J]);
 					}
-					if (Lt == 11) { bits = sc_rate1(R11, acc, lane); L2 = 11; }
+					if (Lt == 5) { bits = sc_rate1<LB>(R5, acc, lane); L2 = 5; }
 				}
-				if (zb >= 10 && !L2) {
-					if (zb == 10) sc_g_half(R10, R11, hb); else sc_f_half(R10, R11);
-					if (Lt == 10) { bits = sc_rate1(R10, acc, lane); L2 = 10; }
+				if (zb >= 4 && L2 < 0) {
+					if (zb == 4) sc_g_half(R4, R5, hb); else sc_f_half(R4, R5);
+					if (Lt == 4) { bits = sc_rate1<LB>(R4, acc, lane); L2 = 4; }
 				}
-				if (zb >= 9 && !L2) {
-					if (zb == 9) sc_g_half(R9, R10, hb); else sc_f_half(R9, R10);
-					if (Lt == 9) { bits = sc_rate1(R9, acc, lane); L2 = 9; }
+				if (zb >= 3 && L2 < 0) {
+					if (zb == 3) sc_g_half(R3, R4, hb); else sc_f_half(R3, R4);
+					if (Lt == 3) { bits = sc_rate1<LB>(R3, acc, lane); L2 = 3; }
 				}
-				if (zb >= 8 && !L2) {
-					if (zb == 8) sc_g_half(R8, R9, hb); else sc_f_half(R8, R9);
-					if (Lt == 8) { bits = sc_rate1(R8, acc, lane); L2 = 8; }
-				}
-				if (zb >= 7 && !L2) {
-					if (zb == 7) sc_g_half(R7, R8, hb); else sc_f_half(R7, R8);
-					if (Lt == 7) {
-						if (frz) sc_rate0(R7, acc, lane); else bits = sc_rate1(R7, acc, lane);
-						L2 = 7;
+				if (zb >= 2 && L2 < 0) {
+					if (zb == 2) sc_g_half(R2, R3, hb); else sc_f_half(R2, R3);
+					if (Lt == 2) {
+						if (frz) sc_rate0<LB>(R2, acc, lane); else bits = sc_rate1<LB>(R2, acc, lane);
+						L2 = 2;
 					}
 				}
-				if (!L2) {
-					if (zb == 6) sc_g_half(R6, R7, hb); else sc_f_half(R6, R7);
-					if (Lt == 6) {
-						if (frz) sc_rate0(R6, acc, lane); else bits = sc_rate1(R6, acc, lane);
-						L2 = 6;
+				if (zb >= 1 && L2 < 0) {
+					if (zb == 1) sc_g_half(R1, R2, hb); else sc_f_half(R1, R2);
+					if (Lt == 1) {
+						if (frz) sc_rate0<LB>(R1, acc, lane); else bits = sc_rate1<LB>(R1, acc, lane);
+						L2 = 1;
 					}
 				}
-				if (L2) {
-					adv = 1 << (L2 - 6);
+				if (L2 < 0) {
+					if (zb == 0) sc_g_half(R0, R1, hb); else sc_f_half(R0, R1);
+					if (Lt == 0) {
+						if (frz) sc_rate0<LB>(R0, acc, lane); else bits = sc_rate1<LB>(R0, acc, lane);
+						L2 = 0;
+					}
+				}
+				if (L2 >= 0) {
+					adv = 1 << L2;
 					HR |= (unsigned long long)bits << b;
 				} else {
-					const uint32_t fz0 = (uint32_t)__builtin_amdgcn_readlane((int)fzl, b), fz1 = (uint32_t)__builtin_amdgcn_readlane((int)fzh, b);
-					HR |= (unsigned long long)sc_walk64(R6[0], fz0, fz1, acc, lane, qp) << b;
+					const uint32_t fz0 = (uint32_t)__builtin_amdgcn_readlane((int)fzl, b), fz1 = LB == 6 ? (uint32_t)__builtin_amdgcn_readlane((int)fzh, b) : 0u;
+					HR |= (unsigned long long)(sc_walk_block<LB>(R0[0], fz0, fz1, acc, L) >> 31) << b;
 				}
-				// partial-sum combines of the nodes of 128..4096 leaves that end here: left half ^= right half
+				// partial-sum combines of the nodes of 2 J .. 64 J leaves that end here: left half ^= right half
 				const int bn = b + adv;
-				for (int m = L2 ? L2 + 1 : 7; m <= 12 && (bn & ((1 << (m - 6)) - 1)) == 0; ++m) {
-					const int half = 1 << (m - 7), b0 = bn - 2 * half;
+				for (int m = L2 >= 0 ? L2 + 1 : 1; m <= 6 && (bn & ((1 << m) - 1)) == 0; ++m) {
+					const int half = 1 << (m - 1), b0 = bn - 2 * half;
 					const unsigned long long lmask = ((1ull << half) - 1ull) << b0;
 					HR = (HR & ~lmask) | ((HR ^ (HR >> half)) & lmask);
 				}
 			}
-			// publish the node's 4096 partial sums as 64 plain words: position q sits on lane q ^ ((q & 4) ? 3 : 0); bring the
-			// bits to their natural lanes (quad_perm [3,2,1,0] on the upper half of every 8), then one ballot per word
+			// publish the sub-tree's partial sums as plain words: position q sits on lane j ^ ((j & 4) ? 3 : 0); bring the bits to their
+			// natural lanes (quad_perm [3,2,1,0] on the upper half of every 8), then one ballot per element x: 64 lanes = one 64-bit
+			// word of one codeword / one 32-bit word of each of two
 			{
 				uint32_t h0 = (uint32_t)HR, h1 = (uint32_t)(HR >> 32);
 				const uint32_t s0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0x1B, 0xf, 0xf, false);
@@ -442,27 +528,34 @@ __global__ __launch_bounds__(64) void k_sc(ListQueue *__restrict__ q, const List
 					if (lane == u)
 						mine = bal;
 				}
-				cw[s * 64 + lane] = mine;
+				const int w = ScIo<LB>::idx(s * 64 + lane);
+				io.cwa[w] = (uint32_t)mine;
+				io.cwb[w] = (uint32_t)(mine >> 32);
 			}
-			// combines of the nodes of 2^13 .. 2^16 leaves that end here, on the published words (every word stays with its lane)
+			// combines of the larger nodes that end here, on the published words (every word stays with its lane)
 			const int sn = s + 1;
-			for (int m = 13; m <= 16 && (sn & ((1 << (m - 12)) - 1)) == 0; ++m) {
-				const int halfw = 64 << (m - 13), w0 = sn * 64 - 2 * halfw;
-				for (int w = lane; w < halfw; w += 64)
-					cw[w0 + w] ^= cw[w0 + halfw + w];
+			for (int m = 1; m <= 16 - Cf::LL && (sn & ((1 << m) - 1)) == 0; ++m) {
+				const int halfw = 64 << (m - 1), w0 = sn * 64 - 2 * halfw;
+				for (int w = lane; w < halfw; w += 64) {
+					const int wl = ScIo<LB>::idx(w0 + w), wr = ScIo<LB>::idx(w0 + halfw + w);
+					io.cwa[wl] ^= io.cwa[wr];
+					io.cwb[wl] ^= io.cwb[wr];
+				}
 			}
 			SC_WAVE_ORDER();
 		}
-		const bool all_finite = __ballot(!finite) == 0;
-		if (lane == 0) {
+		const unsigned long long unf = __ballot(!finite);
+		if (j == 0 && (C == 1 || c == 0 || sb != sa)) {
+			const bool all_finite = ((unf >> (c * J)) & (J == 64 ? ~0ull : ((1ull << J) - 1ull))) == 0;
 			ScStat st;
 			st.metric = acc.M;
 			st.min_fork = __uint_as_float(acc.fork);
 			st.ok = (all_finite && __uint_as_float(acc.fork) > acc.M) ? 1 : 0;   // the rule (a NaN compares false)
 			st.pad = 0;
-			stat_q[slot] = st;
+			stat_q[my_slot] = st;
 		}
 		SC_WAVE_ORDER();
+		}   // second entry of a unit that could not be paired
 	}
 }
 
@@ -602,10 +695,19 @@ __global__ void k_sc_adapt(ListQueue *__restrict__ qs)
 		qs->cert_on = 1;
 }
 
-void launch_sc(hipStream_t s, int grid, ListQueue *q, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
+// grid = resident decoders (waves); lb = log2 of the lanes per codeword: 5 (two codewords per wave, the default) or 6 (one)
+int sc_codewords_per_wave(int lb) { return lb == 6 ? ScCfg<6>::C : ScCfg<5>::C; }
+size_t sc_store_bytes(int lb)                                     // level store per resident decoder
+{
+	return (lb == 6 ? (size_t)ScCfg<6>::DECODER_FLOATS : (size_t)ScCfg<5>::DECODER_FLOATS) * sizeof(float);
+}
+void launch_sc(hipStream_t s, int lb, int grid, ListQueue *q, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
 	unsigned long long *xw_q, ScStat *stat_q, Tables tb)
 {
-	hipLaunchKernelGGL(k_sc, dim3(grid), dim3(64), 0, s, q, slots, llr_q, soft, cw_q, xw_q, stat_q, tb.frozen, tb.node_lev64);
+	if (lb == 6)
+		hipLaunchKernelGGL(k_sc<6>, dim3(grid), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev64);
+	else
+		hipLaunchKernelGGL(k_sc<5>, dim3(grid), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev32);
 }
 void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
 	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of)
@@ -614,6 +716,5 @@ void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListS
 }
 void launch_sc_plan(hipStream_t s, ListQueue *qs) { hipLaunchKernelGGL(k_sc_plan, dim3(1), dim3(1), 0, s, qs); }
 void launch_sc_adapt(hipStream_t s, ListQueue *qs) { hipLaunchKernelGGL(k_sc_adapt, dim3(1), dim3(1), 0, s, qs); }
-size_t sc_store_bytes() { return (size_t)SC_STORE_FLOATS * sizeof(float); }
 
 }  // namespace rx

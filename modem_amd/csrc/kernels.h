@@ -92,6 +92,7 @@ struct Tables {                    // device-resident constants, built once per 
 	const uint32_t *frozen;        // [2][2048] words, bit set = frozen: frozen_64800_43072, frozen_64512_43072 (regenerated)
 	const uint16_t *info_pos;      // [2][44096] ascending unfrozen positions per table
 	const uint8_t *node_lev64;     // [2][1024] the same per 64-leaf block, for k_sc (frozen: 64 or 128 leaves, information: 64 .. 2048)
+	const uint8_t *node_lev32;     // [2][2048] ... per 32-leaf block (frozen: 32 .. 128 leaves, information: 32 .. 1024)
 	const uint8_t *node_lev;       // [2][8192] per 8-leaf group: level of the largest aligned all-frozen (low nibble) /
 	                               // all-information (high nibble) node that starts there (frozen: <= 128 leaves, information: <= 2048), 0 = none
 	const uint32_t *genmat_bits;   // BCH(255,71) systematic generator, [71][8] words, bit i of row j
@@ -181,14 +182,16 @@ void launch_queue_reset(hipStream_t s, ListQueue *q, unsigned cap);
 void launch_queue_snap(hipStream_t s, ListQueue *q, int par);
 void launch_queue_plan(hipStream_t s, ListQueue *q, int par, unsigned unit, int force);
 void launch_queue_fill(hipStream_t s, ListQueue *q, ListSlot *slots, int n, uint8_t *payload, Result *res, int oper_mode);
-// the sign-following path alone + its certificate (k_sc.hip): grid = resident decoders (sc_store_bytes() of level store each)
+// the sign-following path alone + its certificate (k_sc.hip): grid = resident decoders (sc_store_bytes() of level store each),
+// lb = log2 of the lanes per codeword: 5 (two codewords per wave) or 6 (one)
 void launch_sc_plan(hipStream_t s, ListQueue *qs);
-void launch_sc(hipStream_t s, int grid, ListQueue *qs, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
+void launch_sc(hipStream_t s, int lb, int grid, ListQueue *qs, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
 	unsigned long long *xw_q, ScStat *stat_q, Tables tb);
 void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
 	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of);
 void launch_sc_adapt(hipStream_t s, ListQueue *qs);
-size_t sc_store_bytes();
+size_t sc_store_bytes(int lb);  // level store per resident decoder
+int sc_codewords_per_wave(int lb);
 // D9 / D10 for the run `par` of the queue; grid = resident decoders, max_entries = an upper bound of the run's length
 void launch_polar(hipStream_t s, int list, int grid, ListQueue *q, int par, const ListSlot *slots, const float *llr_q, float *soft, uint8_t *hard_q,
 	Tables tb, float *metric_q);

@@ -139,7 +139,8 @@ struct ofdmrx_handle {
 	DevBuf s_ctl, s_slots, s_llr, s_cw, s_xw, s_stat, sc_soft;
 	unsigned s_cap = 0;
 	int sc_mode = 1;          // 1: the list-1 pass (adaptive) in front of the list decoder, 0: off
-	int sc_grid = 0;          // resident SC decoders
+	int sc_grid = 0;          // resident SC decoders (waves)
+	int sc_lb = 5;            // log2 of the lanes per codeword: 5 = two codewords per wave, 6 = one (k_sc.hip)
 	ListQueue *sc_queue() const { return s_ctl.as<ListQueue>(); }
 	ScRing sc_ring() const { return sc_mode ? ScRing{ s_ctl.as<ListQueue>(), s_slots.as<ListSlot>(), s_llr.as<float>() } : ScRing{ nullptr, nullptr, nullptr }; }
 	unsigned flush_unit = 1;  // entries a flush takes at a time (one residency of the list decoder) unless it is forced
@@ -274,6 +275,8 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		if (const char *e3 = std::getenv("OFDMRX_SC_WPC"))
 			swpc = std::max(1, std::atoi(e3));
 		h->sc_grid = swpc * std::max(cus, 1);
+		if (const char *e4 = std::getenv("OFDMRX_SC_LB"))
+			h->sc_lb = std::atoi(e4) == 6 ? 6 : 5;
 	}
 	build_tables(h->host, h->rate);
 	int r = 0;
@@ -288,6 +291,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.info_pos, &h->dev.info_pos);
 	r = r ? r : upload(h, h->host.node_lev, &h->dev.node_lev);
 	r = r ? r : upload(h, h->host.node_lev64, &h->dev.node_lev64);
+	r = r ? r : upload(h, h->host.node_lev32, &h->dev.node_lev32);
 	r = r ? r : upload(h, h->host.genmat_bits, &h->dev.genmat_bits);
 	r = r ? r : upload(h, h->host.osd_pairs, &h->dev.osd_pairs);
 	r = r ? r : upload(h, h->host.osd_triples, &h->dev.osd_triples);
@@ -429,7 +433,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 			r = r ? r : h->s_cw.ensure(S * (CODE_LEN / 8));
 			r = r ? r : h->s_xw.ensure(S * (CODE_LEN / 8));
 			r = r ? r : h->s_stat.ensure(S * sizeof(ScStat));
-			r = r ? r : h->sc_soft.ensure((size_t)(std::min<long>((long)N, (long)h->sc_grid) + 1) * sc_store_bytes());
+			r = r ? r : h->sc_soft.ensure((size_t)(std::min<long>((long)N, (long)h->sc_grid) + 1) * sc_store_bytes(h->sc_lb));
 		}
 		if (!demod_forms_cons(h->rate))                       // (the carriers go through HBM only when k_theil_sen forms the rows)
 			r = r ? r : h->carr.ensure(N * CARR_MAX * sizeof(cf));
@@ -568,7 +572,7 @@ static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_r
 		// list decoder's queue - all in stream order with k_back's own entries there, so the snapshot below sees complete entries only
 		Range r("ofdmrx:sc_path");
 		launch_sc_plan(s, h->sc_queue());
-		launch_sc(s, std::min(h->sc_grid, n), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->sc_soft.as<float>(),
+		launch_sc(s, h->sc_lb, std::min(h->sc_grid, (n + sc_codewords_per_wave(h->sc_lb) - 1) / sc_codewords_per_wave(h->sc_lb)), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->sc_soft.as<float>(),
 			h->s_cw.as<unsigned long long>(), h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev);
 		launch_sc_finish(s, n, h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->s_cw.as<unsigned long long>(),
 			h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev, h->cfg.descramble, h->queue(), h->q_slots.as<ListSlot>(),
@@ -1245,13 +1249,13 @@ extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n
 	r = r ? r : cw.ensure(n * (CODE_LEN / 8));
 	r = r ? r : xw.ensure(n * (CODE_LEN / 8));
 	r = r ? r : stat.ensure(n * sizeof(ScStat));
-	r = r ? r : soft.ensure((size_t)(grid + 1) * sc_store_bytes());
+	r = r ? r : soft.ensure((size_t)(grid + 1) * sc_store_bytes(h->sc_lb));
 	if (!r && (r = host_wait(h)) == 0) {
 		hipError_t e = hipMemcpy(dl.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice);
 		launch_queue_reset(h->stream, ctl.as<ListQueue>(), (unsigned)n);
 		launch_queue_fill(h->stream, ctl.as<ListQueue>(), slots.as<ListSlot>(), (int)n, h->payload.as<uint8_t>(), h->res.as<Result>(), oper_mode);
 		launch_sc_plan(h->stream, ctl.as<ListQueue>());
-		launch_sc(h->stream, grid, ctl.as<ListQueue>(), slots.as<ListSlot>(), dl.as<float>(), soft.as<float>(), cw.as<unsigned long long>(),
+		launch_sc(h->stream, h->sc_lb, grid, ctl.as<ListQueue>(), slots.as<ListSlot>(), dl.as<float>(), soft.as<float>(), cw.as<unsigned long long>(),
 			xw.as<unsigned long long>(), stat.as<ScStat>(), h->dev);
 		e = e == hipSuccess ? hipGetLastError() : e;
 		e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;

@@ -195,27 +195,32 @@ void build_tables(HostTables &t, int rate)
 				}
 			t.node_lev[tab * 8192 + t8] = (uint8_t)(lev[0] | (lev[1] << 4));
 		}
-	// the same for k_sc's 64-leaf blocks: all frozen 6..7 (64 / 128 leaves: the rate-0 step takes at most 128), all information 6..11
-	t.node_lev64.assign(2 * 1024, 0);
-	for (int tab = 0; tab < 2; ++tab)
-		for (int b = 0; b < 1024; ++b) {
-			const int t0 = b * 64;
-			int lev[2] = { 0, 0 };
-			for (int kind = 0; kind < 2; ++kind)
-				for (int L = 6; L <= (kind == 0 ? 7 : 11); ++L) {
-					if (t0 & ((1 << L) - 1))
-						break;
-					bool uniform = true;
-					for (int i = t0; i < t0 + (1 << L) && uniform; ++i) {
-						const int fr = (t.frozen[tab * 2048 + i / 32] >> (i % 32)) & 1;
-						uniform = kind == 0 ? fr == 1 : fr == 0;
+	// the same for k_sc's blocks of 64 / 32 leaves (one or two codewords per wave): all frozen up to 128 leaves (the rate-0 step's
+	// limit), all information up to the level below the sub-tree k_sc keeps in LDS (4096 / 2048 leaves)
+	for (int lb = 5; lb <= 6; ++lb) {
+		std::vector<uint8_t> &nl = lb == 6 ? t.node_lev64 : t.node_lev32;
+		const int nblk = 65536 >> lb;
+		nl.assign(2 * nblk, 0);
+		for (int tab = 0; tab < 2; ++tab)
+			for (int b = 0; b < nblk; ++b) {
+				const int t0 = b << lb;
+				int lev[2] = { 0, 0 };
+				for (int kind = 0; kind < 2; ++kind)
+					for (int L = lb; L <= (kind == 0 ? 7 : lb + 5); ++L) {
+						if (t0 & ((1 << L) - 1))
+							break;
+						bool uniform = true;
+						for (int i = t0; i < t0 + (1 << L) && uniform; ++i) {
+							const int fr = (t.frozen[tab * 2048 + i / 32] >> (i % 32)) & 1;
+							uniform = kind == 0 ? fr == 1 : fr == 0;
+						}
+						if (!uniform)
+							break;
+						lev[kind] = L;
 					}
-					if (!uniform)
-						break;
-					lev[kind] = L;
-				}
-			t.node_lev64[tab * 1024 + b] = (uint8_t)(lev[0] | (lev[1] << 4));
-		}
+				nl[tab * nblk + b] = (uint8_t)(lev[0] | (lev[1] << 4));
+			}
+	}
 	t.info_pos.assign(2 * 44096, 0);
 	for (int tab = 0; tab < 2; ++tab) {
 		int n = 0;

@@ -12,7 +12,7 @@ struct HostTables {
 	std::vector<float> mls1_nrz, mls0_nrz, mls2_nrz;
 	std::vector<uint32_t> frozen, genmat_bits, crc32_tab, crc32_shift168;
 	std::vector<uint16_t> info_pos;
-	std::vector<uint8_t> osd_pairs, osd_triples, scramble, node_lev, node_lev64;
+	std::vector<uint8_t> osd_pairs, osd_triples, scramble, node_lev, node_lev64, node_lev32;
 	FrontCoef front;
 };
 
