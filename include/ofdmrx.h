@@ -243,14 +243,16 @@ int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *dst, size_t
 /* D9+D10: CODE::PolarListDecoder + systematic() (decode.cc:530-531) */
 int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n,
 	uint8_t *lane_mesg /*n*8*5476*/, float *metric /*n*8*/);
-/* the sign-following path of the list decoder alone (k_sc): n LLR vectors of `oper_mode`'s code -> its re-encoded codeword
- * (bit i = bit i % 8 of byte i / 8), the hard decisions of the LLRs packed alike, its path metric, min over the information
- * leaves of fl(metric so far + |llr|), and whether the rule "min_fork > metric, every |llr| < 6e29" holds.  Any output may be NULL. */
-int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n, int oper_mode, uint8_t *codeword /*n*8192*/,
-	uint8_t *hard /*n*8192*/, float *metric /*n*/, float *min_fork /*n*/, int32_t *rule_ok /*n*/);
+/* the sign-following path of the list decoder alone (k_sc): n LLR vectors, vector i of the code of mode oper_modes[i] (NULL: all
+ * mode 6) -> its re-encoded codeword (bit i = bit i % 8 of byte i / 8), the hard decisions of the LLRs packed alike, its path
+ * metric, min over the information leaves of fl(metric so far + |llr|), and whether the rule "min_fork > metric, every |llr| <
+ * 6e29" holds.  Any output may be NULL. */
+int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr /*n*65536*/, size_t n, const int32_t *oper_modes /*n*/,
+	uint8_t *codeword /*n*8192*/, uint8_t *hard /*n*8192*/, float *metric /*n*/, float *min_fork /*n*/, int32_t *rule_ok /*n*/);
 /* D5 output (n x 21600 rotated constellation points of mode-6 frames, cf32) -> payloads + results through D6-D10 as the pipeline
- * chains them: with the syndrome certificate (use_cert != 0) or with the list decoder for every frame; cert_out (nullable): 1 =
- * the frame was finished by the certificate (decode.cc:505-555) */
+ * chains them: use_cert 0 = the list decoder for every frame, 1 = the syndrome certificate in front of it, 2 = syndrome certificate,
+ * list-1 pass, list decoder (the default chain), 3 = list-1 pass, list decoder; cert_out (nullable): 1 = the frame was finished
+ * by the syndrome certificate, 2 = by the list-1 pass, 0 = by the list decoder (decode.cc:505-555) */
 int ofdmrx_debug_decode_cons(ofdmrx_handle *h, const float *cons /*n*21600*2*/, size_t n, int use_cert,
 	uint8_t *payload /*n*5380*/, ofdmrx_frame_result *results /*n*/, int32_t *cert_out /*n*/);
 /* DSP::TheilSenEstimator::compute on rows of y[cols], x = i - cols/2 (decode.cc:488) */

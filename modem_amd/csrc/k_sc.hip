@@ -351,8 +351,11 @@ template <int CNT> __device__ __forceinline__ void sc_g_half(float (&dst)[CNT], 
 // 64 >> LB consecutive entries from the run's counter.  Entries of a unit that share the frozen table are decoded side by side;
 // a unit whose entries do not (a mixed-mode batch), or whose second entry does not exist, is decoded one entry at a time with
 // the lanes of the other codeword doing the same work on the same data.
+#ifndef SC_WAVES_PER_SIMD
+#define SC_WAVES_PER_SIMD 2       // register budget: 2 = 256 VGPRs, 3 = 168 (ten decoders per CU, what the 16 KB of LDS each allows)
+#endif
 template <int LB>
-__global__ __launch_bounds__(64) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
+__global__ __launch_bounds__(64, SC_WAVES_PER_SIMD) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
 	float *__restrict__ soft_all, uint32_t *__restrict__ cw_q, uint32_t *__restrict__ xw_q, ScStat *__restrict__ stat_q,
 	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev_blk)
 {

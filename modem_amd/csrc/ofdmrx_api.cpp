@@ -554,6 +554,21 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int n)
 	return 0;
 }
 
+// The list-1 pass on what k_back put into the SC ring (k_sc.hip): frames it decides are finished, the rest move on to the list
+// decoder's queue - all in stream order with k_back's own entries there, so the snapshot behind it sees complete entries only
+static void run_sc_pass(ofdmrx_handle *h, hipStream_t s, int n)
+{
+	Range r("ofdmrx:sc_path");
+	const int cpw = sc_codewords_per_wave(h->sc_lb);
+	launch_sc_plan(s, h->sc_queue());
+	launch_sc(s, h->sc_lb, std::min(h->sc_grid, (n + cpw - 1) / cpw), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(),
+		h->sc_soft.as<float>(), h->s_cw.as<unsigned long long>(), h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev);
+	launch_sc_finish(s, n, h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->s_cw.as<unsigned long long>(),
+		h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev, h->cfg.descramble, h->queue(), h->q_slots.as<ListSlot>(),
+		h->q_llr.as<float>(), h->slot_of.as<int>());
+	launch_sc_adapt(s, h->sc_queue());
+}
+
 // D5's rotation + D6-D8 + the certificate: frames it finishes get payload + result here, the others a queue slot and their LLRs
 static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_res, float *d_esn0, uint8_t *d_payload,
 	uint8_t *payload_later = nullptr, Result *res_later = nullptr)
@@ -568,16 +583,7 @@ static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_r
 	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
 	if (h->sc_mode) {
-		// the list-1 pass on what k_back put into the SC ring (k_sc.hip): frames it decides are finished, the rest move on to the
-		// list decoder's queue - all in stream order with k_back's own entries there, so the snapshot below sees complete entries only
-		Range r("ofdmrx:sc_path");
-		launch_sc_plan(s, h->sc_queue());
-		launch_sc(s, h->sc_lb, std::min(h->sc_grid, (n + sc_codewords_per_wave(h->sc_lb) - 1) / sc_codewords_per_wave(h->sc_lb)), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->sc_soft.as<float>(),
-			h->s_cw.as<unsigned long long>(), h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev);
-		launch_sc_finish(s, n, h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->s_cw.as<unsigned long long>(),
-			h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev, h->cfg.descramble, h->queue(), h->q_slots.as<ListSlot>(),
-			h->q_llr.as<float>(), h->slot_of.as<int>());
-		launch_sc_adapt(s, h->sc_queue());
+		run_sc_pass(h, s, n);
 		size_t e7 = mark(h, s);
 		h->spans.push_back({ T_SC, e6, e7 });
 	}
@@ -1231,11 +1237,14 @@ extern "C" int ofdmrx_debug_polar(ofdmrx_handle *h, const float *llr, size_t n, 
 }
 
 // the sign-following path alone: n LLR vectors -> k_sc's outputs (codeword, hard decisions, metric, min_fork, rule)
-extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n, int oper_mode, uint8_t *codeword, uint8_t *hard, float *metric,
-	float *min_fork, int32_t *rule_ok)
+extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n, const int32_t *oper_modes, uint8_t *codeword, uint8_t *hard,
+	float *metric, float *min_fork, int32_t *rule_ok)
 {
-	if (!h || !llr || !n || n > (size_t)h->chunk || oper_mode < 6 || oper_mode > 13)
+	if (!h || !llr || !n || n > (size_t)h->chunk)
 		return OFDMRX_E_ARG;
+	for (size_t i = 0; oper_modes && i < n; ++i)
+		if (oper_modes[i] < 6 || oper_modes[i] > 13)
+			return OFDMRX_E_ARG;
 	HIP_OK(hipSetDevice(h->cfg.device));
 	int r = ensure_capacity(h, (int)n, false, 0);
 	if (r)
@@ -1253,7 +1262,15 @@ extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n
 	if (!r && (r = host_wait(h)) == 0) {
 		hipError_t e = hipMemcpy(dl.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice);
 		launch_queue_reset(h->stream, ctl.as<ListQueue>(), (unsigned)n);
-		launch_queue_fill(h->stream, ctl.as<ListQueue>(), slots.as<ListSlot>(), (int)n, h->payload.as<uint8_t>(), h->res.as<Result>(), oper_mode);
+		launch_queue_fill(h->stream, ctl.as<ListQueue>(), slots.as<ListSlot>(), (int)n, h->payload.as<uint8_t>(), h->res.as<Result>(), 6);
+		if (oper_modes && e == hipSuccess) {                      // (the slots' modes decide the frozen table and who sits beside whom)
+			e = hipStreamSynchronize(h->stream);
+			std::vector<ListSlot> ls(n);
+			e = e == hipSuccess ? hipMemcpy(ls.data(), slots.p, n * sizeof(ListSlot), hipMemcpyDeviceToHost) : e;
+			for (size_t i = 0; i < n; ++i)
+				ls[i].oper_mode = oper_modes[i];
+			e = e == hipSuccess ? hipMemcpy(slots.p, ls.data(), n * sizeof(ListSlot), hipMemcpyHostToDevice) : e;
+		}
 		launch_sc_plan(h->stream, ctl.as<ListQueue>());
 		launch_sc(h->stream, h->sc_lb, grid, ctl.as<ListQueue>(), slots.as<ListSlot>(), dl.as<float>(), soft.as<float>(), cw.as<unsigned long long>(),
 			xw.as<unsigned long long>(), stat.as<ScStat>(), h->dev);
@@ -1289,8 +1306,11 @@ extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n
 extern "C" int ofdmrx_debug_decode_cons(ofdmrx_handle *h, const float *cons, size_t n, int use_cert, uint8_t *payload,
 	ofdmrx_frame_result *results, int32_t *cert_out)
 {
-	if (!h || !cons || !n || n > (size_t)h->chunk || !payload || !results || h->list != 8)
+	if (!h || !cons || !n || n > (size_t)h->chunk || !payload || !results || h->list != 8 || use_cert < 0 || use_cert > 3)
 		return OFDMRX_E_ARG;
+	const bool with_sc = use_cert >= 2;                           // 2: syndrome certificate, list-1 pass, list decoder (the default chain); 3: without the first
+	if (with_sc && !h->sc_mode)
+		return OFDMRX_E_UNSUPPORTED;
 	HIP_OK(hipSetDevice(h->cfg.device));
 	int r = ensure_capacity(h, (int)n, false, 0);
 	if (r)
@@ -1306,9 +1326,13 @@ extern "C" int ofdmrx_debug_decode_cons(ofdmrx_handle *h, const float *cons, siz
 	HIP_OK(hipMemsetAsync(h->slope.p, 0, n * ROWS_MAX * sizeof(float), h->stream));
 	HIP_OK(hipMemsetAsync(h->yint.p, 0, n * ROWS_MAX * sizeof(float), h->stream));
 	launch_queue_reset(h->stream, h->queue(), h->q_cap);
-	launch_back(h->stream, h->rate, (int)n, use_cert ? 1 : 0, h->st.as<SyncState>(), h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(),
+	if (with_sc)
+		launch_queue_reset(h->stream, h->sc_queue(), h->s_cap);
+	launch_back(h->stream, h->rate, (int)n, (use_cert == 1 || use_cert == 2) ? 1 : 0, h->st.as<SyncState>(), h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(),
 		h->precision.as<float>(), h->res.as<Result>(), nullptr, h->dev, h->cfg.descramble, h->payload.as<uint8_t>(), h->queue(),
-		h->q_slots.as<ListSlot>(), h->q_llr.as<float>(), h->slot_of.as<int>());
+		h->q_slots.as<ListSlot>(), h->q_llr.as<float>(), h->slot_of.as<int>(), nullptr, nullptr, with_sc ? h->sc_ring() : ScRing{ nullptr, nullptr, nullptr });
+	if (with_sc)
+		run_sc_pass(h, h->stream, (int)n);
 	launch_queue_snap(h->stream, h->queue(), 0);
 	queue_run_all(h, 8);
 	launch_finish(h->stream, 8, (int)n, h->queue(), 0, h->q_slots.as<ListSlot>(), h->q_llr.as<float>(), h->q_hard.as<uint8_t>(), h->dev,
@@ -1321,7 +1345,7 @@ extern "C" int ofdmrx_debug_decode_cons(ofdmrx_handle *h, const float *cons, siz
 		std::vector<int> slot(n);
 		HIP_OK(hipMemcpy(slot.data(), h->slot_of.p, n * sizeof(int), hipMemcpyDeviceToHost));
 		for (size_t i = 0; i < n; ++i)
-			cert_out[i] = slot[i] < 0;
+			cert_out[i] = slot[i] == -1 ? 1 : (slot[i] <= -2 ? 2 : 0);   // finished by the syndrome certificate / the list-1 pass / the list decoder
 	}
 	h->last_n = (int)n;
 	return 0;

@@ -118,7 +118,7 @@ def load_library():
     L.ofdmrx_sc_decided_frames.argtypes = [C.c_void_p]
     L.ofdmrx_sc_decided_frames.restype = C.c_longlong
     L.ofdmrx_get_sc_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
-    L.ofdmrx_debug_sc_path.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ofdmrx_debug_sc_path.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_dump.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
     L.ofdmrx_debug_polar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ofdmrx_debug_decode_cons.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -279,10 +279,12 @@ class Receiver:
         self._check(self._lib.ofdmrx_debug_polar(self._h, _ptr(llr), n, _ptr(mesg), _ptr(metric)))
         return mesg, metric
 
-    def sc_path(self, llr, mode=6):
-        """k_sc alone: codeword bits [n, 65536], hard decisions of the LLRs [n, 65536], metric, min_fork, rule [n]"""
+    def sc_path(self, llr, modes=None):
+        """k_sc alone: codeword bits [n, 65536], hard decisions of the LLRs [n, 65536], metric, min_fork, rule [n]; modes: the
+        operation mode of every vector (its frozen table), None = all mode 6"""
         llr = np.ascontiguousarray(llr, dtype=np.float32).reshape(-1, CODE_LEN)
         n = llr.shape[0]
+        mode = None if modes is None else _ptr(np.ascontiguousarray(np.broadcast_to(np.asarray(modes, np.int32), (n,))))
         cw = np.zeros((n, CODE_LEN // 8), np.uint8)
         hd = np.zeros((n, CODE_LEN // 8), np.uint8)
         metric, fork, ok = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
@@ -290,13 +292,15 @@ class Receiver:
         return np.unpackbits(cw, axis=1, bitorder="little"), np.unpackbits(hd, axis=1, bitorder="little"), metric, fork, ok
 
     def decode_cons(self, cons, use_cert=True):
-        """rotated constellation rows (n x 21600 complex64, mode 6) -> payloads, results, the syndrome certificate's verdict per frame"""
+        """rotated constellation rows (n x 21600 complex64, mode 6) -> payloads, results, who finished each frame (1 the syndrome
+        certificate, 2 the list-1 pass, 0 the list decoder).  use_cert: 0 / False list decoder only, 1 / True syndrome certificate
+        first, 2 the default chain (certificate, list-1 pass, list decoder), 3 list-1 pass then list decoder"""
         cons = np.ascontiguousarray(cons, dtype=np.complex64).reshape(-1, 21600)
         n = cons.shape[0]
         out = np.zeros((n, 5380), np.uint8)
         res = np.zeros(n, RESULT_DTYPE)
         cert = np.zeros(n, np.int32)
-        self._check(self._lib.ofdmrx_debug_decode_cons(self._h, _ptr(cons), n, 1 if use_cert else 0, _ptr(out), _ptr(res), _ptr(cert)))
+        self._check(self._lib.ofdmrx_debug_decode_cons(self._h, _ptr(cons), n, int(use_cert), _ptr(out), _ptr(res), _ptr(cert)))
         return out, res, cert
 
     def theil_sen(self, y):

@@ -629,3 +629,37 @@ int orc_decode_batch(const void *samples, int fmt, int channels, size_t frames_p
 #endif
 	return used;
 }
+
+/* test helper (NOT reference code): orc_decode_batch that also leaves, per frame, what the build's SC-dominance certificate is
+ * checked against - sc[f] = { lane 0's metric of the list decoder, M* and min_fork of the sign-following path on the same LLRs
+ * (orc_polar_sc_path), 1 if the frame reached the payload decoder at all } */
+int orc_decode_batch_sc(const void *samples, int fmt, int channels, size_t frames_per,
+	size_t stride_bytes, int n, int list_size, uint8_t *payload, orc_result *res, float *sc, int threads)
+{
+	mallopt(M_MMAP_THRESHOLD, 512 << 20);
+	mallopt(M_TRIM_THRESHOLD, 1 << 30);
+	#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+	for (int f = 0; f < n; ++f) {
+		float *llr = (float *)malloc(sizeof(float) * ORC_CODE_LEN);
+		int8_t *hard = (int8_t *)malloc(ORC_CODE_LEN);
+		float metric[ORC_MAX_LIST];
+		orc_taps taps;
+		memset(&taps, 0, sizeof(taps));
+		taps.llr = llr;
+		taps.metric = metric;
+		for (int i = 0; i < ORC_CODE_LEN; ++i)
+			llr[i] = NAN;
+		orc_decode((const uint8_t *)samples + (size_t)f * stride_bytes, fmt, channels, frames_per,
+			0, list_size, 1, payload + (size_t)f * ORC_DATA_BYTES, &res[f], &taps);
+		float *o = sc + (size_t)f * 4;
+		o[0] = o[1] = o[2] = o[3] = 0.f;
+		if (res[f].status == 0 || res[f].status == 6) {
+			o[0] = metric[0];
+			orc_polar_sc_path(llr, orc_frozen_get(res[f].oper_mode >= 10), 16, hard, &o[1], &o[2]);
+			o[3] = 1.f;
+		}
+		free(llr);
+		free(hard);
+	}
+	return threads > 0 ? threads : 1;
+}

@@ -269,6 +269,10 @@ unsigned orc_get_numerics(void);
 int orc_decode_batch(const void *samples, int fmt, int channels, size_t frames_per,
 	size_t stride_bytes, int n, int list_size, uint8_t *payload /*n*5380*/,
 	orc_result *res /*n*/, int threads);
+/* test helper: the same, plus per frame { list decoder's lane-0 metric, M*, min_fork of orc_polar_sc_path on the frame's LLRs,
+ * 1 if the payload decoder ran }: what the build's SC-dominance certificate is checked against */
+int orc_decode_batch_sc(const void *samples, int fmt, int channels, size_t frames_per,
+	size_t stride_bytes, int n, int list_size, uint8_t *payload, orc_result *res, float *sc, int threads);
 
 /* ---- build-owned channel models (aicodix/disorders is absent) - */
 /* counter-based RNG: splitmix64(seed,frame,index) -> Box-Muller. noise_db is a

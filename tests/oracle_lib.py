@@ -76,6 +76,9 @@ def lib():
         L.orc_decode_batch.restype = C.c_int
         L.orc_decode_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_decode_batch_sc.restype = C.c_int
+        L.orc_decode_batch_sc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_polar_list_decode.restype = C.c_int
         L.orc_polar_list_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_polar_lane_mesg.restype = C.c_int

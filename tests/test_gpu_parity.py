@@ -313,7 +313,19 @@ def test_syndrome_certificate_is_the_list_decoder(rx):
     r = modem_amd.Receiver(device=0, chunk_frames=16)
     out_c, res_c, cert = r.decode_cons(cons, use_cert=True)
     out_l, res_l, _ = r.decode_cons(cons, use_cert=False)
+    out_s, res_s, who_s = r.decode_cons(cons, use_cert=2)         # the default chain: certificate, list-1 pass (k_sc), list decoder
+    out_3, res_3, who_3 = r.decode_cons(cons, use_cert=3)         # without the certificate: the list-1 pass sees the clean rows too
     r.close()
+    # the list-1 pass: identical outputs whoever finishes the frame.  It decides the noisy frames (-26 .. -20 dB: the
+    # path metric stays under min_fork; at -16 dB it does not), and it must NOT finish the two frames whose sign-following path is
+    # ANOTHER codeword: the rule holds there (metric 0) but that path's CRC-32 fails, and decode.cc:532-541 goes on to a later lane
+    for oo, rr in ((out_s, res_s), (out_3, res_3)):
+        assert (oo == out_l).all()
+        for name in ("status", "best_lane", "bit_flips", "esn0_db_last", "cfo_fine", "sfo_slope", "oper_mode"):
+            assert (rr[name] == res_l[name]).all(), (name, rr[name], res_l[name])
+    assert list(who_s[:3]) == [1, 1, 1] and who_s[3] in (1, 2) and list(who_s[4:6]) == [2, 2] and who_s[6] == 0, who_s
+    assert list(who_s[7:9]) == [0, 0] and who_s[9] in (0, 2), who_s
+    assert list(who_3[:6]) == [2] * 6 and who_3[6] == 0 and list(who_3[7:9]) == [0, 0], who_3
     assert list(cert[:3]) == [1, 1, 1] and list(cert[4:7]) == [0, 0, 0], cert
     assert list(cert[7:10]) == [0, 0, 0], cert                    # syndrome zero but CRC wrong / a zero LLR: the list decoder's case
     for name in ("status", "best_lane", "bit_flips", "esn0_db_last", "cfo_fine", "sfo_slope", "oper_mode"):
@@ -324,6 +336,124 @@ def test_syndrome_certificate_is_the_list_decoder(rx):
         if res_c["status"][q] == 0:                               # then to the transmitted payload, from a later lane
             assert res_c["best_lane"][q] >= 1 and (out_c[q] == out_c[0]).all()
     assert res_c["status"][9] == 0 and (out_c[9] == out_c[0]).all()
+
+
+def _sc_vectors():
+    """LLR vectors for k_sc: the oracle's own soft bits of frames from -30 dB to past the point where the rule gives up, in both
+    frozen tables (modes 6 and 10), plus the special ones"""
+    vec = []
+    for mode in (6, 10):
+        for i, db in enumerate((-30, -24, -20, -19, -18, -16)):
+            pcm = O.encode_pcm(O.payload_for(70 + i), channels=2, mode=mode)
+            pcm = O.impair(pcm, noise_db=db, seed=23, frame=i + 10 * mode)
+            _, res, tb = O.decode(pcm, taps=True)
+            assert res.oper_mode == mode
+            vec.append((mode, tb.llr.copy()))
+    rng = np.random.default_rng(14)
+    g = rng.normal(0, 5, 65536).astype(np.float32)
+    g[64800:] = 9000
+    vec.append((6, g))                                            # not a codeword at all
+    z = np.zeros(65536, np.float32)
+    z[64800:] = 9000
+    vec.append((6, z))                                            # every fork a tie
+    for bad in (np.nan, np.inf, 1e30):
+        v = vec[2][1].copy()
+        v[12345] = bad                                            # not finite / too large for the overflow bound: never decided
+        vec.append((6, v))
+    v = vec[2][1].copy()
+    v[777] = 0.0
+    vec.append((6, v))
+    return vec
+
+
+@pytest.mark.parametrize("lanes_log2", [5, 6])
+def test_sc_path_kernel_is_the_oracles_sign_following_path(lanes_log2, monkeypatch):
+    """k_sc alone (ofdmrx_debug_sc_path) against oracle/polar.c: orc_polar_sc_path on identical LLRs: the re-encoded codeword,
+    the hard decisions of the LLRs, the path metric M* and min_fork BIT-exact (M* is also lane 0's metric of the oracle's list
+    decoder whenever the rule holds), the rule's verdict - with two codewords per wave (the default) and with one, codewords of
+    both frozen tables side by side in one call (pairs of different tables are decoded one after the other), an odd count."""
+    import modem_amd
+    monkeypatch.setenv("OFDMRX_SC_LB", str(lanes_log2))
+    vec = _sc_vectors()
+    order = [0, 6, 1, 2, 7, 8, 3, 4, 5, 9, 10, 11] + list(range(12, len(vec)))     # table 0 next to table 1, then pairs of the same
+    if len(order) % 2 == 0:
+        order.append(1)                                            # an odd count: the last codeword has no neighbour
+    r = modem_amd.Receiver(device=0, chunk_frames=64)
+    try:
+        llr = np.stack([vec[i][1] for i in order])
+        cw, hd, M, F, ok = r.sc_path(llr, modes=[vec[i][0] for i in order])
+        for n_, i in enumerate(order):
+            c, m, f = O.polar_sc_path(vec[i][1], O.frozen(1 if vec[i][0] >= 10 else 0))
+            finite = bool(np.isfinite(vec[i][1]).all() and (np.abs(vec[i][1]) < 6e29).all())
+            if finite:
+                assert (cw[n_] == c).all() and M[n_] == m and F[n_] == f, (i, M[n_], m, F[n_], f)
+                assert (hd[n_] == (vec[i][1] < 0)).all()
+            assert bool(ok[n_]) == bool(finite and f > m), (i, ok[n_], m, f)
+        assert 7 <= ok.sum() <= 11                                 # (-30 .. -19 dB of both modes decided, -18 / -16 dB and the garbage not)
+    finally:
+        r.close()
+
+
+def test_sc_certificate_at_scale():
+    """16 384 device-made frames - AWGN at -24 / -22 / -20 / -19 dB, where every frame has raw bit errors, and the configs[3] chain
+    (multipath -> CFO -> SFO -> AWGN -30 dB) - through the default handle: everything decided equals the ORACLE's full list-8
+    decoder frame by frame (payload, status, best lane, sync position, header; the flip count within its documented slack), and
+    the frames that reach the list decoder are exactly the ones for which the oracle-side rule fails on the oracle's own LLRs
+    (orc_decode_batch_sc: min_fork > M*, lane 0's CRC fine)."""
+    import os
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    per = 3584
+    cases = [(-24.0, False), (-22.0, False), (-20.0, False), (-19.0, False), (-30.0, True)]
+    stream = torch.cuda.Stream(device=dev)
+    threads = min(os.cpu_count() or 1, 128)
+    total = listed_total = 0
+    with torch.cuda.stream(stream):
+        rx = modem_amd.Receiver(device=0, chunk_frames=1024, stream=stream.cuda_stream)
+        spf = rx.tx_frame_samples(6)
+        g = torch.Generator(device=dev)
+        g.manual_seed(2205)
+        for ci, (db, chain) in enumerate(cases):
+            n = 2048 if chain else per
+            d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+            d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+            rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
+            if chain:
+                d_tmp = torch.empty_like(d_in)
+                rx.channel(d_in.data_ptr(), d_tmp.data_ptr(), n, spf, cfo_hz=234.567, sfo_ppm=147.0,
+                           multipath=[(0, 1 + 0j), (5, 0.35 - 0.1j), (11, -0.2 + 0.2j), (23, 0.1 + 0.05j)])   # bench.py's configs[3] taps
+                d_in = d_tmp
+            rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, db, 31 + ci, 0)
+            d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+            d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+            rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
+            rx.synchronize()
+            listed, by_sc = rx.list_decoded_frames(), rx.sc_decided_frames()
+            out = d_out.cpu().numpy()
+            res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+            pcm = np.ascontiguousarray(d_in.cpu().numpy())
+            oout = np.zeros((n, 5380), np.uint8)
+            ores = np.zeros(n * 56, np.uint8)
+            sc = np.zeros((n, 4), np.float32)
+            O.lib().orc_decode_batch_sc(O.ptr(pcm), O.FMT_S16, 2, spf, spf * 4, n, 8, O.ptr(oout), O.ptr(ores), O.ptr(sc), threads)
+            ores = ores.view(M.RESULT_DTYPE).reshape(-1)
+            assert (out == oout).all() and (out == d_pay.cpu().numpy()).all(), db
+            for name in ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects"):
+                assert (res[name] == ores[name]).all(), (db, name)
+            assert (np.abs(res["bit_flips"].astype(np.int64) - ores["bit_flips"]) <= FLIPS_SLACK).all(), db
+            rule = (sc[:, 3] == 1) & (sc[:, 2] > sc[:, 1]) & (ores["status"] == 0) & (ores["best_lane"] == 0)
+            assert (sc[rule, 0] == sc[rule, 1]).all()              # rule holds: P* is the oracle's lane 0, metric for metric
+            want_listed = int(((sc[:, 3] == 1) & ~rule).sum())
+            assert listed == want_listed, (db, chain, listed, want_listed)
+            assert by_sc <= int(rule.sum()) and by_sc + listed <= n   # (the rest: the syndrome certificate)
+            if not chain:
+                assert by_sc >= n - listed - (n // 8 if db <= -24 else 0)   # raw bit errors in (nearly) every frame: the list-1 pass's work
+            total += n
+            listed_total += listed
+        rx.close()
+    assert total == 16384 and listed_total < total // 50
 
 
 # ---------------------------------------------------------------- whole path
@@ -382,6 +512,17 @@ def rxd():
     r.close()
 
 
+def _oracle_sc_decides(tb, ores):
+    """oracle-side restatement of the SC-dominance certificate for a mode-6 frame: the sign-following path of the
+    oracle's own LLRs has min_fork > M* (oracle/polar.c: orc_polar_sc_path), every LLR is finite, and the list decoder's answer is
+    that path (lane 0, CRC-32 fine)"""
+    llr = np.asarray(tb.llr[:65536], np.float32)
+    if not np.isfinite(llr).all() or (np.abs(llr) >= 6e29).any():
+        return False
+    c, M, F = O.polar_sc_path(llr, O.frozen(0))
+    return bool(F > M) and ores.status == 0 and ores.best_lane == 0 and float(tb.metric[0]) == float(M)
+
+
 def _oracle_certifies(tb, ores):
     """oracle-side restatement of the syndrome certificate for a mode-6 frame: the hard decisions of the LLRs the
     oracle's soft demapper produced form a polar codeword (zero on every frozen position after x F), no LLR is zero, and the list
@@ -406,8 +547,9 @@ def _oracle_certifies(tb, ores):
 
 def _check_default_path(rxd, pcm, payload, expect_ok=True):
     """the product path against the oracle: outputs and result record, the taps that exist on it, and WHICH way the frame
-    went - finished by the certificate exactly when the oracle's own LLRs say so (one frame per call: the certificate is
-    on at the start of every call), list-decoded otherwise, and then its LLRs (written by k_back's second pass) are compared too"""
+    went - finished by the syndrome certificate exactly when the oracle's own LLRs say so (one frame per call: both switches are
+    on at the start of every call), by the list-1 pass exactly when the oracle-side rule says so, list-decoded otherwise - and the
+    LLRs of a frame the certificate left (written by k_back's second pass) are compared too.  Returns (.., .., listed, sc_decided)"""
     out, res, (alog, acnt) = rxd.decode(pcm[None], attempts=True)
     oout, ores, tb = O.decode(pcm, taps=True)
     r = res[0]
@@ -416,6 +558,7 @@ def _check_default_path(rxd, pcm, payload, expect_ok=True):
     if expect_ok:
         assert ores.status == 0 and (out[0] == payload).all()
     listed = rxd.list_decoded_frames()
+    by_sc = rxd.sc_decided_frames()
     if ores.sc_start >= 0:
         assert int(r["sc_start"]) == ores.sc_start and int(r["symbol_pos"]) == ores.symbol_pos
         assert abs(float(r["cfo_rad"]) - ores.cfo_rad) <= REL
@@ -437,38 +580,47 @@ def _check_default_path(rxd, pcm, payload, expect_ok=True):
         assert abs(float(r["cfo_fine"]) - ores.cfo_fine) <= REL and abs(float(r["esn0_db_last"]) - ores.esn0_db_last) < 1e-3
         assert abs(float(r["sfo_slope"]) - ores.sfo_slope) <= 5e-8
         want_cert = _oracle_certifies(tb, ores)
-        assert listed == (0 if want_cert else 1), (listed, want_cert)
+        want_sc = not want_cert and _oracle_sc_decides(tb, ores)
+        assert (listed, by_sc) == (0 if (want_cert or want_sc) else 1, 1 if want_sc else 0), (listed, by_sc, want_cert, want_sc)
         if want_cert:
             assert int(r["best_lane"]) == 0 and int(r["bit_flips"]) == 0
             with pytest.raises(Exception):                       # no LLRs were ever written for it: the tap says so
                 rxd.tap("LLR", 0)
         else:
-            llr = rxd.tap("LLR", 0)
+            llr = rxd.tap("LLR", 0)                               # (in the SC ring or in the list decoder's queue)
             _close(llr[:64800], tb.llr[:64800], what="llr of an uncertified frame (k_back's second pass)")
             assert (llr[64800:] == 9000).all()
+            if want_sc:
+                assert int(r["best_lane"]) == 0
+                with pytest.raises(Exception):                   # it never went through the list decoder: no metrics
+                    rxd.tap("METRIC", 0)
     else:
-        assert listed == 0
+        assert (listed, by_sc) == (0, 0)
     if ores.status == 0:
         assert _flips_ok(r["bit_flips"], ores.bit_flips) and int(r["best_lane"]) >= 0
-    return r, ores, listed
+    return r, ores, listed, by_sc
 
 
 def test_default_path_clean_frames(rxd):
     pcms, pays = _frames([(1, None, {}), (2, None, {})])
     for pcm, p in zip(pcms, pays):
-        r, o, listed = _check_default_path(rxd, pcm, p)
-        assert listed == 0 and int(r["bit_flips"]) == 0          # a clean frame is finished by the certificate
+        r, o, listed, by_sc = _check_default_path(rxd, pcm, p)
+        assert listed == 0 and by_sc == 0 and int(r["bit_flips"]) == 0   # a clean frame is finished by the syndrome certificate
 
 
 @pytest.mark.parametrize("db", [-30, -26, -22, -18, -15, -14])
 def test_default_path_awgn(rxd, db):
-    """the product path over the whole operating range: all certified (-30), mixed (-26), all list-decoded, the waterfall"""
+    """the product path over the whole operating range: all finished by the syndrome certificate (-30), mixed (-26), all by the
+    list-1 pass (-22: raw bit errors in every frame, path metrics far below min_fork), all list-decoded (-18: the metrics have
+    outgrown it), the waterfall"""
     pcms, pays = _frames([(2, db, {}), (2, db, {}), (2, db, {})])
-    went = [_check_default_path(rxd, pcm, p, expect_ok=db <= -15)[2] for pcm, p in zip(pcms, pays)]
+    went = [_check_default_path(rxd, pcm, p, expect_ok=db <= -15)[2:] for pcm, p in zip(pcms, pays)]
     if db == -30:
-        assert went == [0, 0, 0]
-    if db >= -22:
-        assert went == [1, 1, 1]
+        assert went == [(0, 0)] * 3
+    if db == -22:
+        assert went == [(0, 1)] * 3
+    if db >= -18:
+        assert went == [(1, 0)] * 3
 
 
 def test_default_path_impairment_chain(rxd):
@@ -488,8 +640,8 @@ def test_default_path_failures(rxd):
     y = pcm.copy()
     s = 8000 + 4 * 1440
     y[s + 10 * 1440: s + 40 * 1440] = 0
-    r, o, listed = _check_default_path(rxd, y, p, expect_ok=False)
-    assert int(r["status"]) == 6 and int(r["best_lane"]) == -1 and listed == 1
+    r, o, listed, by_sc = _check_default_path(rxd, y, p, expect_ok=False)
+    assert int(r["status"]) == 6 and int(r["best_lane"]) == -1 and listed == 1 and by_sc == 0
     _check_default_path(rxd, pcm[:40000], p, expect_ok=False)
 
 
@@ -526,7 +678,7 @@ def test_queue_defers_the_list_decoder_across_chunks():
     n, chunk = 32 * 9, 32
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        rx = modem_amd.Receiver(device=0, stream=stream.cuda_stream, chunk_frames=chunk)
+        rx = modem_amd.Receiver(device=0, stream=stream.cuda_stream, chunk_frames=chunk, no_sc=True)   # (the list-1 pass would take these frames)
         rxs = modem_amd.Receiver(device=0, stream=stream.cuda_stream, chunk_frames=chunk, scl_always=True)
         spf = rx.tx_frame_samples(6)
         g = torch.Generator(device=dev)
