@@ -29,13 +29,19 @@ sys.path.insert(0, ROOT)
 
 B_FRAME_2CH = 95200 * 2 * 2 + 5380      # algorithmic bytes per frame, SURVEY 8(d): 386180
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_FILE = "r04_traffic.json"       # PMC bytes + VALU instructions per kernel and launch, written by tools/profile_round.sh
-SCLK_GHZ = 2.4                          # MI355X_MICROARCH.md: engine clock; 256 CUs x 4 SIMDs, one wave64 VALU instruction = 4 cycles of a SIMD
+TRAFFIC_FILE = "r05_traffic.json"       # PMC bytes + VALU instructions per kernel and launch, written by tools/profile_round.sh
+# Vector-instruction issue, two ceilings (round-4 verdict: the round-4 line priced a wave64 VALU instruction at 4 cycles and came out
+# above 1.0): (i) MI355X_MICROARCH.md: a SIMD retires a wave64 fp32 VALU instruction in 2 cycles, 2.4 GHz nominal engine clock,
+# 256 CUs x 4 SIMDs; (ii) what tools/ubench_issue.hip MEASURES on the box as ns per VALU wave-instruction per SIMD with every CU
+# busy and 4 - 5 waves per SIMD (a time, so no clock enters it; profiles/<ISSUE_FILE>, re-run with the traffic passes)
+SCLK_GHZ = 2.4
+VALU_CYCLES_GUIDE = 2.0
 N_SIMD = 1024
+ISSUE_FILE = "r05_issue_rates_ubench.txt"
 # stage of ofdmrx_get_timing -> (kernel, source file whose hash guards the committed traffic figure)
 STAGE_KERNELS = {"sync": ("k_sync", "k_sync.hip"), "header": ("k_header", "k_header.hip"), "demod": ("k_demod", "k_demod.hip"),
                  "theilsen": ("k_theil_sen", "k_theilsen.hip"), "llr": ("k_back", "k_finish.hip"),
-                 "polar": ("k_polar", "k_polar.hip"), "finish": ("k_finish", "k_finish.hip")}
+                 "polar": ("k_polar", "k_polar.hip"), "finish": ("k_finish", "k_finish.hip"), "sc": ("k_sc", "k_sc.hip")}
 METRIC = "decoded frames/sec + BER, mode-6 8kHz OFDM, batch 65536, 1/2/4/8 MI355X"
 
 
@@ -66,7 +72,7 @@ def parse_args(argv=None):
                          "-> SFO +147 ppm (README.md:49) before the AWGN")
     ap.add_argument("--scl-steps", type=int, default=-1,
                     help="steps of the extra leg with the list decoder forced for every frame (value_scl_forced); -1 = min(steps, 5), 0 = off")
-    ap.add_argument("--leg-steps", type=int, default=2,
+    ap.add_argument("--leg-steps", type=int, default=4,
                     help="steps of each of the two extra legs value_config3 / value_noise_m20 (one GPU, headline workload; 0 = off)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks only rendezvous (gloo), shard the frames and reduce counters (launcher test)")
@@ -292,6 +298,18 @@ def main():
         else:
             rx.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out[q].data_ptr(), d_res[q].data_ptr())
 
+    def timing_of(r):
+        """ofdmrx_get_timing's stages plus the list-1 pass (ofdmrx_get_sc_timing: k_sc + k_sc_finish)"""
+        t = dict(r.timing())
+        t["sc"] = r.sc_timing()
+        return t
+
+    def routes(r, n):
+        """who finished the frames of the handle's last call: the syndrome certificate in k_back (incl. frames without a header,
+        which end there too), the list-1 pass, the list decoder"""
+        ld, sc = r.list_decoded_frames(), r.sc_decided_frames()
+        return {"certified": n - max(ld, 0) - max(sc, 0) if ld >= 0 else 0, "sc_decided": max(sc, 0), "list_decoded": ld if ld >= 0 else n}
+
     def fence():
         torch.cuda.synchronize()
         if dist:
@@ -310,7 +328,7 @@ def main():
             # hipEvents on the streams the kernels run on; synchronises the handle's stream.  (Measured at the end of round 4: with the
             # steps enqueued back to back instead - no host synchronisation inside the timed region - a step takes 38.8 ms, not 36.9:
             # profiles/r04_v23_step_sync_and_deferred_join_ab.txt)
-            t = rx.timing()
+            t = timing_of(rx)
             for k, v in t.items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v[0]
                 stage_launches[k] = stage_launches.get(k, 0) + v[1]
@@ -318,6 +336,7 @@ def main():
     secs = time.perf_counter() - t0
     last = (args.steps - 1) & 1
     list_decoded = rx.list_decoded_frames() if B else 0      # of the last step; -1: no certificate on this handle
+    sc_decided = rx.sc_decided_frames() if B else 0          # ... finished by the list-1 pass; -1: that pass is off
     # one extra, untimed step with every kernel alone on the device (OFDMRX_NO_OVERLAP is read per call): under the pipeline a
     # stage's event span includes the time it shares the machine with others; the kernel that takes the most time ALONE is
     # the one the roofline object describes
@@ -326,7 +345,7 @@ def main():
         prev = os.environ.get("OFDMRX_NO_OVERLAP")
         os.environ["OFDMRX_NO_OVERLAP"] = "1"
         step(0, False)
-        alone_ms = {k: v[0] / max(v[1], 1) for k, v in rx.timing().items()}
+        alone_ms = {k: v[0] / max(v[1], 1) for k, v in timing_of(rx).items()}
         if prev is None:
             del os.environ["OFDMRX_NO_OVERLAP"]
         else:
@@ -394,7 +413,7 @@ def main():
         for s in range(scl_steps):
             if B:
                 rx2.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out2.data_ptr(), d_res2.data_ptr())
-                t = rx2.timing()
+                t = timing_of(rx2)
                 for k, v in t.items():
                     sm2[k] = sm2.get(k, 0.0) + v[0]
                     sl2[k] = sl2.get(k, 0) + v[1]
@@ -413,25 +432,33 @@ def main():
         rx3 = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=stream.cuda_stream, sample_rate=args.rate,
                                  list_size=args.list)
         pop8 = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=dev)
-        for name, db, imp, what in (("value_config3", -30.0, True, "configs[3] (README.md:49): multipath -> CFO +234.567 Hz -> SFO +147 ppm -> AWGN -30 dB"),
-                                    ("value_noise_m20", -20.0, False, "a configs[4] level where no frame is certified: AWGN noise level -20 dB")):
-            generate(rx3, db, imp)
+        for name, db, imp, lch, what in (("value_config3", -30.0, True, 2, "configs[3] (README.md:49): multipath -> CFO +234.567 Hz -> SFO +147 ppm -> AWGN -30 dB"),
+                                         ("value_noise_m20", -20.0, False, 2, "a configs[4] level where every frame has raw bit errors (the syndrome certificate decides nothing): AWGN noise level -20 dB"),
+                                         ("value_config1_mono", None, False, 1, "configs[1] flavour: clean 16-bit MONO frames (the consumers form the analytic signal, DESIGN.md 4h)")):
+            if lch == 2:
+                generate(rx3, db, imp)
+                d_leg = d_in
+            else:                                                     # the same payloads as a real (1-channel) stream, encode.cc:127-128
+                d_leg = torch.empty((B, spf, 1), dtype=torch.int16, device=dev)
+                rx3.tx_encode(d_pay.data_ptr(), B, d_leg.data_ptr(), mode=args.mode, freq_off=2000, call_sign="ANONYMOUS", channels=1)
             rx3.synchronize()
             for _ in range(2):        # first call allocates, second warms the pipeline
-                rx3.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out[0].data_ptr(), d_res[0].data_ptr())
+                rx3.decode_device(d_leg.data_ptr(), M.FMT_S16, lch, spf, spf * 2 * lch, B, d_out[0].data_ptr(), d_res[0].data_ptr())
             fence()
+            lsteps = args.leg_steps if lch == 2 else min(args.leg_steps, 2)
             t0 = time.perf_counter()
-            for _ in range(args.leg_steps):
-                rx3.decode_device(d_in.data_ptr(), M.FMT_S16, ch, spf, spf * 2 * ch, B, d_out[0].data_ptr(), d_res[0].data_ptr())
+            for _ in range(lsteps):
+                rx3.decode_device(d_leg.data_ptr(), M.FMT_S16, lch, spf, spf * 2 * lch, B, d_out[0].data_ptr(), d_res[0].data_ptr())
             fence()
             dt = time.perf_counter() - t0
             ferr = 0
             for lo_ in range(0, B, 8192):
                 ref = d_pay[torch.arange(lo_, min(lo_ + 8192, B), device=dev) % n_base]
                 ferr += int((pop8[(d_out[0][lo_:lo_ + 8192] ^ ref).long()].sum(dim=1) > 0).sum().item())
-            extra[name] = {"value": B * args.leg_steps / dt, "unit": "frames/s", "steps": args.leg_steps, "frames": B, "workload": what,
-                           "list_decoded_frames": rx3.list_decoded_frames(), "fer": ferr / float(B),
+            extra[name] = {"value": B * lsteps / dt, "unit": "frames/s", "steps": lsteps, "frames": B, "workload": what,
+                           "list_decoded_frames": rx3.list_decoded_frames(), "routes": routes(rx3, B), "fer": ferr / float(B),
                            "definition": "default handle, payloads left in HBM, outside `value`"}
+            del d_leg
         rx3.close()
 
     secs_max, (frames_total, frame_err, bit_err, ok_status, ranks, frames_step) = shard.reduce_counters(
@@ -479,16 +506,23 @@ def main():
             valu = None
             if tj and tj.get("valu_insts") and avg_s > 0:
                 insts = tj["valu_insts"] * fpl / traffic_db["frames_per_launch"]
-                valu = {"insts_per_launch": insts, "cycles_per_inst": 4, "simds": N_SIMD, "clock_GHz": SCLK_GHZ,
-                        "achieved_frac": insts * 4.0 / (N_SIMD * SCLK_GHZ * 1e9 * avg_s),
-                        "note": "1.0 = every SIMD issues a vector instruction in every slot at the nominal clock; a few per cent above "
-                                "1.0 means the counted run and this run differ by that much (clock, launch duration)",
+                per_simd = insts / N_SIMD
+                ns_meas = traffic_db.get("valu_ns_per_inst_per_simd")      # tools/ubench_issue.hip on the box of the traffic passes
+                valu = {"insts_per_launch": insts, "simds": N_SIMD,
+                        "frac_of_guide_peak": per_simd * VALU_CYCLES_GUIDE / (SCLK_GHZ * 1e9 * avg_s),
+                        "guide_peak": "%.0f cycles per wave64 VALU instruction per SIMD at the nominal %.1f GHz (MI355X_MICROARCH.md)" % (VALU_CYCLES_GUIDE, SCLK_GHZ),
+                        "frac_of_measured_ceiling": (per_simd * ns_meas * 1e-9 / avg_s) if ns_meas else None,
+                        "measured_ceiling": ("%.3f ns per VALU wave-instruction per SIMD, every CU busy, 4 waves per SIMD (profiles/%s; a measured "
+                                             "time: no clock assumed; shader clock under that load %s GHz)"
+                                             % (ns_meas, ISSUE_FILE, traffic_db.get("sclk_GHz_measured", "n/a"))) if ns_meas else None,
                         "source": "profiles/%s: rocprofv3 --pmc SQ_INSTS_VALU, scaled to this run's frames per launch" % TRAFFIC_FILE}
+                valu["achieved_frac"] = valu["frac_of_measured_ceiling"] if ns_meas else valu["frac_of_guide_peak"]
             hbm_frac_real = (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_s > 0) else None
             bound = "valu" if (valu and hbm_frac_real is not None and valu["achieved_frac"] > hbm_frac_real) else "hbm"
             return {"bound": bound, "kernel": kern, "stage": st, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "valu_issue": valu,
-                    "bound_definition": "the larger of traffic_GBps / peak (HBM) and valu_issue.achieved_frac (vector instruction issue); "
+                    "bound_definition": "the larger of traffic_GBps / peak (HBM) and valu_issue.achieved_frac (vector instruction issue against "
+                                        "the MEASURED ceiling; frac_of_guide_peak prices the same count at the guide's 2 cycles); "
                                         "achieved / peak / frac are the HBM figures on ALGORITHMIC bytes as the contract defines them",
                     "achieved_definition": "ALGORITHMIC bytes of the whole path (B_frame x frames per launch) / average launch duration of "
                                            "the run's dominant kernel (hipEvents on the launch stream); its REAL HBM rate is traffic_GBps",
@@ -499,9 +533,11 @@ def main():
 
         cert_note = ""
         if list_decoded >= 0:
-            cert_note = ("; the syndrome certificate (hard decisions already a codeword with a valid CRC-32 => the list decoder's "
-                         "answer is known, DESIGN.md 4g) decided %d of rank 0's %d frames in the last step, the list decoder the other %d "
-                         "- value_scl_forced is the same batch with the list decoder run for every frame" % (B - list_decoded, B, list_decoded))
+            cert_note = ("; of rank 0's %d frames in the last step the syndrome certificate (hard decisions already a codeword with a valid "
+                         "CRC-32 => the list decoder's answer is known, DESIGN.md 4g) decided %d, the list-1 pass (the sign-following path "
+                         "provably is the list decoder's lane 0, DESIGN.md 4i) %d, the list decoder the other %d - value_scl_forced is the "
+                         "same batch with the list decoder run for every frame"
+                         % (B, B - list_decoded - max(sc_decided, 0), max(sc_decided, 0), list_decoded))
         line = {
             "metric": METRIC,
             "value": value, "unit": "frames/s", "n_gpus": ranks, "steps": args.steps, "warmup": args.warmup,
@@ -516,6 +552,8 @@ def main():
                                             "%d steps, payloads left in HBM; outputs identical to the default path: %s"
                                             % (scl["steps"], scl["identical"])) if scl else None,
             "list_decoded_frames_rank0": list_decoded,
+            "routes_rank0": {"certified": B - max(list_decoded, 0) - max(sc_decided, 0) if list_decoded >= 0 else 0,
+                             "sc_decided": max(sc_decided, 0), "list_decoded": list_decoded if list_decoded >= 0 else B},
             "value_host": host_fps,
             "value_host_definition": ("ofdmrx_decode_batch: %d frames from PINNED host memory -> payload bytes on the host, "
                                       "PCIe both ways inside the time, rank 0 only" % nh) if host_fps else None,

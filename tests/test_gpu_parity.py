@@ -1243,7 +1243,15 @@ def test_device_entry_with_pinned_host_outputs():
     import modem_amd.ofdmrx as M
     dev = torch.device("cuda:0")
     n = 16 * 6 + 5
-    rx = modem_amd.Receiver(device=0, chunk_frames=16)
+    for no_sc in (False, True):                                   # who finishes the stragglers: the list-1 pass (from the chunk's staging,
+        _pinned_outputs_case(dev, n, no_sc)                       # before it leaves) or the list decoder (k_finish, into the pinned arrays)
+
+
+def _pinned_outputs_case(dev, n, no_sc):
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    rx = modem_amd.Receiver(device=0, chunk_frames=16, no_sc=no_sc)
     spf = rx.tx_frame_samples(6)
     g = torch.Generator(device=dev)
     g.manual_seed(5)
@@ -1260,13 +1268,14 @@ def test_device_entry_with_pinned_host_outputs():
     torch.cuda.synchronize()
     rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
     rx.synchronize()
-    listed = rx.list_decoded_frames()
+    listed = rx.list_decoded_frames() + max(rx.sc_decided_frames(), 0)
     for _ in range(2):                                            # twice: the second call reuses the per-chunk buffers of the first
         h_out.zero_()
         rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, h_out.data_ptr(), h_res.data_ptr())
         rx.synchronize()
         assert (h_out.numpy() == d_out.cpu().numpy()).all() and (h_res.numpy() == d_res.cpu().numpy()).all()
-    assert 0 < listed < n and rx.list_decoded_frames() == listed
+    assert 0 < listed < n and rx.list_decoded_frames() + max(rx.sc_decided_frames(), 0) == listed
+    assert (rx.list_decoded_frames() == listed) == no_sc
     assert (h_out.numpy() == d_pay.cpu().numpy()).all()
     pageable = np.zeros((n, 5380), np.uint8)
     with pytest.raises(modem_amd.OfdmRxError):
@@ -1440,8 +1449,14 @@ def test_list_size_4():
         for name in ("status", "best_lane", "bit_flips"):
             assert int(res2[i][name]) == int(res[q][name]), (i, q, name)
         assert (out2[i] == out[q]).all(), (i, q)
-    assert rx4.list_decoded_frames() == sum(1 for q in order if q != 0)
+    assert rx4.list_decoded_frames() + rx4.sc_decided_frames() == sum(1 for q in order if q != 0)   # (the list-1 pass holds for any list size)
     rx4.close()
+    # the same without the list-1 pass: every uncertified frame goes through the paired list decoder
+    rx4n = modem_amd.Receiver(device=0, chunk_frames=16, list_size=4, no_sc=True)
+    out3, res3 = rx4n.decode(np.stack([frames[q] for q in order]))
+    assert (out3 == out2).all() and all((res3[name] == res2[name]).all() for name in ("status", "best_lane", "bit_flips"))
+    assert rx4n.list_decoded_frames() == sum(1 for q in order if q != 0) and rx4n.sc_decided_frames() == -1
+    rx4n.close()
 
 
 def test_encode_cli_is_a_drop_in(tmp_path):
@@ -1547,7 +1562,7 @@ def test_default_chunk_pipeline_at_48k():
         d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, d_out.data_ptr(), d_res.data_ptr())
         rx.synchronize()
-        assert rx.list_decoded_frames() > n // 2
+        assert rx.list_decoded_frames() + rx.sc_decided_frames() > n // 2     # raw bit errors: the list-1 pass or the list decoder
         res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
         assert (res["status"] == 0).all()
         assert bool((d_out == d_pay).all().item())

@@ -5,11 +5,15 @@
 #include <cstdint>
 #define N_IT 2048
 #define REP8(x) x x x x x x x x
+// clk[0..1]: s_memtime ticks and constant-rate (100 MHz) ticks that workgroup 0 spent in the loop: if s_memtime counts shader
+// clocks their ratio is the engine clock under this load, if it counts the reference clock too the ratio is 1 (then unknown)
+__device__ unsigned long long g_clk[2];
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t *out, float seed)
 {
 	float a = threadIdx.x * seed, b = seed, c = seed * 3.f;
 	uint32_t r = 0;
+	const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
 	#pragma unroll 1
 	for (int i = 0; i < N_IT; ++i) {
 		if (OP == 0) asm volatile(REP8("v_add_f32 %0, %1, %0\n v_add_f32 %2, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c));              // 16 independent-ish VALU
@@ -22,6 +26,10 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, float seed)
 		if (OP == 7) asm volatile(REP8("v_pk_add_f32 %0, %1, %0\n v_pk_mul_f32 %2, %1, %2\n") : "+v"(*(double *)&a), "+v"(*(double *)&b), "+v"(*(double *)&c));
 		if (OP == 8) asm volatile(REP8("v_cmp_lt_f32 vcc, %0, %1\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n") : "+v"(a), "+v"(b), "+v"(r) :: "vcc");
 		if (OP == 9) asm volatile(REP8("v_mbcnt_lo_u32_b32 %0, s20, 0\n v_mbcnt_hi_u32_b32 %0, s21, %0\n") : "+v"(r) :: "s20", "s21");
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		g_clk[0] = __builtin_readcyclecounter() - t0;
+		g_clk[1] = wall_clock64() - w0;
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)a + (uint32_t)b + (uint32_t)c + r;
 }
@@ -37,7 +45,11 @@ template <int OP> void run(const char *name, int per_iter)
 		hipEventRecord(e1); hipEventSynchronize(e1);
 		float ms; hipEventElapsedTime(&ms, e0, e1);
 		double n = (double)N_IT * per_iter * wps;      // wave-instructions per SIMD
-		printf("%-34s waves/SIMD=%d  ns/instr/SIMD=%.3f  (cycles at 2.4 GHz: %.2f)\n", name, wps, ms * 1e6 / n, ms * 1e6 / n * 2.4);
+		unsigned long long clk[2] = { 0, 0 };
+		(void)hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk));
+		const double ghz = clk[1] ? 0.1 * (double)clk[0] / (double)clk[1] : 0.0;   // wall_clock64 ticks at 100 MHz
+		printf("%-34s waves/SIMD=%d  ns/instr/SIMD=%.3f  (cycles at 2.4 GHz: %.2f; s_memtime / 100 MHz ticks = %.3f GHz%s)\n", name, wps,
+			ms * 1e6 / n, ms * 1e6 / n * 2.4, ghz, ghz < 0.2 ? ": s_memtime is the reference clock here, engine clock not observable" : "");
 	}
 	hipFree(out);
 }
