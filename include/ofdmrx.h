@@ -40,7 +40,9 @@ extern "C" {
  *      list-decoded from a queue in full residencies of the decoder (same outputs); OFDMRX_TAP_CONS_RAW needs no flag, and the
  *      LLR / METRIC / LANE_MESG taps answer OFDMRX_E_UNSUPPORTED for a frame that never went through the list decoder
  *   4: ofdmrx_decode_batch_device delivers to pinned host memory when both output pointers are pinned host memory
- *   5: ofdmrx_sc_decided_frames, ofdmrx_get_sc_timing, ofdmrx_debug_sc_path, ofdmrx_config.flags bit 2 (OFDMRX_FLAG_NO_SC); frames
+ *   5: ofdmrx_sc_decided_frames, ofdmrx_get_sc_timing, ofdmrx_debug_sc_path, ofdmrx_last_chunk_first_frame, ofdmrx_config.flags bit 2
+ *      (OFDMRX_FLAG_NO_SC); `samples` and the frame stride must be multiples of the sample FRAME size (2-channel input: of the I/Q pair);
+ *      with pinned host outputs the optional Es/N0 rows and attempt log must be pinned host memory as well (else OFDMRX_E_ARG); frames
  *      with raw bit errors whose sign-following path provably is the list decoder's lane 0 are finished by a list-1 decode of
  *      that path (same outputs) */
 #define OFDMRX_ABI_MINOR 5
@@ -187,6 +189,12 @@ int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int samp
 int ofdmrx_synchronize(ofdmrx_handle *h);
 int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t);
 int ofdmrx_chunk_frames(ofdmrx_handle *h);
+/* A decode call runs its frames in chunks of at most ofdmrx_chunk_frames() frames - and a call whose outputs cross PCIe (the
+ * host-pointer entry; the device entry with pinned host outputs) and whose 6144 or more frames fit ONE chunk runs as two halves
+ * (the second half's kernels beside the first half's copies), unless the handle has OFDMRX_FLAG_KEEP_RAW_CONS.  The stage taps
+ * below belong to the LAST chunk a call ran: this is the index, in that call, of the chunk's first frame (frame 0 of
+ * ofdmrx_debug_dump).  Revision 1.5. */
+long long ofdmrx_last_chunk_first_frame(ofdmrx_handle *h);
 /* decode.cc:506-523 prints one Es/N0 value per constellation row.  rows = n_frames x OFDMRX_ROWS_MAX floats (dB; rows a frame's
  * mode does not have, and frames without a header: 0) in the memory space of the RESULTS of the decode calls that follow: a
  * device pointer for ofdmrx_decode_batch_device, a host pointer for ofdmrx_decode_batch.  NULL (the default) turns it off;
@@ -222,7 +230,7 @@ int ofdmrx_set_attempt_log(ofdmrx_handle *h, ofdmrx_attempt *log, int32_t *count
 
 /* ---- stage taps for parity tests (host destination buffers) --------------
  * Valid for frames of the LAST chunk processed (frame index relative to that
- * chunk's first frame).  The rotated constellation is made on demand (the pipeline never stores it); LLR / METRIC /
+ * chunk's first frame, ofdmrx_last_chunk_first_frame()).  The rotated constellation is made on demand (the pipeline never stores it); LLR / METRIC /
  * LANE_MESG exist for frames that went through the list decoder (every frame with a header when the handle was created with
  * OFDMRX_FLAG_KEEP_RAW_CONS or OFDMRX_FLAG_SCL_ALWAYS; LANE_MESG needs the former), otherwise: OFDMRX_E_UNSUPPORTED. */
 enum {

@@ -12,26 +12,18 @@ namespace rx {
 // decode.cc:453-477.  One workgroup per frame walks the pilot and the data symbols in order; samples are read once, straight from
 // the raw PCM.  symbol_len = R1 x NS (1280 = 5 x 256, 2560 = 5 x 512, 7056 = 7 x 1008, 7680 = 5 x 1536): radix-R1 decimation in
 // frequency in registers, then R1 row transforms of NS points - see the kernel.
-#ifndef DEMOD_CONS_OUT
 #define DEMOD_CONS_OUT(R) ((R) != 44100)   // the demodulator forms cons = X_j / X_{j-1} itself, from the carriers of the previous symbol parked in
                             // LDS (5 KB at 8 kHz): k_theil_sen is VALU-bound and 0.42 ms per chunk shorter without the row formation, k_demod is
                             // LDS-bound and 0.16 ms longer with it.  44.1 kHz measured 3 % slower with it and keeps the other form: the
                             // carriers go to HBM and k_theil_sen forms the rows where it reads them
-#endif
 template <int RATE> struct DifCfg {
 	static constexpr int SL = RateCfg<RATE>::SL;
-#ifndef DEMOD_DIF_W
 #define DEMOD_DIF_W(R) ((R) == 48000 ? 3 : (R) == 44100 ? 2 : 1)
-#endif
 	static constexpr int W = DEMOD_DIF_W(RATE);              // waves that share one row's transform (1: wave-private, wave barriers only)
 	static constexpr int R1 = SL % 5 == 0 ? 5 : 7, NS = SL / R1, NT = 64 * W * R1;
 	static constexpr int NQ = (NS + NT - 1) / NT;             // points n' per loader thread
-#ifndef DEMOD_TWR_BYTES
 #define DEMOD_TWR_BYTES 8192
-#endif
-#ifndef DEMOD_DIF_WAVES
 #define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : (R) == 8000 ? 7 : 4)   // 8 kHz: 72 VGPRs = five workgroups per CU (26.6 KB of LDS each); 64 spills with the swizzle
-#endif
 	static constexpr bool TWR_LDS = (R1 - 1) * NS * 8 <= DEMOD_TWR_BYTES;   // w^(n' r) table in LDS (8 / 16 kHz) or read from the global root table
 	static constexpr int WAVES = DEMOD_DIF_WAVES(RATE);      // waves per SIMD the register budget is set for (two workgroups per CU at 44.1 / 48 kHz)
 };
@@ -41,12 +33,8 @@ template <int RATE> struct DifCfg {
 // write at strides of 4 (P = 1) and 16 / 4 (P = 4) elements, which the plain layout puts four lanes deep on a bank; under the
 // swizzle every 16-lane store group touches 32 distinct banks (checked against the bank rules of the guide in a simulation).
 // Same operations in the same order as fft_stage<256, 4, P, 64>: only the addresses change.
-#ifndef DEMOD_PREFETCH_NQ
 #define DEMOD_PREFETCH_NQ 1   // loader points per thread up to which the NEXT symbol's samples are fetched during the transform
-#endif
-#ifndef DEMOD_SWZ
 #define DEMOD_SWZ 1     // 8 kHz (the only rate with wave-private 256-point transforms): demod 1.48 -> 1.35 ms per chunk with the seven-waves budget below
-#endif
 __device__ __forceinline__ int swz256(int i) { return i ^ ((i >> 2) & 3) ^ (((i >> 4) & 3) << 2); }
 template <int P, int TWC> __device__ __forceinline__ void fft256_stage_swz(cf *buf, const cf *tw, int lane, int sl)
 {
@@ -133,9 +121,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 			symrot[tid] = phasor(omega, (long)tid * SYM_STRIDE);
 		const cf p0 = phasor(omega, (long)SYMBOL_LEN + tid);
 		__syncthreads();
-#ifndef DEMOD_QA_LDS
 #define DEMOD_QA_LDS 0        // 1: every instantiation forms the R1 - 1 NCO phasors per symbol from LDS (the mono one, short of registers, always does)
-#endif
 		constexpr bool QA_LDS = MONO == 2 || DEMOD_QA_LDS;
 		cf qa[NQ == 1 ? R1 : 1];                             // one point per loader: the R1 phasors stay in registers
 		if (NQ == 1) {
@@ -255,10 +241,8 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 		auto symbols = [&](auto M) {
 		constexpr int MODE = decltype(M)::value;
 		cf pre[NQ][R1];
-#ifndef DEMOD_RAW_AHEAD
 #define DEMOD_RAW_AHEAD 1     // int16 pairs fetched a symbol ahead stay as they come - one register per point, no conversion (and no wait for
                               // the load) where the load is issued - and are converted where the symbol is taken up
-#endif
 		constexpr bool RAW = DEMOD_RAW_AHEAD && MODE == 1 && MONO == 0 && NQ <= DEMOD_PREFETCH_NQ;
 		int praw[RAW ? NQ : 1][RAW ? R1 : 1];
 		auto fetch = [&](int sym) {

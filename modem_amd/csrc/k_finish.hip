@@ -101,9 +101,7 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	// ---- 1. decode.cc:493-494 + 505-523 (snr_rows) + the signs of the soft bits
 	const int mod_bits = md.mod_bits, cols = md.cols;
 	auto raw = [&](int j, int i) { return cons[j * cols + i]; };
-#ifndef BACK_WALK
 #define BACK_WALK 1
-#endif
 	// the first pass walks a row in steps of 64 columns per lane: one sin / cos for the lane's first column, then one complex
 	// multiplication per step (the phasor's error grows by an ulp per step: seven steps) - a third of the rotation's instructions
 	cf rot_cur = mk(1.f, 0.f), rot_step = mk(1.f, 0.f);
@@ -126,14 +124,17 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	const bool snr_ok = snr_rows(raw, begin_row, rotated, md.rows, cols, mod_bits, tid, rsum, prec, [&](int j, int i, cf c) {
 		if (!try_cert)
 			return;
-		const float are = fabsf(c.re), aim = fabsf(c.im);
+		// This pass walks the row's phasor (a few ulps of drift), the LLRs the decoders see come from rotate_point: a soft bit within
+		// that distance of zero could carry the other sign there.  Such a point is "odd" like a zero: the frame is not certified
+		// and takes the general route, where its LLRs are the second pass's (round-4 advisor).  2e-6 |c| is about 16 ulps.
+		const float are = fabsf(c.re), aim = fabsf(c.im), guard = 2e-6f * (are + aim);
 		uint32_t v;
 		if (mod_bits == 3) {
 			v = (are < aim ? 1u : 0u) | (c.re < 0.f ? 2u : 0u) | (c.im < 0.f ? 4u : 0u);
-			odd |= !(are > 0.f) | !(aim > 0.f) | (are == aim);
+			odd |= !(are > guard) | !(aim > guard) | !(fabsf(are - aim) > guard);
 		} else {
 			v = (c.re < 0.f ? 1u : 0u) | (c.im < 0.f ? 2u : 0u);
-			odd |= !(are > 0.f) | !(aim > 0.f);
+			odd |= !(are > guard) | !(aim > guard);
 		}
 		const int p0 = mod_bits * (j * cols + i), o = p0 & 31;
 		if (v) {

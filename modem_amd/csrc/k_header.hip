@@ -123,7 +123,6 @@ __device__ __forceinline__ bool osd_decode(OsdShared &s, const uint32_t *__restr
 	const uint8_t *__restrict__ triples,
 	uint8_t *hard_out /* LDS or global, 32 B */, int tid)
 {
-#ifndef OSD_NO_SYNDROME_CERT
 	// ---- syndrome certificate (round 3).  The search below maximises the correlation sum_i x_i (1 - 2 c_i) over the candidate
 	// codewords c (oracle/bch_osd.c; osd.hh).  Its upper bound sum |x_i| is reached exactly by the words that equal the hard
 	// decisions h_i = [x_i < 0] wherever x_i != 0.  If h itself is a codeword it is the order-0 candidate of ANY information set
@@ -163,7 +162,6 @@ __device__ __forceinline__ bool osd_decode(OsdShared &s, const uint32_t *__restr
 		}
 		__syncthreads();
 	}
-#endif
 	// reliabilities, stable descending sort by rank counting
 	if (tid < 256)
 		s.rel[tid] = tid < BCH_N ? (unsigned char)abs(max((int)s.soft[tid], -127)) : 0;
@@ -179,9 +177,6 @@ __device__ __forceinline__ bool osd_decode(OsdShared &s, const uint32_t *__restr
 	if (tid == 255)
 		s.perm[255] = 255;
 	__syncthreads();
-#if defined(OSD_PROBE_STOP) && OSD_PROBE_STOP == 1
-	return false;                                             // timing probe: stop after the reliability sort
-#endif
 	// permuted generator: G[j] bit i = genmat[j][perm[i]]
 	for (int it = tid; it < BCH_K * 8; it += 256)
 		s.gen[it] = genmat_bits[it];
@@ -199,9 +194,6 @@ __device__ __forceinline__ bool osd_decode(OsdShared &s, const uint32_t *__restr
 		s.G[j][w] = v;
 	}
 	__syncthreads();
-#if defined(OSD_PROBE_STOP) && OSD_PROBE_STOP == 2
-	return false;                                             // timing probe: stop after the permuted generator is built
-#endif
 	// Gauss-Jordan with the pivoting rule of row_echelon(): pivot = the first row >= k with a one in column k (found
 	// by all rows at once: LDS atomicMin), else the first later column that has a one in some row >= k (rare: serial)
 	if (tid == 0)
@@ -267,9 +259,6 @@ __device__ __forceinline__ bool osd_decode(OsdShared &s, const uint32_t *__restr
 		}
 		__syncthreads();
 	}
-#if defined(OSD_PROBE_STOP) && OSD_PROBE_STOP == 3
-	return false;                                             // timing probe: stop after Gauss-Jordan
-#endif
 	// permuted soft values and the byte-sliced table
 	if (tid < 256)
 		s.x[tid] = tid < BCH_N ? (short)max((int)s.soft[s.perm[tid]], -127) : 0;
@@ -410,10 +399,8 @@ __device__ __forceinline__ bool osd_decode(OsdShared &s, const uint32_t *__restr
 	};
 	// orders 0..2 are done (2557 candidates).  If their best is provably the unique optimum, stop here.
 	reduce_tracks();
-#ifndef OSD_NO_CERTIFICATE
 	if (osd_certify(s, s.cw2, tid))
 		return emit(true);
-#endif
 	// triples (a<b<c) sorted by c: item = the triple itself plus its d-loop (d > c).  Consecutive
 	// items have equal trip counts, so the 64 lanes of a wave stay converged.
 	for (int item = tid; item < NTRIPLES; item += 256) {

@@ -114,11 +114,9 @@ struct Maps {
 // Global accesses are raw buffer loads / stores: one per-lane byte offset in a VGPR (lane * 4, or the mapped
 // lane for the g step), everything else (level base, column, partner distance) in the scalar offset - so 16
 // loads in flight cost 16 data registers and no 64-bit address pairs.
-#ifndef POLAR_NT_LEVEL
 #define POLAR_NT_LEVEL 10   // level-store accesses of levels >= this are non-temporal (written once, read once a long time later: keeping
                             // them out of the caches leaves room for level 9, which is re-read soon).  r02 sweep, k_polar alone at 16
                             // decoders per CU, ms per 65536 codewords: none 316, >= 13 312, >= 12 304, >= 11 300, >= 10 290, all 317
-#endif
 #ifndef POLAR_WAVES_PER_SIMD
 #define POLAR_WAVES_PER_SIMD 5     // register budget: 5 waves per SIMD = 96 VGPRs (13 dwords of scratch) so that Theil-Sen workgroups of the next
                                    // chunk fit beside 12 resident decoders per CU; 1 = unconstrained (125 VGPRs): 2 % faster alone, 12 % slower overlapped
@@ -156,15 +154,9 @@ __device__ __forceinline__ void fused_pass(const PolarBufs &pb, float *ls8, int 
 	static_assert(!TERM || (D == 1 && NG == 0), "terminal passes produce one level");
 	uint32_t mu = 0x7f800000u;
 	constexpr int NT = 1 << (D - 1);          // level-m values per column of the lowest produced level
-#ifndef POLAR_XB3
 #define POLAR_XB3 2
-#endif
-#ifndef POLAR_XB2
 #define POLAR_XB2 4
-#endif
-#ifndef POLAR_XB1
 #define POLAR_XB1 8
-#endif
 	constexpr int XB = SRC_R ? (D == 3 ? 1 : (D == 2 ? 2 : 4)) : (D == 3 ? POLAR_XB3 : (D == 2 ? POLAR_XB2 : POLAR_XB1));   // columns batched: XB * 2 * NT loads in flight
 	const int S = 1 << (m - D + 1 - 3);       // local indices at the lowest produced level
 	const int half = 1 << (m - 3);            // partner distance (local) at level m+1
@@ -478,20 +470,8 @@ template <int LN> struct Block8 {
 // barrier would also drain every outstanding store (s_waitcnt vmcnt(0)) after each tree pass.
 #define WAVE_ORDER() __builtin_amdgcn_wave_barrier()
 
-// -DPOLAR_PROF: shader-clock cycles per phase of the decoder loop, summed over all codewords (debug builds only;
-// printed by launch_polar).  0 passes with a global source, 1 LDS passes, 2 node decisions, 3 the 8-leaf walk,
-// 4 LDS combines, 5 publish + wide combines, 6 table look-ups / loop overhead, 7 codewords
-#ifdef POLAR_PROF
-__device__ unsigned long long g_polar_prof[8];
-#define PROF_DECL() unsigned long long pc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tl_ = __builtin_readcyclecounter()
-#define PROF(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pc_[i] += n_ - tl_; tl_ = n_; } while (0)
-#define PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 7; ++q_) atomicAdd(&g_polar_prof[q_], pc_[q_]); atomicAdd(&g_polar_prof[7], 1ull); } } while (0)
-#else
-#define PROF_DECL() do { } while (0)
-#define PROF(i) do { } while (0)
-#define PROF_FLUSH() do { } while (0)
-#endif
-
+// (The per-phase cycle counters of rounds 2 - 4, -DPOLAR_PROF, and the experiments' knobs are in the history:
+// git show c197dc0:modem_amd/csrc/k_polar.hip.)
 // Decoders per workgroup.  A decoder is one wave and never meets another one (no barrier, its own 8 KB of LDS).  The
 // hardware places at most 16 WORKGROUPS on a CU: sixteen one-wave decoders fill every slot, and whatever kernel another
 // stream launches beside them waits until decoders leave (round 3: the first kernel queued behind a polar launch took
@@ -499,17 +479,12 @@ __device__ unsigned long long g_polar_prof[8];
 // decoders - and the list decoder slows down by exactly their time alone (36.2 -> 43.6 ms per 8192 codewords, 178 k
 // frames/s against 194 k): the machine has no idle issue slots to give.  So the default stays one decoder per workgroup,
 // and the pipeline treats a polar launch as owning the machine (ofdmrx_api.cpp: run_pipeline).
-#ifndef POLAR_WPB
 #define POLAR_WPB 1
-#endif
 template <int LN>
 __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(ListQueue *__restrict__ q, int par, const ListSlot *__restrict__ slots,
 	const float *__restrict__ llr_q, float *__restrict__ soft_all, uint8_t *__restrict__ hard_q, const uint32_t *__restrict__ frozen2,
 	const uint8_t *__restrict__ node_lev2, float *__restrict__ metric_q)
 {
-#ifdef POLAR_PRIO
-	__builtin_amdgcn_s_setprio(POLAR_PRIO);                   // experiments: issue priority against the co-resident Theil-Sen waves
-#endif
 	const int lane = threadIdx.x & 63, j = lane >> 3, k = lane & 7;
 	const int wave_in_block = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 	const int decoder = (int)blockIdx.x * POLAR_WPB + wave_in_block;
@@ -568,7 +543,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 	Maps A;
 	A.w0 = ID0 * (uint32_t)k;
 	A.w1 = ID1 * (uint32_t)k;
-	PROF_DECL();
 
 	// rate-1 test of a uniform node (the predicate of Block8::list_is_stable): mu = this lane's smallest |LLR| of the node
 	auto stable = [&](uint32_t mu) -> bool {
@@ -662,7 +636,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 		const uint32_t fzv = frozen[t256 * 8 + (lane & 7)];
 		const int LtT = t ? __builtin_amdgcn_readfirstlane(nlv) >> 4 : 0;
 		int Ln = 0;
-		PROF(6);
 		// ---------------- level 8 of this 256-leaf node into LDS, through the level store
 		{
 			int cur, kind;                                    // next level to produce and how its first step works
@@ -718,7 +691,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 					WAVE_ORDER();
 					cur -= D;
 					kind = 0;
-					PROF(0);
 				}
 				if (!try_big)
 					break;
@@ -740,7 +712,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 					WAVE_ORDER();
 					if (stable(mu))
 						Ln = LtT;
-					PROF(2);
 					if (Ln)
 						break;
 				}
@@ -767,7 +738,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 				}
 				Ln = 8;
 			}
-			PROF(2);
 		}
 		if (Ln) {
 			A.reset_upto(t ? __builtin_ctz(t) : 16, k);
@@ -792,7 +762,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 				const int glb = zb < 8 ? ((j << 3) | A.get(zb + 1)) : lane;
 				const bool mapped = __ballot(glb != lane) != 0;
 				const uint32_t hb = zb < 8 ? HR >> (b - (1 << (zb - 3))) : 0u;
-				PROF(6);
 				if (zb >= 7) {
 					if (zb == 7) {
 						#pragma unroll
@@ -870,7 +839,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 					if (Lt == 4 && try_node(r4, nl0 == 4, HR, b))
 						L2 = 4;
 				}
-				PROF(1);
 				if (L2) {
 					A.reset_upto(tt ? __builtin_ctz(tt) : 16, k);
 					adv = 1 << (L2 - 3);
@@ -891,7 +859,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 					int H = 0;
 					{
 						Block8<LN> blk{ M, A, H, { 0.f, 0.f, 0.f, r3 }, fz, tt, lane, j, k, hi_alive };
-#ifndef POLAR_NO_FAST_BLOCKS
 						// the five patterns that make up 97 % of the 8-leaf blocks of both frozen tables (0x01: 673 of 2108, 0x17: 447,
 						// 0x00: 429, 0x7f: 323, 0xff: 164) as straight-line code; the rest, and any block with a reordering fork, is walked
 						bool decided = false;
@@ -901,11 +868,9 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 						else if (fz == 0x7fu) decided = blk.template fast_block<0x7fu>();
 						else if (fz == 0xffu) decided = blk.template fast_block<0xffu>();
 						if (!decided)
-#endif
 							blk.template node<3, 0>();
 					}
 					HR = (HR & ~(1u << b)) | ((uint32_t)((H >> j) & 1) << b);   // this lane's own position, own path
-					PROF(3);
 				}
 				// partial-sum combines of the nodes of 16..256 leaves that end here: hard[i] = perm(hard[i]) ^ hard[i + half]
 				const int bn = b + adv;
@@ -918,7 +883,6 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 					const uint32_t lmask = ((1u << half) - 1u) << b0;
 					HR = (HR & ~lmask) | ((Lp ^ (HR >> half)) & lmask);
 				}
-				PROF(4);
 			}
 			// publish the node's 256 partial-sum bytes (bit k = path k): 32 ballots, lanes 0..31 store 8 bytes each
 			{
@@ -939,9 +903,7 @@ __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(
 			combine_wide(hard + tn - (1 << m), 1 << (m - 1), A.get(m - 1));
 		}
 		WAVE_ORDER();
-		PROF(5);
 	}
-	PROF_FLUSH();
 	if (j == 0) {
 		if (LN == 8 || k < 4)
 			metric_q[(size_t)slot * LIST + k] = M;
@@ -957,24 +919,10 @@ void launch_polar(hipStream_t s, int list, int grid, ListQueue *q, int par, cons
 	Tables tb, float *metric_q)
 {
 	grid = (grid + POLAR_WPB - 1) / POLAR_WPB;                // workgroups of POLAR_WPB decoders
-#ifdef POLAR_PROF
-	unsigned long long z8[8] = { 0 };
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_polar_prof), z8, sizeof(z8));
-#endif
 	if (list == 4)
 		hipLaunchKernelGGL(k_polar<4>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, q, par, slots, llr_q, soft, hard_q, tb.frozen, tb.node_lev, metric_q);
 	else
 		hipLaunchKernelGGL(k_polar<8>, dim3(grid), dim3(64 * POLAR_WPB), 0, s, q, par, slots, llr_q, soft, hard_q, tb.frozen, tb.node_lev, metric_q);
-#ifdef POLAR_PROF
-	(void)hipStreamSynchronize(s);
-	(void)hipMemcpyFromSymbol(z8, HIP_SYMBOL(g_polar_prof), sizeof(z8));
-	static const char *nm[7] = { "hbm_pass", "lds_pass", "node", "leaf8", "combine", "publish", "lookup" };
-	double tot = 0;
-	for (int ph = 0; ph < 7; ++ph) tot += (double)z8[ph];
-	fprintf(stderr, "POLAR_PROF grid %d cw %llu: cycles/cw %.0f |", grid, z8[7], tot / (double)(z8[7] ? z8[7] : 1));
-	for (int ph = 0; ph < 7; ++ph) fprintf(stderr, " %s %.1f%%", nm[ph], 100.0 * (double)z8[ph] / tot);
-	fprintf(stderr, "\n");
-#endif
 }
 
 }  // namespace rx

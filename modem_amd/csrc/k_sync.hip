@@ -119,27 +119,22 @@ __global__ __launch_bounds__(256) void k_front_end(FrameBatch fb, MonoArgs ma, c
 	__shared__ typename MonoCover<RATE, 256>::Shared msh;
 	MonoCover<RATE, 256> mc;
 	mc.init(mono_frame(fb, ma.ck, ma.ck_per_frame, f), ma, &msh, z_all + (size_t)f * fb.samples_per_frame, tid);
+	mc.hi = lo + FE_STRETCH < mc.fr.n ? lo + FE_STRETCH : mc.fr.n;   // (cover() runs whole spans: they reach into the next workgroup's stretch)
 	mc.cover(ma, lo, lo + FE_STRETCH, tid);
 }
 
 // ---------------------------------------------------------------- D2 + D3 sync
-#ifndef SYNC_PER
 #define SYNC_PER 8     // sample times per lane and tile: 8 -> 224 VGPRs and 22 KB of LDS, so that a sync wave fits on a SIMD beside
                        // three resident polar decoders (the whole front runs inside the polar phase); 16 -> 256 VGPRs, 30 KB
-#endif
 constexpr int PER = SYNC_PER, TILE = 64 * PER;
 // ring of the last TILE + match_len metric values (a power of two): 1024 at 8 / 16 kHz, 2048 at 44.1 / 48 kHz
 template <int RATE> struct SyncRing { static constexpr int N = TILE + RateCfg<RATE>::MATCH_LEN <= 1024 ? 1024 : 2048; };
 
 // 8 kHz: the two 640-point work arrays of the trigger part live in LDS.  Other rates (1280 / 3528 / 3840
 // points) keep them in a per-frame global scratch so the scanning loop's occupancy does not pay for them.
-#ifndef SYNC_FFT_IN_LDS
 #define SYNC_FFT_IN_LDS 1    // 8 kHz: the two 640-point buffers of the S&C trigger part in LDS (0: global scratch like the other rates)
-#endif
 #define SYNC_FFT_LDS(R) ((R) == 8000 && SYNC_FFT_IN_LDS)
-#ifndef SYNC_WAVES
 #define SYNC_WAVES 2
-#endif
 #ifndef SYNC_WAVES_SPLIT
 #define SYNC_WAVES_SPLIT 4      // register budget of the split scan (k_sync<RATE, true>): 124 VGPRs, 10 KB of LDS = 16 waves per CU
 #endif
@@ -209,9 +204,6 @@ __device__ bool sc_process(cf *buf, cf *xr, const SampleSrc &src, const cf *tw, 
 	constexpr int BUFFER_LEN = RC::BUFFER_LEN, SEARCH_POS = RC::SEARCH_POS, HALF_LEN = RC::HS, GUARD_LEN = RC::GL;
 	const float frac_cfo = phase_max / (float)HALF_LEN;       // decode.cc:110
 	int symbol_pos = SEARCH_POS - index_max;                   // decode.cc:114
-#ifdef SYNC_PROBE_NO_SC
-	symbol_pos_out = symbol_pos; cfo_out = 0.f; return true;   // timing probe: the trigger scan without the accept path
-#endif
 	const long base = t - (BUFFER_LEN - 1);
 	__syncthreads();
 	{   // decode.cc:117-118.  e^{j frac_cfo i}, i = 64 q + lane: one closed-form phasor per lane times one per q (lane q holds the
@@ -285,9 +277,7 @@ __device__ bool sc_process(cf *buf, cf *xr, const SampleSrc &src, const cf *tw, 
 // the accept path by ONE wave through global scratch (256 VGPRs + spills) were 60 % of this kernel's time.
 // MONO: z_all is written here - the analytic signal of the samples the scan walks, span by span ahead of it (mono_front.h)
 struct NoShared {};
-#ifndef SYNC_WAVES_SPLIT_MONO
 #define SYNC_WAVES_SPLIT_MONO 3 // the same for mono input (the scan forms the analytic signal too): 168 VGPRs
-#endif
 template <int RATE, bool SPLIT, bool MONO>
 __global__ __launch_bounds__(64, SPLIT ? (MONO ? SYNC_WAVES_SPLIT_MONO : SYNC_WAVES_SPLIT) : SYNC_WAVES) void k_sync(FrameBatch fb, cf *__restrict__ z_all, const cf *__restrict__ tw,
 	const cf *__restrict__ kern, SyncState *__restrict__ st_all, cf *__restrict__ scratch, MonoArgs ma)
@@ -667,17 +657,13 @@ void launch_front_end(hipStream_t s, int rate, int n, FrameBatch fb, MonoArgs ma
 		RX_RATE_SWITCH(rate, hipLaunchKernelGGL(k_front_end<RATE>, dim3(stretches, nf), dim3(256), 0, s, fbq, maq, z + (size_t)f0 * fb.samples_per_frame));
 	}
 }
-#ifndef SYNC_SPLIT_ROUNDS
 #define SYNC_SPLIT_ROUNDS 2   // rates above 8 kHz: scan + accept pairs before the one-wave catch-all (a frame needs the catch-all only
                               // after that many rejected triggers; finished frames leave every later launch at once)
-#endif
 template <int RATE, bool MONO>
 static void sync_rounds(hipStream_t s, int n, FrameBatch fb, cf *z, Tables tb, SyncState *st, cf *scratch, const MonoArgs &ma)
 {
-#ifndef SYNC_SPLIT_8K
 #define SYNC_SPLIT_8K 1       // 8 kHz too since round 3: the fused one-wave kernel needs 240 VGPRs and 20 KB of LDS (8 waves per CU,
                               // four rounds of 2048 frames per chunk); the scan alone runs at 16 per CU: 0.83 -> 0.73 ms per 8192 frames
-#endif
 	if (RATE != 8000 || SYNC_SPLIT_8K) {
 		for (int r = 0; r < SYNC_SPLIT_ROUNDS; ++r) {
 			hipLaunchKernelGGL((k_sync<RATE, true, MONO>), dim3(n), dim3(64), 0, s, fb, z, tb.tw_sym, tb.sc_kern, st, scratch, ma);

@@ -37,21 +37,11 @@
 
 namespace rx {
 
-#ifndef TS_CAP
 #define TS_CAP 56          // pairs the final bracket may hold (the list holds 64: a few candidates fall outside after the exact division)
-#endif
-#ifndef TS_OPEN_NEED
 #define TS_OPEN_NEED 30    // an open bracket (one counted end) is tried when the wanted rank is at most this far from the count
-#endif
-#ifndef TS_OPEN_MARGIN
 #define TS_OPEN_MARGIN 6   // ranks the uncounted end is placed beyond the wanted one (times 1.25 for the density estimate)
-#endif
-#ifndef TS_MARGIN
 #define TS_MARGIN 12       // a secant step aims this many ranks past the target, on the side still open
-#endif
-#ifndef TS_UNC_STEPS
 #define TS_UNC_STEPS 24    // neighbour distance up to which uncertain pairs are resolved one by one
-#endif
 constexpr int TS_QBITS = 22;
 constexpr uint32_t TS_QREAL = (1u << TS_QBITS) - 8192u;   // quanta [0, TS_QREAL) for the row's points
 constexpr uint32_t TS_QPAD0 = (1u << TS_QBITS) - 4096u;   // slots beyond n: above every real key, 8 quanta apart
@@ -62,16 +52,6 @@ constexpr uint32_t TS_MQ = 2;
 constexpr int TS_MQ1S = (int)((TS_MQ + 1) << 9);
 constexpr int TS_LIST = 64;                               // candidate pairs of the final bracket: one per lane
 constexpr int TS_MAX_IT = 48;
-#ifdef TS_REASON_LOG                                      // variant builds: cumulative slow-path reasons + rank counts, printed after every launch
-__device__ int g_ts_reason[8], g_ts_iters;
-#define TS_PROBE_REASON g_ts_reason
-#define TS_PROBE_ITERS (&g_ts_iters)
-#endif
-#ifdef TS_PROBE_REASON
-#define TS_REASON(r) do { if ((threadIdx.x & 63) == 0) atomicAdd(TS_PROBE_REASON + (r), 1); } while (0)
-#else
-#define TS_REASON(r) do { } while (0)
-#endif
 constexpr uint32_t TS_SENTINEL = 0x7fffffffu;             // above every key, and differences to it stay positive as int32
 
 // LDS images are "register major": element e = 8 * lane + t lives at row t, column lane, so that "my elements" and "the
@@ -85,14 +65,8 @@ constexpr int TS_YS = 68, TS_PS = 76;                     // sk: columns 64..75 
 // 16 workgroups per CU, so one-wave workgroups cap the kernel at 16 waves per CU where its registers would allow 20 - and
 // still 1 row per workgroup is the fastest: 3.3 ms per 8192 frames against 3.5 (2 rows) and 4.1 (4 rows; a workgroup's LDS
 // and slots are released only when its slowest row is through), profiles/r03_v3_theil_sen_rows_per_workgroup.txt.
-#ifndef TS_ROWS_PER_WG
 #define TS_ROWS_PER_WG 1
-#endif
-#if TS_ROWS_PER_WG == 1
 #define TS_SYNC() __syncthreads()
-#else
-#define TS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#endif
 struct TsLds {
 	float y[8 * TS_YS];
 	uint2 sk[8 * TS_PS];       // .x sorted keys of the last count; .y the same elements keyed at the other end of the bracket
@@ -451,7 +425,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 		if (ymin == ymax)                                         // every slope is +0
 			done = true;
 		else if (!(ymax - ymin < 3.0e38f)) {                      // NaN / inf in the row
-			slow = true; TS_REASON(1);
+			slow = true;
 		}
 		float Ta = 0.f, Tb = 0.f, T = 0.f;
 		int ca = 0, cb = count;
@@ -476,10 +450,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 		for (;;) {                                                // search, then the list; again only after an open bracket that failed
 		if (!done && !slow) {
 			for (;; ++it) {
-				if (it >= TS_MAX_IT) { slow = true; TS_REASON(2); break; }
-#ifdef TS_PROBE_ITERS
-				if (lane == 0) atomicAdd(TS_PROBE_ITERS, 1);
-#endif
+				if (it >= TS_MAX_IT) { slow = true; break; }
 				// ---- exact #{s < T}, #{s <= T}
 				qs = ts_quant(T, ymin, ymax, n);
 				{
@@ -503,11 +474,8 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 					}
 					int dlt = 0, dle = 0;
 					if (__builtin_amdgcn_ballot_w64(dmin < TS_MQ1S)) {
-#ifdef TS_PROBE_UNC
-						if (lane == 0) atomicAdd(TS_PROBE_UNC, 1);
-#endif
 						for (int kk = 1;; ++kk) {
-							if (kk > TS_UNC_STEPS) { slow = true; TS_REASON(3); break; }
+							if (kk > TS_UNC_STEPS) { slow = true; break; }
 							uint32_t h = 0;                       // bit 7 - t: the key kk places after my t-th one is within the margin
 							#pragma unroll
 							for (int t = 0; t < 8; ++t)
@@ -587,7 +555,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 					if (km == ka)
 						km = kb;                                  // (only when one side is still open)
 					Tn = fkey_inv(km);
-					if (Tn == T) { slow = true; TS_REASON(4); break; }
+					if (Tn == T) { slow = true; break; }
 				}
 				Tp = T; cp = c_lt; hasP = true;
 				T = ts_uni(Tn);
@@ -614,10 +582,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 			int nc = 0;
 			for (int kk = 1;; ++kk) {
 				if (kk > 8 * (TS_PS - 64)) {
-#ifdef TS_PROBE_PRINT
-					if (lane == 0) printf("reason 5: n %d Ta %.9g Tb %.9g T %.9g ca %d cb %d target %d wq %g scale %g nc %d\n", n, Ta, Tb, T, ca, cb, target, wq, qs.scale, nc);
-#endif
-					slow = true; TS_REASON(5); break;
+					slow = true; break;
 				}
 				uint32_t h = 0;
 				int gmin = 0x7fffffff;
@@ -655,7 +620,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 				if (open_end)
 					retry = true;
 				else {
-					slow = true; TS_REASON(6);
+					slow = true;
 				}
 			}
 			if (!slow && !retry) {
@@ -671,14 +636,11 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 				const int found = __popcll(__builtin_amdgcn_ballot_w64(in));
 				// rank of the wanted slope among the listed ones: counted from the side whose count is exact
 				const int idx = t_is_a ? target - c_at_T : found - (c_at_T - target);
-#ifdef TS_PROBE_PRINT
-				if (lane == 0) printf("list: n %d open %d t_is_a %d T %.9g To %.9g c_at_T %d target %d ca %d cb %d nc %d found %d idx %d it %d\n", n, (int)open_end, (int)t_is_a, T, To, c_at_T, target, ca, cb, nc, found, idx, it);
-#endif
 				if (open_end) {
 					if (idx < 0 || idx >= found)
 						retry = true;                                           // the open end was too close: count it
 				} else if (found != cb - ca) {
-					slow = true; TS_REASON(7);                                  // (cannot happen: the counts are exact)
+					slow = true;                                  // (cannot happen: the counts are exact)
 				}
 				if (!slow && !retry) {
 					key = ts_sort_lanes(key, L);
@@ -686,7 +648,6 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 				}
 			}
 			if (retry) {                                          // the search goes on with a count at the open end
-				TS_REASON(0);
 				open_failed = true;
 				open_end = false;
 				Tp = T; cp = c_at_T; hasP = true;
@@ -697,9 +658,6 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 		}
 		break;
 		}
-#ifdef TS_PROBE_COUNT
-		if (slow && lane == 0) atomicAdd(TS_PROBE_COUNT, 1);
-#endif
 		if (slow) {
 			slope = ts_slow_select(s, n, lane, target);
 			sorted_z = false;
@@ -780,9 +738,7 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 // refined once replace the library's atan2f (38 vector instructions, most of them quadrant and special-case handling): 11 / 15.
 // Anything else - an erased carrier (d = 0), NaN, a point exactly on a decision boundary pushed past the range by rounding -
 // takes the library routine.
-#ifndef TS_OWN_ATAN
 #define TS_OWN_ATAN 1
-#endif
 __device__ __forceinline__ float ts_phase(cf d, int mod_bits)
 {
 	const float lim = mod_bits == 3 ? 0.42f : 1.005f;               // (the fits cover 0.4225 / 1.00995)
@@ -855,12 +811,8 @@ __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const M
 // has more than 50 rows.  A launch of frames x 126 one-row waves, 60 % of which leave at once for mode 6, cost 0.15 ms per
 // 8192 frames.  The loop costs registers (what depends on the row length and the lane alone is hoisted out of it; bounding it
 // to the direct kernel's 96 spills five of them), so it is its own kernel.
-#ifndef TS_MORE_WAVES_N
 #define TS_MORE_WAVES_N 20480
-#endif
-#ifndef TS_MORE_OCC
 #define TS_MORE_OCC 5
-#endif
 constexpr int TS_ROWS_DIRECT = 50, TS_MORE_WAVES = TS_MORE_WAVES_N;
 __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen(const SyncState *__restrict__ st_all, cf *__restrict__ cons_all,
 	const cf *__restrict__ carr_all, float *__restrict__ slope_all, float *__restrict__ yint_all, int n_frames, int *__restrict__ chunk_flags)
@@ -912,22 +864,12 @@ __global__ __launch_bounds__(64 * TS_ROWS_PER_WG, 5) void k_theil_sen_raw(int co
 	if (lane == 0) { slope_all[r] = sy.x; yint_all[r] = sy.y; }
 }
 
-#ifdef TS_REASON_LOG
-__global__ void k_ts_reason_dump()
-{
-	printf("theil-sen so far: rank counts %d, open brackets that failed %d, slow path by reason 1..7: %d %d %d %d %d %d %d\n", g_ts_iters, g_ts_reason[0],
-		g_ts_reason[1], g_ts_reason[2], g_ts_reason[3], g_ts_reason[4], g_ts_reason[5], g_ts_reason[6], g_ts_reason[7]);
-}
-#endif
 void launch_theil_sen(hipStream_t s, int n, const SyncState *st, cf *cons, const cf *carr, float *slope, float *yint, int *chunk_flags)
 {
 	hipLaunchKernelGGL(k_theil_sen, dim3((n * TS_ROWS_DIRECT + TS_ROWS_PER_WG - 1) / TS_ROWS_PER_WG), dim3(64 * TS_ROWS_PER_WG), 0, s, st, cons, carr,
 		slope, yint, n, chunk_flags);
 	hipLaunchKernelGGL(k_theil_sen_more, dim3(TS_MORE_WAVES), dim3(64), 0, s, st, cons, carr, slope, yint, n,
 		chunk_flags);
-#ifdef TS_REASON_LOG
-	hipLaunchKernelGGL(k_ts_reason_dump, dim3(1), dim3(1), 0, s);
-#endif
 }
 void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, float *slope, float *yint)
 {

@@ -122,16 +122,12 @@ __global__ __launch_bounds__(256) void k_tx_code(const uint8_t *__restrict__ pay
 // The 4x oversampled PAPR buffer (encode.cc:50-51 fdom4/tdom4) is 5120 / 10240 points at 8 / 16 kHz and sits in
 // LDS (41 / 82 KB); at 44.1 / 48 kHz it is 28224 / 30720 points (226 / 246 KB > LDS) and lives in a per-workgroup
 // global scratch, worked on by 1024 threads so the in-place radix stages still fit the register file.
-#ifndef TX_TW_GLOBAL
 #define TX_TW_GLOBAL 2     // 0: compact stage twiddles copied to LDS per workgroup; 1: the root table read at a stride through L1;
                            // 2: the compact table read from global memory (consecutive words, L1-resident): 10 KB of LDS less per
                            // workgroup = three workgroups per CU, and a quarter of the transforms' LDS reads gone
-#endif
 template <int RATE> struct TxCfg {
 	static constexpr bool BIG_IN_LDS = RATE <= 16000;
-#ifndef TX_NT_LDS
 #define TX_NT_LDS 256
-#endif
 	static constexpr int NT = BIG_IN_LDS ? TX_NT_LDS : 1024;
 };
 // The payload carriers of data row j are pilot x the product of the PSK symbols of rows 0..j (the transmitter's
@@ -215,9 +211,6 @@ __global__ __launch_bounds__(TxCfg<RATE>::NT, (TxCfg<RATE>::BIG_IN_LDS ? TX_WAVE
 		sh.fdom[i] = mk(0.f, 0.f);
 	__syncthreads();
 	bool papr = true;
-#ifdef TX_PROBE_NO_PAPR
-	papr = false;                                             // timing probe: symbols without the PAPR step
-#endif
 	const int last = tp.nsym - 1;
 	// stream layout (encode.cc:288-313): pilot | count x (S&C, meta, pilot, rows x data) | zero symbol
 	const int per = 3 + md.rows, q = sidx - 1, pay = (sidx > 0 && sidx < last) ? q / per : 0, w = (sidx > 0 && sidx < last) ? q % per : 2;

@@ -112,6 +112,8 @@ template <int RATE, int NT> struct MonoCover {
 	Shared *sh;
 	cf *z;                                                    // the frame's analytic signal
 	long lo, next;                                            // z is valid on [lo, next) once `any`
+	long hi;                                                  // nothing at or beyond it is stored (the frame's end; k_front_end: its stretch's end,
+	                                                          // so that two workgroups never store the same sample from different scan groupings)
 	bool any;
 	double S;                                                 // s[next - 1]
 	float Alane, W16, W32;                                    // a^(8 lane); a^(8 ((lane & 15) + 1)), a^(8 ((lane & 31) + 1)): WScan
@@ -120,6 +122,7 @@ template <int RATE, int NT> struct MonoCover {
 	{
 		fr = frame; sh = shared; z = z_frame;
 		lo = next = 0;
+		hi = frame.n;
 		any = false;
 		S = 0.0;
 		Alane = (float)mono_pow((double)ma.a, PER * (tid & 63));
@@ -204,14 +207,14 @@ template <int RATE, int NT> struct MonoCover {
 			#pragma unroll
 			for (int q = 0; q < PER; ++q)
 				r[q] = mono_hilbert<RATE>(ma.co, [&](int k) { return w[q + k]; });
-			if (next >= lo && next + LEN <= fr.n) {               // (uniform) the whole span is wanted: 64 contiguous bytes per thread
+			if (next >= lo && next + LEN <= hi) {                 // (uniform) the whole span is wanted: 64 contiguous bytes per thread
 				#pragma unroll
 				for (int q = 0; q < PER; ++q)
 					z[i0 + q] = r[q];
 			} else {
 				#pragma unroll
 				for (int q = 0; q < PER; ++q)
-					if (i0 + q >= lo && i0 + q < fr.n)
+					if (i0 + q >= lo && i0 + q < hi)
 						z[i0 + q] = r[q];
 			}
 		} else {
@@ -220,7 +223,7 @@ template <int RATE, int NT> struct MonoCover {
 				const int j = tid + NT * q;                       // consecutive samples across the lanes
 				const long i = next + j;
 				const cf r = mono_hilbert<RATE>(ma.co, [&](int k) { return sh->y[pad(HIST + j - MC::REACH + k)]; });
-				if (i >= lo && i < fr.n)
+				if (i >= lo && i < hi)
 					z[i] = r;
 			}
 		}

@@ -166,6 +166,7 @@ struct ofdmrx_handle {
 	DevBuf carr;                   // payload carriers of every symbol (demod -> Theil-Sen) at the rates whose demodulator does not form the rows
 	DevBuf sc_scratch;             // rates above 8 kHz: 2 x symbol_len/2 cf per frame for the S&C trigger part
 	int last_n = 0;           // frames in the last chunk (for taps)
+	size_t last_first = 0;    // index of that chunk's first frame in its call (ofdmrx_last_chunk_first_frame)
 	bool last_mono = false;
 	FrameBatch last_fb{};     // the last chunk's samples (the ANALYTIC tap forms its frame's analytic signal from them)
 	// timing
@@ -335,6 +336,8 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 }
 
 extern "C" int ofdmrx_chunk_frames(ofdmrx_handle *h) { return h ? h->chunk : OFDMRX_E_ARG; }
+// index (in the last decode call) of the first frame of the LAST chunk that call ran: what frame 0 of ofdmrx_debug_dump is
+extern "C" long long ofdmrx_last_chunk_first_frame(ofdmrx_handle *h) { return h ? (long long)h->last_first : OFDMRX_E_ARG; }
 
 // decode.cc:517-519 prints one Es/N0 value per constellation row; a batch caller gets them here: rows = n_frames x
 // OFDMRX_ROWS_MAX floats (dB; rows a frame's mode does not have, and frames without a header: 0) in the memory space of
@@ -632,9 +635,8 @@ static int check_args(ofdmrx_handle *h, const void *samples, int fmt, int channe
 	size_t bps = fmt == OFDMRX_FMT_S16 ? 2 : fmt == OFDMRX_FMT_U8 ? 1 : 4;
 	if (spf == 0 || spf > (size_t)0x7fffffff / 2 || stride < spf * bps * (size_t)channels)
 		return OFDMRX_E_ARG;
-	if (fmt == OFDMRX_FMT_S16 && channels == 2 && (stride & 3))
-		return OFDMRX_E_ARG;
-	if ((stride % bps) || ((size_t)samples % bps))             // whole samples between the frames, frames on a sample boundary
+	const size_t frame_bytes = bps * (size_t)channels;        // one sample frame: the kernels load I/Q pairs with one access
+	if ((stride % frame_bytes) || ((size_t)samples % frame_bytes))   // whole sample frames between the frames, frames on such a boundary
 		return OFDMRX_E_ARG;
 	return 0;
 }
@@ -674,8 +676,8 @@ static ChunkPlan plan_chunks(const ofdmrx_handle *h, size_t n_frames, bool host_
 {
 	ChunkPlan p;
 	size_t step = (size_t)h->chunk;
-	if (host_side && n_frames <= step && n_frames >= 6144)
-		step = (n_frames + 1) / 2;
+	if (host_side && n_frames <= step && n_frames >= 6144 && !(h->cfg.flags & OFDMRX_FLAG_KEEP_RAW_CONS))   // (a handle with debug taps keeps
+		step = (n_frames + 1) / 2;                                                                     // one chunk: its taps index the call's frames)
 	for (size_t f = 0; f < n_frames; f += step)
 		p.start.push_back(f);
 	p.start.push_back(n_frames);
@@ -761,6 +763,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_fin[c - 2]], 0));
 		r = run_front1(h, sa, fb, n, d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0s[c], att, att_counts,
 			(overlap && c >= 2) ? ev_polar[c - 2] : NONE, &ev_sync);
+		h->last_first = plan.first(c);
 		if (!r && overlap && c >= 1)                              // flush(c - 1): its LLRs are in the queue, sync(c) is on its way
 			r = flush(c - 1, ev_sync);
 		r = r ? r : hooks.after_front1(c, mark(h, sa));
@@ -830,6 +833,10 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	h->spans.clear();
 	const int out_kind = host_pinned(d_payload), res_kind = host_pinned(d_results);
 	if (out_kind < 0 || res_kind < 0 || out_kind != res_kind)
+		return OFDMRX_E_ARG;
+	// the optional outputs live in the memory space of the results: pinned host memory too, then
+	if (out_kind == 1 && ((h->esn0_user && host_pinned(h->esn0_user) != 1) ||
+			(h->att_user && (host_pinned(h->att_user) != 1 || host_pinned(h->att_counts_user) != 1))))
 		return OFDMRX_E_ARG;
 	const ChunkPlan plan = plan_chunks(h, n_frames, out_kind == 1);
 	struct Dev : PipeHooks {

@@ -20,7 +20,7 @@ STAGES = ["front", "sync", "header", "demod", "theilsen", "llr", "polar", "finis
 # every symbol include/ofdmrx.h declares
 EXPORTS = [
     "ofdmrx_abi_version", "ofdmrx_abi_minor", "ofdmrx_strerror", "ofdmrx_create", "ofdmrx_destroy", "ofdmrx_decode_batch",
-    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_list_decoded_frames", "ofdmrx_sc_decided_frames", "ofdmrx_get_sc_timing", "ofdmrx_set_esn0_rows", "ofdmrx_set_attempt_log",
+    "ofdmrx_decode_batch_device", "ofdmrx_synchronize", "ofdmrx_get_timing", "ofdmrx_chunk_frames", "ofdmrx_last_chunk_first_frame", "ofdmrx_list_decoded_frames", "ofdmrx_sc_decided_frames", "ofdmrx_get_sc_timing", "ofdmrx_set_esn0_rows", "ofdmrx_set_attempt_log",
     "ofdmrx_debug_dump", "ofdmrx_debug_polar", "ofdmrx_debug_sc_path", "ofdmrx_debug_decode_cons", "ofdmrx_debug_theil_sen", "ofdmrx_debug_osd", "ofdmrx_debug_fft",
     "ofdmrx_util_awgn_tile", "ofdmrx_util_channel", "ofdmrx_frame_samples", "ofdmrx_tx_frame_samples",
     "ofdmrx_tx_encode_device", "ofdmrx_stream_samples", "ofdmrx_tx_encode_stream_device", "ofdmrx_tx_encode_stream",
@@ -115,6 +115,8 @@ def load_library():
     L.ofdmrx_set_attempt_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ofdmrx_list_decoded_frames.argtypes = [C.c_void_p]
     L.ofdmrx_list_decoded_frames.restype = C.c_longlong
+    L.ofdmrx_last_chunk_first_frame.argtypes = [C.c_void_p]
+    L.ofdmrx_last_chunk_first_frame.restype = C.c_longlong
     L.ofdmrx_sc_decided_frames.argtypes = [C.c_void_p]
     L.ofdmrx_sc_decided_frames.restype = C.c_longlong
     L.ofdmrx_get_sc_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -241,6 +243,10 @@ class Receiver:
     def list_decoded_frames(self):
         """frames of the last decode call the syndrome certificate left to the list decoder (-1: certificate off)"""
         return int(self._lib.ofdmrx_list_decoded_frames(self._h))
+
+    def last_chunk_first_frame(self):
+        """index, in the last decode call, of the first frame of the chunk the taps belong to"""
+        return int(self._lib.ofdmrx_last_chunk_first_frame(self._h))
 
     def sc_decided_frames(self):
         """frames of the last decode call finished by the list-1 pass (-1: that pass is off)"""

@@ -338,6 +338,44 @@ def test_syndrome_certificate_is_the_list_decoder(rx):
     assert res_c["status"][9] == 0 and (out_c[9] == out_c[0]).all()
 
 
+def test_soft_demapper_on_the_reference_vectors(rx):
+    """psk.hh:108-139 on the GPU against the vectors the REAL header produced (tests/golden/psk_vectors.json: 8PSK points incl.
+    exact ties |re| = |im|, zeros of either sign, tiny and huge magnitudes): the points are planted into a row of a clean frame's
+    constellation and go through k_back like any other (ofdmrx_debug_decode_cons, rotation = identity).  The row's precision is the
+    frame's own (decode.cc:516), so a soft value is the vector's times the ratio of the two precisions: exact zeros stay exact,
+    every sign is the header's (the hard decisions, decode.cc:546-555 counts them), magnitudes agree to 4 ulps."""
+    import json
+    import os
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "psk_vectors.json")))["psk8"]
+    pcm = O.encode_pcm(O.payload_for(61), channels=2)
+    _, res, tb = O.decode(pcm, taps=True)
+    cons = tb.cons_rot[:21600].copy().view(np.complex64).reshape(-1)
+    row = 17
+    pts = np.array([complex(float.fromhex(v["re"]), float.fromhex(v["im"])) for v in vec], np.complex64)
+    assert len(pts) <= 432
+    cons[row * 432: row * 432 + len(pts)] = pts
+    rx.decode_cons(cons[None], use_cert=False)
+    llr = rx.tap("LLR", 0)
+    prec = rx.tap("PRECISION", 0)[row]
+    assert prec > 0
+    checked = ties = 0
+    for i, v in enumerate(vec):
+        got = llr[3 * (row * 432 + i): 3 * (row * 432 + i) + 3]
+        ratio = np.float64(prec) / float.fromhex(v["precision"])
+        for b in range(3):
+            want = float.fromhex(v["soft"][b])
+            if want == 0.0:
+                assert got[b] == 0.0, (i, b, got[b])              # a tie / a zero coordinate stays an exact zero
+                ties += 1
+            else:
+                assert (got[b] < 0) == (v["hard"][b] < 0) and (got[b] < 0) == (want < 0), (i, b, got[b], want)
+                if np.isfinite(want * ratio) and abs(want * ratio) > 1e-30:
+                    assert abs(got[b] - want * ratio) <= 4 * 2.0 ** -23 * abs(want * ratio), (i, b, got[b], want * ratio)
+            assert (v["hard"][b] < 0) == (got[b] < 0) or want == 0.0
+            checked += 1
+    assert checked == 3 * len(vec) and ties >= 6
+
+
 def _sc_vectors():
     """LLR vectors for k_sc: the oracle's own soft bits of frames from -30 dB to past the point where the rule gives up, in both
     frozen tables (modes 6 and 10), plus the special ones"""
@@ -848,6 +886,33 @@ def test_misaligned_samples_are_refused(rxd):
     rxd.decode_device(d.data_ptr() + 2, M.FMT_S16, 1, spf, spf * 2, 1, d_out.data_ptr(), d_res.data_ptr())   # (two-byte aligned: fine)
     rxd.synchronize()
     assert int(d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)["status"][0]) == 1                           # silence: no preamble
+    # 2-channel input: the sample FRAME is the I/Q pair (4 bytes of int16, 8 of float32) - a pair on a 2-byte boundary is refused
+    d2 = torch.zeros(spf * 8 + 16, dtype=torch.uint8, device=dev)
+    for fmt, unit in ((M.FMT_S16, 4), (M.FMT_F32, 8)):
+        for ptr, stride in ((d2.data_ptr() + unit // 2, spf * unit), (d2.data_ptr(), spf * unit + unit // 2)):
+            with pytest.raises(modem_amd.OfdmRxError):
+                rxd.decode_device(ptr, fmt, 2, spf, stride, 1, d_out.data_ptr(), d_res.data_ptr())
+        rxd.decode_device(d2.data_ptr() + unit, fmt, 2, spf, spf * unit, 1, d_out.data_ptr(), d_res.data_ptr())
+        rxd.synchronize()
+
+
+def test_taps_after_a_call_that_runs_as_two_halves():
+    """a host-side call of 6144 .. chunk frames runs as two halves (include/ofdmrx.h): the taps then belong to the SECOND half and
+    ofdmrx_last_chunk_first_frame() says where it begins; a handle with debug taps keeps such a call in one chunk"""
+    import modem_amd
+    p = O.payload_for(77)
+    pcm = O.encode_pcm(p, channels=2)
+    n = 6144
+    batch = np.broadcast_to(pcm, (n,) + pcm.shape)
+    for keep, first in ((False, n // 2), (True, 0)):
+        r = modem_amd.Receiver(device=0, keep_raw_cons=keep)
+        out, res = r.decode(np.ascontiguousarray(batch))
+        assert (res["status"] == 0).all() and (out == p).all()
+        assert r.last_chunk_first_frame() == first
+        assert np.abs(r.tap("SLOPE", 0)).max() < 1e-3             # (a clean frame's lines)
+        with pytest.raises(modem_amd.OfdmRxError):
+            r.tap("SLOPE", n - first)                             # beyond the last chunk
+        r.close()
 
 
 def test_8bit_input(rx):
@@ -1371,20 +1436,46 @@ def test_config2_full_size_mono_round_trip():
     rx.close()
 
 
+def _tie_class(i, out, oout, res, ores, pays):
+    """The two documented ways a frame AT the waterfall may differ from the scalar restatement in something decided
+    (include/ofdmrx.h; profiles/r04_v25_waterfall_mismatch_diagnosis_and_integer_scan_sums.txt):
+      "timing"  decode.cc:143's nearbyint of the fine timing estimate sits on a rounding boundary: sync position one sample apart,
+                header and outcome the same
+      "list"    every stage in front of the list decoder agrees, path metrics an ulp apart keep / lose the transmitted path: one
+                side delivers the transmitted payload, the other reports a payload CRC failure
+    anything else: None"""
+    hdr = all(res[nm][i] == ores[nm][i] for nm in ("oper_mode", "call_sign", "n_sync_rejects"))
+    sync = res["sc_start"][i] == ores["sc_start"][i] and res["symbol_pos"][i] == ores["symbol_pos"][i]
+    if not hdr:
+        return None
+    if not sync:
+        d = int(res["sc_start"][i]) - int(ores["sc_start"][i])
+        if abs(d) == 1 and int(res["symbol_pos"][i]) - int(ores["symbol_pos"][i]) == d and res["status"][i] == ores["status"][i] \
+                and res["best_lane"][i] == ores["best_lane"][i] and (out[i] == oout[i]).all():
+            return "timing"
+        return None
+    st = (int(res["status"][i]), int(ores["status"][i]))
+    if st in ((0, 6), (6, 0)):
+        winner = out[i] if st[0] == 0 else oout[i]
+        return "list" if (winner == pays[i]).all() else None
+    return None
+
+
 def test_waterfall_parity_at_scale():
-    """192 device-made frames at the edge of the waterfall (-14.6 dB: a mix of decoded and lost frames, every slow
+    """2048 device-made frames at the edge of the waterfall (-14.6 dB: a mix of decoded and lost frames, every slow
     path of the list decoder: failed node shortcuts, path replacement, CRC failures).  Everything decided - payload,
-    status, winning lane, sync position, header - must equal the oracle's frame by frame; the flip-count diagnostic
-    (sign of LLRs that may sit within the 1e-5 intermediate tolerance of zero) within 2."""
+    status, winning lane, sync position, header - must equal the oracle's frame by frame, except for frames of the two
+    documented tie classes (_tie_class; 6e-5 of the frames in the 65 536-frame sweep: at most two here); the flip-count
+    diagnostic (sign of LLRs that may sit within the 1e-5 intermediate tolerance of zero) within 2."""
     import os
     import torch
     import modem_amd
     import modem_amd.ofdmrx as M
     dev = torch.device("cuda:0")
-    n = 192
+    n = 2048
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        rx = modem_amd.Receiver(device=0, chunk_frames=80, stream=stream.cuda_stream)
+        rx = modem_amd.Receiver(device=0, chunk_frames=160, stream=stream.cuda_stream)
         spf = rx.tx_frame_samples(6)
         g = torch.Generator(device=dev)
         g.manual_seed(146)
@@ -1403,14 +1494,56 @@ def test_waterfall_parity_at_scale():
     rx.close()
     oout = np.zeros((n, 5380), np.uint8)
     ores = np.zeros(n * 56, np.uint8)
-    O.lib().orc_decode_batch(O.ptr(pcm), O.FMT_S16, 2, spf, spf * 4, n, 8, O.ptr(oout), O.ptr(ores), min(os.cpu_count() or 1, 32))
+    O.lib().orc_decode_batch(O.ptr(pcm), O.FMT_S16, 2, spf, spf * 4, n, 8, O.ptr(oout), O.ptr(ores), min(os.cpu_count() or 1, 128))
     ores = ores.view(M.RESULT_DTYPE).reshape(-1)
     ok = res["status"] == 0
-    assert 10 < ok.sum() < n - 10                               # really at the edge
-    assert (out == oout).all() and (out[ok] == pays[ok]).all()
-    for name in ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects"):
-        assert (res[name] == ores[name]).all(), name
-    assert (np.abs(res["bit_flips"].astype(np.int64) - ores["bit_flips"]) <= FLIPS_SLACK).all()
+    assert 100 < ok.sum() < n - 100                             # really at the edge
+    assert (out[ok] == pays[ok]).all()
+    names = ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects")
+    differ = [i for i in range(n) if not (out[i] == oout[i]).all() or any(res[nm][i] != ores[nm][i] for nm in names)]
+    classes = [_tie_class(i, out, oout, res, ores, pays) for i in differ]
+    assert len(differ) <= 2 and all(classes), (differ, classes)
+    same = np.ones(n, bool)
+    same[differ] = False
+    assert (np.abs(res["bit_flips"].astype(np.int64) - ores["bit_flips"])[same] <= FLIPS_SLACK).all()
+
+
+def test_documented_tie_frames_at_the_waterfall():
+    """The five frames in which the sweeps of round 4 found the GPU and the scalar restatement apart in something decided
+    (4 of 65 536 AT the waterfall, one mono frame of 230 000 above it), regenerated from their seeds: each still differs exactly
+    the documented way - so a change of either side's numerics that moves them, or a new kind of difference, shows up here."""
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    # (frames of the sweep, noise level index, frame, noise level, mode, mono: DC offset or None, documented class)
+    cases = [(32768, 0, 13365, -14.5, 6, None, "list"), (32768, 0, 18927, -14.5, 6, None, "list"), (32768, 0, 31302, -14.5, 6, None, "timing"),
+             (32768, 1, 654, -15.0, 6, None, "timing"), (2048, 1, 204, -19.0, 8, -2500, "timing")]
+    rx = modem_amd.Receiver(device=0, chunk_frames=16)
+    got = []
+    for n, li, i, db, mode, dc, want in cases:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + li)
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)[i:i + 1].contiguous()
+        spf = rx.tx_frame_samples(mode)
+        d_in = torch.empty((1, spf, 2), dtype=torch.int16, device=dev)
+        rx.tx_encode(d_pay.data_ptr(), 1, d_in.data_ptr(), mode=mode)
+        rx.awgn_tile(d_in.data_ptr(), 1, d_in.data_ptr(), 1, spf, db, 99, li * n + i)
+        rx.synchronize()
+        ch = 2
+        if dc is not None:
+            d_in = torch.clamp(d_in[:, :, 0].to(torch.int32) + dc, -32768, 32767).to(torch.int16).contiguous()
+            ch = 1
+        torch.cuda.synchronize()
+        pcm = d_in.cpu().numpy()[0]
+        out, res = rx.decode((pcm if ch == 2 else pcm[:, None])[None])
+        oo, orr = O.decode(pcm if ch == 2 else pcm[:, None])
+        ores = np.zeros(1, M.RESULT_DTYPE)
+        for name in ores.dtype.names:
+            ores[name][0] = getattr(orr, name)
+        got.append(_tie_class(0, out, oo[None], res, ores, d_pay.cpu().numpy()))
+    rx.close()
+    assert got == [c[-1] for c in cases], got
 
 
 def test_list_size_4():
