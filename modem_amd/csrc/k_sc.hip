@@ -676,8 +676,9 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 
 // behind k_back of a chunk: the run of k_sc = everything that chunk put into the SC ring; behind k_sc_finish: the adaptive switch.
 // Where k_sc decides few frames (below about -18.5 dB every path metric outgrows min_fork) its pass is spent for nothing:
-// k_back then sends a probe sample only (one frame in sixteen) and the rest straight to the list decoder, and all of them
-// again when an eighth of the sample is decided.  Either way every decision is exact: the list decoder is the general path.
+// k_back then sends a probe sample only (one frame in sixteen of every fourth chunk: a run that small still costs a codeword's
+// latency, 2 ms, with the machine idle) and the rest straight to the list decoder, and all of them again when an eighth of the
+// sample is decided.  (Frames whose Es/N0 estimate rules the pass out never come here at all: k_back.)  Either way every decision is exact: the list decoder is the general path.
 __global__ void k_sc_plan(ListQueue *__restrict__ qs)
 {
 	const unsigned head = qs->head, n = qs->tail - head;
@@ -696,6 +697,7 @@ __global__ void k_sc_adapt(ListQueue *__restrict__ qs)
 			qs->cert_on = 0;
 	} else if (tried >= 8 && done * 8 >= tried)
 		qs->cert_on = 1;
+	qs->epoch += 1;
 }
 
 // grid = resident decoders (waves); lb = log2 of the lanes per codeword: 5 (two codewords per wave, the default) or 6 (one)

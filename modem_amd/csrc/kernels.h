@@ -118,6 +118,7 @@ struct ListQueue {
 	unsigned tried, certified;     // since the last snapshot: frames the certificate was tried for / that it finished
 	unsigned cap;                  // slots
 	unsigned done_total;           // SC ring only: frames k_sc_finish has finished since the call began
+	unsigned epoch;                // SC ring only: chunks since the call began (k_sc_adapt): the probe sample runs in every fourth
 };
 // The SC ring (k_sc.hip) is a second queue of the same shape in front of this one: k_back puts a frame there when the SC pass is
 // on (its cert_on; tried / certified count the last run's entries / decided frames), k_sc | k_sc_finish drain it right behind

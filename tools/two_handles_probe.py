@@ -19,7 +19,7 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
 d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
 rx[0].tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
-rx[0].awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, -30.0, 7, 0)
+rx[0].awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, float(os.environ.get("PROBE_NOISE_DB", "-30")), 7, 0)
 rx[0].synchronize()
 d_out = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
 d_res = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
