@@ -357,7 +357,7 @@ template <int CNT> __device__ __forceinline__ void sc_g_half(float (&dst)[CNT], 
 template <int LB>
 __global__ __launch_bounds__(64, SC_WAVES_PER_SIMD) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
 	float *__restrict__ soft_all, uint32_t *__restrict__ cw_q, uint32_t *__restrict__ xw_q, ScStat *__restrict__ stat_q,
-	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev_blk)
+	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev_blk, int small_run)
 {
 	using Cf = ScCfg<LB>;
 	constexpr int J = Cf::J, C = Cf::C, NBLK = CODE_LEN / J;
@@ -374,6 +374,10 @@ __global__ __launch_bounds__(64, SC_WAVES_PER_SIMD) void k_sc(ListQueue *__restr
 	const int run_n = (int)q->run_n[par];
 	const unsigned run_head = q->run_head[par], cap = q->cap;
 	if (run_n == 0)
+		return;
+	// both layouts are launched behind every k_back; the run's length (known on the device only) picks one: a short run is a
+	// matter of one codeword's latency, and one codeword per wave has the shorter one (1.2 against 1.9 ms); a long one of throughput
+	if (small_run > 0 && (run_n <= small_run) != (LB == 6))
 		return;
 	const int n_units = (run_n + C - 1) / C;
 	float *const my_store = soft_all + (size_t)blockIdx.x * Cf::DECODER_FLOATS;
@@ -700,19 +704,23 @@ __global__ void k_sc_adapt(ListQueue *__restrict__ qs)
 	qs->epoch += 1;
 }
 
-// grid = resident decoders (waves); lb = log2 of the lanes per codeword: 5 (two codewords per wave, the default) or 6 (one)
+// grid5 / grid6 = resident decoders (waves) of the two layouts; lb = 5 / 6: that layout alone; 0: both are launched and the run's
+// length decides on the device (at most `small_run` entries: one codeword per wave)
+constexpr int SC_SMALL_RUN = 5120;
 int sc_codewords_per_wave(int lb) { return lb == 6 ? ScCfg<6>::C : ScCfg<5>::C; }
 size_t sc_store_bytes(int lb)                                     // level store per resident decoder
 {
-	return (lb == 6 ? (size_t)ScCfg<6>::DECODER_FLOATS : (size_t)ScCfg<5>::DECODER_FLOATS) * sizeof(float);
+	const size_t b5 = (size_t)ScCfg<5>::DECODER_FLOATS * sizeof(float), b6 = (size_t)ScCfg<6>::DECODER_FLOATS * sizeof(float);
+	return lb == 6 ? b6 : (lb == 5 ? b5 : (b5 > b6 ? b5 : b6));
 }
-void launch_sc(hipStream_t s, int lb, int grid, ListQueue *q, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
+void launch_sc(hipStream_t s, int lb, int grid5, int grid6, ListQueue *q, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
 	unsigned long long *xw_q, ScStat *stat_q, Tables tb)
 {
-	if (lb == 6)
-		hipLaunchKernelGGL(k_sc<6>, dim3(grid), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev64);
-	else
-		hipLaunchKernelGGL(k_sc<5>, dim3(grid), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev32);
+	const int small_run = lb == 0 ? SC_SMALL_RUN : 0;
+	if (lb != 5)
+		hipLaunchKernelGGL(k_sc<6>, dim3(grid6), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev64, small_run);
+	if (lb != 6)
+		hipLaunchKernelGGL(k_sc<5>, dim3(grid5), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev32, small_run);
 }
 void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
 	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of)

@@ -184,9 +184,9 @@ void launch_queue_snap(hipStream_t s, ListQueue *q, int par);
 void launch_queue_plan(hipStream_t s, ListQueue *q, int par, unsigned unit, int force);
 void launch_queue_fill(hipStream_t s, ListQueue *q, ListSlot *slots, int n, uint8_t *payload, Result *res, int oper_mode);
 // the sign-following path alone + its certificate (k_sc.hip): grid = resident decoders (sc_store_bytes() of level store each),
-// lb = log2 of the lanes per codeword: 5 (two codewords per wave) or 6 (one)
+// lb = log2 of the lanes per codeword: 5 (two codewords per wave), 6 (one), 0: both launched, the run's length picks one on the device
 void launch_sc_plan(hipStream_t s, ListQueue *qs);
-void launch_sc(hipStream_t s, int lb, int grid, ListQueue *qs, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
+void launch_sc(hipStream_t s, int lb, int grid5, int grid6, ListQueue *qs, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
 	unsigned long long *xw_q, ScStat *stat_q, Tables tb);
 void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
 	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of);

@@ -139,8 +139,8 @@ struct ofdmrx_handle {
 	DevBuf s_ctl, s_slots, s_llr, s_cw, s_xw, s_stat, sc_soft;
 	unsigned s_cap = 0;
 	int sc_mode = 1;          // 1: the list-1 pass (adaptive) in front of the list decoder, 0: off
-	int sc_grid = 0;          // resident SC decoders (waves)
-	int sc_lb = 5;            // log2 of the lanes per codeword: 5 = two codewords per wave, 6 = one (k_sc.hip)
+	int sc_grid = 0, sc_grid6 = 0;   // resident SC decoders (waves): two codewords per wave / one (k_sc.hip)
+	int sc_lb = 0;            // 0: the run's length picks the layout on the device; 5 / 6 (OFDMRX_SC_LB): that one always
 	ListQueue *sc_queue() const { return s_ctl.as<ListQueue>(); }
 	ScRing sc_ring() const { return sc_mode ? ScRing{ s_ctl.as<ListQueue>(), s_slots.as<ListSlot>(), s_llr.as<float>() } : ScRing{ nullptr, nullptr, nullptr }; }
 	unsigned flush_unit = 1;  // entries a flush takes at a time (one residency of the list decoder) unless it is forced
@@ -276,8 +276,9 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		if (const char *e3 = std::getenv("OFDMRX_SC_WPC"))
 			swpc = std::max(1, std::atoi(e3));
 		h->sc_grid = swpc * std::max(cus, 1);
+		h->sc_grid6 = (std::getenv("OFDMRX_SC_WPC") ? swpc : 10) * std::max(cus, 1);   // 168 VGPRs, 16 KB of LDS: ten of these per CU
 		if (const char *e4 = std::getenv("OFDMRX_SC_LB"))
-			h->sc_lb = std::atoi(e4) == 6 ? 6 : 5;
+			h->sc_lb = std::atoi(e4) == 6 ? 6 : (std::atoi(e4) == 5 ? 5 : 0);
 	}
 	build_tables(h->host, h->rate);
 	int r = 0;
@@ -436,7 +437,7 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 			r = r ? r : h->s_cw.ensure(S * (CODE_LEN / 8));
 			r = r ? r : h->s_xw.ensure(S * (CODE_LEN / 8));
 			r = r ? r : h->s_stat.ensure(S * sizeof(ScStat));
-			r = r ? r : h->sc_soft.ensure((size_t)(std::min<long>((long)N, (long)h->sc_grid) + 1) * sc_store_bytes(h->sc_lb));
+			r = r ? r : h->sc_soft.ensure((size_t)(std::min<long>((long)N, (long)std::max(h->sc_grid, h->sc_grid6)) + 1) * sc_store_bytes(0));
 		}
 		if (!demod_forms_cons(h->rate))                       // (the carriers go through HBM only when k_theil_sen forms the rows)
 			r = r ? r : h->carr.ensure(N * CARR_MAX * sizeof(cf));
@@ -562,9 +563,8 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int n)
 static void run_sc_pass(ofdmrx_handle *h, hipStream_t s, int n)
 {
 	Range r("ofdmrx:sc_path");
-	const int cpw = sc_codewords_per_wave(h->sc_lb);
 	launch_sc_plan(s, h->sc_queue());
-	launch_sc(s, h->sc_lb, std::min(h->sc_grid, (n + cpw - 1) / cpw), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(),
+	launch_sc(s, h->sc_lb, std::min(h->sc_grid, (n + 1) / 2), std::min(h->sc_grid6, n), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(),
 		h->sc_soft.as<float>(), h->s_cw.as<unsigned long long>(), h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev);
 	launch_sc_finish(s, n, h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->s_cw.as<unsigned long long>(),
 		h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev, h->cfg.descramble, h->queue(), h->q_slots.as<ListSlot>(),
@@ -1258,14 +1258,14 @@ extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n
 		return r;
 	// buffers of this call's own: the handle may have been created without the pass
 	DevBuf ctl, slots, dl, cw, xw, stat, soft;
-	const int grid = (int)std::min<size_t>(n, (size_t)h->sc_grid);
+	const int grid = (int)std::min<size_t>(n, (size_t)std::max(h->sc_grid, h->sc_grid6));
 	r = r ? r : ctl.ensure(sizeof(ListQueue));
 	r = r ? r : slots.ensure(n * sizeof(ListSlot));
 	r = r ? r : dl.ensure(n * CODE_LEN * sizeof(float));
 	r = r ? r : cw.ensure(n * (CODE_LEN / 8));
 	r = r ? r : xw.ensure(n * (CODE_LEN / 8));
 	r = r ? r : stat.ensure(n * sizeof(ScStat));
-	r = r ? r : soft.ensure((size_t)(grid + 1) * sc_store_bytes(h->sc_lb));
+	r = r ? r : soft.ensure((size_t)(grid + 1) * sc_store_bytes(0));
 	if (!r && (r = host_wait(h)) == 0) {
 		hipError_t e = hipMemcpy(dl.p, llr, n * CODE_LEN * sizeof(float), hipMemcpyHostToDevice);
 		launch_queue_reset(h->stream, ctl.as<ListQueue>(), (unsigned)n);
@@ -1279,7 +1279,7 @@ extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n
 			e = e == hipSuccess ? hipMemcpy(slots.p, ls.data(), n * sizeof(ListSlot), hipMemcpyHostToDevice) : e;
 		}
 		launch_sc_plan(h->stream, ctl.as<ListQueue>());
-		launch_sc(h->stream, h->sc_lb, grid, ctl.as<ListQueue>(), slots.as<ListSlot>(), dl.as<float>(), soft.as<float>(), cw.as<unsigned long long>(),
+		launch_sc(h->stream, h->sc_lb ? h->sc_lb : 5, grid, grid, ctl.as<ListQueue>(), slots.as<ListSlot>(), dl.as<float>(), soft.as<float>(), cw.as<unsigned long long>(),
 			xw.as<unsigned long long>(), stat.as<ScStat>(), h->dev);
 		e = e == hipSuccess ? hipGetLastError() : e;
 		e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;

@@ -2,11 +2,13 @@
 # profile_round.sh TAG -- everything profiles/TAG_* holds, collected on the GPU box from the repo root:
 #   kernel traces of the default bench line (pipeline), of the same with kernels back to back, and of the same with the list
 #   decoder forced for every frame (OFDMRX_NO_CERT=1: no syndrome certificate);
-#   PMC passes (FETCH_SIZE, WRITE_SIZE, instruction counters: separate runs, one 8192-frame chunk, kernels back to back), in both modes;
-#   the FETCH_SIZE / WRITE_SIZE calibration (tools/pmc_calib.hip).
-# Only text leaves the box: gpurun_out/TAG_summary.txt, TAG_bench_n1*.json, TAG_traffic.json (copy the last one to
-# profiles/r04_traffic.json: bench.py reads the per-kernel HBM bytes and VALU instruction counts from it)
-TAG=${1:-r04_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
+#   PMC passes (FETCH_SIZE, WRITE_SIZE, instruction counters: separate runs, 4096-frame chunks, kernels back to back), in three modes:
+#   the default path at -30 dB [cert], the list decoder forced [scl], the default path at -20 dB where the list-1 pass decides [sc];
+#   the FETCH_SIZE / WRITE_SIZE calibration (tools/pmc_calib.hip); the issue-rate microbenchmark (tools/ubench_issue.hip).
+# Only text leaves the box: gpurun_out/TAG_summary.txt, TAG_bench_n1*.json, TAG_issue_rates_ubench.txt, TAG_traffic.json (copy the
+# last two to profiles/r05_issue_rates_ubench.txt / profiles/r05_traffic.json: bench.py reads the per-kernel HBM bytes, VALU
+# instruction counts and the measured issue ceiling from the latter)
+TAG=${1:-r05_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
 S=$G/${TAG}_summary.txt; : > $S
 make -C modem_amd/csrc -q all && echo "# library up to date with sources" >> $S || echo "# STALE LIBRARY" >> $S
 cd /tmp; export TMPDIR=/tmp
@@ -20,16 +22,22 @@ python3 $R/profiles/summarize.py $(find /tmp/prof_n -name "*.db" | head -1) >> $
 echo "# OFDMRX_NO_CERT=1 (list decoder for every frame), pipeline" >> $S
 OFDMRX_NO_CERT=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 python3 $R/profiles/summarize.py $(find /tmp/prof_s -name "*.db" | head -1) >> $S 2>&1
+echo "# --noise-db -20 (every frame has raw bit errors: the list-1 pass k_sc decides them), OFDMRX_NO_OVERLAP=1" >> $S
+OFDMRX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_c -o trace -- $B --noise-db -20 --steps 2 --warmup 1 > /dev/null 2>&1
+python3 $R/profiles/summarize.py $(find /tmp/prof_c -name "*.db" | head -1) >> $S 2>&1
 echo "# OFDMRX_NO_CERT=1 OFDMRX_NO_OVERLAP=1" >> $S
 OFDMRX_NO_CERT=1 OFDMRX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_sn -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 python3 $R/profiles/summarize.py $(find /tmp/prof_sn -name "*.db" | head -1) >> $S 2>&1
 export OFDMRX_NO_OVERLAP=1
-for mode in cert scl; do
+# (--chunk 4096: a call of 8192 frames whose outputs go to the host would run as two halves in one of the three steps only)
+for mode in cert scl sc; do
+	unset OFDMRX_NO_CERT; X=""
 	[ $mode = scl ] && export OFDMRX_NO_CERT=1
-	echo "# PMC passes [$mode]: rocprofv3 --pmc <counters> -- python3 bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0 (OFDMRX_NO_OVERLAP=1$([ $mode = scl ] && echo ' OFDMRX_NO_CERT=1'))" >> $S
+	[ $mode = sc ] && X="--noise-db -20"
+	echo "# PMC passes [$mode]: rocprofv3 --pmc <counters> -- python3 bench.py --frames 8192 --chunk 4096 --steps 1 --warmup 0 --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0 $X (OFDMRX_NO_OVERLAP=1$([ $mode = scl ] && echo ' OFDMRX_NO_CERT=1'))" >> $S
 	for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS SQ_WAIT_INST_ANY"; do
 		d=/tmp/pmc_${mode}_$(echo $c | tr ' ' '_')
-		rocprofv3 --pmc $c -d $d -o x -- $B --frames 8192 --steps 1 --warmup 0 > /dev/null 2>&1
+		rocprofv3 --pmc $c -d $d -o x -- $B --frames 8192 --chunk 4096 --steps 1 --warmup 0 $X > /dev/null 2>&1
 		python3 $R/tools/pmc_kernel.py $(find $d -name "*.db" | head -1) rx:: | sed "s/^/[$mode] /" >> $S 2>&1
 	done
 done
@@ -49,9 +57,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 	rocprofv3 --pmc $c -d /tmp/calib_$c -o x -- /tmp/pmc_calib > /dev/null 2>&1
 	python3 $R/tools/pmc_kernel.py $(find /tmp/calib_$c -name "*.db" | head -1) calib >> $S 2>&1
 done
+echo "# issue rates: tools/ubench_issue.hip (ns per wave-instruction per SIMD, every CU busy; s_memtime against the 100 MHz clock)" >> $S
+hipcc -w --offload-arch=gfx950 -O3 $R/tools/ubench_issue.hip -o /tmp/ubench_issue && /tmp/ubench_issue > $G/${TAG}_issue_rates_ubench.txt 2>&1
+head -4 $G/${TAG}_issue_rates_ubench.txt >> $S
 cd $R
 python3 bench.py > $G/${TAG}_bench_n1.json 2>/dev/null
-R=$R python3 - "$S" "$G/${TAG}_traffic.json" <<'PY'
+R=$R python3 - "$S" "$G/${TAG}_traffic.json" "$G/${TAG}_issue_rates_ubench.txt" <<'PY'
 import hashlib, json, os, re, sys
 txt = open(sys.argv[1]).read()
 root = os.environ.get("R", ".")
@@ -70,11 +81,13 @@ def calib(kern, ctr):
     return float(m.group(2)) / int(m.group(1))
 stages = {"sync": ("cert", "k_sync", "k_sync.hip"), "header": ("cert", "k_header", "k_header.hip"), "demod": ("cert", "k_demod", "k_demod.hip"),
           "theilsen": ("cert", "k_theil_sen", "k_theilsen.hip"), "llr": ("cert", "k_back", "k_finish.hip"), "finish": ("cert", "k_finish", "k_finish.hip"),
-          "polar": ("scl", "k_polar", "k_polar.hip")}
-out = {"frames_per_launch": 8192, "fetch_scale": 2097152.0 / calib("calib_read", "FETCH_SIZE"), "write_scale": 2097152.0 / calib("calib_write", "WRITE_SIZE"),
+          "polar": ("scl", "k_polar", "k_polar.hip"), "sc": ("sc", "k_sc", "k_sc.hip")}
+ub = open(sys.argv[3]).read() if len(sys.argv) > 3 and os.path.exists(sys.argv[3]) else ""
+mu = re.search(r"^v_add_f32\s+waves/SIMD=4\s+ns/instr/SIMD=([0-9.]+).*?= ([0-9.]+) GHz", ub, re.M)
+out = {"frames_per_launch": 4096, "valu_ns_per_inst_per_simd": float(mu.group(1)) if mu else None, "sclk_GHz_measured": float(mu.group(2)) if mu else None, "fetch_scale": 2097152.0 / calib("calib_read", "FETCH_SIZE"), "write_scale": 2097152.0 / calib("calib_write", "WRITE_SIZE"),
        "kernels": {},
-       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --frames 8192 --steps 1 --warmup 0 --cpu-frames 0 "
-                 "--host-frames 0 --scl-steps 0 --leg-steps 0, kernels back to back (k_polar: with OFDMRX_NO_CERT=1); KiB per launch; scales = true bytes / counted "
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --frames 8192 --chunk 4096 --steps 1 --warmup 0 --cpu-frames 0 "
+                 "--host-frames 0 --scl-steps 0 --leg-steps 0, kernels back to back (k_polar: with OFDMRX_NO_CERT=1; k_sc: with --noise-db -20); KiB per launch of 4096 frames; scales = true bytes / counted "
                  "bytes of tools/pmc_calib.hip (2 GiB per kernel, one dword per lane) in the same session; valu_insts = SQ_INSTS_VALU (wave instructions) per launch"}
 for st, (mode, kern, src) in stages.items():
     f, w = grab(mode, kern, "FETCH_SIZE"), grab(mode, kern, "WRITE_SIZE")
