@@ -149,3 +149,33 @@ int main(){ rx::HostTables t; rx::build_tables(t, 48000);
     for b in data[:64]:
         crc = (crc >> 8) ^ int(tab[(crc ^ int(b)) & 255])
     assert crc == O.lib().orc_crc32_bytes(0xD419CC15, O.ptr(data), 64)
+
+
+def test_sc_kernel_pattern_list_covers_both_frozen_tables():
+    """k_sc.hip compiles the mixed 16-leaf blocks of the list-1 pass for their frozen pattern (SC_PATTERNS16, straight-line code) and
+    walks any other pattern generically: the list must be exactly the set of mixed 16-leaf patterns the sign-following decoder
+    meets in the two tables of the reference (frozen_64800_43072, frozen_64512_43072) - top-down, a node that is all frozen (up to
+    128 leaves) or all information is decided as a whole and never descended into"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    src = open(os.path.join(ROOT, "modem_amd", "csrc", "k_sc.hip")).read()
+    m = re.search(r"#define SC_PATTERNS16\(X\)(.*?)\n__device__", src, re.S)
+    listed = sorted(int(x, 16) for x in re.findall(r"X\(0x([0-9a-fA-F]+)u\)", m.group(1)))
+    assert len(listed) == len(set(listed))
+    met = set()
+    for table in (0, 1):
+        w = O.frozen(table)
+        fz = ((w[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1).astype(np.uint8)
+
+        def visit(mm, idx):
+            s = int(fz[idx:idx + (1 << mm)].sum())
+            if (s == (1 << mm) and mm <= 7) or s == 0:
+                return
+            if mm == 4:
+                met.add(sum(int(b) << i for i, b in enumerate(fz[idx:idx + 16])))
+                return
+            visit(mm - 1, idx)
+            visit(mm - 1, idx + (1 << (mm - 1)))
+        visit(16, 0)
+    assert sorted(met) == listed, (sorted(hex(x) for x in met), [hex(x) for x in listed])

@@ -2,7 +2,7 @@
 # profile_round.sh TAG -- everything profiles/TAG_* holds, collected on the GPU box from the repo root:
 #   kernel traces of the default bench line (pipeline), of the same with kernels back to back, and of the same with the list
 #   decoder forced for every frame (OFDMRX_NO_CERT=1: no syndrome certificate);
-#   PMC passes (FETCH_SIZE, WRITE_SIZE, instruction counters: separate runs, 4096-frame chunks, kernels back to back), in three modes:
+#   PMC passes (FETCH_SIZE, WRITE_SIZE, instruction counters: separate runs, 8192-frame chunks, kernels back to back), in three modes:
 #   the default path at -30 dB [cert], the list decoder forced [scl], the default path at -20 dB where the list-1 pass decides [sc];
 #   the FETCH_SIZE / WRITE_SIZE calibration (tools/pmc_calib.hip); the issue-rate microbenchmark (tools/ubench_issue.hip).
 # Only text leaves the box: gpurun_out/TAG_summary.txt, TAG_bench_n1*.json, TAG_issue_rates_ubench.txt, TAG_traffic.json (copy the
@@ -19,29 +19,29 @@ python3 $R/profiles/summarize.py $(find /tmp/prof_e -name "*.db" | head -1) >> $
 echo "# same with OFDMRX_NO_OVERLAP=1 (every kernel alone on the device)" >> $S
 OFDMRX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_n -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 python3 $R/profiles/summarize.py $(find /tmp/prof_n -name "*.db" | head -1) >> $S 2>&1
-echo "# OFDMRX_NO_CERT=1 (list decoder for every frame), pipeline" >> $S
-OFDMRX_NO_CERT=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
+echo "# OFDMRX_NO_CERT=1 OFDMRX_NO_SC=1 (list decoder for every frame), pipeline" >> $S
+OFDMRX_NO_CERT=1 OFDMRX_NO_SC=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 python3 $R/profiles/summarize.py $(find /tmp/prof_s -name "*.db" | head -1) >> $S 2>&1
 echo "# --noise-db -20 (every frame has raw bit errors: the list-1 pass k_sc decides them), OFDMRX_NO_OVERLAP=1" >> $S
 OFDMRX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_c -o trace -- $B --noise-db -20 --steps 2 --warmup 1 > /dev/null 2>&1
 python3 $R/profiles/summarize.py $(find /tmp/prof_c -name "*.db" | head -1) >> $S 2>&1
-echo "# OFDMRX_NO_CERT=1 OFDMRX_NO_OVERLAP=1" >> $S
-OFDMRX_NO_CERT=1 OFDMRX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_sn -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
+echo "# OFDMRX_NO_CERT=1 OFDMRX_NO_SC=1 OFDMRX_NO_OVERLAP=1" >> $S
+OFDMRX_NO_CERT=1 OFDMRX_NO_SC=1 OFDMRX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_sn -o trace -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 python3 $R/profiles/summarize.py $(find /tmp/prof_sn -name "*.db" | head -1) >> $S 2>&1
 export OFDMRX_NO_OVERLAP=1
-# (--chunk 4096: a call of 8192 frames whose outputs go to the host would run as two halves in one of the three steps only)
+# (16384 frames = two chunks of 8192 per call: a call of one chunk whose outputs go to the host would run as two halves in one of the three steps only)
 for mode in cert scl sc; do
-	unset OFDMRX_NO_CERT; X=""
-	[ $mode = scl ] && export OFDMRX_NO_CERT=1
+	unset OFDMRX_NO_CERT OFDMRX_NO_SC; X=""
+	[ $mode = scl ] && export OFDMRX_NO_CERT=1 OFDMRX_NO_SC=1
 	[ $mode = sc ] && X="--noise-db -20"
-	echo "# PMC passes [$mode]: rocprofv3 --pmc <counters> -- python3 bench.py --frames 8192 --chunk 4096 --steps 1 --warmup 0 --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0 $X (OFDMRX_NO_OVERLAP=1$([ $mode = scl ] && echo ' OFDMRX_NO_CERT=1'))" >> $S
+	echo "# PMC passes [$mode]: rocprofv3 --pmc <counters> -- python3 bench.py --frames 16384 --steps 1 --warmup 0 --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0 $X (OFDMRX_NO_OVERLAP=1$([ $mode = scl ] && echo ' OFDMRX_NO_CERT=1 OFDMRX_NO_SC=1'))" >> $S
 	for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS SQ_WAIT_INST_ANY"; do
 		d=/tmp/pmc_${mode}_$(echo $c | tr ' ' '_')
-		rocprofv3 --pmc $c -d $d -o x -- $B --frames 8192 --chunk 4096 --steps 1 --warmup 0 $X > /dev/null 2>&1
+		rocprofv3 --pmc $c -d $d -o x -- $B --frames 16384 --steps 1 --warmup 0 $X > /dev/null 2>&1
 		python3 $R/tools/pmc_kernel.py $(find $d -name "*.db" | head -1) rx:: | sed "s/^/[$mode] /" >> $S 2>&1
 	done
 done
-unset OFDMRX_NO_CERT
+unset OFDMRX_NO_CERT OFDMRX_NO_SC
 echo "# mono input (--channels 1: clean 16-bit mono frames, configs[1] flavour), OFDMRX_NO_OVERLAP=1: kernel trace, then PMC passes of one 8192-frame chunk" >> $S
 rocprofv3 --kernel-trace --stats -d /tmp/prof_m -o trace -- $B --channels 1 --steps 2 --warmup 1 > $G/${TAG}_bench_mono_under_profiler.json 2>/dev/null
 python3 $R/profiles/summarize.py $(find /tmp/prof_m -name "*.db" | head -1) >> $S 2>&1
@@ -83,11 +83,12 @@ stages = {"sync": ("cert", "k_sync", "k_sync.hip"), "header": ("cert", "k_header
           "theilsen": ("cert", "k_theil_sen", "k_theilsen.hip"), "llr": ("cert", "k_back", "k_finish.hip"), "finish": ("cert", "k_finish", "k_finish.hip"),
           "polar": ("scl", "k_polar", "k_polar.hip"), "sc": ("sc", "k_sc", "k_sc.hip")}
 ub = open(sys.argv[3]).read() if len(sys.argv) > 3 and os.path.exists(sys.argv[3]) else ""
-mu = re.search(r"^v_add_f32\s+waves/SIMD=4\s+ns/instr/SIMD=([0-9.]+).*?= ([0-9.]+) GHz", ub, re.M)
-out = {"frames_per_launch": 4096, "valu_ns_per_inst_per_simd": float(mu.group(1)) if mu else None, "sclk_GHz_measured": float(mu.group(2)) if mu else None, "fetch_scale": 2097152.0 / calib("calib_read", "FETCH_SIZE"), "write_scale": 2097152.0 / calib("calib_write", "WRITE_SIZE"),
+# the ceiling = the best rate the box reached for plain fp32 vector instructions with two or more waves per SIMD
+mu = min(((float(a), float(g)) for w, a, g in re.findall(r"^v_add_f32\s+waves/SIMD=(\d)\s+ns/instr/SIMD=([0-9.]+).*?= ([0-9.]+) GHz", ub, re.M) if int(w) >= 2), default=None)
+out = {"frames_per_launch": 8192, "valu_ns_per_inst_per_simd": mu[0] if mu else None, "sclk_GHz_measured": mu[1] if mu else None, "fetch_scale": 2097152.0 / calib("calib_read", "FETCH_SIZE"), "write_scale": 2097152.0 / calib("calib_write", "WRITE_SIZE"),
        "kernels": {},
-       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --frames 8192 --chunk 4096 --steps 1 --warmup 0 --cpu-frames 0 "
-                 "--host-frames 0 --scl-steps 0 --leg-steps 0, kernels back to back (k_polar: with OFDMRX_NO_CERT=1; k_sc: with --noise-db -20); KiB per launch of 4096 frames; scales = true bytes / counted "
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --frames 16384 --steps 1 --warmup 0 --cpu-frames 0 "
+                 "--host-frames 0 --scl-steps 0 --leg-steps 0, kernels back to back (k_polar: with OFDMRX_NO_CERT=1; k_sc: with --noise-db -20); KiB per launch of 8192 frames; scales = true bytes / counted "
                  "bytes of tools/pmc_calib.hip (2 GiB per kernel, one dword per lane) in the same session; valu_insts = SQ_INSTS_VALU (wave instructions) per launch"}
 for st, (mode, kern, src) in stages.items():
     f, w = grab(mode, kern, "FETCH_SIZE"), grab(mode, kern, "WRITE_SIZE")
