@@ -249,10 +249,12 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	// ---- 4. a decoder has to look: a slot and the LLRs (decode.cc:520-529) - in the SC ring when that pass is on (all frames, or its
 	// probe sample: k_sc.hip), else in the list decoder's queue
 	// The list-1 pass decides a frame only while its path metric stays under min_fork: on AWGN that ends where the cumulative Es/N0
-	// estimate of decode.cc:516 falls to 11 dB (-18.3 dB noise level: all of 4096 frames decided at 11.25 dB, none at 10.7 dB; the
-	// README's multipath chain already fails at 11.8 dB), so below 10.6 dB a frame goes straight to the list decoder.  Above it the
-	// adaptive switch decides (k_sc_adapt): everything, or a probe sample - one frame in sixteen of every fourth chunk.
-	const bool sc_hope = prec[md.rows - 1] >= 11.48f;                 // 10^(10.6 / 10)
+	// estimate of decode.cc:516 falls to 11 dB in the 8PSK modes (mode 6, -18.3 dB noise level: all of 4096 frames decided at 11.25 dB,
+	// none at 10.7 dB; mode 10 decides at 10.9 dB and not at 10.5; the README's multipath chain already fails at 11.8 dB) and to 6.3 -
+	// 6.5 dB in the QPSK modes (8, 9, 12: decided at -13.5 ... -14 dB noise level, not half a dB below; mode 13 further down): below
+	// 10.4 / 5.8 dB a frame goes straight to the list decoder.  Above it the adaptive switch decides (k_sc_adapt): everything, or a
+	// probe sample - one frame in sixteen of every fourth chunk.
+	const bool sc_hope = prec[md.rows - 1] >= (md.mod_bits == 3 ? 10.96f : 3.8f);   // 10^(10.4 / 10), 10^(5.8 / 10)
 	const bool to_sc = sc.q && sc_hope && (sc.q->cert_on || ((f & 15) == 8 && (sc.q->epoch & 3u) == 0u));   // (uniform in the workgroup)
 	if (to_sc) {
 		q = sc.q;

@@ -1133,6 +1133,38 @@ def test_all_modes_of_the_mode_table(rx, mode, channels, freq):
     assert abs(float(r["esn0_db_last"]) - ores.esn0_db_last) < 1e-3
 
 
+def test_list1_pass_in_every_mode_and_in_mixed_batches(rxd):
+    """the list-1 pass (k_sc) on the DEFAULT handle for frames of every mode - both frozen tables, QPSK and 8PSK, 2-channel and
+    mono input - in ONE batch with raw bit errors in every frame (QPSK modes at -17 dB, 8PSK at -21 dB): neighbours in the SC ring
+    have different tables (decoded one after the other) or the same (side by side); payload, status, lane, sync, header equal
+    the oracle's list decoder, the flip count within its slack, and nearly every frame is finished by the pass"""
+    pcms, want = [], []
+    for i, (mode, ch, db) in enumerate([(6, 2, -21), (10, 2, -21), (7, 2, -21), (8, 2, -17), (12, 2, -17), (11, 2, -21), (13, 2, -17),
+                                        (9, 2, -17), (10, 2, -22), (6, 2, -20), (8, 1, -17)]):
+        p = O.payload_for(900 + i)
+        pcm = O.encode_pcm(p, channels=2, mode=mode, freq_off=1500, call_sign="SC%d" % mode)
+        pcm = O.impair(pcm, noise_db=db, seed=77, frame=i)
+        if ch == 1:
+            pcm = np.ascontiguousarray(pcm[:, :1])
+        pcms.append(pcm)
+        want.append((p, mode))
+    for ch in (2, 1):
+        idx = [i for i, q in enumerate(pcms) if q.shape[1] == ch]
+        n = max(pcms[i].shape[0] for i in idx)
+        batch = np.zeros((len(idx), n, ch), np.int16)
+        for k, i in enumerate(idx):
+            batch[k, :pcms[i].shape[0]] = pcms[i]
+        out, res = rxd.decode(batch)
+        by_sc, listed = rxd.sc_decided_frames(), rxd.list_decoded_frames()
+        for k, i in enumerate(idx):
+            oo, orr = O.decode(batch[k])
+            assert orr.status == 0 and int(res[k]["status"]) == 0 and int(res[k]["oper_mode"]) == want[i][1], (i, orr.status, res[k]["status"])
+            assert (out[k] == oo).all() and (out[k] == want[i][0]).all(), i
+            assert int(res[k]["best_lane"]) == orr.best_lane and int(res[k]["sc_start"]) == orr.sc_start and int(res[k]["symbol_pos"]) == orr.symbol_pos
+            assert orr.bit_flips > 0 and _flips_ok(res[k]["bit_flips"], orr.bit_flips), (i, res[k]["bit_flips"], orr.bit_flips)
+        assert by_sc + listed == len(idx) and by_sc >= len(idx) - 2, (ch, by_sc, listed)
+
+
 def test_mixed_mode_batch(rx):
     """frames of different modes (different lengths padded to one stride) in one batch: the mode comes from each header"""
     specs = [(6, 50), (9, 90), (13, 126), (10, 42)]
