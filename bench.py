@@ -446,9 +446,13 @@ def main():
                 rx3.decode_device(d_leg.data_ptr(), M.FMT_S16, lch, spf, spf * 2 * lch, B, d_out[0].data_ptr(), d_res[0].data_ptr())
             fence()
             lsteps = args.leg_steps if lch == 2 else min(args.leg_steps, 2)
+            lsm, lsl = {}, {}
             t0 = time.perf_counter()
             for _ in range(lsteps):
                 rx3.decode_device(d_leg.data_ptr(), M.FMT_S16, lch, spf, spf * 2 * lch, B, d_out[0].data_ptr(), d_res[0].data_ptr())
+                for k, v in timing_of(rx3).items():
+                    lsm[k] = lsm.get(k, 0.0) + v[0]
+                    lsl[k] = lsl.get(k, 0) + v[1]
             fence()
             dt = time.perf_counter() - t0
             ferr = 0
@@ -457,7 +461,8 @@ def main():
                 ferr += int((pop8[(d_out[0][lo_:lo_ + 8192] ^ ref).long()].sum(dim=1) > 0).sum().item())
             extra[name] = {"value": B * lsteps / dt, "unit": "frames/s", "steps": lsteps, "frames": B, "workload": what,
                            "list_decoded_frames": rx3.list_decoded_frames(), "routes": routes(rx3, B), "fer": ferr / float(B),
-                           "definition": "default handle, payloads left in HBM, outside `value`"}
+                           "definition": "default handle, payloads left in HBM, outside `value`",
+                           "stage_ms_per_step": {k: v / lsteps for k, v in lsm.items()}, "_stage": (lsm, lsl, lsteps, lch)}
             del d_leg
         rx3.close()
 
@@ -531,6 +536,9 @@ def main():
                     "frames_per_launch": fpl, "avg_launch_ms": 1e3 * avg_s,
                     "avg_launch_ms_alone": alone.get(st) if alone else None, "algorithmic_bytes_per_frame": b_frame}
 
+        for leg in extra.values():                                # the roofline object of each leg's dominant kernel (k_sc where the list-1 pass decides)
+            lsm, lsl, lsteps, lch = leg.pop("_stage")
+            leg["roofline"] = roofline(lsm, lsl, lsteps) if lch == ch else None
         cert_note = ""
         if list_decoded >= 0:
             cert_note = ("; of rank 0's %d frames in the last step the syndrome certificate (hard decisions already a codeword with a valid "

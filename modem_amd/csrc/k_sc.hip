@@ -32,6 +32,10 @@
 namespace rx {
 
 #define SC_WAVE_ORDER() __builtin_amdgcn_wave_barrier()
+#ifndef SC_LOADS
+#define SC_LOADS 64               // level-store loads a lane keeps in flight in the top passes.  -20 dB, 65 536 frames, one codeword per wave at ten
+                                  // decoders per CU: 16 loads 777 k frames/s, 32 807 - 812 k, 64 817 - 821 k (11 registers spilled at 168)
+#endif
 
 // ---- how a wave is cut: LB = log2 of the lanes that work on one codeword (6: one codeword per wave, 5: two).  The decoder has
 // NO data-dependent control flow - what it does at every node follows from the frozen table alone - so codewords of the same
@@ -249,7 +253,7 @@ template <int LB, int D, int KIND>
 __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds, const ScIo<LB> &io, int s, int lane, int v_llr0, int v_soft0, bool &finite)
 {
 	using Cf = ScCfg<LB>;
-	constexpr int NS = 1 << D, NH = NS / 2, XB = NS >= 16 ? 1 : 16 / NS, XSTEP = Cf::J * 4;
+	constexpr int NS = 1 << D, NH = NS / 2, XB = NS >= SC_LOADS ? 1 : SC_LOADS / NS, XSTEP = Cf::J * 4;   // SC_LOADS loads in flight per lane
 	const rsrc_t src = KIND == 2 ? soft : llr;
 	constexpr int src_off = KIND == 2 ? sc_off(Cf::LL + D) : 0;
 	uint32_t wa[NH], wb[NH];
@@ -352,10 +356,11 @@ template <int CNT> __device__ __forceinline__ void sc_g_half(float (&dst)[CNT], 
 // a unit whose entries do not (a mixed-mode batch), or whose second entry does not exist, is decoded one entry at a time with
 // the lanes of the other codeword doing the same work on the same data.
 #ifndef SC_WAVES_PER_SIMD
-#define SC_WAVES_PER_SIMD 2       // register budget: 2 = 256 VGPRs, 3 = 168 (ten decoders per CU, what the 16 KB of LDS each allows)
+#define SC_WAVES_PER_SIMD 2       // register budget of the two-codewords layout: 2 = 256 VGPRs (it needs 200 - 250), 3 = 168 (40 spilled)
 #endif
+// (one codeword per wave fits 168 VGPRs = three waves per SIMD: ten decoders per CU, what the 16 KB of LDS each allows)
 template <int LB>
-__global__ __launch_bounds__(64, SC_WAVES_PER_SIMD) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
+__global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
 	float *__restrict__ soft_all, uint32_t *__restrict__ cw_q, uint32_t *__restrict__ xw_q, ScStat *__restrict__ stat_q,
 	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev_blk, int small_run)
 {

@@ -140,7 +140,8 @@ struct ofdmrx_handle {
 	unsigned s_cap = 0;
 	int sc_mode = 1;          // 1: the list-1 pass (adaptive) in front of the list decoder, 0: off
 	int sc_grid = 0, sc_grid6 = 0;   // resident SC decoders (waves): two codewords per wave / one (k_sc.hip)
-	int sc_lb = 0;            // 0: the run's length picks the layout on the device; 5 / 6 (OFDMRX_SC_LB): that one always
+	int sc_lb = 6;            // one codeword per wave (6, the default: with 64 loads in flight it is the faster layout at every run length, and
+	                          // it moves 2.1 MB per codeword against 2.7), two (5), or 0: the run's length picks on the device (OFDMRX_SC_LB)
 	ListQueue *sc_queue() const { return s_ctl.as<ListQueue>(); }
 	ScRing sc_ring() const { return sc_mode ? ScRing{ s_ctl.as<ListQueue>(), s_slots.as<ListSlot>(), s_llr.as<float>() } : ScRing{ nullptr, nullptr, nullptr }; }
 	unsigned flush_unit = 1;  // entries a flush takes at a time (one residency of the list decoder) unless it is forced
@@ -278,7 +279,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		h->sc_grid = swpc * std::max(cus, 1);
 		h->sc_grid6 = (std::getenv("OFDMRX_SC_WPC") ? swpc : 10) * std::max(cus, 1);   // 168 VGPRs, 16 KB of LDS: ten of these per CU
 		if (const char *e4 = std::getenv("OFDMRX_SC_LB"))
-			h->sc_lb = std::atoi(e4) == 6 ? 6 : (std::atoi(e4) == 5 ? 5 : 0);
+			h->sc_lb = std::atoi(e4) == 5 ? 5 : (std::atoi(e4) == 0 ? 0 : 6);
 	}
 	build_tables(h->host, h->rate);
 	int r = 0;
@@ -1279,7 +1280,7 @@ extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n
 			e = e == hipSuccess ? hipMemcpy(slots.p, ls.data(), n * sizeof(ListSlot), hipMemcpyHostToDevice) : e;
 		}
 		launch_sc_plan(h->stream, ctl.as<ListQueue>());
-		launch_sc(h->stream, h->sc_lb ? h->sc_lb : 5, grid, grid, ctl.as<ListQueue>(), slots.as<ListSlot>(), dl.as<float>(), soft.as<float>(), cw.as<unsigned long long>(),
+		launch_sc(h->stream, h->sc_lb ? h->sc_lb : 6, grid, grid, ctl.as<ListQueue>(), slots.as<ListSlot>(), dl.as<float>(), soft.as<float>(), cw.as<unsigned long long>(),
 			xw.as<unsigned long long>(), stat.as<ScStat>(), h->dev);
 		e = e == hipSuccess ? hipGetLastError() : e;
 		e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;
