@@ -682,12 +682,6 @@ static ChunkPlan plan_chunks(const ofdmrx_handle *h, size_t n_frames, bool host_
 	for (size_t f = 0; f < n_frames; f += step)
 		p.start.push_back(f);
 	p.start.push_back(n_frames);
-	// the LAST chunk's copies have nothing to hide behind: cut it once more (its second half's copy is what stays exposed)
-	if (host_side && p.count() >= 2 && std::getenv("OFDMRX_SPLIT_LAST")) {
-		const size_t c = p.count() - 1, a0 = p.start[c], b0 = p.start[c + 1];
-		if (b0 - a0 >= 6144)
-			p.start.insert(p.start.begin() + (long)c + 1, a0 + (b0 - a0 + 1) / 2);
-	}
 	return p;
 }
 
