@@ -359,6 +359,32 @@ __device__ __forceinline__ void fft_fwd_compact(cf *buf, const cf *twc, int tid)
 	FftPlan<N, N, 1, NT, TWN, 0>::run(buf, twc, tid);
 }
 
+// Bank-conflict-free image of a wave-private 256-point buffer: element i lives at i ^ ((i >> 2) & 3) ^ (((i >> 4) & 3) << 2).  The
+// radix-4 stages read 64 consecutive elements per instruction (any bijection of the low six bits keeps that conflict-free) and
+// write at strides of 4 (P = 1) and 16 / 4 (P = 4) elements, which the plain layout puts four lanes deep on a bank; under the
+// swizzle every 16-lane store group touches 32 distinct banks (checked against the bank rules of the guide in a simulation).
+// Same operations in the same order as fft_stage<256, 4, P, 64>: only the addresses change.
+__device__ __forceinline__ int swz256(int i) { return i ^ ((i >> 2) & 3) ^ (((i >> 4) & 3) << 2); }
+template <int P, int TWC> __device__ __forceinline__ void fft256_stage_swz(cf *buf, const cf *tw, int lane, int sl)
+{
+	cf v[4];
+	const int k = lane % P;
+	#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		cf x = buf[sl + t * 64];                              // swz(lane + 64 t) = swz(lane) + 64 t
+		if (t && P > 1)
+			x = cmul(x, tw[TWC + (t - 1) * P + k]);
+		v[t] = x;
+	}
+	Bfly<4>::run(v);
+	fft_sync<64>();
+	const int j = (lane - k) * 4 + k;
+	#pragma unroll
+	for (int t = 0; t < 4; ++t)
+		buf[swz256(j + t * P)] = v[t];
+	fft_sync<64>();
+}
+
 // ---- wave helpers ----------------------------------------------------------
 // a value every lane holds alike, moved to scalar registers (the compiler cannot know that what came out of a vector load is uniform)
 __device__ __forceinline__ long uniform_l(long v)
