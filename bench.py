@@ -517,7 +517,7 @@ def main():
                         "frac_of_guide_peak": per_simd * VALU_CYCLES_GUIDE / (SCLK_GHZ * 1e9 * avg_s),
                         "guide_peak": "%.0f cycles per wave64 VALU instruction per SIMD at the nominal %.1f GHz (MI355X_MICROARCH.md)" % (VALU_CYCLES_GUIDE, SCLK_GHZ),
                         "frac_of_measured_ceiling": (per_simd * ns_meas * 1e-9 / avg_s) if ns_meas else None,
-                        "measured_ceiling": ("%.3f ns per VALU wave-instruction per SIMD, every CU busy, 4 waves per SIMD (profiles/%s; a measured "
+                        "measured_ceiling": ("%.3f ns per VALU wave-instruction per SIMD, every CU busy, the best of 2 - 5 waves per SIMD (profiles/%s; a measured "
                                              "time: no clock assumed; shader clock under that load %s GHz)"
                                              % (ns_meas, ISSUE_FILE, traffic_db.get("sclk_GHz_measured", "n/a"))) if ns_meas else None,
                         "source": "profiles/%s: rocprofv3 --pmc SQ_INSTS_VALU, scaled to this run's frames per launch" % TRAFFIC_FILE}
