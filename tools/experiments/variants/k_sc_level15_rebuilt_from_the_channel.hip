@@ -1,0 +1,803 @@
+// k_sc.hip -- the list decoder's sign-following path, decoded alone (list size 1), and the certificate that it IS the list
+// decoder's answer ("SC dominance") for gfx950.  decode.cc:530-555 needs lane 0's message, its CRC and the flip
+// count - not the eight-path search - whenever lane 0 provably is that path.
+//
+// P* = the path of CODE::PolarListDecoder (decode.cc:201) that takes the sign of its LLR at every information leaf.  k_sc decodes
+// P* with one lane's arithmetic of the list decoder - f_minsum, g_add, frozen penalties max(0, -llr) leaf by leaf, an aligned
+// all-frozen node of 2..128 leaves in the butterfly order at once (k_polar.hip, oracle/polar.c: scl_node) - and carries
+//   M*        P*'s path metric (fp32, same additions in the same order as lane 0's),
+//   min_fork  min over the information leaves i of fl(M*(i) + |llr_i|): the metric of the candidate that leaves P* at leaf i.
+// Rule: min_fork > M*(final)  =>  P* is lane 0 of the list decoder, for any list size.  Every candidate that is not P* either
+// descends from a first deviation at some leaf i - it then carries at least fl(M*(i) + |llr_i|) for ever, fp32 sums of non-negative
+// penalties being monotone - or from one of the placeholder paths (metric 1000 at the start) making P*'s own decisions - never
+// cheaper than P* (monotone again), and P* wins ties through its candidate index (lane 0).  So P* has the smallest metric, ties
+// broken its way, at every fork: never pruned, rank 0 throughout, lane 0 at the end with metric M*.  The syndrome certificate of
+// k_back is the case M* = 0.  k_sc_finish then does decode.cc:532-555 for lane 0: CRC-32 of P*'s systematic bits, payload, flip
+// count; a frame whose rule or CRC fails goes on to the list decoder's queue unchanged (its LLRs are copied there).
+// Checked against the oracle's list decoder by tests/test_oracle_kat.py (the rule, CPU) and tests/test_gpu_parity.py (this kernel).
+//
+// One wavefront per codeword, persistent.  Where the tree lives: the input arrays of the nodes of 2^14 and 2^13 leaves in a
+// level store in HBM (96 KB per resident decoder; each is written once and read once; the two arrays of 2^15 are not kept, the
+// one pass that reads each rebuilds it from the channel LLRs: sc_top_pass15), of the current 4096-leaf node in LDS (16 KB),
+// of the current nodes of 2048..128 leaves in registers (position x * 64 + q of such an array = element x of the lane that holds
+// q: every f / g step down to 128 leaves is lane-local), the 64-leaf block below in one register per lane with DPP / permlane
+// butterflies.  Partial sums are bits: one 64-bit register per lane for the current 4096-leaf node (bit x = position x * 64 + q),
+// published as plain bit-packed words (bit i of the codeword = bit i % 64 of word i / 64) that the upper g steps read back.
+// Uniform nodes are decided in one step: all-frozen ones of up to 128 leaves (the penalty sum above), all-information ones of any
+// size (the SC decisions of such a node are the signs of its input LLRs; the smallest leaf magnitude on P* is the smallest input
+// magnitude, so min_fork takes fl(M* + min |input|)).
+#include "dev_common.h"
+#include "kernels.h"
+#include "polar_common.h"
+
+namespace rx {
+
+#define SC_WAVE_ORDER() __builtin_amdgcn_wave_barrier()
+#ifndef SC_LOADS
+#define SC_LOADS 64               // level-store loads a lane keeps in flight in the top passes.  -20 dB, 65 536 frames, one codeword per wave at ten
+                                  // decoders per CU: 16 loads 777 k frames/s, 32 807 - 812 k, 64 817 - 821 k (11 registers spilled at 168)
+#endif
+
+// ---- how a wave is cut: LB = log2 of the lanes that work on one codeword (6: one codeword per wave, 5: two).  The decoder has
+// NO data-dependent control flow - what it does at every node follows from the frozen table alone - so codewords of the same
+// table run in lock-step in one wave, and whatever a 2^LB-leaf block costs is shared by 64 >> LB codewords.
+template <int LB> struct ScCfg {
+	static constexpr int J = 1 << LB, C = 64 >> LB;
+	static constexpr int LL = LB + 6;                         // the level whose array lives in LDS: 64 elements per lane
+	static constexpr int NSUB = 1 << (16 - LL);               // sub-trees of that size per codeword
+	static constexpr int SUB_BYTES = 64 * J * 4;              // one of them in a level array
+	static constexpr int STORE_FLOATS = 32768 - (2 << LL);    // levels LL+1 .. 14 of one codeword (level 15 is never stored: sc_top_pass15)
+	static constexpr int SPARE_WORDS = 2 * (CODE_LEN / 32);   // behind a decoder's level stores: where the second lane group of an unpaired
+	                                                          // codeword publishes its (identical) words instead of the codeword's own
+	static constexpr int DECODER_FLOATS = C * STORE_FLOATS + SPARE_WORDS;
+};
+__host__ __device__ constexpr int sc_off(int m) { return (32768 - (2 << m)) * 4; }   // level m <= 14 in a codeword's level store, bytes
+
+// ---- positions and lanes.  Lane l holds position q = j ^ ((j & 4) ? 3 : 0), j = l mod 2^LB, of its codeword's block: then "the
+// lane whose position differs in bit 2" is row_half_mirror (l ^ 7), and every butterfly exchange is one DPP / permlane instruction.
+__device__ __forceinline__ int sc_pos(int j) { return j ^ ((j & 4) ? 3 : 0); }
+template <int H> __device__ __forceinline__ int xpos_i(int v, int lane)
+{
+	if constexpr (H == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
+	else if constexpr (H == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+	else if constexpr (H == 4) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);     // row_half_mirror
+	else if constexpr (H == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);     // row_ror:8
+	else if constexpr (H == 16) {
+		auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+		return (int)((lane & 16) ? r[0] : r[1]);
+	} else {
+		auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+		return (int)((lane & 32) ? r[0] : r[1]);
+	}
+}
+template <int H> __device__ __forceinline__ float xpos(float v, int lane) { return __int_as_float(xpos_i<H>(__float_as_int(v), lane)); }
+template <int H> __device__ __forceinline__ uint32_t xpos(uint32_t v, int lane) { return (uint32_t)xpos_i<H>((int)v, lane); }
+
+constexpr uint32_t SC_SIGN = 0x80000000u;
+// what a lane knows about itself: lowsel[L] = the sign bit if its position lies in the LOW half of its level-L node, else 0
+struct ScLane {
+	int lane, q;
+	uint32_t lowsel[7];
+};
+// the decoder's running figures: M* and min_fork (as its bit pattern: non-negative floats order like unsigned integers)
+struct ScAcc {
+	float M;
+	uint32_t fork;
+	__device__ __forceinline__ void info(uint32_t mu_bits)        // an information leaf / all-information node with smallest magnitude mu
+	{
+		const float cand = M + __uint_as_float(mu_bits);
+		fork = min(fork, __float_as_uint(cand));
+	}
+};
+
+// sum over the 2^LV values of a node held one per lane (duplicated over the other position bits) in the butterfly halving
+// order p[i] += p[i + h], h = n/2 .. 1 (oracle/polar.c: scl_node's rate-0 step): both partners form the same sum
+template <int LV> __device__ __forceinline__ float sc_pen_sum(float pen, int lane)
+{
+	if constexpr (LV >= 6) pen = pen + xpos<32>(pen, lane);
+	if constexpr (LV >= 5) pen = pen + xpos<16>(pen, lane);
+	if constexpr (LV >= 4) pen = pen + xpos<8>(pen, lane);
+	if constexpr (LV >= 3) pen = pen + xpos<4>(pen, lane);
+	if constexpr (LV >= 2) pen = pen + xpos<2>(pen, lane);
+	if constexpr (LV >= 1) pen = pen + xpos<1>(pen, lane);
+	return pen;
+}
+template <int LV> __device__ __forceinline__ uint32_t sc_min_mag(uint32_t mu, int lane)
+{
+	if constexpr (LV >= 6) mu = min(mu, xpos<32>(mu, lane));
+	if constexpr (LV >= 5) mu = min(mu, xpos<16>(mu, lane));
+	if constexpr (LV >= 4) mu = min(mu, xpos<8>(mu, lane));
+	if constexpr (LV >= 3) mu = min(mu, xpos<4>(mu, lane));
+	if constexpr (LV >= 2) mu = min(mu, xpos<2>(mu, lane));
+	if constexpr (LV >= 1) mu = min(mu, xpos<1>(mu, lane));
+	return mu;
+}
+// max(0, -llr): what a frozen leaf adds when its LLR is negative (oracle/polar.c: scl_leaf; adding +0 changes nothing)
+__device__ __forceinline__ float sc_pen(float v) { return __builtin_fmaxf(-v, 0.f); }
+__device__ __forceinline__ uint32_t sc_mag(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+// Partial sums inside a block are kept in SIGN-BIT FORM, one register per level: beta = 0x80000000 if the partial sum of the
+// level's current node AT THE LANE'S OWN POSITION (mod the node size) is 1, else 0.  Then
+//   g step     t = beta_left & lowsel[L];  r' = r ^ t;  child = r' + partner(r')      (b + a or b - a: the low half carries a and
+//                                                                                     flips its sign, the sum is the same on both sides)
+//   combine    beta_L = beta_right ^ t                                                (low half: left ^ right, high half: right)
+//   leaf / all-information node   beta = the sign bit of the LLR;  frozen: 0.
+// (A zero LLR at an information leaf carries either sign bit; min_fork then equals M* and the rule cannot hold, see ScAcc.)
+template <int LV> __device__ __forceinline__ float sc_f_cross(float r, const ScLane &L) { return f_minsum(r, xpos<(1 << (LV - 1))>(r, L.lane)); }
+template <int LV> __device__ __forceinline__ float sc_g_cross(float r, uint32_t t, const ScLane &L)
+{
+	const float rp = __uint_as_float(__float_as_uint(r) ^ t);
+	return rp + xpos<(1 << (LV - 1))>(rp, L.lane);
+}
+
+// ---- a sub-tree of 2^LV <= 16 leaves whose frozen pattern FZ is known at compile time: straight-line code, every uniform node
+// decided in one step (all frozen: the penalty sum; all information: signs + smallest magnitude), nothing scalar left
+template <uint32_t FZ, int LV, int P0> __device__ __forceinline__ uint32_t sc_node_ct(float r, ScAcc &acc, const ScLane &L)
+{
+	constexpr int N = 1 << LV;
+	constexpr uint32_t MASK = (N == 32 ? 0xffffffffu : ((1u << N) - 1u)) << P0, pat = FZ & MASK;
+	if constexpr (pat == MASK) {
+		acc.M += sc_pen_sum<LV>(sc_pen(r), L.lane);
+		return 0u;
+	} else if constexpr (pat == 0u) {
+		acc.info(sc_min_mag<LV>(sc_mag(r), L.lane));
+		return __float_as_uint(r) & SC_SIGN;
+	} else {
+		const uint32_t bl = sc_node_ct<FZ, LV - 1, P0>(sc_f_cross<LV>(r, L), acc, L);
+		const uint32_t t = bl & L.lowsel[LV];
+		const uint32_t br = sc_node_ct<FZ, LV - 1, P0 + N / 2>(sc_g_cross<LV>(r, t, L), acc, L);
+		return br ^ t;
+	}
+}
+// the same for a pattern only known at run time (wave-uniform): the general walk
+template <int LV, int P0> __device__ __forceinline__ uint32_t sc_node_rt(float r, uint32_t fz, ScAcc &acc, const ScLane &L)
+{
+	constexpr int N = 1 << LV;
+	constexpr uint32_t MASK = ((1u << N) - 1u) << P0;
+	const uint32_t pat = fz & MASK;
+	if (pat == MASK) {
+		acc.M += sc_pen_sum<LV>(sc_pen(r), L.lane);
+		return 0u;
+	}
+	if (pat == 0u) {
+		acc.info(sc_min_mag<LV>(sc_mag(r), L.lane));
+		return __float_as_uint(r) & SC_SIGN;
+	}
+	if constexpr (LV > 0) {
+		const uint32_t bl = sc_node_rt<LV - 1, P0>(sc_f_cross<LV>(r, L), fz, acc, L);
+		const uint32_t t = bl & L.lowsel[LV];
+		const uint32_t br = sc_node_rt<LV - 1, P0 + N / 2>(sc_g_cross<LV>(r, t, L), fz, acc, L);
+		return br ^ t;
+	} else
+		return 0u;                                                // (a leaf is always uniform)
+}
+// The mixed 16-leaf patterns of both frozen tables (frozen_64800_43072, frozen_64512_43072: fifteen, the same in both; leaf 0 =
+// bit 0) as straight-line code; anything else takes the general walk.  tests/test_abi_cpu.py checks the list against the tables.
+#define SC_PATTERNS16(X) \
+	X(0x0001u) X(0x0117u) X(0x177fu) X(0x7fffu) X(0x17ffu) X(0x011fu) X(0x0017u) X(0x0003u) \
+	X(0x017fu) X(0x037fu) X(0x0007u) X(0x077fu) X(0x3fffu) X(0x1fffu) X(0x013fu)
+__device__ __forceinline__ uint32_t sc_block16(float r4, uint32_t pat, ScAcc &acc, const ScLane &L)
+{
+	switch (pat) {
+#define SC_CASE16(P) case P: return sc_node_ct<P, 4, 0>(r4, acc, L);
+	SC_PATTERNS16(SC_CASE16)
+#undef SC_CASE16
+	default: return sc_node_rt<4, 0>(r4, pat, acc, L);
+	}
+}
+
+// ---- the block of 2^LB leaves one lane group holds: its 16-leaf quarters / halves in turn.  fz0 / fz1: frozen bits of its leaves
+// 0..31 / 32..63.  Returns beta of the whole block (the partial sum of the lane's own position, sign-bit form).
+template <int LB> __device__ __forceinline__ uint32_t sc_walk_block(float rb, uint32_t fz0, uint32_t fz1, ScAcc &acc, const ScLane &L)
+{
+	static_assert(LB == 5 || LB == 6, "blocks of 32 or 64 leaves");
+	uint32_t beta6 = 0;
+	float r5 = rb;
+	uint32_t t6 = 0;
+	#pragma unroll
+	for (int h = 0; h < (LB == 6 ? 2 : 1); ++h) {                 // the 32-leaf halves
+		const uint32_t fzw = h ? fz1 : fz0;
+		if constexpr (LB == 6) {
+			if (h == 0)
+				r5 = sc_f_cross<6>(rb, L);
+			else {
+				t6 = beta6 & L.lowsel[6];                         // (beta6 holds the left half's beta5 here)
+				r5 = sc_g_cross<6>(rb, t6, L);
+			}
+		}
+		uint32_t beta5;
+		if (fzw == 0xffffffffu) {
+			acc.M += sc_pen_sum<5>(sc_pen(r5), L.lane);
+			beta5 = 0u;
+		} else if (fzw == 0u) {
+			acc.info(sc_min_mag<5>(sc_mag(r5), L.lane));
+			beta5 = __float_as_uint(r5) & SC_SIGN;
+		} else {
+			const uint32_t bl = sc_block16(sc_f_cross<5>(r5, L), fzw & 0xffffu, acc, L);
+			const uint32_t t5 = bl & L.lowsel[5];
+			const uint32_t br = sc_block16(sc_g_cross<5>(r5, t5, L), fzw >> 16, acc, L);
+			beta5 = br ^ t5;
+		}
+		beta6 = (LB == 6 && h == 1) ? (beta5 ^ t6) : beta5;
+	}
+	return beta6;
+}
+
+// One pass over the top of the tree: the array of the sub-tree s (64 * 2^LB leaves per codeword) from the level D above it.
+//   KIND 0: f chain from the channel LLRs (s = 0)   KIND 1: g of the channel LLRs, then f (s = NSUB / 2)
+//   KIND 2: g of level LL + D of the level store, then f
+// A lane owns the columns x * J + j (x = 0..63) of its codeword at EVERY level: the chain below the first step is lane-local,
+// each level between is written once (levels > LL to the store, level LL to LDS).  g takes the left child's partial sums from
+// the published words (pa / pb: the two 32-bit halves a wave publishes per 64 lanes - the halves of a 64-bit word of one
+// codeword, or one word of each of two): lane l fetches word l of each sub-tree once, the loop picks word x with v_readlane.
+// KIND 0 also leaves the hard decisions of the channel LLRs (xa / xb, bit-packed like the codeword) for the flip count, and
+// checks that every LLR is finite and small enough that no sum of 65536 of them overflows.
+template <int LB> struct ScIo {                                   // where the wave's 32-bit half-words live: half h, word w
+	uint32_t *cwa, *cwb, *xwa, *xwb;
+	__device__ __forceinline__ static int idx(int w) { return LB == 6 ? 2 * w : w; }
+};
+template <int LB, int LEV, int N> __device__ __forceinline__ void sc_emit(rsrc_t soft, float *lds, int v_dst, int lidx, float (&t)[N])
+{
+	if constexpr (LEV > ScCfg<LB>::LL) {
+		if constexpr (LEV < 15) {                                 // (the two arrays of level 15 are rebuilt from the channel LLRs by their one reader)
+			#pragma unroll
+			for (int k = 0; k < N; ++k)
+				bstore<2>(soft, v_dst, sc_off(LEV) + k * ScCfg<LB>::SUB_BYTES, t[k]);
+		}
+		float u[N / 2];
+		#pragma unroll
+		for (int k = 0; k < N / 2; ++k)
+			u[k] = f_minsum(t[k], t[k + N / 2]);
+		sc_emit<LB, LEV - 1, N / 2>(soft, lds, v_dst, lidx, u);
+	} else
+		lds[lidx] = t[0];
+}
+template <int LB, int D, int KIND>
+__device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds, const ScIo<LB> &io, int s, int lane, int v_llr0, int v_soft0, bool &finite)
+{
+	using Cf = ScCfg<LB>;
+	constexpr int NS = 1 << D, NH = NS / 2, XB = NS >= SC_LOADS ? 1 : SC_LOADS / NS, XSTEP = Cf::J * 4;   // SC_LOADS loads in flight per lane
+	const rsrc_t src = KIND == 2 ? soft : llr;
+	constexpr int src_off = KIND == 2 ? sc_off(Cf::LL + D) : 0;
+	uint32_t wa[NH], wb[NH];
+	if (KIND) {
+		#pragma unroll
+		for (int k = 0; k < NH; ++k) {
+			const int w = ScIo<LB>::idx((s - NH + k) * 64 + lane);
+			wa[k] = io.cwa[w];
+			wb[k] = io.cwb[w];
+		}
+	}
+	const int sh = 31 - (lane & 31);
+	const bool up = lane >= 32;
+	int v_src = KIND == 2 ? v_soft0 : v_llr0, v_dst = v_soft0, lidx = (lane >> LB) * (64 * Cf::J) + (lane & (Cf::J - 1));
+	#pragma unroll 1
+	for (int x0 = 0; x0 < 64; x0 += XB, v_src += XB * XSTEP, v_dst += XB * XSTEP, lidx += XB * Cf::J) {
+		float v[XB][NS];
+		#pragma unroll
+		for (int xb = 0; xb < XB; ++xb)
+			#pragma unroll
+			for (int k = 0; k < NS; ++k)
+				v[xb][k] = KIND == 0 ? bload<0>(src, v_src + xb * XSTEP, src_off + k * Cf::SUB_BYTES) : bload<2>(src, v_src + xb * XSTEP, src_off + k * Cf::SUB_BYTES);
+		#pragma unroll
+		for (int xb = 0; xb < XB; ++xb) {
+			const int x = x0 + xb;
+			float t[NH];
+			#pragma unroll
+			for (int k = 0; k < NH; ++k) {
+				if (KIND == 0)
+					t[k] = f_minsum(v[xb][k], v[xb][k + NH]);
+				else {
+					const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)wa[k], x), b = (uint32_t)__builtin_amdgcn_readlane((int)wb[k], x);
+					const uint32_t sg = ((up ? b : a) << sh) & SC_SIGN;
+					t[k] = __uint_as_float(__float_as_uint(v[xb][k]) ^ sg) + v[xb][k + NH];
+				}
+			}
+			if (KIND == 0) {
+				// the hard decisions of this column's NS elements: word x of sub-tree k, gathered on lane k and stored from there
+				int ma = 0, mb = 0;
+				#pragma unroll
+				for (int k = 0; k < NS; ++k) {
+					const unsigned long long bal = __ballot(v[xb][k] < 0.f);
+					if (lane == k) {
+						ma = (int)(uint32_t)bal;
+						mb = (int)(uint32_t)(bal >> 32);
+					}
+					finite &= sc_mag(v[xb][k]) < 0x71000000u;         // |llr| < 6e29 (and not a NaN)
+				}
+				if (lane < NS) {
+					const int w = ScIo<LB>::idx(lane * 64 + x);
+					io.xwa[w] = (uint32_t)ma;
+					io.xwb[w] = (uint32_t)mb;
+				}
+			}
+			sc_emit<LB, Cf::LL + D - 1, NH>(soft, lds, v_dst + xb * XSTEP, lidx + xb * Cf::J, t);
+		}
+	}
+}
+
+// The g step of a level-15 node (the pass that starts the second half of either half of the codeword) WITHOUT a stored level-15
+// array: that array is f(channel, channel) (left half of the codeword) or g(channel, channel, the left half's partial sums) (right
+// half) - twice the bytes to read, none to write and none to have written, and a write costs this memory system about twice a read
+// (DESIGN.md 4c).  The values are the ones the store would have held: same f / g on the same inputs.
+template <int LB, bool RIGHT>
+__device__ __forceinline__ void sc_top_pass15(rsrc_t soft, rsrc_t llr, float *lds, const ScIo<LB> &io, int s, int lane, int v_llr0, int v_soft0)
+{
+	using Cf = ScCfg<LB>;
+	constexpr int D = 15 - Cf::LL, NS = 1 << D, NH = NS / 2, XSTEP = Cf::J * 4;   // NS level-15 values per column, 2 NS channel LLRs
+	constexpr int XB = 4 * NS >= SC_LOADS ? 1 : SC_LOADS / (4 * NS);      // (half of SC_LOADS in flight: the sign words take the other registers)
+	uint32_t wa[NH], wb[NH], ra[RIGHT ? NS : 1], rb[RIGHT ? NS : 1];
+	#pragma unroll
+	for (int k = 0; k < NH; ++k) {                                // the level-15 node's left child: sub-trees s - NH .. s - 1
+		const int w = ScIo<LB>::idx((s - NH + k) * 64 + lane);
+		wa[k] = io.cwa[w];
+		wb[k] = io.cwb[w];
+	}
+	if (RIGHT) {
+		#pragma unroll
+		for (int k = 0; k < NS; ++k) {                            // the root's left child: sub-trees 0 .. NS - 1
+			const int w = ScIo<LB>::idx(k * 64 + lane);
+			ra[k] = io.cwa[w];
+			rb[k] = io.cwb[w];
+		}
+	}
+	const int sh = 31 - (lane & 31);
+	const bool up = lane >= 32;
+	int v_src = v_llr0, v_dst = v_soft0, lidx = (lane >> LB) * (64 * Cf::J) + (lane & (Cf::J - 1));
+	#pragma unroll 1
+	for (int x0 = 0; x0 < 64; x0 += XB, v_src += XB * XSTEP, v_dst += XB * XSTEP, lidx += XB * Cf::J) {
+		float v[XB][2 * NS];
+		#pragma unroll
+		for (int xb = 0; xb < XB; ++xb)
+			#pragma unroll
+			for (int k = 0; k < 2 * NS; ++k)
+				v[xb][k] = bload<2>(llr, v_src + xb * XSTEP, k * Cf::SUB_BYTES);
+		#pragma unroll
+		for (int xb = 0; xb < XB; ++xb) {
+			const int x = x0 + xb;
+			float a15[NS], t[NH];
+			#pragma unroll
+			for (int k = 0; k < NS; ++k) {
+				if (RIGHT) {
+					const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)ra[k], x), b = (uint32_t)__builtin_amdgcn_readlane((int)rb[k], x);
+					a15[k] = __uint_as_float(__float_as_uint(v[xb][k]) ^ (((up ? b : a) << sh) & SC_SIGN)) + v[xb][k + NS];
+				} else
+					a15[k] = f_minsum(v[xb][k], v[xb][k + NS]);
+			}
+			#pragma unroll
+			for (int k = 0; k < NH; ++k) {
+				const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)wa[k], x), b = (uint32_t)__builtin_amdgcn_readlane((int)wb[k], x);
+				t[k] = __uint_as_float(__float_as_uint(a15[k]) ^ (((up ? b : a) << sh) & SC_SIGN)) + a15[k + NH];
+			}
+			sc_emit<LB, 14, NH>(soft, lds, v_dst + xb * XSTEP, lidx + xb * Cf::J, t);
+		}
+	}
+}
+
+// a uniform node of J * CNT leaves on its register array (element x = position x * J + q)
+template <int LB, int CNT> __device__ __forceinline__ void sc_rate0(const float (&r)[CNT], ScAcc &acc, int lane)
+{
+	float pz[CNT];
+	#pragma unroll
+	for (int x = 0; x < CNT; ++x)
+		pz[x] = sc_pen(r[x]);
+	#pragma unroll
+	for (int hx = CNT / 2; hx >= 1; hx >>= 1)
+		#pragma unroll
+		for (int x = 0; x < hx; ++x)
+			pz[x] = pz[x] + pz[x + hx];
+	acc.M += sc_pen_sum<LB>(pz[0], lane);
+}
+template <int LB, int CNT> __device__ __forceinline__ uint32_t sc_rate1(const float (&r)[CNT], ScAcc &acc, int lane)
+{
+	uint32_t mu = 0x7f800000u, bits = 0;
+	#pragma unroll
+	for (int x = 0; x < CNT; ++x) {
+		mu = min(mu, sc_mag(r[x]));
+		bits |= (__float_as_uint(r[x]) >> 31) << x;
+	}
+	acc.info(sc_min_mag<LB>(mu, lane));
+	return bits;
+}
+template <int CNT> __device__ __forceinline__ void sc_f_half(float (&dst)[CNT], const float (&src)[2 * CNT])
+{
+	#pragma unroll
+	for (int x = 0; x < CNT; ++x)
+		dst[x] = f_minsum(src[x], src[x + CNT]);
+}
+template <int CNT> __device__ __forceinline__ void sc_g_half(float (&dst)[CNT], const float (&src)[2 * CNT], uint32_t hb)
+{
+	#pragma unroll
+	for (int x = 0; x < CNT; ++x)
+		dst[x] = __uint_as_float(__float_as_uint(src[x]) ^ ((hb << (31 - x)) & SC_SIGN)) + src[x + CNT];
+}
+
+// Persistent grid: workgroup = one wave = one decoder (of 64 >> LB codewords) with its own level stores; decoders take units of
+// 64 >> LB consecutive entries from the run's counter.  Entries of a unit that share the frozen table are decoded side by side;
+// a unit whose entries do not (a mixed-mode batch), or whose second entry does not exist, is decoded one entry at a time with
+// the lanes of the other codeword doing the same work on the same data.
+#ifndef SC_WAVES_PER_SIMD
+#define SC_WAVES_PER_SIMD 2       // register budget of the two-codewords layout: 2 = 256 VGPRs (it needs 200 - 250), 3 = 168 (40 spilled)
+#endif
+// (one codeword per wave fits 168 VGPRs = three waves per SIMD: ten decoders per CU, what the 16 KB of LDS each allows)
+template <int LB>
+__global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
+	float *__restrict__ soft_all, uint32_t *__restrict__ cw_q, uint32_t *__restrict__ xw_q, ScStat *__restrict__ stat_q,
+	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev_blk, int small_run)
+{
+	using Cf = ScCfg<LB>;
+	constexpr int J = Cf::J, C = Cf::C, NBLK = CODE_LEN / J;
+	const int lane = threadIdx.x, c = lane >> LB, j = lane & (J - 1);
+	ScLane L;
+	L.lane = lane;
+	L.q = sc_pos(j);
+	L.lowsel[0] = 0;
+	#pragma unroll
+	for (int lv = 1; lv <= 6; ++lv)
+		L.lowsel[lv] = ((L.q >> (lv - 1)) & 1) ? 0u : SC_SIGN;
+	__shared__ float lds[C * 64 * J];                             // the array of the current sub-tree of each codeword, [c][x][position]
+	const int par = 0;
+	const int run_n = (int)q->run_n[par];
+	const unsigned run_head = q->run_head[par], cap = q->cap;
+	if (run_n == 0)
+		return;
+	// both layouts are launched behind every k_back; the run's length (known on the device only) picks one: a short run is a
+	// matter of one codeword's latency, and one codeword per wave has the shorter one (1.2 against 1.9 ms); a long one of throughput
+	if (small_run > 0 && (run_n <= small_run) != (LB == 6))
+		return;
+	const int n_units = (run_n + C - 1) / C;
+	float *const my_store = soft_all + (size_t)blockIdx.x * Cf::DECODER_FLOATS;
+	const rsrc_t soft = make_rsrc(my_store, C * Cf::STORE_FLOATS * 4);
+	const int v_soft0 = c * (Cf::STORE_FLOATS * 4) + j * 4;
+	for (;;) {
+		int unit = 0;
+		if (lane == 0)
+			unit = atomicAdd(&q->next_unit[par], 1);
+		unit = __builtin_amdgcn_readfirstlane(unit);
+		if (unit >= n_units)
+			break;
+		// the unit's entries; which of them go side by side
+		int slot_of_c[2], n_pass = 1;
+		slot_of_c[0] = (int)((run_head + (unsigned)(unit * C)) % cap);
+		slot_of_c[1] = slot_of_c[0];
+		if (C == 2 && unit * C + 1 < run_n) {
+			slot_of_c[1] = (int)((run_head + (unsigned)(unit * C + 1)) % cap);
+			const long dist = ((long)slot_of_c[1] - (long)slot_of_c[0]) * CODE_LEN * 4;
+			if ((slots[slot_of_c[0]].oper_mode >= 10) != (slots[slot_of_c[1]].oper_mode >= 10) || dist < 0 || dist >= (1l << 31))
+				n_pass = 2;                                       // different tables (or slots a ring's wrap apart): one after the other
+		}
+		for (int pass = 0; pass < n_pass; ++pass) {
+		const int sa = n_pass == 2 ? slot_of_c[pass] : slot_of_c[0], sb = n_pass == 2 ? slot_of_c[pass] : slot_of_c[1];
+		const int my_slot = c ? sb : sa;
+		const int tab = slots[sa].oper_mode >= 10;                     // decode.cc:312,344
+		const uint32_t *frozen = frozen2 + (tab ? 2048 : 0);
+		const uint8_t *nlev = node_lev_blk + (tab ? NBLK : 0);
+		const rsrc_t llr = make_rsrc(llr_q + (size_t)sa * CODE_LEN, (sb - sa + 1) * CODE_LEN * 4);
+		const int v_llr0 = (my_slot - sa) * (CODE_LEN * 4) + j * 4;
+		ScIo<LB> io;
+		if (LB == 6) {                                                // halves of one codeword's 64-bit words
+			io.cwa = cw_q + (size_t)sa * (CODE_LEN / 32);
+			io.cwb = io.cwa + 1;
+			io.xwa = xw_q + (size_t)sa * (CODE_LEN / 32);
+			io.xwb = io.xwa + 1;
+		} else {                                                      // 32-bit words of two codewords
+			io.cwa = cw_q + (size_t)sa * (CODE_LEN / 32);
+			io.xwa = xw_q + (size_t)sa * (CODE_LEN / 32);
+			if (sb != sa) {
+				io.cwb = cw_q + (size_t)sb * (CODE_LEN / 32);
+				io.xwb = xw_q + (size_t)sb * (CODE_LEN / 32);
+			} else {                                                  // alone: both lane groups decode it; the second one's words go aside
+				io.cwb = (uint32_t *)(my_store + C * Cf::STORE_FLOATS);
+				io.xwb = io.cwb + CODE_LEN / 32;
+			}
+		}
+		ScAcc acc{ 0.f, 0x7f800000u };
+		bool finite = true;
+		#pragma unroll 1
+		for (int s = 0; s < Cf::NSUB; ++s) {
+			// ---------------- the array of this sub-tree into LDS, through the level store
+			{
+				const int D = s ? __builtin_ctz(s) + 1 : 16 - Cf::LL;
+				#define SC_PASS(DD, KK) sc_top_pass<LB, DD, KK>(soft, llr, lds, io, s, lane, v_llr0, v_soft0, finite)
+				if (s == 0) SC_PASS(16 - Cf::LL, 0);
+				else if (s == Cf::NSUB / 2) SC_PASS(16 - Cf::LL, 1);
+				else if (D == 15 - Cf::LL) {
+					if (s < Cf::NSUB / 2) sc_top_pass15<LB, false>(soft, llr, lds, io, s, lane, v_llr0, v_soft0);
+					else sc_top_pass15<LB, true>(soft, llr, lds, io, s, lane, v_llr0, v_soft0);
+				}
+				else if (D == 1) SC_PASS(1, 2);
+				else if (D == 2) SC_PASS(2, 2);
+				else if (D == 3) SC_PASS(3, 2);
+				else if constexpr (16 - Cf::LL > 4) SC_PASS(4, 2);
+				#undef SC_PASS
+			}
+			SC_WAVE_ORDER();
+			// this sub-tree's 64 table bytes and frozen words, one block per lane; the block loop reads them with v_readlane
+			const int blk0 = s * 64;
+			const int nlv = nlev[blk0 + lane];
+			uint32_t fzl, fzh = 0;
+			if (LB == 6) {
+				fzl = frozen[(blk0 + lane) * 2];
+				fzh = frozen[(blk0 + lane) * 2 + 1];
+			} else
+				fzl = frozen[blk0 + lane];
+			const float *my = lds + c * (64 * J) + L.q;
+			unsigned long long HR = 0;                                // partial sums: bit x = position x * J + q
+			float R5[32], R4[16], R3[8], R2[4], R1[2], R0[1];
+			#pragma unroll 1
+			for (int b = 0, adv = 1; b < 64; b += adv) {
+				adv = 1;
+				const int zb = b ? __builtin_ctz(b) : 6;              // the one g step of this block produces the array of J << zb leaves (6: none)
+				const int nl = __builtin_amdgcn_readlane(nlv, b), nl0 = nl & 15, nl1 = nl >> 4;
+				const int Lt = (nl0 > nl1 ? nl0 : nl1) - LB;          // the largest uniform node that starts here: J << Lt leaves (< 0: none)
+				const bool frz = nl0 > nl1;
+				const uint32_t hb = zb < 6 ? (uint32_t)(HR >> (b - (1 << zb))) : 0u;
+				int L2 = -1;
+				uint32_t bits = 0;
+				if (zb >= 5) {
+					if (zb == 5) {
+						#pragma unroll
+						for (int x = 0; x < 32; ++x)
+							R5[x] = __uint_as_float(__float_as_uint(my[x * J]) ^ ((hb << (31 - x)) & SC_SIGN)) + my[(x + 32) * J];
+					} else {
+						#pragma unroll
+						for (int x = 0; x < 32; ++x)
+							R5[x] = f_minsum(my[x * J], my[(x + 32) * J]);
+					}
+					if (Lt == 5) { bits = sc_rate1<LB>(R5, acc, lane); L2 = 5; }
+				}
+				if (zb >= 4 && L2 < 0) {
+					if (zb == 4) sc_g_half(R4, R5, hb); else sc_f_half(R4, R5);
+					if (Lt == 4) { bits = sc_rate1<LB>(R4, acc, lane); L2 = 4; }
+				}
+				if (zb >= 3 && L2 < 0) {
+					if (zb == 3) sc_g_half(R3, R4, hb); else sc_f_half(R3, R4);
+					if (Lt == 3) { bits = sc_rate1<LB>(R3, acc, lane); L2 = 3; }
+				}
+				if (zb >= 2 && L2 < 0) {
+					if (zb == 2) sc_g_half(R2, R3, hb); else sc_f_half(R2, R3);
+					if (Lt == 2) {
+						if (frz) sc_rate0<LB>(R2, acc, lane); else bits = sc_rate1<LB>(R2, acc, lane);
+						L2 = 2;
+					}
+				}
+				if (zb >= 1 && L2 < 0) {
+					if (zb == 1) sc_g_half(R1, R2, hb); else sc_f_half(R1, R2);
+					if (Lt == 1) {
+						if (frz) sc_rate0<LB>(R1, acc, lane); else bits = sc_rate1<LB>(R1, acc, lane);
+						L2 = 1;
+					}
+				}
+				if (L2 < 0) {
+					if (zb == 0) sc_g_half(R0, R1, hb); else sc_f_half(R0, R1);
+					if (Lt == 0) {
+						if (frz) sc_rate0<LB>(R0, acc, lane); else bits = sc_rate1<LB>(R0, acc, lane);
+						L2 = 0;
+					}
+				}
+				if (L2 >= 0) {
+					adv = 1 << L2;
+					HR |= (unsigned long long)bits << b;
+				} else {
+					const uint32_t fz0 = (uint32_t)__builtin_amdgcn_readlane((int)fzl, b), fz1 = LB == 6 ? (uint32_t)__builtin_amdgcn_readlane((int)fzh, b) : 0u;
+					HR |= (unsigned long long)(sc_walk_block<LB>(R0[0], fz0, fz1, acc, L) >> 31) << b;
+				}
+				// partial-sum combines of the nodes of 2 J .. 64 J leaves that end here: left half ^= right half
+				const int bn = b + adv;
+				for (int m = L2 >= 0 ? L2 + 1 : 1; m <= 6 && (bn & ((1 << m) - 1)) == 0; ++m) {
+					const int half = 1 << (m - 1), b0 = bn - 2 * half;
+					const unsigned long long lmask = ((1ull << half) - 1ull) << b0;
+					HR = (HR & ~lmask) | ((HR ^ (HR >> half)) & lmask);
+				}
+			}
+			// publish the sub-tree's partial sums as plain words: position q sits on lane j ^ ((j & 4) ? 3 : 0); bring the bits to their
+			// natural lanes (quad_perm [3,2,1,0] on the upper half of every 8), then one ballot per element x: 64 lanes = one 64-bit
+			// word of one codeword / one 32-bit word of each of two
+			{
+				uint32_t h0 = (uint32_t)HR, h1 = (uint32_t)(HR >> 32);
+				const uint32_t s0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0x1B, 0xf, 0xf, false);
+				const uint32_t s1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0x1B, 0xf, 0xf, false);
+				if (lane & 4) { h0 = s0; h1 = s1; }
+				unsigned long long mine = 0;
+				#pragma unroll
+				for (int u = 0; u < 64; ++u) {
+					const unsigned long long bal = __ballot(((u < 32 ? h0 >> u : h1 >> (u - 32)) & 1u) != 0u);
+					if (lane == u)
+						mine = bal;
+				}
+				const int w = ScIo<LB>::idx(s * 64 + lane);
+				io.cwa[w] = (uint32_t)mine;
+				io.cwb[w] = (uint32_t)(mine >> 32);
+			}
+			// combines of the larger nodes that end here, on the published words (every word stays with its lane)
+			const int sn = s + 1;
+			for (int m = 1; m <= 16 - Cf::LL && (sn & ((1 << m) - 1)) == 0; ++m) {
+				const int halfw = 64 << (m - 1), w0 = sn * 64 - 2 * halfw;
+				for (int w = lane; w < halfw; w += 64) {
+					const int wl = ScIo<LB>::idx(w0 + w), wr = ScIo<LB>::idx(w0 + halfw + w);
+					io.cwa[wl] ^= io.cwa[wr];
+					io.cwb[wl] ^= io.cwb[wr];
+				}
+			}
+			SC_WAVE_ORDER();
+		}
+		const unsigned long long unf = __ballot(!finite);
+		if (j == 0 && (C == 1 || c == 0 || sb != sa)) {
+			const bool all_finite = ((unf >> (c * J)) & (J == 64 ? ~0ull : ((1ull << J) - 1ull))) == 0;
+			ScStat st;
+			st.metric = acc.M;
+			st.min_fork = __uint_as_float(acc.fork);
+			st.ok = (all_finite && __uint_as_float(acc.fork) > acc.M) ? 1 : 0;   // the rule (a NaN compares false)
+			st.pad = 0;
+			stat_q[my_slot] = st;
+		}
+		SC_WAVE_ORDER();
+		}   // second entry of a unit that could not be paired
+	}
+}
+
+// ---------------------------------------------------------------- k_sc_finish: decode.cc:532-555 for the frames k_sc decided
+// One workgroup per entry of the run.  Rule holds: P* is lane 0 - its systematic bits (P*'s codeword at the unfrozen positions,
+// decode.cc:254-261), their CRC-32 (decode.cc:533-541); CRC zero: the reference takes lane 0 - payload (descrambled,
+// decode.cc:613-615), best_lane 0, the flip count against the channel's hard decisions (decode.cc:546-555): the frame is finished.
+// Rule or CRC fails: the frame takes a slot of the list decoder's queue and its LLRs are copied there - the general path, unchanged.
+// slot_of[frame]: -2 - (slot in the SC ring) for a frame finished here (its LLRs stay there until the next chunk), else its slot
+// in the list decoder's queue.
+__global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, const ListSlot *__restrict__ slots_s, const float *__restrict__ llr_s,
+	const unsigned long long *__restrict__ cw_q, const unsigned long long *__restrict__ xw_q, const ScStat *__restrict__ stat_q, Tables tb, int descramble,
+	ListQueue *__restrict__ ql, ListSlot *__restrict__ slots_l, float *__restrict__ llr_l, int *__restrict__ slot_of)
+{
+	const int rel = blockIdx.x, tid = threadIdx.x;
+	const unsigned run_n = qs->run_n[0], run_head = qs->run_head[0], cap = qs->cap;
+	if ((unsigned)rel >= run_n)
+		return;
+	const int slot = (int)((run_head + (unsigned)rel) % cap);
+	const ListSlot ls = slots_s[slot];
+	const ScStat st = stat_q[slot];
+	__shared__ uint32_t bits[CODE_LEN / 32];
+	__shared__ uint8_t mesg[MESG_BYTES_MAX];
+	__shared__ uint32_t ctab[256], csh[1024], cpart[32];
+	__shared__ uint32_t crc_sh;
+	__shared__ int flips_red[4], slot_sh;
+	const ModeDesc md = mode_desc(ls.oper_mode);
+	bool done = false;
+	if (st.ok) {
+		const uint32_t *cw = (const uint32_t *)(cw_q + (size_t)slot * (CODE_LEN / 64));
+		for (int w = tid; w < CODE_LEN / 32; w += 256)
+			bits[w] = cw[w];
+		ctab[tid] = tb.crc32_tab[tid];
+		#pragma unroll
+		for (int w = 0; w < 4; ++w)
+			csh[tid + 256 * w] = tb.crc32_shift168[tid + 256 * w];
+		__syncthreads();
+		const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
+		const int mesg_bytes = md.mesg_bits / 8;
+		for (int bi = tid; bi < mesg_bytes; bi += 256) {
+			uint32_t o = 0;
+			#pragma unroll
+			for (int b = 0; b < 8; ++b) {
+				const int p = info_pos[8 * bi + b];
+				o |= ((bits[p >> 5] >> (p & 31)) & 1u) << b;
+			}
+			mesg[bi] = (uint8_t)o;
+		}
+		__syncthreads();
+		constexpr int SEG = 168, NSEG = 32, TAIL = CRC_BITS / 8 - SEG * NSEG;   // 5384 = 32 * 168 + 8 (k_finish's scheme)
+		if (tid < NSEG) {
+			const uint8_t *mp = mesg + tid * SEG;
+			uint32_t crc = 0;
+			for (int i = 0; i < SEG; ++i)
+				crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
+			cpart[tid] = crc;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			uint32_t crc = 0;
+			for (int e = 0; e < NSEG; ++e) {
+				crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
+				crc ^= cpart[e];
+			}
+			for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
+				crc = (crc >> 8) ^ ctab[(crc ^ mesg[i]) & 255];
+			crc_sh = crc;
+		}
+		__syncthreads();
+		done = crc_sh == 0;
+	}
+	if (done) {
+		// decode.cc:546-554: received hard decision against decoded bit over the data bits = the unfrozen positions below the one
+		// of message bit DATA_BITS
+		const uint32_t *xwp = (const uint32_t *)(xw_q + (size_t)slot * (CODE_LEN / 64));
+		const uint32_t *frozen = tb.frozen + (md.table ? CODE_LEN / 32 : 0);
+		const int p_end = (tb.info_pos + (md.table ? MESG_BITS_MAX : 0))[DATA_BITS];
+		int flips = 0;
+		for (int w = tid; w * 32 < p_end; w += 256) {
+			uint32_t m = ~frozen[w];
+			if (p_end - w * 32 < 32)
+				m &= (1u << (p_end - w * 32)) - 1u;
+			flips += __builtin_popcount((bits[w] ^ xwp[w]) & m);
+		}
+		#pragma unroll
+		for (int m = 32; m; m >>= 1)
+			flips += __shfl_xor(flips, m);
+		if ((tid & 63) == 0)
+			flips_red[tid >> 6] = flips;
+		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
+			ls.payload_now[i] = mesg[i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);
+		__syncthreads();
+		if (tid == 0) {
+			ls.res_now->best_lane = 0;
+			ls.res_now->bit_flips = flips_red[0] + flips_red[1] + flips_red[2] + flips_red[3];
+			slot_of[ls.frame] = -2 - slot;
+			atomicAdd(&qs->certified, 1u);
+			atomicAdd(&qs->done_total, 1u);
+		}
+		return;
+	}
+	if (tid == 0) {
+		const unsigned e = atomicAdd(&ql->tail, 1u);
+		const int lslot = (int)(e % ql->cap);
+		slots_l[lslot] = ls;
+		slot_of[ls.frame] = lslot;
+		slot_sh = lslot;
+	}
+	__syncthreads();
+	const float4 *src = (const float4 *)(llr_s + (size_t)slot * CODE_LEN);
+	float4 *dst = (float4 *)(llr_l + (size_t)slot_sh * CODE_LEN);
+	for (int i = tid; i < CODE_LEN / 4; i += 256)
+		dst[i] = src[i];
+}
+
+// behind k_back of a chunk: the run of k_sc = everything that chunk put into the SC ring; behind k_sc_finish: the adaptive switch.
+// Where k_sc decides few frames (below about -18.5 dB every path metric outgrows min_fork) its pass is spent for nothing:
+// k_back then sends a probe sample only (one frame in sixteen of every fourth chunk: a run that small still costs a codeword's
+// latency, 2 ms, with the machine idle) and the rest straight to the list decoder, and all of them again when an eighth of the
+// sample is decided.  (Frames whose Es/N0 estimate rules the pass out never come here at all: k_back.)  Either way every decision is exact: the list decoder is the general path.
+__global__ void k_sc_plan(ListQueue *__restrict__ qs)
+{
+	const unsigned head = qs->head, n = qs->tail - head;
+	qs->run_head[0] = head;
+	qs->run_n[0] = n;
+	qs->head = head + n;
+	qs->next_unit[0] = 0;
+	qs->tried = n;
+	qs->certified = 0;
+}
+__global__ void k_sc_adapt(ListQueue *__restrict__ qs)
+{
+	const unsigned tried = qs->tried, done = qs->certified;
+	if (qs->cert_on) {
+		if (tried >= 64 && done * 8 < tried)
+			qs->cert_on = 0;
+	} else if (tried >= 8 && done * 8 >= tried)
+		qs->cert_on = 1;
+	qs->epoch += 1;
+}
+
+// grid5 / grid6 = resident decoders (waves) of the two layouts; lb = 5 / 6: that layout alone; 0: both are launched and the run's
+// length decides on the device (at most `small_run` entries: one codeword per wave)
+constexpr int SC_SMALL_RUN = 5120;
+int sc_codewords_per_wave(int lb) { return lb == 6 ? ScCfg<6>::C : ScCfg<5>::C; }
+size_t sc_store_bytes(int lb)                                     // level store per resident decoder
+{
+	const size_t b5 = (size_t)ScCfg<5>::DECODER_FLOATS * sizeof(float), b6 = (size_t)ScCfg<6>::DECODER_FLOATS * sizeof(float);
+	return lb == 6 ? b6 : (lb == 5 ? b5 : (b5 > b6 ? b5 : b6));
+}
+void launch_sc(hipStream_t s, int lb, int grid5, int grid6, ListQueue *q, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
+	unsigned long long *xw_q, ScStat *stat_q, Tables tb)
+{
+	const int small_run = lb == 0 ? SC_SMALL_RUN : 0;
+	if (lb != 5)
+		hipLaunchKernelGGL(k_sc<6>, dim3(grid6), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev64, small_run);
+	if (lb != 6)
+		hipLaunchKernelGGL(k_sc<5>, dim3(grid5), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev32, small_run);
+}
+void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
+	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of)
+{
+	hipLaunchKernelGGL(k_sc_finish, dim3(max_entries), dim3(256), 0, s, qs, slots_s, llr_s, cw_q, xw_q, stat_q, tb, descramble, ql, slots_l, llr_l, slot_of);
+}
+void launch_sc_plan(hipStream_t s, ListQueue *qs) { hipLaunchKernelGGL(k_sc_plan, dim3(1), dim3(1), 0, s, qs); }
+void launch_sc_adapt(hipStream_t s, ListQueue *qs) { hipLaunchKernelGGL(k_sc_adapt, dim3(1), dim3(1), 0, s, qs); }
+
+}  // namespace rx
