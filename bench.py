@@ -507,7 +507,8 @@ def main():
                         "back to back; scales calibrated in the same session on tools/pmc_calib.hip), scaled to this run's frames per launch"
                         % (TRAFFIC_FILE, traffic_db.get("fetch_scale", 2.0), traffic_db.get("write_scale", 1.0), traffic_db["frames_per_launch"]))
             # which resource the kernel is closer to: HBM (its real traffic against the peak) or vector-instruction issue (the
-            # committed SQ_INSTS_VALU pass: wave instructions per launch x 4 cycles each on one of 1024 SIMDs against the launch time)
+            # committed SQ_INSTS_VALU pass: wave instructions per launch on 1024 SIMDs against the launch time, priced at the guide's
+            # 2 cycles each and at the measured ceiling of tools/ubench_issue.hip)
             valu = None
             if tj and tj.get("valu_insts") and avg_s > 0:
                 insts = tj["valu_insts"] * fpl / traffic_db["frames_per_launch"]
