@@ -17,6 +17,7 @@ mode = int(os.environ.get("SWEEP_MODE", "6"))
 rate = int(os.environ.get("SWEEP_RATE", "8000"))
 channels = int(os.environ.get("SWEEP_CHANNELS", "2"))   # 1: the real part of the noisy analytic stream + a DC offset (SWEEP_DC, LSB): mono input
 dc = int(os.environ.get("SWEEP_DC", "700"))
+chain = int(os.environ.get("SWEEP_CHAIN", "0"))         # 1: configs[3]'s chain in front of the noise - multipath (4 taps) -> CFO +234.567 Hz -> SFO +147 ppm
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 levels = [float(x) for x in sys.argv[2:]] or [-17.0, -15.5, -15.0, -14.5]
 dev = torch.device("cuda:0")
@@ -25,7 +26,8 @@ torch.cuda.set_stream(stream)
 rx = modem_amd.Receiver(device=0, chunk_frames=96, stream=stream.cuda_stream, sample_rate=rate)
 spf = rx.tx_frame_samples(mode)
 O.lib().orc_decode_rate   # (loads the library)
-print("mode %d, %d Hz, %d channel%s" % (mode, rate, channels, "s" if channels == 2 else " (DC offset %d LSB)" % dc), flush=True)
+print("mode %d, %d Hz, %d channel%s%s" % (mode, rate, channels, "s" if channels == 2 else " (DC offset %d LSB)" % dc,
+                                          ", multipath (4 taps) -> CFO +234.567 Hz -> SFO +147 ppm in front of the noise" if chain else ""), flush=True)
 threads = min(os.cpu_count() or 1, int(os.environ.get("SWEEP_THREADS", "32")))
 bad = 0
 bad_decisions = 0
@@ -35,6 +37,13 @@ for li, db in enumerate(levels):
     d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
     d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
     rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr(), mode=mode)
+    if chain:
+        d_imp = torch.empty_like(d_in)
+        for lo in range(0, n, 8192):
+            hi = min(lo + 8192, n)
+            rx.channel(d_in[lo:hi].data_ptr(), d_imp[lo:hi].data_ptr(), hi - lo, spf, cfo_hz=234.567, sfo_ppm=147.0,
+                       multipath=[(0, 1 + 0j), (5, 0.35 - 0.1j), (11, -0.2 + 0.2j), (23, 0.1 + 0.05j)])
+        d_in = d_imp
     rx.awgn_tile(d_in.data_ptr(), n, d_in.data_ptr(), n, spf, db, 99, li * n)
     rx.synchronize()
     if channels == 1:
@@ -46,6 +55,7 @@ for li, db in enumerate(levels):
     rx.synchronize()
     out = d_out.cpu().numpy()
     res = d_res.cpu().numpy().view(M.RESULT_DTYPE).reshape(-1)
+    n_list, n_sc = rx.list_decoded_frames(), rx.sc_decided_frames()
     pcm = np.ascontiguousarray(d_in.cpu().numpy())
     oout = np.zeros((n, 5380), np.uint8)
     ores = np.zeros(n * 56, np.uint8)
@@ -75,7 +85,8 @@ for li, db in enumerate(levels):
     nok = int((res["status"] == 0).sum())
     bad += int((~same).sum())
     print("%6.1f dB: %d frames, %d decoded, GPU == oracle (payload, status, lane, sync, header) on %d, flip count identical on %d, within 2 on %d, "
-          "largest difference %d (oracle %.1f s on %d threads)" % (db, n, nok, int(decided.sum()), flips_equal, int(same.sum()), worst_flips, dt, threads), flush=True)
+          "largest difference %d (oracle %.1f s on %d threads; GPU routes: list-1 pass %d, list decoder %d)"
+          % (db, n, nok, int(decided.sum()), flips_equal, int(same.sum()), worst_flips, dt, threads, n_sc, n_list), flush=True)
     if not same.all():
         i = int(np.argmin(same))
         differ = [nm for nm in ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects") if res[nm][i] != ores[nm][i]]
