@@ -1,5 +1,9 @@
 #!/bin/bash
 # sc_time.sh "LIB:ENV[,ENV] ..." -- k_sc's launch duration on 8192 random codewords per library / environment (rocprofv3 kernel trace)
+# The timing probe "sclds8" of profiles/r05_v7_sc_resident_decoders_timing_probe.txt (half the LDS array, wrong arithmetic on purpose) was:
+#   sed -e 's/__shared__ float lds\[C \* 64 \* J\];/__shared__ float lds[C * 32 * J];/' -e 's/my\[(x + 32) \* J\]/my[((x + 1) \& 31) * J]/g' \
+#       -e 's/\t\tlds\[lidx\] = t\[0\];/\t\tlds[lidx \& (32 * ScCfg<LB>::J - 1)] = t[0];/' modem_amd/csrc/k_sc.hip > /tmp/k_sc_lds8_probe.hip
+#   SRC_k_sc=<that file, under the repo> tools/build_variant.sh sclds8 ""
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for spec in "$@"; do
