@@ -43,12 +43,21 @@ struct MonoFrame {
 		if (fmt == 1) return (float)((int)((const uint8_t *)base)[i] - 128);
 		return ((const float *)base)[i];
 	}
-	// eight consecutive raw samples from pos (pos a multiple of 8): one 16-byte load for int16 input inside the frame
+	// eight consecutive raw samples from pos (pos a multiple of 8): for int16 input inside the frame one 16-byte load, or four 4-byte
+	// ones where the frame does not start on 16 bytes (a 44.1 kHz frame is 1 049 580 bytes: three frames in four of a batch; the
+	// per-sample path with its range checks took the front pass from 21 to 29 ms there)
 	__device__ __forceinline__ void load8(long pos, float (&x)[8]) const
 	{
-		if (fmt == 0 && pos >= 0 && pos + 8 <= n && (((size_t)base + (size_t)pos * 2) & 15) == 0) {
-			const int4 v = *(const int4 *)((const int16_t *)base + pos);
-			const int w[4] = { v.x, v.y, v.z, v.w };
+		if (fmt == 0 && pos >= 0 && pos + 8 <= n) {
+			int w[4];
+			if ((((size_t)base + (size_t)pos * 2) & 15) == 0) {
+				const int4 v = *(const int4 *)((const int16_t *)base + pos);
+				w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+			} else {
+				typedef int __attribute__((aligned(2))) int_at_2;
+				const int_at_2 *q = (const int_at_2 *)((const int16_t *)base + pos);
+				w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
+			}
 			#pragma unroll
 			for (int q = 0; q < 4; ++q) {
 				x[2 * q] = (float)(short)(w[q] & 0xffff);
@@ -102,11 +111,19 @@ template <int RATE, int NT> struct MonoCover {
 	typedef MonoCfg<RATE> MC;
 	static constexpr int PER = 8, LEN = NT * PER, HIST = MC::HIST, NW = NT / 64;
 	static constexpr bool CONTIG = MC::REACH <= 24;           // (8 kHz) see span()
+	static constexpr int RS = (HIST + LEN) / 8;               // the long filters' layout: row stride
+	static constexpr int ZS = NT + 8;                         // ... and the row stride of the span's outputs on their way to memory
 	struct Shared {
 		float y[HIST + LEN + (HIST + LEN) / 32 + 1];          // [0, HIST): the samples before the span; one pad word per 32
 		double wave_end[NW];
+		float zt[CONTIG ? 1 : 2 * 8 * ZS];                    // long filters: a span's z, real and imaginary parts register major, so that
+		                                                      // it leaves in the order of the samples (512 contiguous bytes per wave and store)
 	};
-	static __device__ __forceinline__ int pad(int p) { return p + (p >> 5); }
+	// where sample p of the buffer lives.  8 kHz: in place, one pad word per 32 (a thread's eight samples are consecutive words; the pad
+	// keeps the lanes on different banks).  The long filters (41 - 125 taps): "register major" - sample 8 c + i at row i, column c -
+	// so that the k-th value of EVERY thread's window sits at that thread's column plus a compile-time constant: no address
+	// arithmetic per read, consecutive lanes on consecutive words.
+	static __device__ __forceinline__ int pad(int p) { return CONTIG ? p + (p >> 5) : (p & 7) * RS + (p >> 3); }
 
 	MonoFrame fr;
 	Shared *sh;
@@ -218,13 +235,47 @@ template <int RATE, int NT> struct MonoCover {
 						z[i0 + q] = r[q];
 			}
 		} else {
-			#pragma unroll 2
+			// The long filters: a thread filters its own eight samples too, out of a window of REACH + 7 values around them.  The odd
+			// taps of a sample reach values of the other parity only, so the window is taken one parity class at a time (66 registers
+			// at 48 kHz instead of 130): the class holds the taps of four of the samples and the centre taps of the other four.
+			// (Before round 5 a lane took samples tid + 256 q and read its 63 values per sample through pad(): three address
+			// instructions per read - 36 ms per 8192 frames of 48 kHz, on vector issue.)
+			static_assert(PER == 8 && HIST % 8 == 0 && HIST >= MC::REACH, "window layout");
+			constexpr int WN = MC::REACH + PER - 1, CEN = MC::REACH - MC::C, K0 = HIST - MC::REACH;   // w(k) = buffer sample K0 + 8 tid + k
+			const float *col = sh->y + tid;
+			float rre[PER], rim[PER];
+			#pragma unroll
+			for (int ph = 0; ph < 2; ++ph) {
+				float ww[(WN + 1) / 2];                           // w(2 m + ph)
+				#pragma unroll
+				for (int m = 0; 2 * m + ph < WN; ++m)
+					ww[m] = col[((K0 + 2 * m + ph) & 7) * RS + ((K0 + 2 * m + ph) >> 3)];
+				#pragma unroll
+				for (int q = 0; q < PER; ++q) {
+					if (((q + CEN) & 1) == ph)                    // the centre tap
+						rre[q] = ma.co.reco * ww[(q + CEN - ph) / 2];
+					else {                                        // the odd taps, in mono_hilbert's order
+						float im = ma.co.imco[0] * (ww[(q + CEN - 1 - ph) / 2] - ww[(q + CEN + 1 - ph) / 2]);
+						#pragma unroll
+						for (int k = 1; k < MC::NIM; ++k)
+							im += ma.co.imco[k] * (ww[(q + CEN - (2 * k + 1) - ph) / 2] - ww[(q + CEN + (2 * k + 1) - ph) / 2]);
+						rim[q] = im;
+					}
+				}
+			}
+			#pragma unroll
+			for (int q = 0; q < PER; ++q) {
+				sh->zt[q * ZS + tid] = rre[q];
+				sh->zt[(8 + q) * ZS + tid] = rim[q];
+			}
+			sync();
+			#pragma unroll
 			for (int q = 0; q < PER; ++q) {
 				const int j = tid + NT * q;                       // consecutive samples across the lanes
 				const long i = next + j;
-				const cf r = mono_hilbert<RATE>(ma.co, [&](int k) { return sh->y[pad(HIST + j - MC::REACH + k)]; });
+				const int a = (j & 7) * ZS + (j >> 3);
 				if (i >= lo && i < hi)
-					z[i] = r;
+					z[i] = mk(sh->zt[a], sh->zt[8 * ZS + a]);
 			}
 		}
 		sync();
