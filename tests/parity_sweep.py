@@ -95,5 +95,12 @@ for li, db in enumerate(levels):
         print("   first mismatch frame %d: gpu status %d lane %d flips %d | oracle status %d lane %d flips %d | fields that differ: %s; "
               "cfo gpu %.9g oracle %.9g" % (i, res["status"][i], res["best_lane"][i], res["bit_flips"][i], ores["status"][i],
               ores["best_lane"][i], ores["bit_flips"][i], ", ".join(differ) or "none but the flip count", res["cfo_rad"][i], ores["cfo_rad"][i]))
+    for i in np.nonzero(~decided)[0][:16]:                     # every frame that differs in something decided, field by field
+        differ = [nm for nm in ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects") if res[nm][i] != ores[nm][i]]
+        if not (out[i] == oout[i]).all():
+            differ.append("payload")
+        print("   decided differently, frame %d: %s | gpu status %d lane %d sc_start %d symbol_pos %d | oracle status %d lane %d sc_start %d symbol_pos %d"
+              % (i, ", ".join(differ), res["status"][i], res["best_lane"][i], res["sc_start"][i], res["symbol_pos"][i],
+                 ores["status"][i], ores["best_lane"][i], ores["sc_start"][i], ores["symbol_pos"][i]), flush=True)
 print("mismatches: %d in what is decided, %d more in the flip-count diagnostic (beyond +-2)" % (bad_decisions, bad - bad_decisions))
 sys.exit(1 if bad else 0)
