@@ -152,12 +152,6 @@ struct SampleSrc {
 	int channels;
 	long n;                // samples in the frame
 	const cf *analytic;    // mono: output of the front-end kernel (D1), else nullptr
-	__device__ __forceinline__ float scalar(long idx) const
-	{
-		if (fmt == 0) return div_32767((float)((const int16_t *)base)[idx]);
-		if (fmt == 1) return div_127((float)((int)((const uint8_t *)base)[idx] - 128));
-		return ((const float *)base)[idx];
-	}
 	__device__ __forceinline__ cf at(long i) const
 	{
 		if (i < 0 || i >= n)
@@ -168,7 +162,17 @@ struct SampleSrc {
 			short2 v = ((const short2 *)base)[i];
 			return mk(div_32767((float)v.x), div_32767((float)v.y));
 		}
-		return mk(scalar(2 * i), scalar(2 * i + 1));
+		return pair_other(i);
+	}
+	// 8-bit / float32 pairs: one access per I/Q pair too (check_args keeps frames on sample-frame boundaries)
+	__device__ __forceinline__ cf pair_other(long i) const
+	{
+		if (fmt == 1) {
+			const unsigned v = ((const uint16_t *)base)[i];
+			return mk(div_127((float)((int)(v & 255u) - 128)), div_127((float)((int)(v >> 8) - 128)));
+		}
+		const float2 v = ((const float2 *)base)[i];
+		return mk(v.x, v.y);
 	}
 	// the same with the format decided once per kernel instead of once per sample: 0 = analytic (mono), 1 = int16 pairs, 2 = the rest
 	__device__ __forceinline__ int mode() const { return analytic ? 0 : (fmt == 0 ? 1 : 2); }
@@ -182,7 +186,7 @@ struct SampleSrc {
 			short2 v = ((const short2 *)base)[i];
 			return mk(div_32767((float)v.x), div_32767((float)v.y));
 		}
-		return mk(scalar(2 * i), scalar(2 * i + 1));
+		return pair_other(i);
 	}
 	template <class F> __device__ __forceinline__ void with_mode(F f) const
 	{

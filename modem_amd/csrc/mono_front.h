@@ -63,6 +63,19 @@ struct MonoFrame {
 				x[2 * q] = (float)(short)(w[q] & 0xffff);
 				x[2 * q + 1] = (float)(short)(w[q] >> 16);
 			}
+		} else if (fmt == 1 && pos >= 0 && pos + 8 <= n) {            // 8-bit samples: eight bytes in two accesses
+			typedef uint32_t __attribute__((aligned(1))) u32_at_1;
+			const u32_at_1 *q = (const u32_at_1 *)((const uint8_t *)base + pos);
+			const uint32_t w[2] = { q[0], q[1] };
+			#pragma unroll
+			for (int i = 0; i < 8; ++i)
+				x[i] = (float)((int)((w[i >> 2] >> (8 * (i & 3))) & 255u) - 128);
+		} else if (fmt == 2 && pos >= 0 && pos + 8 <= n) {            // float32 samples: two 16-byte accesses
+			typedef float4 __attribute__((aligned(4))) float4_at_4;
+			const float4_at_4 *q = (const float4_at_4 *)((const float *)base + pos);
+			const float4 a = q[0], b = q[1];
+			x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+			x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
 		} else {
 			#pragma unroll
 			for (int i = 0; i < 8; ++i)
