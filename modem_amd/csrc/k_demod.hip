@@ -28,7 +28,10 @@ template <int RATE> struct DifCfg {
 	static constexpr int WAVES = DEMOD_DIF_WAVES(RATE);      // waves per SIMD the register budget is set for (two workgroups per CU at 44.1 / 48 kHz)
 };
 
-#define DEMOD_PREFETCH_NQ 1   // loader points per thread up to which the NEXT symbol's samples are fetched during the transform
+#define DEMOD_PREFETCH_NQ(R) ((R) >= 44100 ? 2 : 1)   // loader points per thread up to which the NEXT symbol's samples are fetched during the
+                        // transform.  44.1 / 48 kHz run ONE workgroup of 14 / 15 waves per CU (registers and LDS), so nothing else hides the load
+                        // at the top of a symbol: with the next symbol's two points per loader in flight meanwhile 13.5 -> 11.3 and 12.0 -> 11.2 ms
+                        // per 8192 frames; 16 kHz (two points too, four workgroups per CU) 3.44 -> 3.51: stays without
 #define DEMOD_SWZ 1     // 8 kHz (the only rate with wave-private 256-point transforms): demod 1.48 -> 1.35 ms per chunk with the seven-waves budget below
 // (swz256 / fft256_stage_swz: dev_common.h, shared with the transmitter's transforms)
 
@@ -75,7 +78,10 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 		__shared__ cf tw_sub[TWC];                            // compact twiddles of the NS-point plan
 		__shared__ cf tw_r[DC::TWR_LDS ? (R1 - 1) * NS : 1];  // w^(n' r), r = 1..R1-1
 		__shared__ cf rotA[R1], rotQ[NQ], symrot[ROWS_MAX + 1];
-		__shared__ cf prevc[2][DEMOD_CONS_OUT(RATE) ? NT : 1];   // a thread's (at most two) carriers of the previous symbol
+		// a thread's (at most two) carriers of the previous symbol.  A frame has at most COLS_MAX = 512 carriers: with 512 threads or
+		// more only e = 0 and tid < 512 ever come here (48 kHz: 4 KB instead of 15 - what keeps a second workgroup off the CU)
+		constexpr int PC_E = NT >= COLS_MAX ? 1 : 2, PC_T = NT >= COLS_MAX ? COLS_MAX : NT;
+		__shared__ cf prevc[PC_E][DEMOD_CONS_OUT(RATE) ? PC_T : 1];
 		// MONO = 2: y of the span from (about) 32 samples before the body on (the filter reaches 19 back), and the waves' end states
 		constexpr int MPER = 5, MTH = SYM_STRIDE / MPER, YOFF = (GUARD_LEN - 32) / MPER * MPER, YB = GUARD_LEN - YOFF;   // body sample m at ybuf[YB + m]
 		static_assert(MONO != 2 || (MTH * MPER == SYM_STRIDE && MTH <= NT && NS == 256 && NQ == 1 && MonoCfg<RATE>::REACH <= 32 && GUARD_LEN % MPER == 0
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 		cf pre[NQ][R1];
 #define DEMOD_RAW_AHEAD 1     // int16 pairs fetched a symbol ahead stay as they come - one register per point, no conversion (and no wait for
                               // the load) where the load is issued - and are converted where the symbol is taken up
-		constexpr bool RAW = DEMOD_RAW_AHEAD && MODE == 1 && MONO == 0 && NQ <= DEMOD_PREFETCH_NQ;
+		constexpr bool RAW = DEMOD_RAW_AHEAD && MODE == 1 && MONO == 0 && NQ <= DEMOD_PREFETCH_NQ(RATE);
 		int praw[RAW ? NQ : 1][RAW ? R1 : 1];
 		auto fetch = [&](int sym) {
 			const long t0 = body0 + (long)sym * SYM_STRIDE;       // wave-uniform
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 				}
 			}
 		};
-		constexpr bool AHEAD = NQ <= DEMOD_PREFETCH_NQ && MONO == 0;   // (mono: the points are formed at the top of the symbol)
+		constexpr bool AHEAD = NQ <= DEMOD_PREFETCH_NQ(RATE) && MONO == 0;   // (mono: the points are formed at the top of the symbol)
 		if (AHEAD)
 			fetch(0);
 		cf *carr = carr_all + (size_t)f * CARR_MAX;
