@@ -23,7 +23,7 @@ template <int RATE> struct DifCfg {
 	static constexpr int R1 = SL % 5 == 0 ? 5 : 7, NS = SL / R1, NT = 64 * W * R1;
 	static constexpr int NQ = (NS + NT - 1) / NT;             // points n' per loader thread
 #define DEMOD_TWR_BYTES 8192
-#define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : (R) == 8000 ? 7 : 4)   // 8 kHz: 72 VGPRs = five workgroups per CU (26.6 KB of LDS each); 64 spills with the swizzle
+#define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : (R) == 8000 ? 7 : 5)   // 8 kHz: 72 VGPRs = five workgroups per CU (26.6 KB of LDS each); 64 spills with the swizzle
 	static constexpr bool TWR_LDS = (R1 - 1) * NS * 8 <= DEMOD_TWR_BYTES;   // w^(n' r) table in LDS (8 / 16 kHz) or read from the global root table
 	static constexpr int WAVES = DEMOD_DIF_WAVES(RATE);      // waves per SIMD the register budget is set for (two workgroups per CU at 44.1 / 48 kHz)
 };
@@ -220,6 +220,31 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 			mono_raw(1);
 			__syncthreads();
 		}
+		// 48 kHz: the w^(n' r) of a loader's two points, the same in every symbol, stay in registers (they came from the global root
+		// table in every symbol: eight loads per thread at the top of the symbol, in front of the row writes)
+		constexpr bool TWR_REG = !DC::TWR_LDS && NQ * (R1 - 1) <= 8;
+		cf twq[TWR_REG ? NQ : 1][TWR_REG ? R1 - 1 : 1];
+		if constexpr (TWR_REG) {
+			#pragma unroll
+			for (int q = 0; q < NQ; ++q)
+				#pragma unroll
+				for (int r = 1; r < R1; ++r)
+					twq[q][r - 1] = tid + NT * q < NS ? tb.tw_sym[r * (tid + NT * q)] : mk(0.f, 0.f);
+		}
+		// ... and so do the NCO phasors of its two points (two complex multiplications per sample and symbol otherwise).  48 kHz only: its
+		// one workgroup per CU has the registers (102 -> 117 of 128; 11.2 -> 10.7 ms per 8192 frames with both); at 16 kHz the same
+		// twenty registers cost the fourth workgroup per CU (3.45 -> 4.08 ms)
+		constexpr bool QA_REG2 = NQ == 2 && R1 == 5 && RATE == 48000;
+		cf qa2[QA_REG2 ? NQ : 1][QA_REG2 ? R1 : 1];
+		if constexpr (QA_REG2) {
+			#pragma unroll
+			for (int q = 0; q < NQ; ++q) {
+				const cf pq = q ? cmul(p0, rotQ[q]) : p0;
+				#pragma unroll
+				for (int a = 0; a < R1; ++a)
+					qa2[q][a] = a ? cmul(pq, rotA[a]) : pq;
+			}
+		}
 		auto symbols = [&](auto M) {
 		constexpr int MODE = decltype(M)::value;
 		cf pre[NQ][R1];
@@ -305,6 +330,10 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 						#pragma unroll
 						for (int a = 0; a < R1; ++a)
 							v[a] = cmul(pre[q][a], (QA_LDS && a) ? cmul(p0, rotA[a]) : qa[a]);
+					} else if constexpr (QA_REG2) {
+						#pragma unroll
+						for (int a = 0; a < R1; ++a)
+							v[a] = cmul(pre[q][a], qa2[q][a]);
 					} else {
 						const cf pq = q ? cmul(p0, rotQ[q]) : p0;
 						#pragma unroll
@@ -316,7 +345,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 					row[npw] = v[0];
 					#pragma unroll
 					for (int r = 1; r < R1; ++r)
-						row[r * NS + npw] = cmul(v[r], DC::TWR_LDS ? tw_r[(r - 1) * NS + np] : tb.tw_sym[r * np]);
+						row[r * NS + npw] = cmul(v[r], DC::TWR_LDS ? tw_r[(r - 1) * NS + np] : TWR_REG ? twq[TWR_REG ? q : 0][TWR_REG ? r - 1 : 0] : tb.tw_sym[r * np]);
 				}
 			}
 			if (AHEAD)
