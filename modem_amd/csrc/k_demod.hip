@@ -24,7 +24,8 @@ template <int RATE> struct DifCfg {
 	static constexpr int NQ = (NS + NT - 1) / NT;             // points n' per loader thread
 #define DEMOD_TWR_BYTES 8192
 #define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : (R) == 8000 ? 7 : 5)   // 8 kHz: 72 VGPRs = five workgroups per CU (26.6 KB of LDS each); 64 spills with the swizzle
-	static constexpr bool TWR_LDS = (R1 - 1) * NS * 8 <= DEMOD_TWR_BYTES;   // w^(n' r) table in LDS (8 / 16 kHz) or read from the global root table
+	static constexpr bool TWR_LDS = (R1 - 1) * NS * 8 <= DEMOD_TWR_BYTES || SL == 7056;   // w^(n' r) table in LDS (8 / 16 kHz; 44.1 kHz: 47 KB - its one
+	                                                          // workgroup per CU has the room) or read from the global root table (48 kHz: registers)
 	static constexpr int WAVES = DEMOD_DIF_WAVES(RATE);      // waves per SIMD the register budget is set for (two workgroups per CU at 44.1 / 48 kHz)
 };
 
