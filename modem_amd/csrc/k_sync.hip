@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_mono_carries(FrameBatch fb, FrontCoef c
 // that state
 constexpr int FE_STRETCH = 4 * 2048 - 256;
 template <int RATE>
-__global__ __launch_bounds__(256, RATE >= 44100 ? 3 : 4) void k_front_end(FrameBatch fb, MonoArgs ma, cf *__restrict__ z_all)
+__global__ __launch_bounds__(256, RATE == 8000 ? 4 : 5) void k_front_end(FrameBatch fb, MonoArgs ma, cf *__restrict__ z_all)
 {
 	static_assert(MonoCfg<RATE>::REACH + MONO_CK <= 256, "a stretch and its lead-in fit four spans");
 	const int f = blockIdx.y, tid = threadIdx.x;

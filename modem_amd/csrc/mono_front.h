@@ -249,31 +249,47 @@ template <int RATE, int NT> struct MonoCover {
 			}
 		} else {
 			// The long filters: a thread filters its own eight samples too, out of a window of REACH + 7 values around them.  The odd
-			// taps of a sample reach values of the other parity only, so the window is taken one parity class at a time (66 registers
-			// at 48 kHz instead of 130): the class holds the taps of four of the samples and the centre taps of the other four.
-			// (Before round 5 a lane took samples tid + 256 q and read its 63 values per sample through pad(): three address
-			// instructions per read - 36 ms per 8192 frames of 48 kHz, on vector issue.)
-			static_assert(PER == 8 && HIST % 8 == 0 && HIST >= MC::REACH, "window layout");
-			constexpr int WN = MC::REACH + PER - 1, CEN = MC::REACH - MC::C, K0 = HIST - MC::REACH;   // w(k) = buffer sample K0 + 8 tid + k
+			// taps of a sample reach values of the other parity only, so the window is taken one parity class at a time: the class
+			// holds the taps of four of the samples (q0, q0 + 2, q0 + 4, q0 + 6) and the centre taps of the other four.  Tap pair k of
+			// those four samples reads four neighbouring values of the class below the centre and four above it, and the next pair the
+			// same two windows moved by one: two new LDS reads per pair, eight live values - the sums run in mono_hilbert's order.
+			// (Round 5, first form: the whole class in registers - 66 at 48 kHz, 125 VGPRs, four workgroups per CU: 16.1 ms per 8192
+			// frames of 48 kHz, 15.4 this way - the pass writes 8 bytes per sample, and 37 GB of writes are 13 - 15 ms on this memory
+			// system.  Before round 5 a lane took samples tid + 256 q and read its 63 values per sample through pad(): three address
+			// instructions per read, 34 - 36 ms.)
+			static_assert(PER == 8 && HIST % 8 == 0 && HIST >= MC::REACH && MC::NIM >= 2, "window layout");
+			constexpr int CEN = MC::REACH - MC::C, K0 = HIST - MC::REACH;   // w(k) = buffer sample K0 + 8 tid + k
 			const float *col = sh->y + tid;
+			auto wv = [&](int k) { return col[((K0 + k) & 7) * RS + ((K0 + k) >> 3)]; };   // (k: a compile-time constant wherever it is called)
 			float rre[PER], rim[PER];
 			#pragma unroll
 			for (int ph = 0; ph < 2; ++ph) {
-				float ww[(WN + 1) / 2];                           // w(2 m + ph)
+				const int q0 = ((CEN + 1 + ph) & 1);                  // the samples whose odd taps lie in this class: q0 + 2 j
+				float lo[4], hi[4], im[4];
 				#pragma unroll
-				for (int m = 0; 2 * m + ph < WN; ++m)
-					ww[m] = col[((K0 + 2 * m + ph) & 7) * RS + ((K0 + 2 * m + ph) >> 3)];
+				for (int j = 0; j < 4; ++j) {
+					lo[j] = wv(q0 + 2 * j + CEN - 1);
+					hi[j] = wv(q0 + 2 * j + CEN + 1);
+					im[j] = ma.co.imco[0] * (lo[j] - hi[j]);
+				}
 				#pragma unroll
-				for (int q = 0; q < PER; ++q) {
-					if (((q + CEN) & 1) == ph)                    // the centre tap
-						rre[q] = ma.co.reco * ww[(q + CEN - ph) / 2];
-					else {                                        // the odd taps, in mono_hilbert's order
-						float im = ma.co.imco[0] * (ww[(q + CEN - 1 - ph) / 2] - ww[(q + CEN + 1 - ph) / 2]);
-						#pragma unroll
-						for (int k = 1; k < MC::NIM; ++k)
-							im += ma.co.imco[k] * (ww[(q + CEN - (2 * k + 1) - ph) / 2] - ww[(q + CEN + (2 * k + 1) - ph) / 2]);
-						rim[q] = im;
-					}
+				for (int k = 1; k < MC::NIM; ++k) {
+					#pragma unroll
+					for (int j = 3; j > 0; --j)
+						lo[j] = lo[j - 1];                            // the window below the centres moves down by one value of the class
+					lo[0] = wv(q0 + CEN - (2 * k + 1));
+					#pragma unroll
+					for (int j = 0; j < 3; ++j)
+						hi[j] = hi[j + 1];                            // ... the one above them up
+					hi[3] = wv(q0 + 6 + CEN + (2 * k + 1));
+					#pragma unroll
+					for (int j = 0; j < 4; ++j)
+						im[j] += ma.co.imco[k] * (lo[j] - hi[j]);
+				}
+				#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					rim[q0 + 2 * j] = im[j];
+					rre[(q0 ^ 1) + 2 * j] = ma.co.reco * wv((q0 ^ 1) + 2 * j + CEN);   // the centre taps of the other four samples
 				}
 			}
 			#pragma unroll
