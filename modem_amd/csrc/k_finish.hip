@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
 	Result *__restrict__ res_all, float *__restrict__ esn0_rows, Tables tb, int descramble, uint8_t *__restrict__ payload_all,
 	ListQueue *__restrict__ q, ListSlot *__restrict__ slots, float *__restrict__ llr_q, int *__restrict__ slot_of,
-	uint8_t *__restrict__ payload_later, Result *__restrict__ res_later, ScRing sc)
+	uint8_t *__restrict__ payload_later, Result *__restrict__ res_later, ScRing sc, int chunk_seq)
 {
 	const int f = blockIdx.x, tid = threadIdx.x;
 	const SyncState st = st_all[f];
@@ -271,6 +271,8 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 		ls.res_now = res_all + f;
 		ls.oper_mode = st.oper_mode;
 		ls.frame = f;
+		ls.chunk = chunk_seq;
+		ls.pad = 0;
 		slots[slot] = ls;
 		slot_of[f] = to_sc ? -2 - slot : slot;
 		res_all[f] = r;                                       // k_sc_finish / k_finish completes the record (best_lane, bit_flips, status)
@@ -340,6 +342,7 @@ __global__ void k_queue_reset(ListQueue *__restrict__ q, unsigned cap)
 	q->cap = cap;
 	q->done_total = 0;
 	q->epoch = 0;
+	q->probe_tried = q->probe_done = 0;
 }
 // behind k_back of a chunk: what the flush of that chunk may take, and the adaptive certificate's next state
 __global__ void k_queue_snap(ListQueue *__restrict__ q, int par)
@@ -347,10 +350,22 @@ __global__ void k_queue_snap(ListQueue *__restrict__ q, int par)
 	q->snap[par] = q->tail;
 	const unsigned tried = q->tried, cert = q->certified;
 	if (q->cert_on) {
-		if (tried >= 64 && cert * 20 < tried)
+		if (tried >= 64 && cert * 20 < tried) {
 			q->cert_on = 0;
-	} else if (tried >= 8 && cert * 5 >= tried)
-		q->cert_on = 1;
+			q->probe_tried = q->probe_done = 0;
+		}
+	} else {
+		// the probe sample (one frame in sixteen) of a small chunk is a handful of frames: summed over chunks until eight have been tried
+		const unsigned pt = q->probe_tried + tried, pd = q->probe_done + cert;
+		if (pt >= 8) {
+			if (pd * 5 >= pt)
+				q->cert_on = 1;
+			q->probe_tried = q->probe_done = 0;
+		} else {
+			q->probe_tried = pt;
+			q->probe_done = pd;
+		}
+	}
 	q->tried = q->certified = 0;
 }
 // in front of k_polar: the entries of this flush.  Nothing until `unit` entries wait (one full residency of the list decoder),
@@ -377,6 +392,8 @@ __global__ void k_queue_fill(ListQueue *__restrict__ q, ListSlot *__restrict__ s
 		ls.res_now = ls.res;
 		ls.oper_mode = oper_mode;
 		ls.frame = i;
+		ls.chunk = 0;
+		ls.pad = 0;
 		slots[i] = ls;
 	}
 	if (i == 0) {
@@ -532,11 +549,11 @@ void launch_finish(hipStream_t s, int list, int max_entries, const ListQueue *q,
 }
 void launch_back(hipStream_t s, int rate, int n, int cert_mode, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, ListQueue *q, ListSlot *slots,
-	float *llr_q, int *slot_of, uint8_t *payload_later, Result *res_later, ScRing sc)
+	float *llr_q, int *slot_of, uint8_t *payload_later, Result *res_later, ScRing sc, int chunk_seq)
 {
 	const int sym_stride = rate_symbol_len(rate) + rate_symbol_len(rate) / 8;
 	hipLaunchKernelGGL(k_back, dim3(n), dim3(256), 0, s, sym_stride, cert_mode, st, cons, slope, yint, precision, res, esn0_rows, tb, descramble,
-		payload, q, slots, llr_q, slot_of, payload_later, res_later, sc);
+		payload, q, slots, llr_q, slot_of, payload_later, res_later, sc, chunk_seq);
 }
 
 }  // namespace rx

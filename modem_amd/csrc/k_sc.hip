@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 // in the list decoder's queue.
 __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, const ListSlot *__restrict__ slots_s, const float *__restrict__ llr_s,
 	const unsigned long long *__restrict__ cw_q, const unsigned long long *__restrict__ xw_q, const ScStat *__restrict__ stat_q, Tables tb, int descramble,
-	ListQueue *__restrict__ ql, ListSlot *__restrict__ slots_l, float *__restrict__ llr_l, int *__restrict__ slot_of)
+	ListQueue *__restrict__ ql, ListSlot *__restrict__ slots_l, float *__restrict__ llr_l, int *__restrict__ slot_of, int chunk_seq)
 {
 	const int rel = blockIdx.x, tid = threadIdx.x;
 	const unsigned run_n = qs->run_n[0], run_head = qs->run_head[0], cap = qs->cap;
@@ -589,6 +589,11 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 	const int slot = (int)((run_head + (unsigned)rel) % cap);
 	const ListSlot ls = slots_s[slot];
 	const ScStat st = stat_q[slot];
+	// an entry a run left over for this one (k_sc_plan): its chunk's own arrays (a staging buffer, when the outputs go to the host) have
+	// left, its outputs go where the list decoder's would, and the per-chunk slot table is another chunk's by now
+	const bool late = ls.chunk != chunk_seq;
+	uint8_t *const pay_dst = late ? ls.payload : ls.payload_now;
+	Result *const res_dst = late ? ls.res : ls.res_now;
 	__shared__ uint32_t bits[CODE_LEN / 32];
 	__shared__ uint8_t mesg[MESG_BYTES_MAX];
 	__shared__ uint32_t ctab[256], csh[1024], cpart[32];
@@ -658,12 +663,13 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 		if ((tid & 63) == 0)
 			flips_red[tid >> 6] = flips;
 		for (int i = tid; i < PAYLOAD_BYTES; i += 256)
-			ls.payload_now[i] = mesg[i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);
+			pay_dst[i] = mesg[i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);
 		__syncthreads();
 		if (tid == 0) {
-			ls.res_now->best_lane = 0;
-			ls.res_now->bit_flips = flips_red[0] + flips_red[1] + flips_red[2] + flips_red[3];
-			slot_of[ls.frame] = -2 - slot;
+			res_dst->best_lane = 0;
+			res_dst->bit_flips = flips_red[0] + flips_red[1] + flips_red[2] + flips_red[3];
+			if (!late)
+				slot_of[ls.frame] = -2 - slot;
 			atomicAdd(&qs->certified, 1u);
 			atomicAdd(&qs->done_total, 1u);
 		}
@@ -673,7 +679,8 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 		const unsigned e = atomicAdd(&ql->tail, 1u);
 		const int lslot = (int)(e % ql->cap);
 		slots_l[lslot] = ls;
-		slot_of[ls.frame] = lslot;
+		if (!late)
+			slot_of[ls.frame] = lslot;
 		slot_sh = lslot;
 	}
 	__syncthreads();
@@ -688,9 +695,13 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 // k_back then sends a probe sample only (one frame in sixteen of every fourth chunk: a run that small still costs a codeword's
 // latency, 2 ms, with the machine idle) and the rest straight to the list decoder, and all of them again when an eighth of the
 // sample is decided.  (Frames whose Es/N0 estimate rules the pass out never come here at all: k_back.)  Either way every decision is exact: the list decoder is the general path.
-__global__ void k_sc_plan(ListQueue *__restrict__ qs)
+// A run takes whole multiples of `unit` (one residency of k_sc's persistent decoders: a codeword is one decoder's serial work, so the
+// tail of a run is a round in which most decoders idle) and leaves the rest to the next chunk's run; force (the last chunk of a
+// call, calls whose outputs leave chunk by chunk) and the probe sample take everything.
+__global__ void k_sc_plan(ListQueue *__restrict__ qs, unsigned unit, int force)
 {
-	const unsigned head = qs->head, n = qs->tail - head;
+	const unsigned head = qs->head, waiting = qs->tail - head;
+	const unsigned n = (force || !qs->cert_on || unit <= 1) ? waiting : (waiting / unit) * unit;
 	qs->run_head[0] = head;
 	qs->run_n[0] = n;
 	qs->head = head + n;
@@ -702,10 +713,22 @@ __global__ void k_sc_adapt(ListQueue *__restrict__ qs)
 {
 	const unsigned tried = qs->tried, done = qs->certified;
 	if (qs->cert_on) {
-		if (tried >= 64 && done * 8 < tried)
+		if (tried >= 64 && done * 8 < tried) {
 			qs->cert_on = 0;
-	} else if (tried >= 8 && done * 8 >= tried)
-		qs->cert_on = 1;
+			qs->probe_tried = qs->probe_done = 0;
+		}
+	} else {
+		// (a chunk of fewer than 128 frames sends fewer than eight probe frames: the sample is summed over chunks - round-5 advisor)
+		const unsigned pt = qs->probe_tried + tried, pd = qs->probe_done + done;
+		if (pt >= 8) {
+			if (pd * 8 >= pt)
+				qs->cert_on = 1;
+			qs->probe_tried = qs->probe_done = 0;
+		} else {
+			qs->probe_tried = pt;
+			qs->probe_done = pd;
+		}
+	}
 	qs->epoch += 1;
 }
 
@@ -728,11 +751,11 @@ void launch_sc(hipStream_t s, int lb, int grid5, int grid6, ListQueue *q, const 
 		hipLaunchKernelGGL(k_sc<5>, dim3(grid5), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev32, small_run);
 }
 void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
-	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of)
+	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of, int chunk_seq)
 {
-	hipLaunchKernelGGL(k_sc_finish, dim3(max_entries), dim3(256), 0, s, qs, slots_s, llr_s, cw_q, xw_q, stat_q, tb, descramble, ql, slots_l, llr_l, slot_of);
+	hipLaunchKernelGGL(k_sc_finish, dim3(max_entries), dim3(256), 0, s, qs, slots_s, llr_s, cw_q, xw_q, stat_q, tb, descramble, ql, slots_l, llr_l, slot_of, chunk_seq);
 }
-void launch_sc_plan(hipStream_t s, ListQueue *qs) { hipLaunchKernelGGL(k_sc_plan, dim3(1), dim3(1), 0, s, qs); }
+void launch_sc_plan(hipStream_t s, ListQueue *qs, unsigned unit, int force) { hipLaunchKernelGGL(k_sc_plan, dim3(1), dim3(1), 0, s, qs, unit, force); }
 void launch_sc_adapt(hipStream_t s, ListQueue *qs) { hipLaunchKernelGGL(k_sc_adapt, dim3(1), dim3(1), 0, s, qs); }
 
 }  // namespace rx

@@ -119,10 +119,14 @@ struct ListQueue {
 	unsigned cap;                  // slots
 	unsigned done_total;           // SC ring only: frames k_sc_finish has finished since the call began
 	unsigned epoch;                // SC ring only: chunks since the call began (k_sc_adapt): the probe sample runs in every fourth
+	unsigned probe_tried, probe_done;   // while cert_on = 0: the probe sample's counts, summed over chunks until eight frames have been tried
 };
 // The SC ring (k_sc.hip) is a second queue of the same shape in front of this one: k_back puts a frame there when the SC pass is
-// on (its cert_on; tried / certified count the last run's entries / decided frames), k_sc | k_sc_finish drain it right behind
-// k_back of the same chunk on the same stream, and what they cannot decide moves on to the list decoder's queue.
+// on (its cert_on; tried / certified count the last run's entries / decided frames), k_sc_plan | k_sc | k_sc_finish run right behind
+// k_back of every chunk on the same stream, and what they cannot decide moves on to the list decoder's queue.  Like a flush of the
+// list decoder, a run takes WHOLE residencies of k_sc's persistent decoders (round 6: a codeword is one decoder's serial work of
+// 1.2 ms, so a run of 8192 entries on 2560 decoders took the time of four rounds for 3.2 rounds of work); what is left over waits
+// for the next chunk's run, and the last run of a call takes everything.
 struct ScStat { float metric, min_fork; int32_t ok, pad; };   // per SC-ring slot: P*'s metric, min_fork, rule holds
 struct ListSlot {                  // what k_polar / k_finish need to know about a queued frame
 	uint8_t *payload;              // where its 5380 bytes go when the list decoder's flush delivers them (k_finish)
@@ -131,6 +135,8 @@ struct ListSlot {                  // what k_polar / k_finish need to know about
 	struct Result *res_now;        // before a staging buffer of the chunk leaves (launch_back: payload_later)
 	int oper_mode;
 	int frame;                     // index in its chunk
+	int chunk;                     // which chunk of its call: a frame the list-1 pass finishes in a LATER chunk's run goes to payload / res
+	int pad;
 };
 struct ScRing { ListQueue *q; ListSlot *slots; float *llr; };  // what k_back needs of the SC ring (q = nullptr: the pass is off)
 
@@ -177,7 +183,7 @@ void launch_theil_sen_raw(hipStream_t s, int rows, int cols, const float *y, flo
 // chunk's own arrays may be a staging buffer that has been copied out and reused by the time their flush comes
 void launch_back(hipStream_t s, int rate, int n, int cert_mode, const SyncState *st, const cf *cons, const float *slope, const float *yint,
 	float *precision, Result *res, float *esn0_rows, Tables tb, int descramble, uint8_t *payload, ListQueue *q, ListSlot *slots,
-	float *llr_q, int *slot_of, uint8_t *payload_later = nullptr, Result *res_later = nullptr, ScRing sc = ScRing{ nullptr, nullptr, nullptr });
+	float *llr_q, int *slot_of, uint8_t *payload_later = nullptr, Result *res_later = nullptr, ScRing sc = ScRing{ nullptr, nullptr, nullptr }, int chunk_seq = 0);
 void launch_rotate_tap(hipStream_t s, const SyncState *st, const cf *cons, const float *slope, const float *yint, cf *out);   // one frame, CONS_MAX points
 void launch_queue_reset(hipStream_t s, ListQueue *q, unsigned cap);
 void launch_queue_snap(hipStream_t s, ListQueue *q, int par);
@@ -185,11 +191,12 @@ void launch_queue_plan(hipStream_t s, ListQueue *q, int par, unsigned unit, int 
 void launch_queue_fill(hipStream_t s, ListQueue *q, ListSlot *slots, int n, uint8_t *payload, Result *res, int oper_mode);
 // the sign-following path alone + its certificate (k_sc.hip): grid = resident decoders (sc_store_bytes() of level store each),
 // lb = log2 of the lanes per codeword: 5 (two codewords per wave), 6 (one), 0: both launched, the run's length picks one on the device
-void launch_sc_plan(hipStream_t s, ListQueue *qs);
+// unit: a run takes whole multiples of it (0 / force: everything that waits)
+void launch_sc_plan(hipStream_t s, ListQueue *qs, unsigned unit = 0, int force = 1);
 void launch_sc(hipStream_t s, int lb, int grid5, int grid6, ListQueue *qs, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
 	unsigned long long *xw_q, ScStat *stat_q, Tables tb);
 void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
-	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of);
+	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of, int chunk_seq = 0);
 void launch_sc_adapt(hipStream_t s, ListQueue *qs);
 size_t sc_store_bytes(int lb);  // level store per resident decoder
 int sc_codewords_per_wave(int lb);

@@ -138,6 +138,7 @@ struct ofdmrx_handle {
 	// decisions, ScStat), one level store per resident decoder
 	DevBuf s_ctl, s_slots, s_llr, s_cw, s_xw, s_stat, sc_soft;
 	unsigned s_cap = 0;
+	unsigned sc_unit = 1;     // entries a run of the list-1 pass takes at a time: one residency of its decoders (the last run of a call: everything)
 	int sc_mode = 1;          // 1: the list-1 pass (adaptive) in front of the list decoder, 0: off
 	int sc_grid = 0, sc_grid6 = 0;   // resident SC decoders (waves): two codewords per wave / one (k_sc.hip)
 	int sc_lb = 6;            // one codeword per wave (6, the default: with 64 loads in flight it is the faster layout at every run length, and
@@ -429,8 +430,11 @@ static int ensure_capacity(ofdmrx_handle *h, int n, bool mono, long samples)
 		r = r ? r : h->q_metric.ensure(Q * LIST * sizeof(float));
 		if (h->cfg.flags & 1)                                     // (the per-lane messages are a debug tap)
 			r = r ? r : h->q_lane_mesg.ensure(Q * LIST * MESG_BYTES);
-		if (h->sc_mode) {                                         // the SC ring is drained right behind k_back of every chunk: one chunk of slots
-			h->s_cap = (unsigned)(N + 8);
+		if (h->sc_mode) {                                         // the SC ring: a run behind k_back of every chunk takes whole residencies of
+			// k_sc's decoders and leaves less than one of them to the next chunk (k_sc_plan): one chunk of slots + that
+			const int sc_waves = h->sc_lb == 5 ? h->sc_grid * sc_codewords_per_wave(5) : h->sc_grid6;
+			h->sc_unit = (unsigned)std::max<long>(1, std::min<long>((long)N, (long)sc_waves));
+			h->s_cap = (unsigned)(N + h->sc_unit + 8);
 			const size_t S = h->s_cap;
 			r = r ? r : h->s_ctl.ensure(sizeof(ListQueue));
 			r = r ? r : h->s_slots.ensure(S * sizeof(ListSlot));
@@ -561,33 +565,34 @@ static int run_front2(ofdmrx_handle *h, hipStream_t s, int n)
 
 // The list-1 pass on what k_back put into the SC ring (k_sc.hip): frames it decides are finished, the rest move on to the list
 // decoder's queue - all in stream order with k_back's own entries there, so the snapshot behind it sees complete entries only
-static void run_sc_pass(ofdmrx_handle *h, hipStream_t s, int n)
+static void run_sc_pass(ofdmrx_handle *h, hipStream_t s, int n, bool force = true, int chunk_seq = 0)
 {
 	Range r("ofdmrx:sc_path");
-	launch_sc_plan(s, h->sc_queue());
+	launch_sc_plan(s, h->sc_queue(), h->sc_unit, force ? 1 : 0);
 	launch_sc(s, h->sc_lb, std::min(h->sc_grid, (n + 1) / 2), std::min(h->sc_grid6, n), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(),
 		h->sc_soft.as<float>(), h->s_cw.as<unsigned long long>(), h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev);
-	launch_sc_finish(s, n, h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->s_cw.as<unsigned long long>(),
+	launch_sc_finish(s, (int)std::min<unsigned>(h->s_cap, (unsigned)n + h->sc_unit), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->s_cw.as<unsigned long long>(),
 		h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev, h->cfg.descramble, h->queue(), h->q_slots.as<ListSlot>(),
-		h->q_llr.as<float>(), h->slot_of.as<int>());
+		h->q_llr.as<float>(), h->slot_of.as<int>(), chunk_seq);
 	launch_sc_adapt(s, h->sc_queue());
 }
 
 // D5's rotation + D6-D8 + the certificate: frames it finishes get payload + result here, the others a queue slot and their LLRs
+// sc_force: the list-1 pass takes everything that waits in its ring (else whole residencies); chunk_seq: which chunk of its call
 static int run_back(ofdmrx_handle *h, hipStream_t s, int par, int n, Result *d_res, float *d_esn0, uint8_t *d_payload,
-	uint8_t *payload_later = nullptr, Result *res_later = nullptr)
+	uint8_t *payload_later = nullptr, Result *res_later = nullptr, bool sc_force = true, int chunk_seq = 0)
 {
 	size_t e5 = mark(h, s);
 	{
 		Range r("ofdmrx:back");
 		launch_back(s, h->rate, n, h->cert_mode, h->st.as<SyncState>(), h->cons.as<cf>(), h->slope.as<float>(), h->yint.as<float>(),
 			h->precision.as<float>(), d_res, d_esn0, h->dev, h->cfg.descramble, d_payload, h->queue(), h->q_slots.as<ListSlot>(),
-			h->q_llr.as<float>(), h->slot_of.as<int>(), payload_later, res_later, h->sc_ring());
+			h->q_llr.as<float>(), h->slot_of.as<int>(), payload_later, res_later, h->sc_ring(), chunk_seq);
 	}
 	size_t e6 = mark(h, s);
 	h->spans.push_back({ OFDMRX_T_LLR, e5, e6 });
 	if (h->sc_mode) {
-		run_sc_pass(h, s, n);
+		run_sc_pass(h, s, n, sc_force, chunk_seq);
 		size_t e7 = mark(h, s);
 		h->spans.push_back({ T_SC, e6, e7 });
 	}
@@ -726,7 +731,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 	const bool overlap = n_chunks > 1 && !std::getenv("OFDMRX_NO_OVERLAP");
 	hipStream_t sa = h->stream, sb = overlap ? h->stream_b : sa, sc = overlap ? h->stream_fin : sa;
 	const bool every = hooks.outputs_leave_by_chunk();
-	std::vector<size_t> ev_back(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_fin(n_chunks, NONE), t0s(n_chunks, 0);
+	std::vector<size_t> ev_back(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_fin(n_chunks, NONE), ev_out(n_chunks, NONE), t0s(n_chunks, 0);
 	launch_queue_reset(sa, h->queue(), h->q_cap);
 	if (h->sc_mode)
 		launch_queue_reset(sa, h->sc_queue(), h->s_cap);
@@ -740,6 +745,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 				HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_fin[p - 2]], 0));   // k_finish(p - 2) has read the run of this parity
 		}
 		int rr = hooks.before_flush(p, sc, h->ev_pool[ev_back[p]]);
+		ev_out[p] = mark(h, sc);                                  // (the chunk's own arrays have left for the host, if that is where they go)
 		rr = rr ? rr : run_flush(h, sb, sc, par, every || p + 1 == n_chunks, t0s[p], &ev_polar[p]);
 		rr = rr ? rr : hooks.after_flush(p, sc);
 		ev_fin[p] = mark(h, sc);
@@ -776,7 +782,11 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 		uint8_t *pay_later;
 		Result *res_later;
 		hooks.dst_later(c, &pay_later, &res_later);
-		r = run_back(h, sa, (int)(c & 1), n, res, hooks.esn0(c), pay, pay_later, res_later);
+		// a frame the list-1 pass left over from chunk c - 1 is finished by this chunk's run and delivered where the list decoder's
+		// frames are (pay_later: the caller's arrays): behind the copy that took chunk c - 1's own arrays there
+		if (overlap && c >= 1 && h->sc_mode && ev_out[c - 1] != NONE)
+			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_out[c - 1]], 0));
+		r = run_back(h, sa, (int)(c & 1), n, res, hooks.esn0(c), pay, pay_later, res_later, every || c + 1 == n_chunks, (int)c);
 		ev_back[c] = mark(h, sa);
 		if (!r && !overlap)
 			r = flush(c, NONE);
