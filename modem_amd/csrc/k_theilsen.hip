@@ -686,14 +686,12 @@ __device__ __forceinline__ float2 theil_sen_wave(TsLds &s, int n, int lane)
 		TS_SYNC();
 		uint32_t cand = s.lst[0];
 		for (int round = 0; round < 6 && !have; ++round) {
-			int lt = 0, le = 0;
+			int both = 0;                                         // #{b < cand} in the low half, #{b <= cand} in the high half (n <= 512): one wave sum
 			#pragma unroll
-			for (int t = 0; t < 8; ++t) {
-				lt += bk[t] < cand;
-				le += bk[t] <= cand;
-			}
-			lt = wave_sum_i(lt);
-			le = wave_sum_i(le);
+			for (int t = 0; t < 8; ++t)
+				both += (int)(bk[t] < cand) + ((int)(bk[t] <= cand) << 16);
+			both = wave_sum_i(both);
+			const int lt = both & 0xffff, le = both >> 16;
 			if (lt <= n / 2 && n / 2 < le) {
 				have = true;
 			} else if (lt > n / 2) {                              // too high: the largest value below it
@@ -780,16 +778,29 @@ __device__ __forceinline__ void ts_row(TsLds &s, int f, int j, int lane, const M
 	const int cols = md.cols;
 	cf *row = cons_all + (size_t)f * CONS_MAX + (size_t)j * cols;
 	const cf *cr = carr_all ? carr_all + (size_t)f * CARR_MAX + (size_t)j * cols : nullptr;
-	#pragma unroll 1
-	for (int q = 0; q < 8; ++q) {                                 // decode.cc:482-487
+	// decode.cc:482-487.  The lane's points lane + 64 q are fetched together, then turned into phases: one point per round trip (the
+	// round-5 form) left a wave parked at s_waitcnt for 80 % of this stage - a fifth of its life (profiles/r06_theil_sen_by_stage.txt)
+	cf pt[8], pv[8];
+	#pragma unroll
+	for (int q = 0; q < 8; ++q) {
 		const int i = lane + 64 * q;
 		if (i < cols) {
-			cf c;
-			if (cr) {                                             // decode.cc:474-475
-				c = demod_or_erase(cr[cols + i], cr[i]);
-				row[i] = c;
+			if (cr) {
+				pt[q] = cr[cols + i];
+				pv[q] = cr[i];
 			} else
-				c = row[i];
+				pt[q] = row[i];
+		}
+	}
+	#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		const int i = lane + 64 * q;
+		if (i < cols) {
+			cf c = pt[q];
+			if (cr) {                                             // decode.cc:474-475
+				c = demod_or_erase(pt[q], pv[q]);
+				row[i] = c;
+			}
 			cf d = cmul(c, cconj(md.mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c)));
 			s.y[ts_yaddr(i)] = ts_phase(d, md.mod_bits);
 		}

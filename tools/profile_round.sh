@@ -6,9 +6,9 @@
 #   the default path at -30 dB [cert], the list decoder forced [scl], the default path at -20 dB where the list-1 pass decides [sc];
 #   the FETCH_SIZE / WRITE_SIZE calibration (tools/pmc_calib.hip); the issue-rate microbenchmark (tools/ubench_issue.hip).
 # Only text leaves the box: gpurun_out/TAG_summary.txt, TAG_bench_n1*.json, TAG_issue_rates_ubench.txt, TAG_traffic.json (copy the
-# last two to profiles/r05_issue_rates_ubench.txt / profiles/r05_traffic.json: bench.py reads the per-kernel HBM bytes, VALU
+# last two to profiles/r06_issue_rates_ubench.txt / profiles/r06_traffic.json: bench.py reads the per-kernel HBM bytes, VALU
 # instruction counts and the measured issue ceiling from the latter)
-TAG=${1:-r05_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
+TAG=${1:-r06_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
 S=$G/${TAG}_summary.txt; : > $S
 make -C modem_amd/csrc -q all && echo "# library up to date with sources" >> $S || echo "# STALE LIBRARY" >> $S
 cd /tmp; export TMPDIR=/tmp
@@ -83,8 +83,8 @@ stages = {"sync": ("cert", "k_sync", "k_sync.hip"), "header": ("cert", "k_header
           "theilsen": ("cert", "k_theil_sen", "k_theilsen.hip"), "llr": ("cert", "k_back", "k_finish.hip"), "finish": ("cert", "k_finish", "k_finish.hip"),
           "polar": ("scl", "k_polar", "k_polar.hip"), "sc": ("sc", "k_sc", "k_sc.hip")}
 ub = open(sys.argv[3]).read() if len(sys.argv) > 3 and os.path.exists(sys.argv[3]) else ""
-# the ceiling = the best rate the box reached for plain fp32 vector instructions with two or more waves per SIMD
-mu = min(((float(a), float(g)) for w, a, g in re.findall(r"^v_add_f32\s+waves/SIMD=(\d)\s+ns/instr/SIMD=([0-9.]+).*?= ([0-9.]+) GHz", ub, re.M) if int(w) >= 2), default=None)
+# the ceiling = the best in-kernel rate of plain fp32 FMAs with one workgroup per CU and 2 - 4 waves per SIMD (placement verified by the benchmark itself)
+mu = min(((float(a), float(g)) for w, a, g in re.findall(r"^v_fma_f32 x8 independent\s+waves/SIMD=(\d)\s+ns/valu/SIMD: in-kernel ([0-9.]+).*?clock=([0-9.]+) GHz", ub, re.M) if 2 <= int(w) <= 4), default=None)
 out = {"frames_per_launch": 8192, "valu_ns_per_inst_per_simd": mu[0] if mu else None, "sclk_GHz_measured": mu[1] if mu else None, "fetch_scale": 2097152.0 / calib("calib_read", "FETCH_SIZE"), "write_scale": 2097152.0 / calib("calib_write", "WRITE_SIZE"),
        "kernels": {},
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --frames 16384 --steps 1 --warmup 0 --cpu-frames 0 "
@@ -94,6 +94,13 @@ for st, (mode, kern, src) in stages.items():
     f, w = grab(mode, kern, "FETCH_SIZE"), grab(mode, kern, "WRITE_SIZE")
     if f is not None and w is not None:
         out["kernels"][st] = {"kernel": kern, "fetch_KiB": f, "write_KiB": w, "valu_insts": grab(mode, kern, "SQ_INSTS_VALU"), "src_sha": sha(src)}
+# mono input (configs[1]): the same stages from the [mono] passes (one 8192-frame chunk); `front` = k_mono_carries
+out["kernels_mono"] = {}
+for st, (kern, src) in {"front": ("k_mono_carries", "k_sync.hip"), "sync": ("k_sync", "k_sync.hip"), "header": ("k_header", "k_header.hip"),
+                        "demod": ("k_demod", "k_demod.hip"), "theilsen": ("k_theil_sen", "k_theilsen.hip"), "llr": ("k_back", "k_finish.hip")}.items():
+    f, w = grab("mono", kern, "FETCH_SIZE"), grab("mono", kern, "WRITE_SIZE")
+    if f is not None and w is not None:
+        out["kernels_mono"][st] = {"kernel": kern, "fetch_KiB": f, "write_KiB": w, "valu_insts": grab("mono", kern, "SQ_INSTS_VALU"), "src_sha": sha(src)}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 PY
 tail -5 $S; cat $G/${TAG}_traffic.json; cat $G/${TAG}_bench_n1.json | cut -c1-600

@@ -17,7 +17,7 @@
 #include <map>
 #include <algorithm>
 #define N_IT 4096
-struct WgRec { unsigned long long t0, t1; uint32_t hw_id, xcc_id; };
+struct WgRec { unsigned long long t0, t1, w0, w1; uint32_t hw_id, xcc_id; };   // s_memtime span, 100 MHz wall-clock span
 
 #define R8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 template <int OP>
@@ -36,7 +36,7 @@ __global__ void k(uint32_t *out, WgRec *rec, float seed)
 	uint32_t hw = 0, xcc = 0;
 	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
 	__syncthreads();
-	const unsigned long long t0 = __builtin_readcyclecounter();
+	const unsigned long long w0 = wall_clock64(), t0 = __builtin_readcyclecounter();
 	#pragma unroll 1
 	for (int i = 0; i < N_IT; ++i) {
 		// 16 instructions per iteration in every stream
@@ -104,9 +104,9 @@ __global__ void k(uint32_t *out, WgRec *rec, float seed)
 			: "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]),
 			  "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(m) : "s20", "s21", "scc");
 	}
-	const unsigned long long t1 = __builtin_readcyclecounter();
+	const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
 	if (threadIdx.x == 0)
-		rec[blockIdx.x] = WgRec{ t0, t1, hw, xcc };
+		rec[blockIdx.x] = WgRec{ t0, t1, w0, w1, hw, xcc };
 	float s = 0.f;
 	#pragma unroll
 	for (int i = 0; i < 8; ++i)
@@ -138,8 +138,9 @@ template <int OP> void run(const char *name, int valu_per_iter)
 		hipMemcpy(h.data(), rec, grid * sizeof(WgRec), hipMemcpyDeviceToHost);
 		// placement: (xcc, se, sh, cu) of every workgroup; how many ran on the same CU with overlapping spans
 		std::map<uint32_t, std::vector<int>> by_cu;
-		double cyc_sum = 0; unsigned long long cyc_max = 0;
+		double cyc_sum = 0, wall_sum = 0; unsigned long long cyc_max = 0;
 		for (int i = 0; i < grid; ++i) {
+			wall_sum += (double)(h[i].w1 - h[i].w0) * 10.0;          // ns: wall_clock64 ticks at 100 MHz
 			const uint32_t key = ((h[i].xcc_id & 15u) << 16) | (h[i].hw_id & 0xff00u);   // HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
 			by_cu[key].push_back(i);
 			const unsigned long long dt = h[i].t1 - h[i].t0;
@@ -157,11 +158,13 @@ template <int OP> void run(const char *name, int valu_per_iter)
 			max_conc = std::max(max_conc, conc);
 			cus_with_wrong += conc != c.wg_per_cu;
 		}
-		const double n = (double)N_IT * valu_per_iter * c.w;       // vector wave-instructions per SIMD
-		const double cyc = cyc_sum / grid;
-		printf("%-30s waves/SIMD=%d  ns/valu/SIMD=%.3f  s_memtime cycles/valu/SIMD=%.2f (slowest workgroup %.2f)  clock=%.2f GHz  | placement: %zu distinct CUs, "
-			"%d workgroups at once on the fullest, %d CUs off the plan\n", name, c.w, ms * 1e6 / n, cyc / n, (double)cyc_max / n,
-			cyc_max ? (double)cyc_max / (ms * 1e6) : 0.0, by_cu.size(), max_conc, cus_with_wrong);
+		// per SIMD: a workgroup's waves issue N_IT x valu_per_iter x (waves per SIMD OF THAT WORKGROUP) instructions during its own span;
+		// with two workgroups on a CU the spans overlap (checked below) and the SIMD issues both streams
+		const double n_wg = (double)N_IT * valu_per_iter * c.w / c.wg_per_cu, n = n_wg * c.wg_per_cu;
+		const double cyc = cyc_sum / grid, wall_wg = wall_sum / grid;
+		printf("%-30s waves/SIMD=%d  ns/valu/SIMD: in-kernel %.3f, launch %.3f  cycles/valu/SIMD=%.2f (slowest workgroup %.2f)  clock=%.2f GHz  workgroup spans cover %.0f%% of the launch"
+			"  | placement: %zu distinct CUs, %d workgroups at once on the fullest, %d CUs off the plan\n", name, c.w, wall_wg / n, ms * 1e6 / n, cyc / n, (double)cyc_max / n,
+			wall_wg > 0 ? cyc / wall_wg : 0.0, 100.0 * wall_wg / (ms * 1e6), by_cu.size(), max_conc, cus_with_wrong);
 	}
 	hipFree(out); hipFree(rec);
 }
@@ -169,7 +172,8 @@ int main()
 {
 	hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
 	g_cus = p.multiProcessorCount;
-	printf("# %s, %d CUs; clock = the slowest workgroup's s_memtime ticks / the launch's wall time (a lower bound of the shader clock)\n", p.gcnArchName, g_cus);
+	printf("# %s, %d CUs; in-kernel = a workgroup's own span on the 100 MHz wall clock (wall_clock64) / the vector instructions its SIMD issued; launch = hipEvent time of the\n"
+		"# launch / the same (includes the dispatch of the workgroups); clock = s_memtime ticks / wall-clock span of a workgroup\n", p.gcnArchName, g_cus);
 	run<0>("v_fma_f32 x8 independent", 16);
 	run<1>("v_pk_fma_f32 x4 independent", 16);
 	run<2>("v_min/max_u32 x8", 16);
