@@ -26,6 +26,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (GPU_MAX_HW_QUEUES is left at the runtime's default, 4: HIP maps streams onto that many hardware queues and kernels of streams that
+# share one run in order.  With 8 or 16 the two-lane legs below gain more (+7 % instead of +3.5 %), but a list-decoder stream with a
+# queue of its own lets the EMPTY k_polar launches of the one-lane path - 4096 workgroups that leave at once - contend with the front
+# kernels: 0.9 ms per chunk whenever the mapping falls that way.  profiles/r06_hw_queues_and_two_lanes.txt)
 
 B_FRAME_2CH = 95200 * 2 * 2 + 5380      # algorithmic bytes per frame, SURVEY 8(d): 386180
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -484,8 +488,24 @@ def main():
                     rx3.decode_device(d_leg.data_ptr(), M.FMT_S16, lch, spf, spf * 2 * lch, 8192, d_out[1].data_ptr(), d_res[1].data_ptr())
                 fence()
                 share = 8192 * 4 / (time.perf_counter() - t0)
+            # the same batch through a handle with OFDMRX_FLAG_TWO_LANES (include/ofdmrx.h revision 1.6: the call's second half runs
+            # through a second pipeline beside the first); opt-in, so outside the leg's `value`
+            lanes2 = None
+            if lch == 2 and B >= 4 * rx3.chunk_frames:
+                rx4 = modem_amd.Receiver(device=local_rank, chunk_frames=args.chunk, stream=stream.cuda_stream, sample_rate=args.rate,
+                                         list_size=args.list, two_lanes=True)
+                for _ in range(2):
+                    rx4.decode_device(d_leg.data_ptr(), M.FMT_S16, lch, spf, spf * 2 * lch, B, d_out[1].data_ptr(), d_res[1].data_ptr())
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    rx4.decode_device(d_leg.data_ptr(), M.FMT_S16, lch, spf, spf * 2 * lch, B, d_out[1].data_ptr(), d_res[1].data_ptr())
+                fence()
+                lanes2 = {"value": B * 3 / (time.perf_counter() - t0), "steps": 3,
+                          "outputs_identical_to_one_lane": bool((d_out[1] == d_out[0]).all().item()) and bool((d_res[1] == d_res[0]).all().item())}
+                rx4.close()
             extra[name] = {"value": B * lsteps / dt, "unit": "frames/s", "steps": lsteps, "frames": B, "workload": what,
-                           "value_one_call_of_8192_frames": share,
+                           "value_one_call_of_8192_frames": share, "value_two_lanes": lanes2,
                            "list_decoded_frames": leg_listed, "routes": leg_routes, "fer": ferr / float(B),
                            "definition": "default handle, payloads left in HBM, outside `value`",
                            "stage_ms_per_step": {k: v / lsteps for k, v in lsm.items()}, "_stage": (lsm, lsl, lsteps, lch)}

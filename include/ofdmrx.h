@@ -44,8 +44,11 @@ extern "C" {
  *      (OFDMRX_FLAG_NO_SC); `samples` and the frame stride must be multiples of the sample FRAME size (2-channel input: of the I/Q pair);
  *      with pinned host outputs the optional Es/N0 rows and attempt log must be pinned host memory as well (else OFDMRX_E_ARG); frames
  *      with raw bit errors whose sign-following path provably is the list decoder's lane 0 are finished by a list-1 decode of
- *      that path (same outputs) */
-#define OFDMRX_ABI_MINOR 5
+ *      that path (same outputs)
+ *   6: ofdmrx_config.flags bit 3 (OFDMRX_FLAG_TWO_LANES): a device-entry call of four chunks or more runs its second half through a
+ *      second pipeline beside the first (same outputs; the handle then holds the state of two pipelines); the list-1 pass takes whole
+ *      residencies of its decoders and leaves the rest to the next chunk's run (same outputs) */
+#define OFDMRX_ABI_MINOR 6
 
 #define OFDMRX_PAYLOAD_BYTES 5380     /* decode.cc:587  data_len = 43040/8 */
 #define OFDMRX_CODE_LEN 65536         /* decode.cc:309  code_order 16 */
@@ -75,6 +78,7 @@ enum {
 #define OFDMRX_FLAG_KEEP_RAW_CONS 1
 #define OFDMRX_FLAG_SCL_ALWAYS 2
 #define OFDMRX_FLAG_NO_SC 4
+#define OFDMRX_FLAG_TWO_LANES 8
 
 typedef struct ofdmrx_handle ofdmrx_handle;
 
@@ -99,7 +103,13 @@ typedef struct {
 	                            * there when that path provably is the list decoder's lane 0 (min over the information leaves of
 	                            * fl(metric so far + |llr|) > the path's final metric) and its CRC-32 is zero - again
 	                            * with identical payload, status, best_lane (0) and bit_flips; every other frame is list-decoded;
-	                            * bit 2 (OFDMRX_FLAG_NO_SC): without that list-1 pass (syndrome check, then the list decoder) */
+	                            * bit 2 (OFDMRX_FLAG_NO_SC): without that list-1 pass (syndrome check, then the list decoder);
+	                            * bit 3 (OFDMRX_FLAG_TWO_LANES): cut a device-entry call of four chunks or more in two and run the second
+	                            * half through a second pipeline beside the first (created on first use; it doubles the handle's device
+	                            * state, about 18 GB at the default chunk).  For input in which most frames have raw bit errors (-20 dB:
+	                            * +6 %, the README's multipath chain: +8 %; clean input: -1 %); wants GPU_MAX_HW_QUEUES=8 or more in the
+	                            * environment before the HIP runtime starts.  OFDMRX_LANES=2 / =1 in the
+	                            * environment overrides the flag */
 	void *stream;              /* hipStream_t to run on, NULL = library-owned stream.  Batches longer than one chunk
 	                            * also use library-owned streams for the list decoder and its finishing kernel (chunk
 	                            * pipeline); the given stream waits for them, so work enqueued on `stream` after a

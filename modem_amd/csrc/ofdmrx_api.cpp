@@ -179,6 +179,18 @@ struct ofdmrx_handle {
 	ofdmrx_timing timing{};
 	float sc_ms = 0.f;        // the list-1 pass (stage T_SC: ofdmrx_timing keeps its layout, ofdmrx_get_sc_timing reports it)
 	int sc_launches = 0;
+	// Two lanes (round 6, opt-in: OFDMRX_FLAG_TWO_LANES / OFDMRX_LANES=2): a device-entry call of four chunks or more is cut in two,
+	// the second half runs through a second pipeline of the same configuration - `lane2`, a handle of its own with its own streams
+	// and state - beside the first.  Kernels of the two lanes fill each other's gaps - the tail of a k_sc run in which most
+	// persistent decoders have run out of codewords, the dispatch ramp of every launch: -20 dB 816 -> 850 - 865 k frames/s,
+	// configs[3] 892 -> 950 - 990 k, -26 dB 1.42 -> 1.56 M.  Where the syndrome certificate finishes every frame there is nothing
+	// to share (the front kernels are bound by vector issue): 1.82 M with one lane, 1.79 - 1.80 M with two - hence opt-in.  It needs
+	// hardware queues of its own: HIP maps streams onto GPU_MAX_HW_QUEUES of them (default 4) and kernels of streams that share
+	// one run in order (with 4 the lanes mostly alternate: 794 k at -20 dB).  profiles/r06_hw_queues_and_two_lanes.txt
+	ofdmrx_handle *lane2 = nullptr;
+	int lanes = 1;
+	size_t split_at = 0;      // frames of the last call that went through this handle's own pipeline (0: all of them)
+	hipEvent_t ev_lane_in = nullptr, ev_lane_done = nullptr;
 };
 
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -259,7 +271,9 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		}
 		h->own_stream = true;
 	}
-	for (hipStream_t *sx : { &h->stream_b, &h->stream_fin, &h->stream_c }) {
+	// (stream_c, the host-pointer entry's copy stream, is made by its first call: HIP maps streams onto a few hardware queues, and
+	// every stream that exists takes part in that)
+	for (hipStream_t *sx : { &h->stream_b, &h->stream_fin }) {
 		hipError_t e = hipStreamCreateWithFlags(sx, hipStreamNonBlocking);
 		if (e != hipSuccess) {
 			g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
@@ -281,6 +295,13 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		h->sc_grid6 = (std::getenv("OFDMRX_SC_WPC") ? swpc : 10) * std::max(cus, 1);   // 168 VGPRs, 16 KB of LDS: ten of these per CU
 		if (const char *e4 = std::getenv("OFDMRX_SC_LB"))
 			h->sc_lb = std::atoi(e4) == 5 ? 5 : (std::atoi(e4) == 0 ? 0 : 6);
+		h->lanes = (cfg->flags & OFDMRX_FLAG_TWO_LANES) ? 2 : 1;
+		if (const char *e5 = std::getenv("OFDMRX_LANES"))
+			h->lanes = std::atoi(e5) == 2 ? 2 : 1;
+		// handles with debug taps have one pipeline; the list decoder for every frame runs at the memory system's rate whatever is
+		// beside it
+		if (cfg->flags & (OFDMRX_FLAG_KEEP_RAW_CONS | OFDMRX_FLAG_SCL_ALWAYS))
+			h->lanes = 1;
 	}
 	build_tables(h->host, h->rate);
 	int r = 0;
@@ -315,6 +336,13 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 	if (!h)
 		return;
 	(void)hipSetDevice(h->cfg.device);
+	if (h->lane2)
+		ofdmrx_destroy(h->lane2);
+	h->lane2 = nullptr;
+	for (hipEvent_t e : { h->ev_lane_in, h->ev_lane_done })
+		if (e)
+			(void)hipEventDestroy(e);
+
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
 	for (hipStream_t sx : { h->stream_b, h->stream_fin, h->stream_c })
@@ -340,7 +368,12 @@ extern "C" void ofdmrx_destroy(ofdmrx_handle *h)
 
 extern "C" int ofdmrx_chunk_frames(ofdmrx_handle *h) { return h ? h->chunk : OFDMRX_E_ARG; }
 // index (in the last decode call) of the first frame of the LAST chunk that call ran: what frame 0 of ofdmrx_debug_dump is
-extern "C" long long ofdmrx_last_chunk_first_frame(ofdmrx_handle *h) { return h ? (long long)h->last_first : OFDMRX_E_ARG; }
+extern "C" long long ofdmrx_last_chunk_first_frame(ofdmrx_handle *h)
+{
+	if (!h)
+		return OFDMRX_E_ARG;
+	return (h->split_at && h->lane2) ? (long long)(h->split_at + h->lane2->last_first) : (long long)h->last_first;
+}
 
 // decode.cc:517-519 prints one Es/N0 value per constellation row; a batch caller gets them here: rows = n_frames x
 // OFDMRX_ROWS_MAX floats (dB; rows a frame's mode does not have, and frames without a header: 0) in the memory space of
@@ -377,9 +410,12 @@ extern "C" long long ofdmrx_list_decoded_frames(ofdmrx_handle *h)
 	if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
 		return OFDMRX_E_HIP;
 	ListQueue q;
-	if (hipMemcpy(&q, h->q_ctl.p, sizeof(q), hipMemcpyDeviceToHost) != hipSuccess)
+	if (hipMemcpyAsync(&q, h->q_ctl.p, sizeof(q), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
 		return OFDMRX_E_HIP;
-	return (long long)q.tail;                                 // entries queued since the call began
+	long long more = 0;
+	if (h->split_at && h->lane2 && (more = ofdmrx_list_decoded_frames(h->lane2)) < 0)
+		return more;
+	return (long long)q.tail + more;                          // entries queued since the call began (both lanes)
 }
 
 // frames of the last decode call that the list-1 pass finished; -1: that pass is off for this handle
@@ -394,9 +430,12 @@ extern "C" long long ofdmrx_sc_decided_frames(ofdmrx_handle *h)
 	if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
 		return OFDMRX_E_HIP;
 	ListQueue q;
-	if (hipMemcpy(&q, h->s_ctl.p, sizeof(q), hipMemcpyDeviceToHost) != hipSuccess)
+	if (hipMemcpyAsync(&q, h->s_ctl.p, sizeof(q), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
 		return OFDMRX_E_HIP;
-	return (long long)q.done_total;
+	long long more = 0;
+	if (h->split_at && h->lane2 && (more = ofdmrx_sc_decided_frames(h->lane2)) < 0)
+		return more;
+	return (long long)q.done_total + more;
 }
 
 // device state for chunks of up to n frames; the list decoder's queue for calls whose chunks have up to n frames
@@ -731,6 +770,10 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 	const bool overlap = n_chunks > 1 && !std::getenv("OFDMRX_NO_OVERLAP");
 	hipStream_t sa = h->stream, sb = overlap ? h->stream_b : sa, sc = overlap ? h->stream_fin : sa;
 	const bool every = hooks.outputs_leave_by_chunk();
+	// (The scan's slot of its own - sync(c) waits for polar(c - 2), polar(c - 1) for sync(c) - also keeps the list decoder's mostly
+	// EMPTY launches of the default path in a fixed place between the front kernels: without the two waits the headline loses 2 - 3 %,
+	// profiles/r06_hw_queues_and_two_lanes.txt)
+	const bool scan_slot = overlap;
 	std::vector<size_t> ev_back(n_chunks, NONE), ev_polar(n_chunks, NONE), ev_fin(n_chunks, NONE), ev_out(n_chunks, NONE), t0s(n_chunks, 0);
 	launch_queue_reset(sa, h->queue(), h->q_cap);
 	if (h->sc_mode)
@@ -739,7 +782,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 		const int par = (int)(p & 1);
 		if (overlap) {
 			HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_back[p]], 0));
-			if (ev_sync_next != NONE)
+			if (ev_sync_next != NONE && scan_slot)
 				HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_sync_next], 0));
 			if (p >= 2)
 				HIP_OK(hipStreamWaitEvent(sb, h->ev_pool[ev_fin[p - 2]], 0));   // k_finish(p - 2) has read the run of this parity
@@ -769,7 +812,7 @@ static int run_pipeline(ofdmrx_handle *h, PipeHooks &hooks, const ChunkPlan &pla
 		if (att && overlap && c >= 2)                             // (host entry: the log's staging of this parity has left with chunk c - 2)
 			HIP_OK(hipStreamWaitEvent(sa, h->ev_pool[ev_fin[c - 2]], 0));
 		r = run_front1(h, sa, fb, n, d_skip ? d_skip + plan.first(c) : nullptr, max_skip, &t0s[c], att, att_counts,
-			(overlap && c >= 2) ? ev_polar[c - 2] : NONE, &ev_sync);
+			(scan_slot && c >= 2) ? ev_polar[c - 2] : NONE, &ev_sync);
 		h->last_first = plan.first(c);
 		if (!r && overlap && c >= 1)                              // flush(c - 1): its LLRs are in the queue, sync(c) is on its way
 			r = flush(c - 1, ev_sync);
@@ -822,13 +865,10 @@ static int finish_call(ofdmrx_handle *h, int r)
 	return r;
 }
 
-extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int fmt, int channels,
+static int decode_device_lane(ofdmrx_handle *h, const void *d_samples, int fmt, int channels,
 	size_t spf, size_t stride, size_t n_frames, const int32_t *d_skip, uint8_t *d_payload, ofdmrx_frame_result *d_results)
 {
-	int r = check_args(h, d_samples, fmt, channels, spf, stride, n_frames, d_payload, d_results);
-	if (r)
-		return r;
-	HIP_OK(hipSetDevice(h->cfg.device));
+	int r = 0;
 	int max_skip = 0;
 	if (d_skip) {
 		// the counts steer the host loop (rounds of sync + header): fetched on the handle's stream, so they are ordered
@@ -922,10 +962,61 @@ extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_sample
 	return finish_call(h, run_pipeline(h, hooks, plan, fmt, channels, spf, stride, d_skip, max_skip));
 }
 
+extern "C" int ofdmrx_decode_batch_device(ofdmrx_handle *h, const void *d_samples, int fmt, int channels,
+	size_t spf, size_t stride, size_t n_frames, const int32_t *d_skip, uint8_t *d_payload, ofdmrx_frame_result *d_results)
+{
+	int r = check_args(h, d_samples, fmt, channels, spf, stride, n_frames, d_payload, d_results);
+	if (r)
+		return r;
+	HIP_OK(hipSetDevice(h->cfg.device));
+	// two lanes: whole chunks to each, the second half through lane2 (see ofdmrx_handle).  Not for calls with SKIP counts (their
+	// rounds are steered from the host), nor below four chunks of at least 1024 frames: a pipeline that short has nothing to share
+	const size_t chunk = (size_t)h->chunk;
+	const bool could_split = h->lanes == 2 && !d_skip && chunk >= 1024 && n_frames >= 4 * chunk;
+	h->split_at = 0;
+	if (!could_split)
+		return decode_device_lane(h, d_samples, fmt, channels, spf, stride, n_frames, d_skip, d_payload, d_results);
+	if (!h->lane2) {
+		ofdmrx_config c2 = h->cfg;
+		c2.stream = nullptr;                                      // a stream of its own
+		c2.chunk_frames = h->chunk;
+		c2.flags &= ~OFDMRX_FLAG_TWO_LANES;
+		r = ofdmrx_create(&c2, &h->lane2);
+		if (r) {                                                  // (no room for a second pipeline: one lane)
+			h->lane2 = nullptr;
+			h->lanes = 1;
+			return decode_device_lane(h, d_samples, fmt, channels, spf, stride, n_frames, d_skip, d_payload, d_results);
+		}
+		h->lane2->cert_mode = h->cert_mode;
+		h->lane2->sc_mode = h->sc_mode;
+		HIP_OK(hipEventCreateWithFlags(&h->ev_lane_in, hipEventDisableTiming));
+		HIP_OK(hipEventCreateWithFlags(&h->ev_lane_done, hipEventDisableTiming));
+	}
+	ofdmrx_handle *g = h->lane2;
+	const size_t n1 = ((n_frames / chunk + 1) / 2) * chunk, n2 = n_frames - n1;
+	// whatever the caller's stream has enqueued so far (the samples' producer) comes first for the second lane too
+	HIP_OK(hipEventRecord(h->ev_lane_in, h->stream));
+	HIP_OK(hipStreamWaitEvent(g->stream, h->ev_lane_in, 0));
+	g->esn0_user = h->esn0_user ? h->esn0_user + n1 * ROWS_MAX : nullptr;
+	g->att_user = h->att_user ? h->att_user + n1 * ATTEMPTS_MAX : nullptr;
+	g->att_counts_user = h->att_counts_user ? h->att_counts_user + n1 : nullptr;
+	r = decode_device_lane(h, d_samples, fmt, channels, spf, stride, n1, nullptr, d_payload, d_results);
+	if (r)
+		return r;
+	r = decode_device_lane(g, (const char *)d_samples + n1 * stride, fmt, channels, spf, stride, n2, nullptr, d_payload + n1 * PAYLOAD_BYTES, d_results + n1);
+	h->split_at = n1;
+	// the caller's stream sees the finished batch
+	HIP_OK(hipEventRecord(h->ev_lane_done, g->stream));
+	HIP_OK(hipStreamWaitEvent(h->stream, h->ev_lane_done, 0));
+	return r;
+}
+
 // the host waits for everything the handle has enqueued
 static int host_wait(ofdmrx_handle *h)
 {
 	HIP_OK(hipStreamSynchronize(h->stream));
+	if (h->lane2)
+		HIP_OK(hipStreamSynchronize(h->lane2->stream));
 	return 0;
 }
 extern "C" int ofdmrx_synchronize(ofdmrx_handle *h)
@@ -955,6 +1046,9 @@ extern "C" int ofdmrx_decode_batch(ofdmrx_handle *h, const void *samples, int fm
 	}
 	h->ev_used = 0;
 	h->spans.clear();
+	h->split_at = 0;
+	if (!h->stream_c)
+		HIP_OK(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
 	const ChunkPlan plan = plan_chunks(h, n_frames, true);
 	const size_t n_chunks = plan.count(), nc = plan.largest();
 	r = ensure_events(h, n_chunks * (events_per_chunk(max_skip) + 4) + 8);
@@ -1131,6 +1225,17 @@ extern "C" int ofdmrx_get_timing(ofdmrx_handle *h, ofdmrx_timing *t)
 			}
 		}
 	}
+	if (h->split_at && h->lane2) {                                // the second lane's spans of the same call
+		ofdmrx_timing t2;
+		if (int r = ofdmrx_get_timing(h->lane2, &t2))
+			return r;
+		for (int i = 0; i < OFDMRX_T_COUNT; ++i) {
+			h->timing.ms[i] += t2.ms[i];
+			h->timing.launches[i] += t2.launches[i];
+		}
+		h->sc_ms += h->lane2->sc_ms;
+		h->sc_launches += h->lane2->sc_launches;
+	}
 	*t = h->timing;
 	return 0;
 }
@@ -1155,7 +1260,11 @@ extern "C" int ofdmrx_get_sc_timing(ofdmrx_handle *h, float *ms, int32_t *launch
 // OFDMRX_FLAG_KEEP_RAW_CONS.
 extern "C" int ofdmrx_debug_dump(ofdmrx_handle *h, int tap, size_t frame, void *dst, size_t dst_bytes)
 {
-	if (!h || !dst || frame >= (size_t)h->last_n)
+	if (!h || !dst)
+		return OFDMRX_E_ARG;
+	if (h->split_at && h->lane2)                                  // the call's last chunk went through the second lane
+		return ofdmrx_debug_dump(h->lane2, tap, frame, dst, dst_bytes);
+	if (frame >= (size_t)h->last_n)
 		return OFDMRX_E_ARG;
 	HIP_OK(hipSetDevice(h->cfg.device));
 	if (int r = host_wait(h))

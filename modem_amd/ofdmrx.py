@@ -165,13 +165,13 @@ class Receiver:
     """
 
     def __init__(self, device=0, chunk_frames=0, max_samples=0, descramble=True, keep_raw_cons=False, stream=None,
-                 sample_rate=8000, list_size=8, scl_always=False, no_sc=False):
+                 sample_rate=8000, list_size=8, scl_always=False, no_sc=False, two_lanes=False):
         self._lib = load_library()
         if self._lib.ofdmrx_abi_version() != 1:
             raise OfdmRxError("ABI mismatch")
         self.sample_rate = int(sample_rate)
         cfg = Config(1, self.sample_rate, int(list_size), device, chunk_frames, max_samples, 1 if descramble else 0,
-                     (1 if keep_raw_cons else 0) | (2 if scl_always else 0) | (4 if no_sc else 0), stream)
+                     (1 if keep_raw_cons else 0) | (2 if scl_always else 0) | (4 if no_sc else 0) | (8 if two_lanes else 0), stream)
         self._h = C.c_void_p()
         self._check(self._lib.ofdmrx_create(C.byref(cfg), C.byref(self._h)))
 

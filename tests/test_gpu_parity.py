@@ -747,6 +747,68 @@ def test_queue_defers_the_list_decoder_across_chunks():
     assert listed[-30.0] == 0, listed             # every call starts with the certificate on
 
 
+def test_two_lanes_equal_one_lane(monkeypatch):
+    """With OFDMRX_FLAG_TWO_LANES a device-entry call of four chunks or more is cut in two and its second half runs through the
+    handle's second pipeline (include/ofdmrx.h revision 1.6).  Same batch through such a handle and a default one, chunks of 1024 frames,
+    at levels where the syndrome certificate, the list-1 pass (with runs left over from chunk to chunk) and the list decoder each
+    take a share, outputs in HBM and in pinned host memory: payloads, result records and the per-row Es/N0 values are identical,
+    the route counters add up over the lanes, the LLR tap of the call's last chunk comes from the lane that decoded it."""
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    chunk, n = 1024, 1024 * 5 + 300
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        monkeypatch.delenv("OFDMRX_LANES", raising=False)
+        rx2 = modem_amd.Receiver(device=0, stream=stream.cuda_stream, chunk_frames=chunk, two_lanes=True)
+        rx1 = modem_amd.Receiver(device=0, stream=stream.cuda_stream, chunk_frames=chunk)
+        spf = rx2.tx_frame_samples(6)
+        g = torch.Generator(device=dev)
+        g.manual_seed(77)
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+        d_clean = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+        rx2.tx_encode(d_pay.data_ptr(), n, d_clean.data_ptr())
+        d_in = torch.empty_like(d_clean)
+        # thirds of the batch at -30 / -25 / -18.3 dB: certified, certified + list-1, list-1 + list decoder
+        third = n // 3
+        for k, db in enumerate((-30.0, -25.0, -18.3)):
+            lo, hi = k * third, (n if k == 2 else (k + 1) * third)
+            rx2.awgn_tile(d_clean[lo:hi].data_ptr(), hi - lo, d_in[lo:hi].data_ptr(), hi - lo, spf, db, 5, lo)
+        rx2.synchronize()
+        ref = None
+        for host in (False, True):
+            outs = []
+            for r in (rx2, rx1):
+                if host:
+                    o = torch.zeros((n, 5380), dtype=torch.uint8, pin_memory=True)
+                    rs = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, pin_memory=True)
+                else:
+                    o = torch.zeros((n, 5380), dtype=torch.uint8, device=dev)
+                    rs = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+                r.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, o.data_ptr(), rs.data_ptr())
+                r.synchronize()
+                outs.append((o.cpu().numpy().copy(), rs.cpu().numpy().copy().view(M.RESULT_DTYPE).reshape(-1),
+                             (r.list_decoded_frames(), r.sc_decided_frames())))
+            (oa, ra, ca), (ob, rb, cb) = outs
+            assert (oa == ob).all(), host
+            for name in ra.dtype.names:
+                assert ((ra[name] == rb[name]) | ((ra[name] != ra[name]) & (rb[name] != rb[name]))).all(), (host, name)
+            assert ca == cb and ca[0] > 0 and ca[1] > 0, (ca, cb)
+            ok = ra["status"] == 0
+            assert (oa[ok] == d_pay.cpu().numpy()[ok]).all() and ok[: 2 * third].all()
+            if ref is not None:
+                assert (oa == ref).all()
+            ref = oa
+        # the call's last chunk went through the second lane: its first frame and a tap of one of its list-1 frames
+        first = rx2.last_chunk_first_frame()
+        assert first == (n // chunk) * chunk, first
+        assert rx1.last_chunk_first_frame() == first
+        assert (rx2.tap("LLR", 5) == rx1.tap("LLR", 5)).all()
+        rx1.close()
+        rx2.close()
+
+
 def test_clean_frames_mono_and_analytic(rx):
     """config 2 flavour: clean mode-6 frames, 16-bit mono (front end D1) and 2-channel analytic"""
     pcms, pays = _frames([(1, None, {}), (2, None, {})])
