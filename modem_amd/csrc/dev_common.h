@@ -4,6 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The tuning macros the kernel files define unconditionally are frozen (rounds 2 - 5 measured them: DESIGN.md, profiles/HISTORY.md).
+// One of them on the command line (tools/build_variant.sh FLAGS / PERFILE_*) would be silently overridden and an A/B run would
+// compare two identical binaries - so it is an error.  (The few that are still open keep an #ifndef next to their definition.)
+#if defined(BACK_WALK) || defined(DEMOD_QA_LDS) || defined(DEMOD_RAW_AHEAD) || defined(DEMOD_SWZ) || defined(DEMOD_TWR_BYTES) || defined(POLAR_NT_LEVEL) || defined(POLAR_WPB) || defined(POLAR_XB1) || defined(POLAR_XB2) || defined(POLAR_XB3) || defined(SYNC_FFT_IN_LDS) || defined(SYNC_PER) || defined(SYNC_SPLIT_8K) || defined(SYNC_SPLIT_ROUNDS) || defined(SYNC_WAVES) || defined(SYNC_WAVES_SPLIT_MONO) || defined(TS_CAP) || defined(TS_MARGIN) || defined(TS_MORE_OCC) || defined(TS_MORE_WAVES_N) || defined(TS_OPEN_MARGIN) || defined(TS_OPEN_NEED) || defined(TS_OWN_ATAN) || defined(TS_ROWS_PER_WG) || defined(TS_UNC_STEPS) || defined(TX_NT_LDS) || defined(TX_TW_GLOBAL)
+#error "a frozen tuning macro was passed with -D: edit a patched copy of the source instead (tools/experiments/ts_stage_probe.py shows how)"
+#endif
+
 namespace rx {
 
 // the lengths that depend on the sample rate: one instantiation per rate like the reference's

@@ -478,7 +478,7 @@ template <int LN> struct Block8 {
 // 27 ms instead of 1, whichever kernel it was).  With four decoders per workgroup the other kernels do run beside the
 // decoders - and the list decoder slows down by exactly their time alone (36.2 -> 43.6 ms per 8192 codewords, 178 k
 // frames/s against 194 k): the machine has no idle issue slots to give.  So the default stays one decoder per workgroup,
-// and the pipeline treats a polar launch as owning the machine (ofdmrx_api.cpp: run_pipeline).
+// and the pipeline treats a polar launch as owning the machine (api_pipeline.cpp: run_pipeline).
 #define POLAR_WPB 1
 template <int LN>
 __global__ __launch_bounds__(64 * POLAR_WPB, POLAR_WAVES_PER_SIMD) void k_polar(ListQueue *__restrict__ q, int par, const ListSlot *__restrict__ slots,

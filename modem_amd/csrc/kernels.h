@@ -1,4 +1,4 @@
-// kernels.h -- structs shared by the host API (ofdmrx_api.cpp) and the HIP kernels.
+// kernels.h -- structs shared by the host API (api_*.cpp) and the HIP kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -105,7 +105,7 @@ struct Tables {                    // device-resident constants, built once per 
 
 // ---- the list decoder's work queue (round 4).  Frames the syndrome certificate cannot finish are queued by k_back with their
 // LLRs - entry e in slot e % cap of the slot arrays (LLRs, partial sums, metrics, ListSlot) - and k_polar / k_finish take
-// whole runs of entries: a flush (ofdmrx_api.cpp) is k_queue_plan | k_polar | k_finish, and it takes nothing until one full
+// whole runs of entries: a flush (api_pipeline.cpp) is k_queue_plan | k_polar | k_finish, and it takes nothing until one full
 // residency of the list decoder waits, so a few stragglers per chunk no longer cost a decoder round each.  All counters live
 // on the device: the host never waits to learn how many frames a chunk left.
 struct ListQueue {
