@@ -213,14 +213,17 @@ long long ofdmrx_last_chunk_first_frame(ofdmrx_handle *h);
 int ofdmrx_set_esn0_rows(ofdmrx_handle *h, float *rows);
 /* frames of the last decode call that went through the list decoder; the rest were decided by the syndrome certificate
  * (see ofdmrx_config.flags).  -1 if the certificate is off for this handle.  Synchronises the handle's stream.
- * (The certificate is adaptive: after a chunk in which it finished fewer than one frame in twenty it is tried for a sample of
- * one frame in sixteen only, until a fifth of the sample passes again - a frame it was not tried for is list-decoded, with the
- * same outputs.  Every call starts with the certificate on.) */
+ * (The certificate is adaptive: after a chunk in which it was tried for 64 frames or more and finished fewer than one in twenty it
+ * is tried for a sample of one frame in sixteen only, until a fifth of the sample - summed over chunks until eight frames have been
+ * tried - passes again; a frame it was not tried for is list-decoded, with the same outputs.  Every call starts with the certificate on.) */
 long long ofdmrx_list_decoded_frames(ofdmrx_handle *h);
 /* frames of the last decode call that the list-1 pass finished (neither the syndrome check nor the list decoder); -1 if that
  * pass is off for this handle (OFDMRX_FLAG_KEEP_RAW_CONS / _SCL_ALWAYS / _NO_SC).  Synchronises the handle's stream.  The pass is
- * adaptive like the syndrome check: after a chunk in which it finished fewer than an eighth of its frames only a sample of one
- * frame in sixteen goes through it, until an eighth of the sample is finished again; the others go straight to the list decoder. */
+ * adaptive like the syndrome check: after a run of 64 entries or more of which it finished fewer than an eighth only a probe sample
+ * goes through it - one frame in sixteen of every FOURTH chunk - until an eighth of the sample (summed over chunks until eight frames
+ * have been tried) is finished again; the others go straight to the list decoder.  Default layout: one codeword per wave, ten resident
+ * decoders per CU (OFDMRX_SC_LB / OFDMRX_SC_WPC in the environment change it); a run takes whole residencies of them and leaves the rest
+ * to the next chunk's run (revision 1.6), the last run of a call takes everything. */
 long long ofdmrx_sc_decided_frames(ofdmrx_handle *h);
 /* hipEvent time and launches of that pass (k_sc + k_sc_finish) in the last decode call, like ofdmrx_timing's stages (which keep
  * their layout); either pointer may be NULL */

@@ -15,7 +15,7 @@ extern "C" const char *ofdmrx_strerror(int err)
 {
 	switch (err) {
 	case 0: return "ok";
-	case OFDMRX_E_ARG: return "invalid argument";
+	case OFDMRX_E_ARG: return "invalid argument (a null pointer, a count out of range, or samples / frame stride that are not multiples of one sample frame: bytes per sample x channels)";
 	case OFDMRX_E_NOMEM: return g_last_error.empty() ? "out of device memory" : g_last_error.c_str();
 	case OFDMRX_E_HIP: return g_last_error.empty() ? "HIP error" : g_last_error.c_str();
 	case OFDMRX_E_NODEV: return "no usable HIP device (the receive path has no CPU fallback)";

@@ -408,7 +408,7 @@ def _sc_vectors():
 def test_sc_path_kernel_is_the_oracles_sign_following_path(lanes_log2, monkeypatch):
     """k_sc alone (ofdmrx_debug_sc_path) against oracle/polar.c: orc_polar_sc_path on identical LLRs: the re-encoded codeword,
     the hard decisions of the LLRs, the path metric M* and min_fork BIT-exact (M* is also lane 0's metric of the oracle's list
-    decoder whenever the rule holds), the rule's verdict - with two codewords per wave (the default) and with one, codewords of
+    decoder whenever the rule holds), the rule's verdict - with one codeword per wave (OFDMRX_SC_LB=6, the default) and with two (=5), codewords of
     both frozen tables side by side in one call (pairs of different tables are decoded one after the other), an odd count."""
     import modem_amd
     monkeypatch.setenv("OFDMRX_SC_LB", str(lanes_log2))
