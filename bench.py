@@ -515,6 +515,14 @@ def main():
     secs_max, (frames_total, frame_err, bit_err, ok_status, ranks, frames_step) = shard.reduce_counters(
         (secs, [B * args.steps, frame_err, bit_err, ok_status, 1, B]), world, dist, dev)
     secs_k_max, _ = shard.reduce_counters((secs_k, [0]), world, dist, dev)
+    # which rank decoded how many frames, and what the process group says about itself (RCCL, the world size it sees)
+    frames_by_rank, dist_info = [B], {"backend": None, "world_size": 1}
+    if dist:
+        tb_ = torch.zeros(world, dtype=torch.int64, device=dev)
+        tb_[rank] = B
+        dist.all_reduce(tb_, op=dist.ReduceOp.SUM)
+        frames_by_rank = [int(x) for x in tb_.tolist()]
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
 
     secs2_max = None
     if scl is not None:
@@ -627,7 +635,7 @@ def main():
                                        args.noise_db, source, cert_note)) if ch == 2 else
                                    ("configs[1] flavour: batch %d clean 16-bit mono mode-6 8 kHz frames per GPU, inputs resident "
                                     "in HBM; %s%s" % (B, source, cert_note)),
-                       "frames_per_step": frames_step, "frames_rank0": B, "list_size": args.list, "chunk_frames": chunk_frames_used,
+                       "frames_per_step": frames_step, "frames_rank0": B, "frames_by_rank": frames_by_rank, "process_group": dist_info, "list_size": args.list, "chunk_frames": chunk_frames_used,
                        "parallelism": "frames x%d" % ranks},
             "ber": bit_err / (43040.0 * max(frames_step, 1)), "fer": frame_err / float(max(frames_step, 1)),
             "frames_ok": ok_status, "frames": frames_step,

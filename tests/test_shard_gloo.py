@@ -95,3 +95,6 @@ def test_two_gpus_for_real():
     d = lines[0]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["frames"] == 8192
     assert d["frames_ok"] == 8192 and d["fer"] == 0.0 and d["value"] > 0
+    # each rank decoded its own half, and the counters came through RCCL's process group of two
+    assert d["config"]["frames_by_rank"] == [4096, 4096], d["config"]
+    assert d["config"]["process_group"] == {"backend": "nccl", "world_size": 2}, d["config"]
