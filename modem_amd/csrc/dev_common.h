@@ -396,6 +396,90 @@ template <int P, int TWC> __device__ __forceinline__ void fft256_stage_swz(cf *b
 	fft_sync<64>();
 }
 
+// ---- a 256-point forward transform of ONE wave in registers (round 6): four radix-4 steps, decimation in frequency; between the
+// steps the lane's four values are exchanged with other lanes by data-parallel-primitive moves and lane swaps instead of a trip
+// through LDS (k_demod waits for LDS half of its time and uses 29 % of the vector unit: profiles/r06_sq_counters.txt).
+//   n = 64 n3 + 16 n2 + 4 n1 + n0.  Lane l = n mod 64 reads buf[sl + 64 t], t = n3 (sl = the caller's address of element l).
+//   step A: butterfly over the register index (n3 -> k0), twiddle w256^(l k0);          registers <-> lane bits (5, 4)
+//   step B: butterfly (n2 -> k1), twiddle w64^((l & 15) k1);                            registers <-> lane bits (3, 2)
+//   step C: butterfly (n1 -> k2), twiddle w16^((l & 3) k2);                             registers <-> lane bits (1, 0)
+//   step D: butterfly (n0 -> k3).  Register t of lane l then holds X[k0 + 4 k1 + 16 k2 + 64 t], k0 = l >> 4, k1 = (l >> 2) & 3, k2 = l & 3,
+//   and goes to buf[l + 64 t]: the caller reads X[q] at fft256_pos(q).
+// An exchange of a register pair (A: register bit 0, B: register bit 1) with lane bit b: A keeps its lanes with bit b clear and takes B's
+// value of lane ^ 2^b where bit b is set; B the other way round.  Bits 5 / 4: one v_permlane32_swap / v_permlane16_swap per pair; bits
+// 3 / 2: row_ror:8 / row_shr:4 + row_shl:4 with a bank mask, one move per register; bits 1 / 0: quad_perm + a select.
+// twl: [9][64] per-lane twiddles, (step, k) major: w256^(l k), w64^((l & 15) k), w16^((l & 3) k), k = 1..3 (fft256_lane_twiddles).
+__host__ __device__ constexpr int fft256_pos(int q)
+{
+	return (q & 192) | ((q & 3) << 4) | (q & 12) | ((q >> 4) & 3);
+}
+template <int NT> __device__ __forceinline__ void fft256_lane_twiddles(cf *twl, const cf *tw1280, int tid)
+{
+	for (int i = tid; i < 9 * 64; i += NT) {
+		const int l = i & 63, k = (i >> 6) % 3 + 1, step = i / 192;
+		const int e = step == 0 ? 5 * (l * k) : step == 1 ? 20 * ((l & 15) * k) : 80 * ((l & 3) * k);   // w256 = w1280^5, w64 = w1280^20, w16 = w1280^80
+		twl[i] = tw1280[e % 1280];
+	}
+}
+template <int BIT> __device__ __forceinline__ void fft256_xchg(float &A, float &B, int lane)
+{
+	const int a = __float_as_int(A), b = __float_as_int(B);
+	if constexpr (BIT == 5) {
+		auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+		A = __int_as_float((int)r[0]); B = __int_as_float((int)r[1]);
+	} else if constexpr (BIT == 4) {
+		auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+		A = __int_as_float((int)r[0]); B = __int_as_float((int)r[1]);
+	} else if constexpr (BIT == 3) {                              // row_ror:8 = lane ^ 8; banks 2, 3 = lanes with bit 3 set
+		A = __int_as_float(__builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xC, false));
+		B = __int_as_float(__builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false));
+	} else if constexpr (BIT == 2) {                              // row_shr:4 (from lane - 4) into banks 1, 3; row_shl:4 (from lane + 4) into banks 0, 2
+		A = __int_as_float(__builtin_amdgcn_update_dpp(a, b, 0x114, 0xf, 0xA, false));
+		B = __int_as_float(__builtin_amdgcn_update_dpp(b, a, 0x104, 0xf, 0x5, false));
+	} else {
+		constexpr int CTRL = BIT == 1 ? 0x4E : 0xB1;              // quad_perm [2,3,0,1] = lane ^ 2, [1,0,3,2] = lane ^ 1
+		const int pb = __builtin_amdgcn_update_dpp(0, b, CTRL, 0xf, 0xf, true), pa = __builtin_amdgcn_update_dpp(0, a, CTRL, 0xf, 0xf, true);
+		const bool set = (lane >> BIT) & 1;
+		A = __int_as_float(set ? pb : a);
+		B = __int_as_float(set ? b : pa);
+	}
+}
+template <int HI, int LO> __device__ __forceinline__ void fft256_transpose(cf (&v)[4], int lane)
+{
+	fft256_xchg<HI>(v[0].re, v[2].re, lane); fft256_xchg<HI>(v[0].im, v[2].im, lane);
+	fft256_xchg<HI>(v[1].re, v[3].re, lane); fft256_xchg<HI>(v[1].im, v[3].im, lane);
+	fft256_xchg<LO>(v[0].re, v[1].re, lane); fft256_xchg<LO>(v[0].im, v[1].im, lane);
+	fft256_xchg<LO>(v[2].re, v[3].re, lane); fft256_xchg<LO>(v[2].im, v[3].im, lane);
+}
+__device__ __forceinline__ void fft256_regs(cf *buf, const cf *twl, int lane, int sl)
+{
+	cf v[4];
+	#pragma unroll
+	for (int t = 0; t < 4; ++t)
+		v[t] = buf[sl + t * 64];
+	Bfly<4>::run(v);
+	#pragma unroll
+	for (int k = 1; k < 4; ++k)
+		v[k] = cmul(v[k], twl[(k - 1) * 64 + lane]);
+	fft256_transpose<5, 4>(v, lane);
+	Bfly<4>::run(v);
+	#pragma unroll
+	for (int k = 1; k < 4; ++k)
+		v[k] = cmul(v[k], twl[(3 + k - 1) * 64 + lane]);
+	fft256_transpose<3, 2>(v, lane);
+	Bfly<4>::run(v);
+	#pragma unroll
+	for (int k = 1; k < 4; ++k)
+		v[k] = cmul(v[k], twl[(6 + k - 1) * 64 + lane]);
+	fft256_transpose<1, 0>(v, lane);
+	Bfly<4>::run(v);
+	fft_sync<64>();                                           // (every lane's reads of buf come before any lane's writes: one wave, LDS in order)
+	#pragma unroll
+	for (int t = 0; t < 4; ++t)
+		buf[lane + t * 64] = v[t];
+	fft_sync<64>();
+}
+
 // ---- wave helpers ----------------------------------------------------------
 // a value every lane holds alike, moved to scalar registers (the compiler cannot know that what came out of a vector load is uniform)
 __device__ __forceinline__ long uniform_l(long v)

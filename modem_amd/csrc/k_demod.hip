@@ -35,6 +35,10 @@ template <int RATE> struct DifCfg {
                         // per 8192 frames; 16 kHz (two points too, four workgroups per CU) 3.44 -> 3.51: stays without
 #define DEMOD_SWZ 1     // 8 kHz (the only rate with wave-private 256-point transforms): demod 1.48 -> 1.35 ms per chunk with the seven-waves budget below
 // (swz256 / fft256_stage_swz: dev_common.h, shared with the transmitter's transforms)
+#ifndef DEMOD_REGS
+#define DEMOD_REGS 1    // 8 kHz: the wave's 256-point transform in registers (fft256_regs, dev_common.h): the rows are read from LDS once and the
+                        // spectrum written once, the three exchanges between the radix-4 steps are lane moves (32 LDS accesses of 75 per wave and symbol gone)
+#endif
 
 // Mono input (mono_front.h).  MONO = 2 (8 kHz): the workgroup walks the frame's symbols in order, so it carries the DC blocker's
 // state along: a symbol's span is its guard interval and body, [t0 - guard_len, t0 + symbol_len) - 1440 samples, five per thread
@@ -76,7 +80,9 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 		static_assert(R1 * NS == SYMBOL_LEN, "plan");
 		constexpr int TWC = fft_compact_size<NS, SYMBOL_LEN>();
 		__shared__ cf row[R1 * NS];
-		__shared__ cf tw_sub[TWC];                            // compact twiddles of the NS-point plan
+		constexpr bool REGS = DEMOD_REGS && DEMOD_SWZ && NS == 256 && DC::W == 1;
+		__shared__ cf tw_sub[REGS ? 1 : TWC];                 // compact twiddles of the NS-point plan
+		__shared__ cf twl[REGS ? 9 * 64 : 1];                 // ... or the per-lane twiddles of the in-register transform
 		__shared__ cf tw_r[DC::TWR_LDS ? (R1 - 1) * NS : 1];  // w^(n' r), r = 1..R1-1
 		__shared__ cf rotA[R1], rotQ[NQ], symrot[ROWS_MAX + 1];
 		// a thread's (at most two) carriers of the previous symbol.  A frame has at most COLS_MAX = 512 carriers: with 512 threads or
@@ -89,7 +95,10 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 			&& (MTH + 63) / 64 == 5 && MTH % 64 == 32), "span layout");
 		__shared__ float ybuf[MONO == 2 ? SYM_STRIDE - YOFF : 1];
 		__shared__ float mwe[5];
-		fft_compact_twiddles<NS, NT, SYMBOL_LEN>(tw_sub, tb.tw_sym, tid);
+		if constexpr (REGS)
+			fft256_lane_twiddles<NT>(twl, tb.tw_sym, tid);
+		else
+			fft_compact_twiddles<NS, NT, SYMBOL_LEN>(tw_sub, tb.tw_sym, tid);
 		if (DC::TWR_LDS)
 			for (int i = tid; i < (R1 - 1) * NS; i += NT)
 				tw_r[i] = tb.tw_sym[(i / NS + 1) * (i % NS)];
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 		#pragma unroll
 		for (int e = 0; e < 2; ++e) {
 			const int i = tid + NT * e, k = (i + code_off + SYMBOL_LEN) % SYMBOL_LEN;
-			coff[e] = i < md.cols ? (k % R1) * NS + ((DEMOD_SWZ && NS == 256 && DC::W == 1) ? swz256(k / R1) : k / R1) : -1;
+			coff[e] = i < md.cols ? (k % R1) * NS + (REGS ? fft256_pos(k / R1) : (DEMOD_SWZ && NS == 256 && DC::W == 1) ? swz256(k / R1) : k / R1) : -1;
 		}
 		// ---- MONO = 2: the span recurrence (see the head of the kernel)
 		const MonoFrame mfr = mono_frame(fb, ma.ck, ma.ck_per_frame, f);
@@ -352,7 +361,9 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 			if (AHEAD)
 				fetch(s + 1);
 			__syncthreads();
-			if constexpr (DEMOD_SWZ && NS == 256 && DC::W == 1) {
+			if constexpr (REGS) {
+				fft256_regs(row + wave * NS, twl, lane, swz256(lane));
+			} else if constexpr (DEMOD_SWZ && NS == 256 && DC::W == 1) {
 				cf *sub = row + wave * NS;
 				const int sl = swz256(lane);
 				fft256_stage_swz<1, 0>(sub, tw_sub, lane, sl);
