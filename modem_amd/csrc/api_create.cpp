@@ -123,6 +123,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.osd_triples, &h->dev.osd_triples);
 	r = r ? r : upload(h, h->host.crc32_tab, &h->dev.crc32_tab);
 	r = r ? r : upload(h, h->host.crc32_shift168, &h->dev.crc32_shift168);
+	r = r ? r : upload(h, h->host.crc32_adv, &h->dev.crc32_adv);
 	r = r ? r : upload(h, h->host.scramble, &h->dev.scramble);
 	if (r) {
 		ofdmrx_destroy(h);

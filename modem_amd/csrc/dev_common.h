@@ -605,32 +605,38 @@ __device__ __forceinline__ cf rotate_point(cf c, float slope, float yint, int i,
 // decode.cc:505-516 for one frame: the running sp / np of the SNR estimate.  Wave w reduces rows w, w + 4, ... by itself
 // (per-lane double sums over its 7 carriers, one wave butterfly) - no workgroup barrier per row; after ONE barrier thread 0
 // folds the row sums in order into the fp32 running sums and leaves the cumulative precision of every row in prec[].
-// raw(j, i) loads the constellation point (row j, column i); begin_row(j) is called once per row and lane, then
-// rotated(j, i, c) for i = lane, lane + 64, ... in that order: it delivers the point as decode.cc:505 sees it (rotated);
-// visit(j, i, c) sees every point once (the caller collects what it needs from it).  A lane's points of a row - at most eight -
-// are loaded together, and the NEXT row's while this one is worked on: the kernel is latency-bound otherwise (one HBM round
-// trip per point and lane: k_back 0.70 ms per 8192 frames with the plain loop).
+// A lane owns NPL = ceil(cols / 64) CONSECUTIVE columns lane NPL .. lane NPL + NPL - 1 of every row (round 6; until then the columns
+// lane + 64 q: the caller's sign bits of 64 neighbouring points were then ORed into LDS by 64 lanes hitting six words - ten lanes per
+// word, serialised - and the kernel spent 70 % of its time in the LDS pipe; with consecutive columns a lane assembles its 21 bits in
+// a register and ORs one or two words per row).  raw(j, i) loads the point (row j, column i); begin_row(j, i0) is called once per row
+// and lane with the lane's first column, then rotated(j, i, c) for its columns in ascending order: it delivers the point as
+// decode.cc:505 sees it (rotated); visit(j, i, c) sees every point once, end_row(j, i0) closes the row (the caller collects what it needs).
+// A lane's points of a row - at most eight - are loaded together, and the NEXT row's while this one is worked on: the kernel is
+// latency-bound otherwise (one HBM round trip per point and lane: k_back 0.70 ms per 8192 frames with the plain loop).
 // Returns false in every thread if a precision is not a positive finite number.
 // sp: every hard-decision point has the same norm (psk.hh:82-85,132-139: (cos, sin) of pi/8 in either order, or (r, r)) - also the
 // one an erased carrier maps to - so a lane's share of the row's sp is its point count times that constant: exactly the sum of
 // its terms (up to 8 x a 49-bit value fits a double), two conversions and two multiplications per point less.
-template <typename Raw, typename Begin, typename Rotated, typename Visit>
+template <typename Raw, typename Begin, typename Rotated, typename Visit, typename End>
 __device__ __forceinline__ bool snr_rows(Raw raw, Begin begin_row, Rotated rotated, int rows, int cols, int mod_bits, int tid, double (*rsum)[2],
-	float *prec, Visit visit)
+	float *prec, Visit visit, End end_row)
 {
 	const int wave = tid >> 6, lane = tid & 63;
 	const cf h1 = mod_bits == 3 ? psk8_hard_map(mk(1.f, 0.f)) : psk4_hard_map(mk(1.f, 0.f));
 	const double h_norm = (double)h1.re * h1.re + (double)h1.im * h1.im;
-	const double dsp_lane = (double)((cols - lane + 63) / 64) * h_norm;
-	constexpr int NP = COLS_MAX / 64;                             // points per lane and row
+	constexpr int NP = COLS_MAX / 64;                             // points per lane and row, at most
+	const int npl = (cols + 63) >> 6, i0 = lane * npl;            // this lane's columns: i0 .. i0 + npl - 1 (those below cols)
+	const int mine = min(max(cols - i0, 0), npl);
+	const double dsp_lane = (double)mine * h_norm;
 	cf nxt[NP];
 	auto fetch = [&](int j) {
 		#pragma unroll
 		for (int q = 0; q < NP; ++q)
-			if (j < rows && lane + 64 * q < cols)
-				nxt[q] = raw(j, lane + 64 * q);
+			if (j < rows && q < mine)
+				nxt[q] = raw(j, i0 + q);
 	};
 	fetch(wave);
+	const double dsp = wave_sum_d(dsp_lane);                      // the same for every row of the frame
 	for (int j = wave; j < rows; j += 4) {
 		cf cur[NP];
 		#pragma unroll
@@ -638,11 +644,11 @@ __device__ __forceinline__ bool snr_rows(Raw raw, Begin begin_row, Rotated rotat
 			cur[q] = nxt[q];
 		fetch(j + 4);
 		double dnp = 0.0;
-		begin_row(j);
+		begin_row(j, i0);
 		#pragma unroll
 		for (int q = 0; q < NP; ++q) {
-			const int i = lane + 64 * q;
-			if (i < cols) {
+			if (q < mine) {
+				const int i = i0 + q;
 				const cf c = rotated(j, i, cur[q]);
 				const cf h = mod_bits == 3 ? psk8_hard_map(c) : psk4_hard_map(c);   // decode.cc:509-511
 				const double er = (double)c.re - h.re, ei = (double)c.im - h.im;
@@ -650,7 +656,7 @@ __device__ __forceinline__ bool snr_rows(Raw raw, Begin begin_row, Rotated rotat
 				visit(j, i, c);
 			}
 		}
-		const double dsp = wave_sum_d(dsp_lane);
+		end_row(j, i0);
 		dnp = wave_sum_d(dnp);
 		if (lane == 0) { rsum[j][0] = dsp; rsum[j][1] = dnp; }
 	}
@@ -670,6 +676,44 @@ __device__ __forceinline__ bool snr_rows(Raw raw, Begin begin_row, Rotated rotat
 	}
 	__syncthreads();
 	return snr_ok != 0;
+}
+// CRC<uint32_t>(0xD419CC15) over the first 43072 bits = 5384 bytes of mesg[] (decode.cc:533-541), zero start, by a workgroup of 256
+// threads (round 6; until then 32 threads walked 168 bytes each - two dependent LDS round trips per byte - and one thread folded the
+// 32 results: 125 of k_back's 547 us per chunk with seven eighths of the workgroup waiting, profiles/r06_back_by_stage.txt).
+// Thread k takes bytes 21 k .. 21 k + 20 (the last one 29) from a zero state; the CRC is linear over GF(2), so that state advanced
+// by the bytes that follow the segment - bit by bit through adv[k][32] (tables.cpp: crc32_adv) - is the segment's share of the whole
+// CRC, and the shares are XORed over the workgroup.  ctab: the byte table in LDS; red: four words of LDS.  All threads get the CRC.
+__device__ __forceinline__ uint32_t crc32_wg256(const uint8_t *mesg, const uint32_t *ctab, const uint32_t *__restrict__ adv, uint32_t *red, int tid)
+{
+	const uint4 *m = (const uint4 *)(adv + tid * 32);
+	uint4 row[8];
+	#pragma unroll
+	for (int w = 0; w < 8; ++w)
+		row[w] = m[w];                                            // (in flight while the bytes are walked)
+	const uint8_t *mp = mesg + 21 * tid;
+	uint32_t crc = 0;
+	#pragma unroll
+	for (int i = 0; i < 21; ++i)
+		crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
+	if (tid == 255)
+		for (int i = 21; i < 29; ++i)
+			crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
+	uint32_t acc = 0;
+	#pragma unroll
+	for (int w = 0; w < 8; ++w) {
+		acc ^= (0u - ((crc >> (4 * w)) & 1u)) & row[w].x;
+		acc ^= (0u - ((crc >> (4 * w + 1)) & 1u)) & row[w].y;
+		acc ^= (0u - ((crc >> (4 * w + 2)) & 1u)) & row[w].z;
+		acc ^= (0u - ((crc >> (4 * w + 3)) & 1u)) & row[w].w;
+	}
+	#pragma unroll
+	for (int d = 32; d; d >>= 1)
+		acc ^= (uint32_t)__shfl_xor((int)acc, d);
+	__syncthreads();                                              // (red may still be read from an earlier call)
+	if ((tid & 63) == 0)
+		red[tid >> 6] = acc;
+	__syncthreads();
+	return red[0] ^ red[1] ^ red[2] ^ red[3];
 }
 __device__ __forceinline__ int wave_min_i(int v)
 {

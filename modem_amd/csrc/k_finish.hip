@@ -34,7 +34,10 @@ namespace rx {
 // sample is.  Either way every decision is exact: the list decoder is the general path.  cert_mode 0: never tried (the
 // reference's behaviour, OFDMRX_FLAG_SCL_ALWAYS; handles with debug taps).
 // slot_of[f] (per chunk): the queue slot of the frame, -1 if it needs none (no header; finished here).
-__global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
+#ifndef BACK_WAVES
+#define BACK_WAVES 6      // register budget (waves per SIMD): 6 = 80 VGPRs, two of them spilled; the 19.5 KB of LDS allow eight workgroups per CU
+#endif
+__global__ __launch_bounds__(256, BACK_WAVES) void k_back(int sym_stride, int cert_mode, const SyncState *__restrict__ st_all, const cf *__restrict__ cons_all,
 	const float *__restrict__ slope_all, const float *__restrict__ yint_all, float *__restrict__ precision_all,
 	Result *__restrict__ res_all, float *__restrict__ esn0_rows, Tables tb, int descramble, uint8_t *__restrict__ payload_all,
 	ListQueue *__restrict__ q, ListSlot *__restrict__ slots, float *__restrict__ llr_q, int *__restrict__ slot_of,
@@ -72,8 +75,7 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 	__shared__ float prec[ROWS_MAX], row_slope[ROWS_MAX], row_yint[ROWS_MAX];
 	__shared__ cf row_step[ROWS_MAX];
 	__shared__ uint8_t mesg[MESG_BYTES_MAX];
-	__shared__ uint32_t ctab[256], csh[1024], cpart[32];
-	__shared__ uint32_t crc_sh;
+	__shared__ uint32_t ctab[256], cpart[4];
 	__shared__ int slot_sh;
 	ListQueue *const q_cert = q;                                      // the syndrome certificate's switch and counters (the list queue's block)
 	const bool try_cert = cert_mode && (q->cert_on || (f & 15) == 0);   // (uniform in the workgroup)
@@ -86,32 +88,33 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 		row_slope[tid] = sl;
 		row_yint[tid] = yint_all[(size_t)f * ROWS_MAX + tid];
 		float sn, cs;
-		row_sincos(-64.f * sl, sn, cs);                           // the rotation advances by this factor from column i to i + 64
+		row_sincos(-sl, sn, cs);                                  // the rotation advances by this factor from a lane's column i to i + 1
 		row_step[tid] = mk(cs, sn);
 	}
 	if (try_cert) {
 		for (int w = tid; w < CODE_LEN / 32; w += 256)
 			bits[w] = 0;
 		ctab[tid] = tb.crc32_tab[tid];
-		#pragma unroll
-		for (int w = 0; w < 4; ++w)
-			csh[tid + 256 * w] = tb.crc32_shift168[tid + 256 * w];
 	}
 	__syncthreads();
 	// ---- 1. decode.cc:493-494 + 505-523 (snr_rows) + the signs of the soft bits
 	const int mod_bits = md.mod_bits, cols = md.cols;
 	auto raw = [&](int j, int i) { return cons[j * cols + i]; };
 #define BACK_WALK 1
-	// the first pass walks a row in steps of 64 columns per lane: one sin / cos for the lane's first column, then one complex
-	// multiplication per step (the phasor's error grows by an ulp per step: seven steps) - a third of the rotation's instructions
+	// the first pass walks a lane's (at most eight) consecutive columns of a row: one sin / cos for the first, then one complex
+	// multiplication per column (the phasor's error grows by an ulp per step: seven steps) - a third of the rotation's instructions
 	cf rot_cur = mk(1.f, 0.f), rot_step = mk(1.f, 0.f);
-	auto begin_row = [&](int j) {
+	uint32_t acc_lo = 0;                                          // the sign bits of the lane's points of the running row, from bit 0
+	int acc_n = 0;
+	auto begin_row = [&](int j, int i0) {
 		if (BACK_WALK) {
 			float sn, cs;
-			row_sincos(-(row_yint[j] + row_slope[j] * (float)((tid & 63) - cols / 2)), sn, cs);
+			row_sincos(-(row_yint[j] + row_slope[j] * (float)(i0 - cols / 2)), sn, cs);
 			rot_cur = mk(cs, sn);
 			rot_step = row_step[j];
 		}
+		acc_lo = 0;
+		acc_n = 0;
 	};
 	auto rotated = [&](int j, int i, cf c0) {
 		if (!BACK_WALK)
@@ -136,11 +139,15 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 			v = (c.re < 0.f ? 1u : 0u) | (c.im < 0.f ? 2u : 0u);
 			odd |= !(are > guard) | !(aim > guard);
 		}
-		const int p0 = mod_bits * (j * cols + i), o = p0 & 31;
-		if (v) {
-			atomicOr(&bits[p0 >> 5], v << o);
-			if (o + mod_bits > 32)
-				atomicOr(&bits[(p0 >> 5) + 1], v >> (32 - o));
+		acc_lo |= v << acc_n;                                     // (at most 8 x 3 = 24 bits)
+		acc_n += mod_bits;
+	}, [&](int j, int i0) {
+		// the lane's acc_n bits go to code positions mod_bits (j cols + i0) ...: one word, or two
+		if (try_cert && acc_lo) {
+			const int p0 = mod_bits * (j * cols + i0), o = p0 & 31;
+			atomicOr(&bits[p0 >> 5], acc_lo << o);
+			if (o + acc_n > 32)
+				atomicOr(&bits[(p0 >> 5) + 1], acc_lo >> (32 - o));
 		}
 	});
 	odd |= !snr_ok;                                               // (LLR = value * DIST * precision)
@@ -208,31 +215,9 @@ __global__ __launch_bounds__(256) void k_back(int sym_stride, int cert_mode, con
 		for (int e = 0; e < 8; ++e)
 			syn |= w[e] & frozen[tid + 256 * e];
 		bad = __syncthreads_or((syn != 0) | (odd ? 1 : 0));
-		// ---- 3b. CRC<uint32_t>(0xD419CC15) over the first 43072 bits (decode.cc:533-541), as k_finish does it for a lane: 32 segments
-		// of 168 bytes from a zero state, folded in order with the "advance by 168 zero bytes" operator
-		if (!bad) {
-			constexpr int SEG = 168, NSEG = 32, TAIL = CRC_BITS / 8 - SEG * NSEG;   // 5384 = 32 * 168 + 8
-			if (tid < NSEG) {
-				const uint8_t *mp = mesg + tid * SEG;
-				uint32_t crc = 0;
-				for (int i = 0; i < SEG; ++i)
-					crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
-				cpart[tid] = crc;
-			}
-			__syncthreads();
-			if (tid == 0) {
-				uint32_t crc = 0;
-				for (int e = 0; e < NSEG; ++e) {
-					crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
-					crc ^= cpart[e];
-				}
-				for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
-					crc = (crc >> 8) ^ ctab[(crc ^ mesg[i]) & 255];
-				crc_sh = crc;
-			}
-			__syncthreads();
-			bad = crc_sh != 0;
-		}
+			// ---- 3b. CRC<uint32_t>(0xD419CC15) over the first 43072 bits (decode.cc:533-541): crc32_wg256, dev_common.h
+		if (!bad)                                                 // (uniform in the workgroup)
+			bad = crc32_wg256(mesg, ctab, tb.crc32_adv, cpart, tid) != 0;
 		if (!bad) {
 			for (int i = tid; i < PAYLOAD_BYTES; i += 256)
 				payload[i] = mesg[i] ^ (descramble ? tb.scramble[i] : (uint8_t)0);

@@ -596,8 +596,7 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 	Result *const res_dst = late ? ls.res : ls.res_now;
 	__shared__ uint32_t bits[CODE_LEN / 32];
 	__shared__ uint8_t mesg[MESG_BYTES_MAX];
-	__shared__ uint32_t ctab[256], csh[1024], cpart[32];
-	__shared__ uint32_t crc_sh;
+	__shared__ uint32_t ctab[256], cpart[4];
 	__shared__ int flips_red[4], slot_sh;
 	const ModeDesc md = mode_desc(ls.oper_mode);
 	bool done = false;
@@ -606,9 +605,6 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 		for (int w = tid; w < CODE_LEN / 32; w += 256)
 			bits[w] = cw[w];
 		ctab[tid] = tb.crc32_tab[tid];
-		#pragma unroll
-		for (int w = 0; w < 4; ++w)
-			csh[tid + 256 * w] = tb.crc32_shift168[tid + 256 * w];
 		__syncthreads();
 		const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
 		const int mesg_bytes = md.mesg_bits / 8;
@@ -622,27 +618,7 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 			mesg[bi] = (uint8_t)o;
 		}
 		__syncthreads();
-		constexpr int SEG = 168, NSEG = 32, TAIL = CRC_BITS / 8 - SEG * NSEG;   // 5384 = 32 * 168 + 8 (k_finish's scheme)
-		if (tid < NSEG) {
-			const uint8_t *mp = mesg + tid * SEG;
-			uint32_t crc = 0;
-			for (int i = 0; i < SEG; ++i)
-				crc = (crc >> 8) ^ ctab[(crc ^ mp[i]) & 255];
-			cpart[tid] = crc;
-		}
-		__syncthreads();
-		if (tid == 0) {
-			uint32_t crc = 0;
-			for (int e = 0; e < NSEG; ++e) {
-				crc = csh[crc & 255] ^ csh[256 + ((crc >> 8) & 255)] ^ csh[512 + ((crc >> 16) & 255)] ^ csh[768 + (crc >> 24)];
-				crc ^= cpart[e];
-			}
-			for (int i = SEG * NSEG; i < SEG * NSEG + TAIL; ++i)
-				crc = (crc >> 8) ^ ctab[(crc ^ mesg[i]) & 255];
-			crc_sh = crc;
-		}
-		__syncthreads();
-		done = crc_sh == 0;
+		done = crc32_wg256(mesg, ctab, tb.crc32_adv, cpart, tid) == 0;   // decode.cc:533-541 (dev_common.h)
 	}
 	if (done) {
 		// decode.cc:546-554: received hard decision against decoded bit over the data bits = the unfrozen positions below the one

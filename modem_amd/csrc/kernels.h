@@ -100,6 +100,7 @@ struct Tables {                    // device-resident constants, built once per 
 	const uint8_t *osd_triples;    // [57155][3] (a,b,c) sorted by c (equal d-loop lengths are adjacent)
 	const uint32_t *crc32_tab;     // 256-entry byte table of CRC<uint32_t>(0xD419CC15)
 	const uint32_t *crc32_shift168; // [4][256]: the CRC state advanced by 168 zero bytes, per state byte (k_finish)
+	const uint32_t *crc32_adv;     // [256][32]: bit b of a state advanced by what follows segment k of the 5384 message bytes (crc32_wg256)
 	const uint8_t *scramble;       // 5380 bytes of the Xorshift32 stream (decode.cc:613-615)
 };
 

@@ -259,6 +259,23 @@ void build_tables(HostTables &t, int rate)
 				c = (c >> 8) ^ t.crc32_tab[c & 255];
 			t.crc32_shift168[b * 256 + v] = c;
 		}
+	// crc32_adv[k][b]: bit b of a CRC state advanced by the bytes that follow segment k of crc32_wg256's split of the 5384 message
+	// bytes (decode.cc:533-541: 43072 bits) - 255 segments of 21 bytes and a last one of 29: the advance is linear over GF(2), so a
+	// segment's CRC from a zero state, advanced bit by bit through this table, is its share of the whole CRC
+	t.crc32_adv.resize(256 * 32);
+	{
+		uint32_t cur[32];
+		for (int b = 0; b < 32; ++b)
+			cur[b] = 1u << b;                                     // behind the last segment: nothing follows
+		for (int k = 255; k >= 0; --k) {
+			for (int b = 0; b < 32; ++b)
+				t.crc32_adv[k * 32 + b] = cur[b];
+			const int len = k == 255 ? 29 : 21;                   // the bytes of segment k itself follow segment k - 1
+			for (int b = 0; b < 32; ++b)
+				for (int i = 0; i < len; ++i)
+					cur[b] = (cur[b] >> 8) ^ t.crc32_tab[cur[b] & 255];
+		}
+	}
 	t.scramble.resize(5380);
 	{
 		uint32_t y = 2463534242u;   // CODE::Xorshift32 default seed, decode.cc:613
