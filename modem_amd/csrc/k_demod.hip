@@ -23,8 +23,15 @@ template <int RATE> struct DifCfg {
 	static constexpr int R1 = SL % 5 == 0 ? 5 : 7, NS = SL / R1, NT = 64 * W * R1;
 	static constexpr int NQ = (NS + NT - 1) / NT;             // points n' per loader thread
 #define DEMOD_TWR_BYTES 8192
-#define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : (R) == 8000 ? 7 : 5)   // 8 kHz: 72 VGPRs = five workgroups per CU (26.6 KB of LDS each); 64 spills with the swizzle
-	static constexpr bool TWR_LDS = (R1 - 1) * NS * 8 <= DEMOD_TWR_BYTES || SL == 7056;   // w^(n' r) table in LDS (8 / 16 kHz; 44.1 kHz: 47 KB - its one
+#ifndef DEMOD_WAVES_8K
+#define DEMOD_WAVES_8K 7
+#endif
+#define DEMOD_DIF_WAVES(R) ((R) >= 44100 ? 3 : (R) == 8000 ? DEMOD_WAVES_8K : 5)   // 8 kHz: 72 VGPRs = five workgroups per CU (26.6 KB of LDS each); 64 spills with the swizzle
+#ifndef DEMOD_TWR_8K
+#define DEMOD_TWR_8K 1    // 8 kHz: 1 = the w^(n' r) of the radix-5 step in LDS (8 KB: five workgroups per CU); 0 = read from the global root table through L1:
+                          // 1.21 ms per 8192 frames against 1.16, and 1.36 with the register budget of eight waves per SIMD that lets a sixth workgroup in (round 6)
+#endif
+	static constexpr bool TWR_LDS = ((R1 - 1) * NS * 8 <= DEMOD_TWR_BYTES && (RATE != 8000 || DEMOD_TWR_8K)) || SL == 7056;   // w^(n' r) table in LDS (8 / 16 kHz; 44.1 kHz: 47 KB - its one
 	                                                          // workgroup per CU has the room) or read from the global root table (48 kHz: registers)
 	static constexpr int WAVES = DEMOD_DIF_WAVES(RATE);      // waves per SIMD the register budget is set for (two workgroups per CU at 44.1 / 48 kHz)
 };
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(DifCfg<RATE>::NT, MONO == 2 ? DEMOD_MONO_WAVES : Di
 		}
 		// 48 kHz: the w^(n' r) of a loader's two points, the same in every symbol, stay in registers (they came from the global root
 		// table in every symbol: eight loads per thread at the top of the symbol, in front of the row writes)
-		constexpr bool TWR_REG = !DC::TWR_LDS && NQ * (R1 - 1) <= 8;
+		constexpr bool TWR_REG = !DC::TWR_LDS && NQ * (R1 - 1) <= 8 && RATE != 8000;   // (8 kHz has no registers to spare: 64 = eight waves per SIMD)
 		cf twq[TWR_REG ? NQ : 1][TWR_REG ? R1 - 1 : 1];
 		if constexpr (TWR_REG) {
 			#pragma unroll
