@@ -5,7 +5,7 @@ make -C modem_amd/csrc -q all && echo "library up to date with sources" >> $O ||
 timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "${K:-two_lanes}" 2>&1 | tail -5 >> $O
 pick='import json,sys
 d=json.loads(sys.stdin.readline()); print("value", round(d["value"]), "kernel_only", round(d.get("value_kernel_only") or 0), "routes", d.get("routes_rank0"), "fer", d["fer"])'
-for env in ${ENVS:-"OFDMRX_LANES=1 GPU_MAX_HW_QUEUES=4" "OFDMRX_LANES=0 GPU_MAX_HW_QUEUES=8"}; do
+for env in ${ENVS:-"OFDMRX_LANES=1 GPU_MAX_HW_QUEUES=4" "OFDMRX_LANES=2 GPU_MAX_HW_QUEUES=4" "OFDMRX_LANES=2 GPU_MAX_HW_QUEUES=8"}; do
 	echo "== $env" >> $O
 	for x in "" "--noise-db -20" "--impair" "--noise-db -26"; do
 		echo -n "bench $x: " >> $O
