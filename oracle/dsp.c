@@ -171,13 +171,29 @@ void orc_front_end_rate(int rate, const void *samples, int fmt, int channels, si
 	const float s = 2 * (rc.symbol_len + rc.guard_len);
 	const float a = (s - 1.f) / s, b = (1.f + a) / 2.f;
 	float *dc = (float *)malloc(sizeof(float) * (n + 1));
-	float x1 = 0.f, y1 = 0.f;
-	for (size_t i = 0; i < n; ++i) {
-		float x0 = sample_at(samples, fmt, i);
-		float y0 = b * (x0 - x1) + a * y1;
-		x1 = x0;
-		y1 = y0;
-		dc[i] = y0;
+	if (orc_get_numerics() & ORC_NUM_BLOCKDC_FP32) {
+		/* the plain form: the recurrence in fp32, as a scalar build of the reference runs it */
+		float x1 = 0.f, y1 = 0.f;
+		for (size_t i = 0; i < n; ++i) {
+			float x0 = sample_at(samples, fmt, i);
+			float y0 = b * (x0 - x1) + a * y1;
+			x1 = x0;
+			y1 = y0;
+			dc[i] = y0;
+		}
+	} else {
+		/* default (round 6): the same recurrence with its state in double, every output rounded to fp32 once.  The fp32 recurrence
+		 * feeds its own rounding back through a = 1 - 1 / 2880: its outputs walk about 3e-6 of their magnitude away from the exact ones,
+		 * in an order -Ofast does not fix; a blocked scan (the GPU's front end) cannot follow that walk, and two sides 1e-6 apart pick
+		 * neighbouring samples where the Schmidl-Cox arg-max sits on a plateau.  Both sides now round the exact value. */
+		double x1 = 0.0, y1 = 0.0;
+		for (size_t i = 0; i < n; ++i) {
+			const double x0 = (double)sample_at(samples, fmt, i);
+			const double y0 = (double)b * (x0 - x1) + (double)a * y1;
+			x1 = x0;
+			y1 = y0;
+			dc[i] = (float)y0;
+		}
 	}
 	const int C = (rc.filter_len - 1) / 2;
 	for (size_t i = 0; i < n; ++i) {

@@ -259,7 +259,8 @@ enum {
 	ORC_NUM_SMA_TREE = 4,            /* sliding sums of decode.cc:86-90 as a fp32 ring of leaves under a binary add tree
 	                                  * (default: differences of double prefix sums) */
 	ORC_NUM_PHASOR_RECURSIVE = 8,    /* NCO as prev *= delta; prev /= |prev| in fp32 (default: closed form, phase in double) */
-	ORC_NUM_SNR_FP32 = 16            /* sp/np of decode.cc:507-517 accumulated term by term in fp32 (default: per-row double) */
+	ORC_NUM_SNR_FP32 = 16,           /* sp/np of decode.cc:507-517 accumulated term by term in fp32 (default: per-row double) */
+	ORC_NUM_BLOCKDC_FP32 = 32        /* the DC blocker of decode.cc:299 as an fp32 recurrence (default: state in double, outputs rounded once) */
 };
 void orc_set_numerics(unsigned flags);
 unsigned orc_get_numerics(void);

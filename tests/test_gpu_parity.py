@@ -1603,16 +1603,18 @@ def test_waterfall_parity_at_scale():
 
 
 def test_documented_tie_frames_at_the_waterfall():
-    """The five frames in which the sweeps of round 4 found the GPU and the scalar restatement apart in something decided
-    (4 of 65 536 AT the waterfall, one mono frame of 230 000 above it), regenerated from their seeds: each still differs exactly
-    the documented way - so a change of either side's numerics that moves them, or a new kind of difference, shows up here."""
+    """The frames in which the sweeps of round 4 found the GPU and the scalar restatement apart in something decided (4 of 65 536 AT
+    the waterfall), regenerated from their seeds: each still differs exactly the documented way - so a change of either side's numerics
+    that moves them, or a new kind of difference, shows up here.  The fifth, a MONO frame of 230 000 above the waterfall (timing tie),
+    no longer differs in anything since the oracle's DC blocker keeps its state in double (round 6: both sides round the exact value
+    instead of one following the other's fp32 rounding walk): it must now be identical."""
     import torch
     import modem_amd
     import modem_amd.ofdmrx as M
     dev = torch.device("cuda:0")
     # (frames of the sweep, noise level index, frame, noise level, mode, mono: DC offset or None, documented class)
     cases = [(32768, 0, 13365, -14.5, 6, None, "list"), (32768, 0, 18927, -14.5, 6, None, "list"), (32768, 0, 31302, -14.5, 6, None, "timing"),
-             (32768, 1, 654, -15.0, 6, None, "timing"), (2048, 1, 204, -19.0, 8, -2500, "timing")]
+             (32768, 1, 654, -15.0, 6, None, "timing"), (2048, 1, 204, -19.0, 8, -2500, "identical")]
     rx = modem_amd.Receiver(device=0, chunk_frames=16)
     got = []
     for n, li, i, db, mode, dc, want in cases:
@@ -1635,7 +1637,8 @@ def test_documented_tie_frames_at_the_waterfall():
         ores = np.zeros(1, M.RESULT_DTYPE)
         for name in ores.dtype.names:
             ores[name][0] = getattr(orr, name)
-        got.append(_tie_class(0, out, oo[None], res, ores, d_pay.cpu().numpy()))
+        same = (out[0] == oo).all() and all(res[nm][0] == ores[nm][0] for nm in ("status", "best_lane", "sc_start", "symbol_pos", "oper_mode", "call_sign", "n_sync_rejects"))
+        got.append("identical" if same else _tie_class(0, out, oo[None], res, ores, d_pay.cpu().numpy()))
     rx.close()
     assert got == [c[-1] for c in cases], got
 

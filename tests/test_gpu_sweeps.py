@@ -138,14 +138,12 @@ def test_sweep_waterfall():
 
 
 def test_sweep_mono():
-    """4096 MONO frames (DC offset 700 LSB) at -19 dB, where the list-1 pass decides: the front end is a blocked scan here and a serial
-    fp32 recurrence in the oracle (1e-6 of full scale apart) - everything decided identical but for timing ties
-    (measured: 1 in 8192), at most two"""
-    s = _sweep(4096, -19.0, 3004, channels=1, dc=700, explain=False)
+    """4096 MONO frames (DC offset 700 LSB) at -19 dB, where the list-1 pass decides.  Until round 6 the mono front end was 1e-6 of full
+    scale from the oracle's (the oracle followed the reference's fp32 DC-blocker recurrence through its own rounding walk, the GPU
+    runs a blocked scan): where the Schmidl-Cox arg-max sits on a plateau the two then took the coarse CFO from neighbouring samples,
+    carrier ratios differed by up to 5e-4 and flip counts by up to 24.  With the oracle's DC blocker in double (both sides round the exact
+    value; ORC_NUM_BLOCKDC_FP32 is the plain form, tests/test_oracle_numerics.py) mono input is as close as 2-channel input:
+    everything decided identical but for timing ties (at most two), every flip-count difference explained position by position."""
+    s = _sweep(4096, -19.0, 3004, channels=1, dc=700, allow_row_ties=True)
     assert s["ok"] == 4096
     assert len(s["differ"]) <= 2 and all(c == "timing" for c in s["classes"]), (s["differ"], s["classes"])
-    # The flip count on mono input is NOT explained position by position: where the Schmidl-Cox arg-max (decode.cc:99-103) sits on a
-    # plateau the two sides take the coarse CFO from neighbouring samples (1e-6 rad per sample apart), every carrier ratio of the frame
-    # then differs by up to 5e-4 and soft bits near zero fall either way.  Bounded as measured over 230 000 frames (DESIGN.md 3):
-    d = np.abs(s["res"]["bit_flips"].astype(np.int64) - s["ores"]["bit_flips"])
-    assert d.max() <= 24 and (d > 2).mean() <= 0.01, (int(d.max()), float((d > 2).mean()))

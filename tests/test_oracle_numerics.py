@@ -104,3 +104,45 @@ def test_each_plain_form_alone(frames, baseline, flag, lanes_equal):
         _set(0)
     ref = (baseline[0][idx], {k: v[idx] for k, v in baseline[1].items()})
     _same_decisions(ref, got, lanes_equal)
+
+
+def test_blockdc_in_double_changes_no_decision_on_mono_input():
+    """ORC_NUM_BLOCKDC_FP32 (round 6): the DC blocker of decode.cc:299 runs with its state in double and rounds every output once by
+    default; the plain form is the fp32 recurrence.  96 MONO frames (the real part of the noisy analytic stream + a DC offset, what a
+    1-channel WAV holds, encode.cc:127-128) from -24 dB through the waterfall: payload, status, sync position, header and lane are the
+    same with either form, and the analytic signals differ by no more than the fp32 recurrence's own rounding walk (a few 1e-6)."""
+    clean = [O.encode_pcm(O.payload_for(700 + i), channels=2) for i in range(4)]
+    levels = [-24.0, -19.0, -17.0, -16.0, -15.0, -14.5]
+    per = 16
+    pcm = np.zeros((len(levels) * per, clean[0].shape[0], 1), np.int16)
+    f = 0
+    for db in levels:
+        for q in range(per):
+            z = O.impair(clean[q % 4], noise_db=db, seed=79, frame=f)
+            pcm[f, :, 0] = np.clip(z[:, 0].astype(np.int32) + (700 if q % 2 else -2500), -32768, 32767)
+            f += 1
+
+    def run():
+        n, spf = pcm.shape[0], pcm.shape[1]
+        out = np.zeros((n, 5380), np.uint8)
+        res = (O.Result * n)()
+        O.lib().orc_decode_batch(O.ptr(pcm), O.FMT_S16, 1, spf, spf * 2, n, 8, O.ptr(out), C.cast(res, C.c_void_p), THREADS)
+        return out, {fl: np.array([getattr(r, fl) for r in res]) for fl, _ in O.Result._fields_}
+
+    def analytic(frame):
+        z = np.zeros((frame.shape[0], 2), np.float32)
+        O.lib().orc_front_end(O.ptr(np.ascontiguousarray(frame)), O.FMT_S16, 1, frame.shape[0], O.ptr(z))
+        return z
+
+    try:
+        _set(0)
+        base, z0 = run(), analytic(pcm[3])
+        _set(32)
+        plain, z1 = run(), analytic(pcm[3])
+    finally:
+        _set(0)
+    _same_decisions(base, plain, lanes_equal=True)
+    st = base[1]["status"]
+    assert (st[:per] == 0).all() and (st[-per:] != 0).sum() >= per // 2     # from all decoded to mostly lost
+    scale = np.abs(z0).max()
+    assert 1e-8 * scale < np.abs(z0 - z1).max() <= 2e-5 * scale
