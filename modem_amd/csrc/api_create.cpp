@@ -115,6 +115,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.tw_symc, &h->dev.tw_symc);
 	r = r ? r : upload(h, h->host.frozen, &h->dev.frozen);
 	r = r ? r : upload(h, h->host.info_pos, &h->dev.info_pos);
+	r = r ? r : upload(h, h->host.info_compress, &h->dev.info_compress);
 	r = r ? r : upload(h, h->host.node_lev, &h->dev.node_lev);
 	r = r ? r : upload(h, h->host.node_lev64, &h->dev.node_lev64);
 	r = r ? r : upload(h, h->host.node_lev32, &h->dev.node_lev32);

@@ -677,6 +677,33 @@ __device__ __forceinline__ bool snr_rows(Raw raw, Begin begin_row, Rotated rotat
 	__syncthreads();
 	return snr_ok != 0;
 }
+// The systematic message (decode.cc:254-261: the codeword at the unfrozen positions, ascending) out of a bit-packed codeword, by a workgroup
+// of 256 threads: code word w holds cnt consecutive message bits from bit `off` on - its unfrozen bits pushed together ("compress",
+// Hacker's Delight 7-4, the five move masks precomputed per word: tables.cpp info_compress) and ORed into the message at that bit.
+// Round 6; until then every message byte gathered its eight bits one by one through the list of unfrozen positions (171 two-byte loads
+// and as many LDS reads per thread: 87 us of k_back's 547 per chunk).  code: 2048 words in LDS; mesg32: the message as little-endian
+// words in LDS, ZEROED by the caller and synchronised before and after; rec: this table's [2048][8] records.
+__device__ __forceinline__ void message_gather(const uint32_t *code, uint32_t *mesg32, const uint32_t *__restrict__ rec, int tid)
+{
+	#pragma unroll
+	for (int e = 0; e < CODE_LEN / 32 / 256; ++e) {
+		const int w = tid + 256 * e;
+		const uint4 a = ((const uint4 *)rec)[2 * w], b = ((const uint4 *)rec)[2 * w + 1];
+		uint32_t x = code[w] & b.y, t;
+		t = x & a.x; x = (x ^ t) | (t >> 1);
+		t = x & a.y; x = (x ^ t) | (t >> 2);
+		t = x & a.z; x = (x ^ t) | (t >> 4);
+		t = x & a.w; x = (x ^ t) | (t >> 8);
+		t = x & b.x; x = (x ^ t) | (t >> 16);
+		const int off = (int)(b.z & 0xffffu), cnt = (int)(b.z >> 16), o = off & 31;
+		if (x) {
+			atomicOr(&mesg32[off >> 5], x << o);
+			if (o + cnt > 32)
+				atomicOr(&mesg32[(off >> 5) + 1], x >> (32 - o));
+		}
+	}
+}
+
 // CRC<uint32_t>(0xD419CC15) over the first 43072 bits = 5384 bytes of mesg[] (decode.cc:533-541), zero start, by a workgroup of 256
 // threads (round 6; until then 32 threads walked 168 bytes each - two dependent LDS round trips per byte - and one thread folded the
 // 32 results: 125 of k_back's 547 us per chunk with seven eighths of the workgroup waiting, profiles/r06_back_by_stage.txt).

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256, BACK_WAVES) void k_back(int sym_stride, int ce
 	__shared__ uint32_t bits[CODE_LEN / 32];
 	__shared__ float prec[ROWS_MAX], row_slope[ROWS_MAX], row_yint[ROWS_MAX];
 	__shared__ cf row_step[ROWS_MAX];
-	__shared__ uint8_t mesg[MESG_BYTES_MAX];
+	__shared__ uint32_t mesg32[MESG_BYTES_MAX / 4];               // the systematic message, little-endian words
+	uint8_t *const mesg = (uint8_t *)mesg32;
 	__shared__ uint32_t ctab[256], cpart[4];
 	__shared__ int slot_sh;
 	ListQueue *const q_cert = q;                                      // the syndrome certificate's switch and counters (the list queue's block)
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(256, BACK_WAVES) void k_back(int sym_stride, int ce
 	if (try_cert) {
 		for (int w = tid; w < CODE_LEN / 32; w += 256)
 			bits[w] = 0;
+		for (int w = tid; w < MESG_BYTES_MAX / 4; w += 256)
+			mesg32[w] = 0;
 		ctab[tid] = tb.crc32_tab[tid];
 	}
 	__syncthreads();
@@ -169,17 +172,7 @@ __global__ __launch_bounds__(256, BACK_WAVES) void k_back(int sym_stride, int ce
 	int bad = 1;
 	if (try_cert) {
 		// ---- 3a. (before the transform overwrites the bit array) the systematic message = x at the unfrozen positions, decode.cc:254-261
-		const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
-		const int mesg_bytes = md.mesg_bits / 8;
-		for (int bi = tid; bi < mesg_bytes; bi += 256) {
-			uint32_t o = 0;
-			#pragma unroll
-			for (int b = 0; b < 8; ++b) {
-				const int p = info_pos[8 * bi + b];
-				o |= ((bits[p >> 5] >> (p & 31)) & 1u) << b;
-			}
-			mesg[bi] = (uint8_t)o;
-		}
+		message_gather(bits, mesg32, tb.info_compress + (md.table ? 2048 * 8 : 0), tid);   // (mesg32 was zeroed with the bit array)
 		// ---- 2. u = x F: at every level the left half of a block takes the XOR with the right half (the involution the partial-sum
 		// combines of the decoder apply the other way round).  Word a = tid + 256 w: distances >= 256 words are inside the thread.
 		uint32_t w[8];

@@ -595,7 +595,8 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 	uint8_t *const pay_dst = late ? ls.payload : ls.payload_now;
 	Result *const res_dst = late ? ls.res : ls.res_now;
 	__shared__ uint32_t bits[CODE_LEN / 32];
-	__shared__ uint8_t mesg[MESG_BYTES_MAX];
+	__shared__ uint32_t mesg32[MESG_BYTES_MAX / 4];               // the systematic message, little-endian words
+	uint8_t *const mesg = (uint8_t *)mesg32;
 	__shared__ uint32_t ctab[256], cpart[4];
 	__shared__ int flips_red[4], slot_sh;
 	const ModeDesc md = mode_desc(ls.oper_mode);
@@ -604,19 +605,11 @@ __global__ __launch_bounds__(256) void k_sc_finish(ListQueue *__restrict__ qs, c
 		const uint32_t *cw = (const uint32_t *)(cw_q + (size_t)slot * (CODE_LEN / 64));
 		for (int w = tid; w < CODE_LEN / 32; w += 256)
 			bits[w] = cw[w];
+		for (int w = tid; w < MESG_BYTES_MAX / 4; w += 256)
+			mesg32[w] = 0;
 		ctab[tid] = tb.crc32_tab[tid];
 		__syncthreads();
-		const uint16_t *info_pos = tb.info_pos + (md.table ? MESG_BITS_MAX : 0);
-		const int mesg_bytes = md.mesg_bits / 8;
-		for (int bi = tid; bi < mesg_bytes; bi += 256) {
-			uint32_t o = 0;
-			#pragma unroll
-			for (int b = 0; b < 8; ++b) {
-				const int p = info_pos[8 * bi + b];
-				o |= ((bits[p >> 5] >> (p & 31)) & 1u) << b;
-			}
-			mesg[bi] = (uint8_t)o;
-		}
+		message_gather(bits, mesg32, tb.info_compress + (md.table ? 2048 * 8 : 0), tid);   // decode.cc:254-261
 		__syncthreads();
 		done = crc32_wg256(mesg, ctab, tb.crc32_adv, cpart, tid) == 0;   // decode.cc:533-541 (dev_common.h)
 	}

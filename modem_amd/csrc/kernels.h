@@ -91,6 +91,7 @@ struct Tables {                    // device-resident constants, built once per 
 	const cf *tw_symc;             // compact per-stage twiddles of the symbol_len-point plan (transmitter: read through L1)
 	const uint32_t *frozen;        // [2][2048] words, bit set = frozen: frozen_64800_43072, frozen_64512_43072 (regenerated)
 	const uint16_t *info_pos;      // [2][44096] ascending unfrozen positions per table
+	const uint32_t *info_compress; // [2][2048][8] per code word: compress move masks, unfrozen mask, first message bit | count << 16 (message_gather)
 	const uint8_t *node_lev64;     // [2][1024] the same per 64-leaf block, for k_sc (frozen: 64 or 128 leaves, information: 64 .. 2048)
 	const uint8_t *node_lev32;     // [2][2048] ... per 32-leaf block (frozen: 32 .. 128 leaves, information: 32 .. 1024)
 	const uint8_t *node_lev;       // [2][8192] per 8-leaf group: level of the largest aligned all-frozen (low nibble) /

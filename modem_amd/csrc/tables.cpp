@@ -228,6 +228,30 @@ void build_tables(HostTables &t, int rate)
 			if (!((t.frozen[tab * 2048 + i / 32] >> (i % 32)) & 1))
 				t.info_pos[tab * 44096 + n++] = (uint16_t)i;
 	}
+	// info_compress[tab][w][8]: what message_gather (dev_common.h) needs to take the message bits out of code word w in one go: the
+	// word's mask of unfrozen positions m, the five move masks of the parallel-suffix "compress" of x & m (Hacker's Delight 7-4: they depend
+	// on m alone), the message bit the word's first unfrozen position is (low 16 bits) and how many it holds (high 16)
+	t.info_compress.assign(2 * 2048 * 8, 0);
+	for (int tab = 0; tab < 2; ++tab) {
+		uint32_t off = 0;
+		for (int w = 0; w < 2048; ++w) {
+			uint32_t *rec = &t.info_compress[(size_t)(tab * 2048 + w) * 8];
+			uint32_t m = ~t.frozen[tab * 2048 + w];
+			rec[5] = m;
+			uint32_t mk = ~m << 1;
+			for (int i = 0; i < 5; ++i) {
+				uint32_t mp = mk ^ (mk << 1);
+				mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16;
+				const uint32_t mv = mp & m;
+				rec[i] = mv;
+				m = (m ^ mv) | (mv >> (1 << i));
+				mk &= ~mp;
+			}
+			const uint32_t cnt = (uint32_t)__builtin_popcount(rec[5]);
+			rec[6] = off | (cnt << 16);
+			off += cnt;
+		}
+	}
 	t.genmat_bits.resize(71 * 8);
 	bch_genmat_bits(t.genmat_bits.data());
 	t.osd_pairs.clear();
