@@ -94,6 +94,8 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 			swpc = std::max(1, std::atoi(e3));
 		h->sc_grid = swpc * std::max(cus, 1);
 		h->sc_grid6 = (std::getenv("OFDMRX_SC_WPC") ? swpc : 10) * std::max(cus, 1);   // 168 VGPRs, 16 KB of LDS: ten of these per CU
+		if (const char *e6 = std::getenv("OFDMRX_SC_TOP"))
+			h->sc_top = std::atoi(e6) != 0;
 		if (const char *e4 = std::getenv("OFDMRX_SC_LB"))
 			h->sc_lb = std::atoi(e4) == 5 ? 5 : (std::atoi(e4) == 0 ? 0 : 6);
 		h->lanes = (cfg->flags & OFDMRX_FLAG_TWO_LANES) ? 2 : 1;
@@ -119,6 +121,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 	r = r ? r : upload(h, h->host.node_lev, &h->dev.node_lev);
 	r = r ? r : upload(h, h->host.node_lev64, &h->dev.node_lev64);
 	r = r ? r : upload(h, h->host.node_lev32, &h->dev.node_lev32);
+	r = r ? r : upload(h, h->host.frozen_t, &h->dev.frozen_t);
 	r = r ? r : upload(h, h->host.genmat_bits, &h->dev.genmat_bits);
 	r = r ? r : upload(h, h->host.osd_pairs, &h->dev.osd_pairs);
 	r = r ? r : upload(h, h->host.osd_triples, &h->dev.osd_triples);

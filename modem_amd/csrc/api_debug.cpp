@@ -149,7 +149,7 @@ extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n
 		}
 		launch_sc_plan(h->stream, ctl.as<ListQueue>());
 		launch_sc(h->stream, h->sc_lb ? h->sc_lb : 6, grid, grid, ctl.as<ListQueue>(), slots.as<ListSlot>(), dl.as<float>(), soft.as<float>(), cw.as<unsigned long long>(),
-			xw.as<unsigned long long>(), stat.as<ScStat>(), h->dev);
+			xw.as<unsigned long long>(), stat.as<ScStat>(), h->dev, h->sc_top);
 		e = e == hipSuccess ? hipGetLastError() : e;
 		e = e == hipSuccess ? hipStreamSynchronize(h->stream) : e;
 		if (e == hipSuccess && codeword)

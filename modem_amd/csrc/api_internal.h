@@ -139,6 +139,7 @@ struct ofdmrx_handle {
 	unsigned sc_unit = 1;     // entries a run of the list-1 pass takes at a time: one residency of its decoders (the last run of a call: everything)
 	int sc_mode = 1;          // 1: the list-1 pass (adaptive) in front of the list decoder, 0: off
 	int sc_grid = 0, sc_grid6 = 0;   // resident SC decoders (waves): two codewords per wave / one (k_sc.hip)
+	int sc_top = 1;           // k_sc skips clean nodes of 16384 / 32768 leaves on a lower bound of their share of min_fork (OFDMRX_SC_TOP=0: every figure exact)
 	int sc_lb = 6;            // one codeword per wave (6, the default: with 64 loads in flight it is the faster layout at every run length, and
 	                          // it moves 2.1 MB per codeword against 2.7), two (5), or 0: the run's length picks on the device (OFDMRX_SC_LB)
 	ListQueue *sc_queue() const { return s_ctl.as<ListQueue>(); }

@@ -108,7 +108,7 @@ void run_sc_pass(ofdmrx_handle *h, hipStream_t s, int n, bool force, int chunk_s
 	Range r("ofdmrx:sc_path");
 	launch_sc_plan(s, h->sc_queue(), h->sc_unit, force ? 1 : 0);
 	launch_sc(s, h->sc_lb, std::min(h->sc_grid, (n + 1) / 2), std::min(h->sc_grid6, n), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(),
-		h->sc_soft.as<float>(), h->s_cw.as<unsigned long long>(), h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev);
+		h->sc_soft.as<float>(), h->s_cw.as<unsigned long long>(), h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev, h->sc_top);
 	launch_sc_finish(s, (int)std::min<unsigned>(h->s_cap, (unsigned)n + h->sc_unit), h->sc_queue(), h->s_slots.as<ListSlot>(), h->s_llr.as<float>(), h->s_cw.as<unsigned long long>(),
 		h->s_xw.as<unsigned long long>(), h->s_stat.as<ScStat>(), h->dev, h->cfg.descramble, h->queue(), h->q_slots.as<ListSlot>(),
 		h->q_llr.as<float>(), h->slot_of.as<int>(), chunk_seq);

@@ -260,6 +260,9 @@ __global__ __launch_bounds__(256, BACK_WAVES) void k_back(int sym_stride, int ce
 	}
 	__syncthreads();
 	float *llr = llr_q + (size_t)slot_sh * CODE_LEN;
+	typedef float vf4 __attribute__((ext_vector_type(4)));
+	const int lane = tid & 63;
+	float *const stage = (float *)bits + (tid >> 6) * 192;        // (the bit array has done its work)
 	cf nxt[2];
 	auto fetch = [&](int j) {
 		#pragma unroll
@@ -279,13 +282,27 @@ __global__ __launch_bounds__(256, BACK_WAVES) void k_back(int sym_stride, int ce
 				const cf c = rotate_point(cur[e], row_slope[j], row_yint[j], i, cols);
 				float *b = llr + mod_bits * (j * cols + i);
 				if (mod_bits == 3) {
-					b[1] = c.re * sc;
-					b[2] = c.im * sc;
-					b[0] = (rcp_sqrt_2 * (fabsf(c.re) - fabsf(c.im))) * sc;
+					stage[3 * lane + 1] = c.re * sc;
+					stage[3 * lane + 2] = c.im * sc;
+					stage[3 * lane + 0] = (rcp_sqrt_2 * (fabsf(c.re) - fabsf(c.im))) * sc;
 				} else {
 					b[0] = c.re * sc;
 					b[1] = c.im * sc;
 				}
+			}
+			if (mod_bits == 3) {
+				// three soft bits per point: a lane's own stores would be 4 bytes every 12 (every store instruction a third of each line it touches:
+				// 2.6 TB/s).  The wave's 64 points are 768 consecutive bytes: through LDS, written as 16-byte pieces
+				const int i0 = i - lane, nfl = 3 * min(64, cols - i0);              // (wave-uniform; <= 0: this wave has no points here)
+				__builtin_amdgcn_wave_barrier();
+				if (nfl > 0) {
+					float *dst = llr + 3 * (j * cols + i0);
+					if (lane < (nfl >> 2))
+						__builtin_nontemporal_store(((const vf4 *)stage)[lane], (vf4 *)dst + lane);
+					else if (lane < (nfl >> 2) + (nfl & 3))
+						dst[(nfl & ~3) + lane - (nfl >> 2)] = stage[(nfl & ~3) + lane - (nfl >> 2)];
+				}
+				__builtin_amdgcn_wave_barrier();
 			}
 		}
 	}

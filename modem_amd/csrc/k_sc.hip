@@ -249,10 +249,26 @@ template <int LB, int LEV, int N> __device__ __forceinline__ void sc_emit(rsrc_t
 	} else
 		lds[lidx] = t[0];
 }
+// (one codeword per wave) the pass's first array - the node of NH sub-trees that starts at sub-tree s - is tested for being CLEAN
+// (see sc_clean below) while it goes by, when skipping it saves level-store traffic (NH >= 4): a clean one leaves its hard decisions
+// in LDS (word k * 64 + lane of the stash = this lane's 64 elements of sub-tree s + k) and the smallest magnitude of its array.
+#ifndef SC_CLEAN_TOP
+#define SC_CLEAN_TOP 1
+#endif
+struct ScTop {
+	const uint32_t *ft;       // frozen_t of the codeword's table
+	bool allow;               // the caller skips a clean node (else nothing is tested: LDS keeps the first sub-tree's array)
+	int nskip;                // out: sub-trees covered by the clean node (0: none)
+	uint32_t mu;              // out: smallest magnitude of its array
+};
 template <int LB, int D, int KIND>
-__device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds, const ScIo<LB> &io, int s, int lane, int v_llr0, int v_soft0, bool &finite)
+__device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds, const ScIo<LB> &io, int s, int lane, int v_llr0, int v_soft0, bool &finite,
+	ScTop &top, const uint32_t (&lowsel)[7])
 {
 	using Cf = ScCfg<LB>;
+	constexpr bool TOPCHK = LB == 6 && D >= 3 && SC_CLEAN_TOP;
+	unsigned long long Hs[TOPCHK ? (1 << (D - 1)) : 1] = {};
+	uint32_t mu_top = 0x7f800000u;
 	constexpr int NS = 1 << D, NH = NS / 2, XB = NS >= SC_LOADS ? 1 : SC_LOADS / NS, XSTEP = Cf::J * 4;   // SC_LOADS loads in flight per lane
 	const rsrc_t src = KIND == 2 ? soft : llr;
 	constexpr int src_off = KIND == 2 ? sc_off(Cf::LL + D) : 0;
@@ -290,6 +306,14 @@ __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds,
 					t[k] = __uint_as_float(__float_as_uint(v[xb][k]) ^ sg) + v[xb][k + NH];
 				}
 			}
+			if constexpr (TOPCHK) {
+				#pragma unroll
+				for (int k = 0; k < NH; ++k) {
+					const uint32_t tb = __float_as_uint(t[k]);
+					mu_top = min(mu_top, tb & 0x7fffffffu);
+					Hs[k] |= (unsigned long long)(tb >> 31) << x;
+				}
+			}
 			if (KIND == 0) {
 				// the hard decisions of this column's NS elements: word x of sub-tree k, gathered on lane k and stored from there
 				int ma = 0, mb = 0;
@@ -309,6 +333,53 @@ __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds,
 				}
 			}
 			sc_emit<LB, Cf::LL + D - 1, NH>(soft, lds, v_dst + xb * XSTEP, lidx + xb * Cf::J, t);
+		}
+	}
+	if (TOPCHK && top.allow) {
+		// u = h F over the node's NH * 4096 positions (sub-tree, element, lane position); zero wherever a leaf is frozen?
+		// (the pass holds position `lane` of every block, the walk and its tables position sc_pos(lane): quad_perm [3,2,1,0] where lane & 4)
+		unsigned long long U[NH];
+		#pragma unroll
+		for (int k = 0; k < NH; ++k) {
+			const uint32_t a0 = (uint32_t)Hs[k], a1 = (uint32_t)(Hs[k] >> 32);
+			const uint32_t s0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a0, 0x1B, 0xf, 0xf, false);
+			const uint32_t s1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a1, 0x1B, 0xf, 0xf, false);
+			if (lane & 4)
+				Hs[k] = (unsigned long long)s0 | ((unsigned long long)s1 << 32);
+			U[k] = Hs[k];
+		}
+		#pragma unroll
+		for (int tt = NH / 2; tt >= 1; tt >>= 1)
+			#pragma unroll
+			for (int k = 0; k < NH; ++k)
+				if (!(k & tt))
+					U[k] ^= U[k + tt];
+		bool bad = mu_top == 0u;
+		#pragma unroll
+		for (int k = 0; k < NH; ++k) {
+			unsigned long long h = U[k];
+			h ^= (h >> 32) & 0x00000000ffffffffull;
+			h ^= (h >> 16) & 0x0000ffff0000ffffull;
+			h ^= (h >> 8) & 0x00ff00ff00ff00ffull;
+			h ^= (h >> 4) & 0x0f0f0f0f0f0f0f0full;
+			h ^= (h >> 2) & 0x3333333333333333ull;
+			h ^= (h >> 1) & 0x5555555555555555ull;
+			uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+			#define SC_XL(H, LV) { \
+				const uint32_t m = (uint32_t)((int)lowsel[LV] >> 31); \
+				h0 ^= xpos<H>(h0, lane) & m; \
+				h1 ^= xpos<H>(h1, lane) & m; }
+			SC_XL(32, 6) SC_XL(16, 5) SC_XL(8, 4) SC_XL(4, 3) SC_XL(2, 2) SC_XL(1, 1)
+			#undef SC_XL
+			const uint2 ft = ((const uint2 *)top.ft)[(s + k) * 64 + lane];
+			bad |= ((h0 & ft.x) | (h1 & ft.y)) != 0u;
+		}
+		if (__ballot(bad) == 0ull) {
+			#pragma unroll
+			for (int k = 0; k < NH; ++k)
+				((unsigned long long *)lds)[k * 64 + lane] = Hs[k];
+			top.nskip = NH;
+			top.mu = mu_top;
 		}
 	}
 }
@@ -351,6 +422,100 @@ template <int CNT> __device__ __forceinline__ void sc_g_half(float (&dst)[CNT], 
 		dst[x] = __uint_as_float(__float_as_uint(src[x]) ^ ((hb << (31 - x)) & SC_SIGN)) + src[x + CNT];
 }
 
+// ---- CLEAN nodes (round 6; one codeword per wave only).  A node is clean when the hard decisions h of its input LLRs are a codeword of its
+// sub-code (h F vanishes on the node's frozen leaves) and no input is zero.  Then successive cancellation returns h and no frozen leaf of
+// the node adds a penalty, without the node being walked: by induction over the two halves (a, b) of the array - the left child's input
+// f(a, b) has the hard decisions ha ^ hb, which are its part of the codeword, so it is clean and returns them; the right child's input
+// is then b + a where ha = hb and b - a where they differ: a sum of two numbers of b's sign, hard decisions hb, magnitudes |a| + |b|, clean
+// again - down to leaves whose hard decision is the message bit and, where frozen, zero (a positive LLR: no penalty; an all-frozen node
+// below sees positive inputs only: penalty +0).  No magnitude on the way is smaller than the smallest input, so no zero turns up.
+// What min_fork needs from such a node is the smallest leaf magnitude over its information leaves: magnitudes obey |f| = min(|a|, |b|),
+// |g| = fl(|a| + |b|) (an fp32 sum of two numbers of one sign is the sum of their magnitudes), the partial sums no longer matter, and the
+// whole sub-tree of magnitudes is evaluated level by level, every lane busy at every level (sc_clean_fork) - the same fp32 values the walk
+// would have met, so M*, min_fork and the rule's outcome are the walk's, bit for bit.  At -20 dB 94 % of the leaves sit under a clean
+// node of 64 .. 4096 leaves, in configs[3] 99.9 % (tools/experiments/sc_clean_nodes.py).
+// The node's array: element x of the lane at position q = position x * 64 + q, CNT elements per lane; fz: bit x = that position frozen.
+#ifndef SC_CLEAN_MIN
+#define SC_CLEAN_MIN 0            // the smallest node tested: 64 << SC_CLEAN_MIN leaves (7: none)
+#endif
+template <int CNT> struct ScWord { typedef uint32_t T; };
+template <> struct ScWord<64> { typedef unsigned long long T; };
+template <int CNT> __device__ __forceinline__ bool sc_clean(const float (&r)[CNT], unsigned long long fz, const ScLane &L, typename ScWord<CNT>::T &hard)
+{
+	typedef typename ScWord<CNT>::T W;
+	uint32_t mu = 0x7f800000u;
+	W h = 0;
+	#pragma unroll
+	for (int x = 0; x < CNT; ++x) {
+		mu = min(mu, sc_mag(r[x]));
+		h |= (W)(__float_as_uint(r[x]) >> 31) << x;
+	}
+	hard = h;
+	// u = h F: the element levels inside the lane's word, the position levels across the lanes
+	if constexpr (CNT > 32) h ^= (h >> 32) & (W)0x00000000ffffffffull;
+	if constexpr (CNT > 16) h ^= (h >> 16) & (W)0x0000ffff0000ffffull;
+	if constexpr (CNT > 8) h ^= (h >> 8) & (W)0x00ff00ff00ff00ffull;
+	if constexpr (CNT > 4) h ^= (h >> 4) & (W)0x0f0f0f0f0f0f0f0full;
+	if constexpr (CNT > 2) h ^= (h >> 2) & (W)0x3333333333333333ull;
+	if constexpr (CNT > 1) h ^= (h >> 1) & (W)0x5555555555555555ull;
+	uint32_t h0 = (uint32_t)h, h1 = CNT > 32 ? (uint32_t)((unsigned long long)h >> 32) : 0u;
+	#define SC_XL(H, LV) { \
+		const uint32_t m = (uint32_t)((int)L.lowsel[LV] >> 31); \
+		h0 ^= xpos<H>(h0, L.lane) & m; \
+		if constexpr (CNT > 32) h1 ^= xpos<H>(h1, L.lane) & m; }
+	SC_XL(32, 6) SC_XL(16, 5) SC_XL(8, 4) SC_XL(4, 3) SC_XL(2, 2) SC_XL(1, 1)
+	#undef SC_XL
+	const W keep = CNT == 64 ? ~(W)0 : (W)(((unsigned long long)1 << (CNT & 63)) - 1ull);
+	const bool bad = ((h0 & (uint32_t)fz & (uint32_t)keep) | (CNT > 32 ? h1 & (uint32_t)(fz >> 32) : 0u)) != 0u || mu == 0u;
+	return __ballot(bad) == 0ull;
+}
+// the smallest leaf magnitude over the information leaves of a clean node (in place on its array)
+template <int H, int LV, int CNT> __device__ __forceinline__ void sc_mag_cross(float (&a)[CNT], const ScLane &L)
+{
+	const bool low = L.lowsel[LV] != 0u;
+	#pragma unroll
+	for (int x = 0; x < CNT; ++x) {
+		const float p = xpos<H>(a[x], L.lane);
+		a[x] = low ? __builtin_fminf(a[x], p) : a[x] + p;
+	}
+}
+template <int CNT> __device__ __forceinline__ uint32_t sc_clean_fork(float (&a)[CNT], unsigned long long fz, const ScLane &L)
+{
+	#pragma unroll
+	for (int x = 0; x < CNT; ++x)
+		a[x] = __builtin_fabsf(a[x]);
+	#pragma unroll
+	for (int t = CNT / 2; t >= 1; t >>= 1)
+		#pragma unroll
+		for (int x = 0; x < CNT; ++x)
+			if (!(x & t)) {
+				const float lo = __builtin_fminf(a[x], a[x + t]), hi = a[x] + a[x + t];
+				a[x] = lo;
+				a[x + t] = hi;
+			}
+	sc_mag_cross<32, 6>(a, L);
+	sc_mag_cross<16, 5>(a, L);
+	sc_mag_cross<8, 4>(a, L);
+	sc_mag_cross<4, 3>(a, L);
+	sc_mag_cross<2, 2>(a, L);
+	sc_mag_cross<1, 1>(a, L);
+	uint32_t mu = 0x7f800000u;
+	#pragma unroll
+	for (int x = 0; x < CNT; ++x)
+		mu = min(mu, ((fz >> x) & 1ull) ? 0x7f800000u : __float_as_uint(a[x]));
+	return sc_min_mag<6>(mu, L.lane);
+}
+// a node on a register array: clean -> its bits, its share of min_fork
+template <int CNT> __device__ __forceinline__ bool sc_try_clean(float (&r)[CNT], unsigned long long fz, ScAcc &acc, const ScLane &L, uint32_t &bits)
+{
+	typename ScWord<CNT>::T h;
+	if (!sc_clean(r, fz, L, h))
+		return false;
+	bits = (uint32_t)h;
+	acc.info(sc_clean_fork(r, fz, L));
+	return true;
+}
+
 // Persistent grid: workgroup = one wave = one decoder (of 64 >> LB codewords) with its own level stores; decoders take units of
 // 64 >> LB consecutive entries from the run's counter.  Entries of a unit that share the frozen table are decoded side by side;
 // a unit whose entries do not (a mixed-mode batch), or whose second entry does not exist, is decoded one entry at a time with
@@ -362,7 +527,7 @@ template <int CNT> __device__ __forceinline__ void sc_g_half(float (&dst)[CNT], 
 template <int LB>
 __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
 	float *__restrict__ soft_all, uint32_t *__restrict__ cw_q, uint32_t *__restrict__ xw_q, ScStat *__restrict__ stat_q,
-	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev_blk, int small_run)
+	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev_blk, const uint32_t *__restrict__ frozen_t, int small_run, int top_skip)
 {
 	using Cf = ScCfg<LB>;
 	constexpr int J = Cf::J, C = Cf::C, NBLK = CODE_LEN / J;
@@ -430,14 +595,22 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 				io.xwb = io.cwb + CODE_LEN / 32;
 			}
 		}
+		// A clean node of 16384 / 32768 leaves (sc_top_pass) is skipped with the smallest magnitude of its ARRAY in place of the smallest
+		// leaf magnitude over its information leaves - a lower bound: a rule that holds with it holds (min_fork is no smaller), one that fails
+		// with it says nothing, and the codeword is decoded once more without such skips (attempt 1: every figure exact).
+		#pragma unroll 1
+		for (int attempt = 0; attempt < 2; ++attempt) {
+		bool weak = false;
+		int skip_left = 0, skip_lg = 0, skip_k = 0;
 		ScAcc acc{ 0.f, 0x7f800000u };
 		bool finite = true;
 		#pragma unroll 1
 		for (int s = 0; s < Cf::NSUB; ++s) {
 			// ---------------- the array of this sub-tree into LDS, through the level store
-			{
+			if (skip_left == 0) {
 				const int D = s ? __builtin_ctz(s) + 1 : 16 - Cf::LL;
-				#define SC_PASS(DD, KK) sc_top_pass<LB, DD, KK>(soft, llr, lds, io, s, lane, v_llr0, v_soft0, finite)
+				ScTop top{ frozen_t + tab * (16 * 64 * 2), attempt == 0 && top_skip != 0, 0, 0u };
+				#define SC_PASS(DD, KK) sc_top_pass<LB, DD, KK>(soft, llr, lds, io, s, lane, v_llr0, v_soft0, finite, top, L.lowsel)
 				if (s == 0) SC_PASS(16 - Cf::LL, 0);
 				else if (s == Cf::NSUB / 2) SC_PASS(16 - Cf::LL, 1);
 				else if (D == 1) SC_PASS(1, 2);
@@ -445,6 +618,13 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 				else if (D == 3) SC_PASS(3, 2);
 				else if constexpr (16 - Cf::LL > 4) SC_PASS(4, 2);
 				#undef SC_PASS
+				if (top.nskip) {
+					skip_left = top.nskip;
+					skip_lg = 31 - __builtin_clz(top.nskip);
+					skip_k = 0;
+					acc.info(sc_min_mag<6>(top.mu, lane));
+					weak = true;
+				}
 			}
 			SC_WAVE_ORDER();
 			// this sub-tree's 64 table bytes and frozen words, one block per lane; the block loop reads them with v_readlane
@@ -458,9 +638,32 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 				fzl = frozen[blk0 + lane];
 			const float *my = lds + c * (64 * J) + L.q;
 			unsigned long long HR = 0;                                // partial sums: bit x = position x * J + q
+			// the sub-tree itself clean?  (frozen bits the way this lane holds the sub-tree: tables.cpp frozen_t)
+			unsigned long long FT = 0;
+			bool clean12 = false;
+			int m_first = 1;                                          // the first level of partial-sum combines on the published words below
+			if (skip_left) {                                          // inside a clean node: its hard decisions are the words of its sub-trees as they stand
+				HR = ((const unsigned long long *)lds)[skip_k * 64 + lane];
+				clean12 = true;
+				++skip_k;
+				m_first = --skip_left ? 99 : skip_lg + 1;
+			} else
+			if constexpr (LB == 6 && SC_CLEAN_MIN <= 6) {
+				const uint2 ft = ((const uint2 *)frozen_t)[(tab * 16 + s) * 64 + lane];
+				FT = (unsigned long long)ft.x | ((unsigned long long)ft.y << 32);
+				float V[64];
+				#pragma unroll
+				for (int x = 0; x < 64; ++x)
+					V[x] = my[x * J];
+				if (sc_clean(V, FT, L, HR)) {
+					acc.info(sc_clean_fork(V, FT, L));
+					clean12 = true;
+				} else
+					HR = 0;
+			}
 			float R5[32], R4[16], R3[8], R2[4], R1[2], R0[1];
 			#pragma unroll 1
-			for (int b = 0, adv = 1; b < 64; b += adv) {
+			for (int b = 0, adv = 1; b < 64 && !clean12; b += adv) {
 				adv = 1;
 				const int zb = b ? __builtin_ctz(b) : 6;              // the one g step of this block produces the array of J << zb leaves (6: none)
 				const int nl = __builtin_amdgcn_readlane(nlv, b), nl0 = nl & 15, nl1 = nl >> 4;
@@ -480,35 +683,38 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 							R5[x] = f_minsum(my[x * J], my[(x + 32) * J]);
 					}
 					if (Lt == 5) { bits = sc_rate1<LB>(R5, acc, lane); L2 = 5; }
+					else if constexpr (LB == 6 && SC_CLEAN_MIN <= 5) { if (sc_try_clean(R5, FT >> b, acc, L, bits)) L2 = 5; }
 				}
 				if (zb >= 4 && L2 < 0) {
 					if (zb == 4) sc_g_half(R4, R5, hb); else sc_f_half(R4, R5);
 					if (Lt == 4) { bits = sc_rate1<LB>(R4, acc, lane); L2 = 4; }
+					else if constexpr (LB == 6 && SC_CLEAN_MIN <= 4) { if (sc_try_clean(R4, FT >> b, acc, L, bits)) L2 = 4; }
 				}
 				if (zb >= 3 && L2 < 0) {
 					if (zb == 3) sc_g_half(R3, R4, hb); else sc_f_half(R3, R4);
 					if (Lt == 3) { bits = sc_rate1<LB>(R3, acc, lane); L2 = 3; }
+					else if constexpr (LB == 6 && SC_CLEAN_MIN <= 3) { if (sc_try_clean(R3, FT >> b, acc, L, bits)) L2 = 3; }
 				}
 				if (zb >= 2 && L2 < 0) {
 					if (zb == 2) sc_g_half(R2, R3, hb); else sc_f_half(R2, R3);
 					if (Lt == 2) {
 						if (frz) sc_rate0<LB>(R2, acc, lane); else bits = sc_rate1<LB>(R2, acc, lane);
 						L2 = 2;
-					}
+					} else if constexpr (LB == 6 && SC_CLEAN_MIN <= 2) { if (sc_try_clean(R2, FT >> b, acc, L, bits)) L2 = 2; }
 				}
 				if (zb >= 1 && L2 < 0) {
 					if (zb == 1) sc_g_half(R1, R2, hb); else sc_f_half(R1, R2);
 					if (Lt == 1) {
 						if (frz) sc_rate0<LB>(R1, acc, lane); else bits = sc_rate1<LB>(R1, acc, lane);
 						L2 = 1;
-					}
+					} else if constexpr (LB == 6 && SC_CLEAN_MIN <= 1) { if (sc_try_clean(R1, FT >> b, acc, L, bits)) L2 = 1; }
 				}
 				if (L2 < 0) {
 					if (zb == 0) sc_g_half(R0, R1, hb); else sc_f_half(R0, R1);
 					if (Lt == 0) {
 						if (frz) sc_rate0<LB>(R0, acc, lane); else bits = sc_rate1<LB>(R0, acc, lane);
 						L2 = 0;
-					}
+					} else if constexpr (LB == 6 && SC_CLEAN_MIN <= 0) { if (sc_try_clean(R0, FT >> b, acc, L, bits)) L2 = 0; }
 				}
 				if (L2 >= 0) {
 					adv = 1 << L2;
@@ -546,7 +752,7 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 			}
 			// combines of the larger nodes that end here, on the published words (every word stays with its lane)
 			const int sn = s + 1;
-			for (int m = 1; m <= 16 - Cf::LL && (sn & ((1 << m) - 1)) == 0; ++m) {
+			for (int m = m_first; m <= 16 - Cf::LL && (sn & ((1 << m) - 1)) == 0; ++m) {
 				const int halfw = 64 << (m - 1), w0 = sn * 64 - 2 * halfw;
 				for (int w = lane; w < halfw; w += 64) {
 					const int wl = ScIo<LB>::idx(w0 + w), wr = ScIo<LB>::idx(w0 + halfw + w);
@@ -557,6 +763,8 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 			SC_WAVE_ORDER();
 		}
 		const unsigned long long unf = __ballot(!finite);
+		if (LB == 6 && attempt == 0 && weak && !(unf == 0ull && __uint_as_float(acc.fork) > acc.M))
+			continue;                                                 // (wave-uniform: one codeword per wave)
 		if (j == 0 && (C == 1 || c == 0 || sb != sa)) {
 			const bool all_finite = ((unf >> (c * J)) & (J == 64 ? ~0ull : ((1ull << J) - 1ull))) == 0;
 			ScStat st;
@@ -567,6 +775,8 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 			stat_q[my_slot] = st;
 		}
 		SC_WAVE_ORDER();
+		break;
+		}   // attempt
 		}   // second entry of a unit that could not be paired
 	}
 }
@@ -711,13 +921,13 @@ size_t sc_store_bytes(int lb)                                     // level store
 	return lb == 6 ? b6 : (lb == 5 ? b5 : (b5 > b6 ? b5 : b6));
 }
 void launch_sc(hipStream_t s, int lb, int grid5, int grid6, ListQueue *q, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
-	unsigned long long *xw_q, ScStat *stat_q, Tables tb)
+	unsigned long long *xw_q, ScStat *stat_q, Tables tb, int top_skip)
 {
 	const int small_run = lb == 0 ? SC_SMALL_RUN : 0;
 	if (lb != 5)
-		hipLaunchKernelGGL(k_sc<6>, dim3(grid6), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev64, small_run);
+		hipLaunchKernelGGL(k_sc<6>, dim3(grid6), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev64, tb.frozen_t, small_run, top_skip);
 	if (lb != 6)
-		hipLaunchKernelGGL(k_sc<5>, dim3(grid5), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev32, small_run);
+		hipLaunchKernelGGL(k_sc<5>, dim3(grid5), dim3(64), 0, s, q, slots, llr_q, soft, (uint32_t *)cw_q, (uint32_t *)xw_q, stat_q, tb.frozen, tb.node_lev32, tb.frozen_t, small_run, 0);
 }
 void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
 	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of, int chunk_seq)

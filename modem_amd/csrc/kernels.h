@@ -93,6 +93,7 @@ struct Tables {                    // device-resident constants, built once per 
 	const uint16_t *info_pos;      // [2][44096] ascending unfrozen positions per table
 	const uint32_t *info_compress; // [2][2048][8] per code word: compress move masks, unfrozen mask, first message bit | count << 16 (message_gather)
 	const uint8_t *node_lev64;     // [2][1024] the same per 64-leaf block, for k_sc (frozen: 64 or 128 leaves, information: 64 .. 2048)
+	const uint32_t *frozen_t;      // [2][16][64][2] frozen bits of a 4096-leaf sub-tree as lane `lane` of k_sc<6> holds it (bit x = leaf s * 4096 + x * 64 + position)
 	const uint8_t *node_lev32;     // [2][2048] ... per 32-leaf block (frozen: 32 .. 128 leaves, information: 32 .. 1024)
 	const uint8_t *node_lev;       // [2][8192] per 8-leaf group: level of the largest aligned all-frozen (low nibble) /
 	                               // all-information (high nibble) node that starts there (frozen: <= 128 leaves, information: <= 2048), 0 = none
@@ -196,7 +197,7 @@ void launch_queue_fill(hipStream_t s, ListQueue *q, ListSlot *slots, int n, uint
 // unit: a run takes whole multiples of it (0 / force: everything that waits)
 void launch_sc_plan(hipStream_t s, ListQueue *qs, unsigned unit = 0, int force = 1);
 void launch_sc(hipStream_t s, int lb, int grid5, int grid6, ListQueue *qs, const ListSlot *slots, const float *llr_q, float *soft, unsigned long long *cw_q,
-	unsigned long long *xw_q, ScStat *stat_q, Tables tb);
+	unsigned long long *xw_q, ScStat *stat_q, Tables tb, int top_skip = 1);
 void launch_sc_finish(hipStream_t s, int max_entries, ListQueue *qs, const ListSlot *slots_s, const float *llr_s, const unsigned long long *cw_q,
 	const unsigned long long *xw_q, const ScStat *stat_q, Tables tb, int descramble, ListQueue *ql, ListSlot *slots_l, float *llr_l, int *slot_of, int chunk_seq = 0);
 void launch_sc_adapt(hipStream_t s, ListQueue *qs);

@@ -221,6 +221,19 @@ void build_tables(HostTables &t, int rate)
 				nl[tab * nblk + b] = (uint8_t)(lev[0] | (lev[1] << 4));
 			}
 	}
+	// frozen_t[tab][s][lane] (two words each): the frozen bits of k_sc's sub-tree s (4096 leaves) the way a lane of the one-codeword layout
+	// holds that sub-tree - bit x = leaf s * 4096 + x * 64 + q, q = the position lane `lane` holds (k_sc.hip: sc_pos) - for its clean-node test
+	t.frozen_t.assign(2 * 16 * 64 * 2, 0);
+	for (int tab = 0; tab < 2; ++tab)
+		for (int s = 0; s < 16; ++s)
+			for (int lane = 0; lane < 64; ++lane) {
+				const int q = lane ^ ((lane & 4) ? 3 : 0);
+				for (int x = 0; x < 64; ++x) {
+					const int i = s * 4096 + x * 64 + q;
+					if ((t.frozen[tab * 2048 + i / 32] >> (i % 32)) & 1)
+						t.frozen_t[(size_t)((tab * 16 + s) * 64 + lane) * 2 + x / 32] |= 1u << (x % 32);
+				}
+			}
 	t.info_pos.assign(2 * 44096, 0);
 	for (int tab = 0; tab < 2; ++tab) {
 		int n = 0;

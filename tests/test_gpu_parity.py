@@ -401,17 +401,38 @@ def _sc_vectors():
     v = vec[2][1].copy()
     v[777] = 0.0
     vec.append((6, v))
+    # clean nodes (round 6).  One raw error in an otherwise clean frame: every node off the error's path is clean, the halves and quarters
+    # among them are skipped on the smallest magnitude of their arrays
+    for p in (100, 20000, 40000):
+        v = vec[0][1].copy()
+        v[p] = -0.05 * np.sign(v[p])
+        vec.append((6, v))
+    # a clean left half whose array holds a tiny magnitude, then errors that cost: the lower bound fails (0.001 < M*), the exact figure does
+    # not - the codeword is decoded a second time without the skips and decided
+    rng = np.random.default_rng(3)
+    for lo, cnt, fac in ((61440, 40, -0.6), (32768, 300, -0.5)):
+        v = vec[0][1].copy()
+        v[5] = 1e-3 * np.sign(v[5])
+        for p in rng.integers(lo, 64800, cnt):
+            v[p] = fac * v[p]
+        vec.append((6, v))
     return vec
 
 
-@pytest.mark.parametrize("lanes_log2", [5, 6])
-def test_sc_path_kernel_is_the_oracles_sign_following_path(lanes_log2, monkeypatch):
+@pytest.mark.parametrize("lanes_log2,top", [(5, 1), (6, 1), (6, 0)])
+def test_sc_path_kernel_is_the_oracles_sign_following_path(lanes_log2, top, monkeypatch):
     """k_sc alone (ofdmrx_debug_sc_path) against oracle/polar.c: orc_polar_sc_path on identical LLRs: the re-encoded codeword,
     the hard decisions of the LLRs, the path metric M* and min_fork BIT-exact (M* is also lane 0's metric of the oracle's list
     decoder whenever the rule holds), the rule's verdict - with one codeword per wave (OFDMRX_SC_LB=6, the default) and with two (=5), codewords of
-    both frozen tables side by side in one call (pairs of different tables are decoded one after the other), an odd count."""
+    both frozen tables side by side in one call (pairs of different tables are decoded one after the other), an odd count.
+    Round 6: clean nodes (hard decisions of the input array already a codeword of the sub-code) are not walked.  Up to 4096 leaves
+    their share of min_fork is exact; a clean node of 16384 / 32768 leaves is skipped on a LOWER bound (OFDMRX_SC_TOP=1, the default:
+    the reported min_fork may then be smaller than the oracle's, never larger, and a codeword whose rule fails with it is decoded again
+    without such skips, so the verdict is the oracle's); OFDMRX_SC_TOP=0 reports the exact figure."""
     import modem_amd
     monkeypatch.setenv("OFDMRX_SC_LB", str(lanes_log2))
+    monkeypatch.setenv("OFDMRX_SC_TOP", str(top))
+    lower_bound = lanes_log2 == 6 and top == 1
     vec = _sc_vectors()
     order = [0, 6, 1, 2, 7, 8, 3, 4, 5, 9, 10, 11] + list(range(12, len(vec)))     # table 0 next to table 1, then pairs of the same
     if len(order) % 2 == 0:
@@ -424,10 +445,11 @@ def test_sc_path_kernel_is_the_oracles_sign_following_path(lanes_log2, monkeypat
             c, m, f = O.polar_sc_path(vec[i][1], O.frozen(1 if vec[i][0] >= 10 else 0))
             finite = bool(np.isfinite(vec[i][1]).all() and (np.abs(vec[i][1]) < 6e29).all())
             if finite:
-                assert (cw[n_] == c).all() and M[n_] == m and F[n_] == f, (i, M[n_], m, F[n_], f)
+                assert (cw[n_] == c).all() and M[n_] == m and (F[n_] <= f if lower_bound else F[n_] == f), (i, M[n_], m, F[n_], f)
                 assert (hd[n_] == (vec[i][1] < 0)).all()
             assert bool(ok[n_]) == bool(finite and f > m), (i, ok[n_], m, f)
-        assert 7 <= ok.sum() <= 11                                 # (-30 .. -19 dB of both modes decided, -18 / -16 dB and the garbage not)
+        assert 12 <= ok.sum() <= 16                                # (-30 .. -19 dB of both modes and the clean-node vectors decided, -18 / -16 dB and the garbage not)
+        assert all(ok[n_] for n_, i in enumerate(order) if i >= len(vec) - 5)
     finally:
         r.close()
 
