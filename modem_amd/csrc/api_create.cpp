@@ -93,7 +93,7 @@ extern "C" int ofdmrx_create(const ofdmrx_config *cfg, ofdmrx_handle **out)
 		if (const char *e3 = std::getenv("OFDMRX_SC_WPC"))
 			swpc = std::max(1, std::atoi(e3));
 		h->sc_grid = swpc * std::max(cus, 1);
-		h->sc_grid6 = (std::getenv("OFDMRX_SC_WPC") ? swpc : 10) * std::max(cus, 1);   // 168 VGPRs, 16 KB of LDS: ten of these per CU
+		h->sc_grid6 = swpc * std::max(cus, 1);                   // one codeword per wave: the same eight per CU (256 VGPRs; k_sc.hip SC6_WAVES)
 		if (const char *e6 = std::getenv("OFDMRX_SC_TOP"))
 			h->sc_top = std::atoi(e6) != 0;
 		if (const char *e4 = std::getenv("OFDMRX_SC_LB"))

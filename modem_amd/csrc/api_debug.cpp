@@ -1,4 +1,5 @@
 // api_debug.cpp -- stage taps and single-stage entry points of include/ofdmrx.h (the parity tests' way in).
+#include <cstdlib>
 #include "api_internal.h"
 
 // Stage taps of the LAST chunk the handle decoded.  CONS_RAW is the constellation as the demodulator left it (decode.cc:474-475),
@@ -127,7 +128,9 @@ extern "C" int ofdmrx_debug_sc_path(ofdmrx_handle *h, const float *llr, size_t n
 		return r;
 	// buffers of this call's own: the handle may have been created without the pass
 	DevBuf ctl, slots, dl, cw, xw, stat, soft;
-	const int grid = (int)std::min<size_t>(n, (size_t)std::max(h->sc_grid, h->sc_grid6));
+	int grid = (int)std::min<size_t>(n, (size_t)std::max(h->sc_grid, h->sc_grid6));
+	if (const char *e = std::getenv("OFDMRX_SC_DECODERS"))          // (tests: a few decoders take the codewords one after the other - what a decoder
+		grid = std::max(1, std::min(grid, std::atoi(e)));          // carries from one codeword to the next, k_sc.hip look_first, is exercised)
 	r = r ? r : ctl.ensure(sizeof(ListQueue));
 	r = r ? r : slots.ensure(n * sizeof(ListSlot));
 	r = r ? r : dl.ensure(n * CODE_LEN * sizeof(float));

@@ -261,7 +261,11 @@ struct ScTop {
 	int nskip;                // out: sub-trees covered by the clean node (0: none)
 	uint32_t mu;              // out: smallest magnitude of its array
 };
-template <int LB, int D, int KIND>
+// EMIT false: the pass only looks (signs, smallest magnitude, and the channel's hard decisions where it makes them) - nothing goes to the level
+// store or to LDS.  A decoder runs the passes that can end in a skip that way when the same pass of its previous codeword found a clean node
+// (the store traffic of a skipped node's first pass is for nothing: 224 KB at the halves, 96 KB at the quarters), and runs them again, storing,
+// when this time the node is not clean.
+template <int LB, int D, int KIND, bool EMIT = true>
 __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds, const ScIo<LB> &io, int s, int lane, int v_llr0, int v_soft0, bool &finite,
 	ScTop &top, const uint32_t (&lowsel)[7])
 {
@@ -332,7 +336,8 @@ __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds,
 					io.xwb[w] = (uint32_t)mb;
 				}
 			}
-			sc_emit<LB, Cf::LL + D - 1, NH>(soft, lds, v_dst + xb * XSTEP, lidx + xb * Cf::J, t);
+			if constexpr (EMIT)
+				sc_emit<LB, Cf::LL + D - 1, NH>(soft, lds, v_dst + xb * XSTEP, lidx + xb * Cf::J, t);
 		}
 	}
 	if (TOPCHK && top.allow) {
@@ -523,9 +528,14 @@ template <int CNT> __device__ __forceinline__ bool sc_try_clean(float (&r)[CNT],
 #ifndef SC_WAVES_PER_SIMD
 #define SC_WAVES_PER_SIMD 2       // register budget of the two-codewords layout: 2 = 256 VGPRs (it needs 200 - 250), 3 = 168 (40 spilled)
 #endif
-// (one codeword per wave fits 168 VGPRs = three waves per SIMD: ten decoders per CU, what the 16 KB of LDS each allows)
+// One codeword per wave: 256 VGPRs, two waves per SIMD, eight decoders per CU.  Until the clean-node tests (round 6) the kernel fitted 168
+// (three waves per SIMD: ten decoders, what the 16 KB of LDS each allows); with them 120 registers spill at 168 and the smaller residency
+// is the faster one (-20 dB, 65 536 frames: 27.9 against 26.1 ms; 128 loads in flight: 36 ms).
+#ifndef SC6_WAVES
+#define SC6_WAVES 2
+#endif
 template <int LB>
-__global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
+__global__ __launch_bounds__(64, LB == 6 ? SC6_WAVES : SC_WAVES_PER_SIMD) void k_sc(ListQueue *__restrict__ q, const ListSlot *__restrict__ slots, const float *__restrict__ llr_q,
 	float *__restrict__ soft_all, uint32_t *__restrict__ cw_q, uint32_t *__restrict__ xw_q, ScStat *__restrict__ stat_q,
 	const uint32_t *__restrict__ frozen2, const uint8_t *__restrict__ node_lev_blk, const uint32_t *__restrict__ frozen_t, int small_run, int top_skip)
 {
@@ -553,6 +563,7 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 	float *const my_store = soft_all + (size_t)blockIdx.x * Cf::DECODER_FLOATS;
 	const rsrc_t soft = make_rsrc(my_store, C * Cf::STORE_FLOATS * 4);
 	const int v_soft0 = c * (Cf::STORE_FLOATS * 4) + j * 4;
+	uint32_t look_first = 0;                                      // bit s: this decoder's last codeword had a clean node at the pass of sub-tree s
 	for (;;) {
 		int unit = 0;
 		if (lane == 0)
@@ -601,6 +612,8 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 		#pragma unroll 1
 		for (int attempt = 0; attempt < 2; ++attempt) {
 		bool weak = false;
+		if (attempt)
+			look_first = 0;
 		int skip_left = 0, skip_lg = 0, skip_k = 0;
 		ScAcc acc{ 0.f, 0x7f800000u };
 		bool finite = true;
@@ -610,13 +623,28 @@ __global__ __launch_bounds__(64, LB == 6 ? 3 : SC_WAVES_PER_SIMD) void k_sc(List
 			if (skip_left == 0) {
 				const int D = s ? __builtin_ctz(s) + 1 : 16 - Cf::LL;
 				ScTop top{ frozen_t + tab * (16 * 64 * 2), attempt == 0 && top_skip != 0, 0, 0u };
-				#define SC_PASS(DD, KK) sc_top_pass<LB, DD, KK>(soft, llr, lds, io, s, lane, v_llr0, v_soft0, finite, top, L.lowsel)
-				if (s == 0) SC_PASS(16 - Cf::LL, 0);
-				else if (s == Cf::NSUB / 2) SC_PASS(16 - Cf::LL, 1);
-				else if (D == 1) SC_PASS(1, 2);
-				else if (D == 2) SC_PASS(2, 2);
-				else if (D == 3) SC_PASS(3, 2);
-				else if constexpr (16 - Cf::LL > 4) SC_PASS(4, 2);
+				#define SC_PASS(DD, KK, EE) sc_top_pass<LB, DD, KK, EE>(soft, llr, lds, io, s, lane, v_llr0, v_soft0, finite, top, L.lowsel)
+				if constexpr (LB == 6 && SC_CLEAN_TOP) {
+					if (D >= 3 && top.allow && ((look_first >> s) & 1u)) {   // look before storing (see sc_top_pass)
+						if (s == 0) SC_PASS(4, 0, false);
+						else if (s == Cf::NSUB / 2) SC_PASS(4, 1, false);
+						else SC_PASS(3, 2, false);
+						if (!top.nskip) {
+							look_first &= ~(1u << s);
+							top.allow = false;
+						}
+					}
+				}
+				if (!top.nskip) {
+					if (s == 0) SC_PASS(16 - Cf::LL, 0, true);
+					else if (s == Cf::NSUB / 2) SC_PASS(16 - Cf::LL, 1, true);
+					else if (D == 1) SC_PASS(1, 2, true);
+					else if (D == 2) SC_PASS(2, 2, true);
+					else if (D == 3) SC_PASS(3, 2, true);
+					else if constexpr (16 - Cf::LL > 4) SC_PASS(4, 2, true);
+					if (top.nskip)
+						look_first |= 1u << s;
+				}
 				#undef SC_PASS
 				if (top.nskip) {
 					skip_left = top.nskip;

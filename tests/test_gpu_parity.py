@@ -419,8 +419,8 @@ def _sc_vectors():
     return vec
 
 
-@pytest.mark.parametrize("lanes_log2,top", [(5, 1), (6, 1), (6, 0)])
-def test_sc_path_kernel_is_the_oracles_sign_following_path(lanes_log2, top, monkeypatch):
+@pytest.mark.parametrize("lanes_log2,top,decoders", [(5, 1, 0), (6, 1, 0), (6, 0, 0), (6, 1, 2), (6, 1, 1)])
+def test_sc_path_kernel_is_the_oracles_sign_following_path(lanes_log2, top, decoders, monkeypatch):
     """k_sc alone (ofdmrx_debug_sc_path) against oracle/polar.c: orc_polar_sc_path on identical LLRs: the re-encoded codeword,
     the hard decisions of the LLRs, the path metric M* and min_fork BIT-exact (M* is also lane 0's metric of the oracle's list
     decoder whenever the rule holds), the rule's verdict - with one codeword per wave (OFDMRX_SC_LB=6, the default) and with two (=5), codewords of
@@ -428,10 +428,14 @@ def test_sc_path_kernel_is_the_oracles_sign_following_path(lanes_log2, top, monk
     Round 6: clean nodes (hard decisions of the input array already a codeword of the sub-code) are not walked.  Up to 4096 leaves
     their share of min_fork is exact; a clean node of 16384 / 32768 leaves is skipped on a LOWER bound (OFDMRX_SC_TOP=1, the default:
     the reported min_fork may then be smaller than the oracle's, never larger, and a codeword whose rule fails with it is decoded again
-    without such skips, so the verdict is the oracle's); OFDMRX_SC_TOP=0 reports the exact figure."""
+    without such skips, so the verdict is the oracle's); OFDMRX_SC_TOP=0 reports the exact figure.  decoders = 1 / 2: one / two waves take all
+    the codewords in turn - a decoder that found a clean half or quarter runs the same pass of its next codeword without storing first and
+    again, storing, when that one is not clean (k_sc.hip: look_first); the vectors alternate between the two cases."""
     import modem_amd
     monkeypatch.setenv("OFDMRX_SC_LB", str(lanes_log2))
     monkeypatch.setenv("OFDMRX_SC_TOP", str(top))
+    if decoders:
+        monkeypatch.setenv("OFDMRX_SC_DECODERS", str(decoders))
     lower_bound = lanes_log2 == 6 and top == 1
     vec = _sc_vectors()
     order = [0, 6, 1, 2, 7, 8, 3, 4, 5, 9, 10, 11] + list(range(12, len(vec)))     # table 0 next to table 1, then pairs of the same
