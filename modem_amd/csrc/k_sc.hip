@@ -25,6 +25,11 @@
 // Uniform nodes are decided in one step: all-frozen ones of up to 128 leaves (the penalty sum above), all-information ones of any
 // size (the SC decisions of such a node are the signs of its input LLRs; the smallest leaf magnitude on P* is the smallest input
 // magnitude, so min_fork takes fl(M* + min |input|)).
+// Round 6: CLEAN nodes - any node, of 64 leaves up to half the code, whose input hard decisions are a codeword of its sub-code - are not
+// walked either (sc_clean, sc_clean_fork, sc_top_pass below: the proof, what min_fork takes from them, and how the halves and quarters
+// are found while the pass that makes them goes by).  A frame with raw bit errors is walked only along the few paths that lead to them:
+// 133 k instructions per codeword in place of 323 k at -20 dB (433 raw errors in a frame), a fifth of that on the configs[3] chain (one
+// or two), and the level-store traffic of the skipped halves and quarters is never made.
 #include "dev_common.h"
 #include "kernels.h"
 #include "polar_common.h"

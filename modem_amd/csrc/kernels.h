@@ -128,7 +128,8 @@ struct ListQueue {
 // on (its cert_on; tried / certified count the last run's entries / decided frames), k_sc_plan | k_sc | k_sc_finish run right behind
 // k_back of every chunk on the same stream, and what they cannot decide moves on to the list decoder's queue.  Like a flush of the
 // list decoder, a run takes WHOLE residencies of k_sc's persistent decoders (round 6: a codeword is one decoder's serial work of
-// 1.2 ms, so a run of 8192 entries on 2560 decoders took the time of four rounds for 3.2 rounds of work); what is left over waits
+// 1.2 ms, so a run of 8192 entries on the 2560 decoders of that time took four rounds for 3.2 rounds of work; 2048 decoders since the
+// clean-node tests, k_sc.hip SC6_WAVES); what is left over waits
 // for the next chunk's run, and the last run of a call takes everything.
 struct ScStat { float metric, min_fork; int32_t ok, pad; };   // per SC-ring slot: P*'s metric, min_fork, rule holds
 struct ListSlot {                  // what k_polar / k_finish need to know about a queued frame
