@@ -224,6 +224,10 @@ static ChunkPlan plan_chunks(const ofdmrx_handle *h, size_t n_frames, bool host_
 		step = (n_frames + 1) / 2;                                                                     // one chunk: its taps index the call's frames)
 	for (size_t f = 0; f < n_frames; f += step)
 		p.start.push_back(f);
+	// the last chunk of a longer call likewise: nothing runs beside the copies of the call's last chunk, so it is the smaller the better
+	// (headline: 1.845 -> 1.855 M frames/s; three or four parts: 1.84 / 1.81 M - OFDMRX_NO_TAIL_SPLIT=1 keeps the chunk whole)
+	if (host_side && p.start.size() > 1 && n_frames - p.start.back() >= 6144 && !(h->cfg.flags & OFDMRX_FLAG_KEEP_RAW_CONS) && !std::getenv("OFDMRX_NO_TAIL_SPLIT"))
+		p.start.push_back(p.start.back() + (n_frames - p.start.back() + 1) / 2);
 	p.start.push_back(n_frames);
 	return p;
 }
