@@ -5,7 +5,7 @@ S=$G/${TAG}_sc_counters.txt; : > $S
 cd /tmp; export TMPDIR=/tmp
 A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 B="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD"
-export OFDMRX_NO_OVERLAP=1
+export OFDMRX_NO_OVERLAP=1 OFDMRX_NO_TAIL_SPLIT=1
 BN="python3 $R/bench.py --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0 --frames 16384 --steps 1 --warmup 0"
 for mode in m20 chain; do
 	X="--noise-db -20"; [ $mode = chain ] && X="--impair"

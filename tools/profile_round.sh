@@ -12,6 +12,7 @@ TAG=${1:-r06_vX}; R=$PWD; G=$R/gpurun_out; mkdir -p $G
 S=$G/${TAG}_summary.txt; : > $S
 make -C modem_amd/csrc -q all && echo "# library up to date with sources" >> $S || echo "# STALE LIBRARY" >> $S
 cd /tmp; export TMPDIR=/tmp
+export OFDMRX_NO_TAIL_SPLIT=1     # (every launch of the profiled runs a whole chunk of 8192 frames: the per-launch figures below divide by the launches)
 B="python3 $R/bench.py --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0"
 echo "# $TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 --scl-steps 0 --leg-steps 0   (default: pipeline, syndrome certificate on)" >> $S
 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o trace -- $B --steps 2 --warmup 1 > $G/${TAG}_bench_n1_under_profiler.json 2>/dev/null
@@ -61,6 +62,7 @@ echo "# issue rates: tools/ubench_issue.hip (ns per wave-instruction per SIMD, e
 hipcc -w --offload-arch=gfx950 -O3 $R/tools/ubench_issue.hip -o /tmp/ubench_issue && /tmp/ubench_issue > $G/${TAG}_issue_rates_ubench.txt 2>&1
 head -4 $G/${TAG}_issue_rates_ubench.txt >> $S
 cd $R
+unset OFDMRX_NO_TAIL_SPLIT
 python3 bench.py > $G/${TAG}_bench_n1.json 2>/dev/null
 R=$R python3 - "$S" "$G/${TAG}_traffic.json" "$G/${TAG}_issue_rates_ubench.txt" <<'PY'
 import hashlib, json, os, re, sys
