@@ -151,6 +151,56 @@ int main(){ rx::HostTables t; rx::build_tables(t, 48000);
     assert crc == O.lib().orc_crc32_bytes(0xD419CC15, O.ptr(data), 64)
 
 
+def test_round6_host_tables_gather_and_clean_node_masks():
+    """tables.cpp, round 6.  info_compress: the records message_gather (dev_common.h) takes the systematic message out of a codeword with -
+    per code word its mask of unfrozen positions, five "compress" move masks, the message bit its first unfrozen position is and how many it
+    holds: replayed here on random codewords, both frozen tables, the result must be the codeword at the unfrozen positions in ascending order
+    (decode.cc:254-261).  frozen_t: the frozen bits of a 4096-leaf sub-tree the way lane `lane` of k_sc holds it (bit x = leaf
+    s * 4096 + x * 64 + position, position = lane ^ 3 where lane & 4)."""
+    import oracle_lib as O
+    import tempfile
+    exe_src = r'''
+#include "tables.h"
+#include <cstdio>
+int main(){ rx::HostTables t; rx::build_tables(t, 8000);
+  fwrite(t.info_compress.data(),4,2*2048*8,stdout); fwrite(t.frozen_t.data(),4,2*16*64*2,stdout); return 0; }
+'''
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "m.cpp"), "w").write(exe_src)
+    csrc = os.path.join(ROOT, "modem_amd", "csrc")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-I", csrc, os.path.join(d, "m.cpp"),
+                           os.path.join(csrc, "tables.cpp"), "-o", os.path.join(d, "m")])
+    raw = subprocess.check_output([os.path.join(d, "m")])
+    rec = np.frombuffer(raw[:2 * 2048 * 8 * 4], np.uint32).reshape(2, 2048, 8)
+    ft = np.frombuffer(raw[2 * 2048 * 8 * 4:], np.uint32).reshape(2, 16, 64, 2)
+    rng = np.random.default_rng(66)
+    for table in (0, 1):
+        fr = O.frozen(table)
+        fz = ((fr[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1).astype(bool)
+        code = rng.integers(0, 2 ** 32, 2048, dtype=np.uint64).astype(np.uint32)
+        bits = ((code[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1).astype(np.uint8)
+        want = bits[~fz]
+        mesg = np.zeros(want.size + 64, np.uint8)
+        for w in range(2048):
+            mv, m, oc = rec[table, w, :5], int(rec[table, w, 5]), int(rec[table, w, 6])
+            assert m == (~int(fr[w])) & 0xffffffff
+            x = int(code[w]) & m
+            for i in range(5):
+                t = x & int(mv[i])
+                x = (x ^ t) | (t >> (1 << i))
+            off, cnt = oc & 0xffff, oc >> 16
+            assert cnt == bin(m).count("1") and x < (1 << cnt)
+            for b in range(cnt):
+                mesg[off + b] |= (x >> b) & 1
+        assert (mesg[:want.size] == want).all() and not mesg[want.size:].any()
+        for s_ in range(16):
+            for lane in range(64):
+                q = lane ^ (3 if lane & 4 else 0)
+                word = int(ft[table, s_, lane, 0]) | (int(ft[table, s_, lane, 1]) << 32)
+                for x in (0, 1, 31, 32, 63, int(rng.integers(0, 64))):
+                    assert ((word >> x) & 1) == int(fz[s_ * 4096 + x * 64 + q])
+
+
 def test_sc_kernel_pattern_list_covers_both_frozen_tables():
     """k_sc.hip compiles the mixed 16-leaf blocks of the list-1 pass for their frozen pattern (SC_PATTERNS16, straight-line code) and
     walks any other pattern generically: the list must be exactly the set of mixed 16-leaf patterns the sign-following decoder
