@@ -240,19 +240,42 @@ template <int LB> struct ScIo {                                   // where the w
 	uint32_t *cwa, *cwb, *xwa, *xwb;
 	__device__ __forceinline__ static int idx(int w) { return LB == 6 ? 2 * w : w; }
 };
-template <int LB, int LEV, int N> __device__ __forceinline__ void sc_emit(rsrc_t soft, float *lds, int v_dst, int lidx, float (&t)[N])
+// The array of a node of 2 * 64 * J leaves (level LL + 1) is stored as HALF an array (round 6).  Its pair (a, b) at a column is needed once
+// more, by the g step of the sub-tree that follows - and by then the f of the pair still sits in LDS (the walk only reads its array).
+// f = sign(a) sign(b) min(|a|, |b|) holds the smaller magnitude and the product of the signs: stored is only d = the element of the larger
+// magnitude (a on a tie) and one bit per column saying which of the two it was (`which`, a lane's 64 columns in one word, stored behind d);
+// the other element is |f| with the sign bit of f ^ d - the pair comes back bit for bit (sc_pair_back).  16 KB less written and 16 KB less read
+// per pair of sub-trees: 256 KB of the 2.05 MB a codeword's full walk moves.
+#ifndef SC_HALF13
+#define SC_HALF13 1
+#endif
+template <int LB, int LEV, int N> __device__ __forceinline__ void sc_emit(rsrc_t soft, float *lds, int v_dst, int lidx, float (&t)[N], unsigned long long &which, int x)
 {
 	if constexpr (LEV > ScCfg<LB>::LL) {
-		#pragma unroll
-		for (int k = 0; k < N; ++k)
-			bstore<2>(soft, v_dst, sc_off(LEV) + k * ScCfg<LB>::SUB_BYTES, t[k]);
+		if constexpr (SC_HALF13 && LEV == ScCfg<LB>::LL + 1) {
+			static_assert(N == 2, "the level above the LDS array holds one pair per column");
+			const bool hi = sc_mag(t[1]) > sc_mag(t[0]);
+			bstore<2>(soft, v_dst, sc_off(LEV), hi ? t[1] : t[0]);
+			which |= (unsigned long long)(hi ? 1u : 0u) << x;
+		} else {
+			#pragma unroll
+			for (int k = 0; k < N; ++k)
+				bstore<2>(soft, v_dst, sc_off(LEV) + k * ScCfg<LB>::SUB_BYTES, t[k]);
+		}
 		float u[N / 2];
 		#pragma unroll
 		for (int k = 0; k < N / 2; ++k)
 			u[k] = f_minsum(t[k], t[k + N / 2]);
-		sc_emit<LB, LEV - 1, N / 2>(soft, lds, v_dst, lidx, u);
+		sc_emit<LB, LEV - 1, N / 2>(soft, lds, v_dst, lidx, u, which, x);
 	} else
 		lds[lidx] = t[0];
+}
+// the pair (a, b) of sc_emit's half array: d = the larger element, hi = it was b, f = f_minsum(a, b)
+__device__ __forceinline__ void sc_pair_back(float d, float f, bool hi, float &a, float &b)
+{
+	const float small = __uint_as_float(__float_as_uint(f) ^ (__float_as_uint(d) & SC_SIGN));
+	a = hi ? small : d;
+	b = hi ? d : small;
 }
 // (one codeword per wave) the pass's first array - the node of NH sub-trees that starts at sub-tree s - is tested for being CLEAN
 // (see sc_clean below) while it goes by, when skipping it saves level-store traffic (NH >= 4): a clean one leaves its hard decisions
@@ -292,15 +315,32 @@ __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds,
 	}
 	const int sh = 31 - (lane & 31);
 	const bool up = lane >= 32;
+	// (sc_emit) the which-word of a lane's 64 columns: behind the half array, at the lane's own 8 bytes
+	constexpr bool HALF_IN = SC_HALF13 && KIND == 2 && D == 1, HALF_OUT = SC_HALF13 && EMIT && D >= 2;
+	const int v_which = v_soft0 + (lane & (Cf::J - 1)) * 4;
+	unsigned long long which = 0;
+	if constexpr (HALF_IN)
+		which = (unsigned long long)__float_as_uint(bload<2>(soft, v_which, sc_off(Cf::LL + 1) + Cf::SUB_BYTES))
+			| ((unsigned long long)__float_as_uint(bload<2>(soft, v_which, sc_off(Cf::LL + 1) + Cf::SUB_BYTES + 4)) << 32);
 	int v_src = KIND == 2 ? v_soft0 : v_llr0, v_dst = v_soft0, lidx = (lane >> LB) * (64 * Cf::J) + (lane & (Cf::J - 1));
 	#pragma unroll 1
 	for (int x0 = 0; x0 < 64; x0 += XB, v_src += XB * XSTEP, v_dst += XB * XSTEP, lidx += XB * Cf::J) {
 		float v[XB][NS];
+		if constexpr (HALF_IN) {
+			float dd[XB];
+			#pragma unroll
+			for (int xb = 0; xb < XB; ++xb)
+				dd[xb] = bload<2>(src, v_src + xb * XSTEP, src_off);
+			#pragma unroll
+			for (int xb = 0; xb < XB; ++xb)
+				sc_pair_back(dd[xb], lds[lidx + xb * Cf::J], ((which >> (x0 + xb)) & 1ull) != 0ull, v[xb][0], v[xb][1]);
+		} else {
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
 			#pragma unroll
 			for (int k = 0; k < NS; ++k)
 				v[xb][k] = KIND == 0 ? bload<0>(src, v_src + xb * XSTEP, src_off + k * Cf::SUB_BYTES) : bload<2>(src, v_src + xb * XSTEP, src_off + k * Cf::SUB_BYTES);
+		}
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb) {
 			const int x = x0 + xb;
@@ -342,8 +382,12 @@ __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds,
 				}
 			}
 			if constexpr (EMIT)
-				sc_emit<LB, Cf::LL + D - 1, NH>(soft, lds, v_dst + xb * XSTEP, lidx + xb * Cf::J, t);
+				sc_emit<LB, Cf::LL + D - 1, NH>(soft, lds, v_dst + xb * XSTEP, lidx + xb * Cf::J, t, which, x);
 		}
+	}
+	if constexpr (HALF_OUT) {
+		bstore<2>(soft, v_which, sc_off(Cf::LL + 1) + Cf::SUB_BYTES, __uint_as_float((uint32_t)which));
+		bstore<2>(soft, v_which, sc_off(Cf::LL + 1) + Cf::SUB_BYTES + 4, __uint_as_float((uint32_t)(which >> 32)));
 	}
 	if (TOPCHK && top.allow) {
 		// u = h F over the node's NH * 4096 positions (sub-tree, element, lane position); zero wherever a leaf is frozen?
