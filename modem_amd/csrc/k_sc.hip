@@ -249,14 +249,27 @@ template <int LB> struct ScIo {                                   // where the w
 #ifndef SC_HALF13
 #define SC_HALF13 1
 #endif
-template <int LB, int LEV, int N> __device__ __forceinline__ void sc_emit(rsrc_t soft, float *lds, int v_dst, int lidx, float (&t)[N], unsigned long long &which, int x)
+// The same for the two nodes of 32768 leaves (level 15, one codeword per wave): the f of their pairs is the array of the 16384-leaf node below,
+// stored in full and still in place when the g step of the other 16384-leaf node reads the pairs (that pass then writes its own level-14
+// array over it, column by column behind its own reads).  64 KB less written per half of the tree; the level between stays whole - a half
+// array needs the f array whole.
+struct ScWhich { unsigned long long w13, w15[4]; };
+template <int LB, int LEV, int N> __device__ __forceinline__ void sc_emit(rsrc_t soft, float *lds, int v_dst, int lidx, float (&t)[N], ScWhich &which, int x)
 {
 	if constexpr (LEV > ScCfg<LB>::LL) {
 		if constexpr (SC_HALF13 && LEV == ScCfg<LB>::LL + 1) {
 			static_assert(N == 2, "the level above the LDS array holds one pair per column");
 			const bool hi = sc_mag(t[1]) > sc_mag(t[0]);
 			bstore<2>(soft, v_dst, sc_off(LEV), hi ? t[1] : t[0]);
-			which |= (unsigned long long)(hi ? 1u : 0u) << x;
+			which.w13 |= (unsigned long long)(hi ? 1u : 0u) << x;
+		} else if constexpr (SC_HALF13 && LB == 6 && LEV == 15) {
+			static_assert(N == 8, "the halves of the tree: eight sub-trees each");
+			#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const bool hi = sc_mag(t[k + 4]) > sc_mag(t[k]);
+				bstore<2>(soft, v_dst, sc_off(LEV) + k * ScCfg<LB>::SUB_BYTES, hi ? t[k + 4] : t[k]);
+				which.w15[k] |= (unsigned long long)(hi ? 1u : 0u) << x;
+			}
 		} else {
 			#pragma unroll
 			for (int k = 0; k < N; ++k)
@@ -317,11 +330,23 @@ __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds,
 	const bool up = lane >= 32;
 	// (sc_emit) the which-word of a lane's 64 columns: behind the half array, at the lane's own 8 bytes
 	constexpr bool HALF_IN = SC_HALF13 && KIND == 2 && D == 1, HALF_OUT = SC_HALF13 && EMIT && D >= 2;
+	constexpr bool HALF_IN15 = SC_HALF13 && LB == 6 && KIND == 2 && Cf::LL + D == 15, HALF_OUT15 = SC_HALF13 && LB == 6 && EMIT && Cf::LL + D == 16;
 	const int v_which = v_soft0 + (lane & (Cf::J - 1)) * 4;
-	unsigned long long which = 0;
+	ScWhich which{ 0ull, { 0ull, 0ull, 0ull, 0ull } };
+	auto which_at = [&](int off) {
+		return (unsigned long long)__float_as_uint(bload<2>(soft, v_which, off)) | ((unsigned long long)__float_as_uint(bload<2>(soft, v_which, off + 4)) << 32);
+	};
+	auto which_to = [&](int off, unsigned long long w) {
+		bstore<2>(soft, v_which, off, __uint_as_float((uint32_t)w));
+		bstore<2>(soft, v_which, off + 4, __uint_as_float((uint32_t)(w >> 32)));
+	};
 	if constexpr (HALF_IN)
-		which = (unsigned long long)__float_as_uint(bload<2>(soft, v_which, sc_off(Cf::LL + 1) + Cf::SUB_BYTES))
-			| ((unsigned long long)__float_as_uint(bload<2>(soft, v_which, sc_off(Cf::LL + 1) + Cf::SUB_BYTES + 4)) << 32);
+		which.w13 = which_at(sc_off(Cf::LL + 1) + Cf::SUB_BYTES);
+	if constexpr (HALF_IN15) {
+		#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			which.w15[k] = which_at(sc_off(15) + 4 * Cf::SUB_BYTES + k * 512);
+	}
 	int v_src = KIND == 2 ? v_soft0 : v_llr0, v_dst = v_soft0, lidx = (lane >> LB) * (64 * Cf::J) + (lane & (Cf::J - 1));
 	#pragma unroll 1
 	for (int x0 = 0; x0 < 64; x0 += XB, v_src += XB * XSTEP, v_dst += XB * XSTEP, lidx += XB * Cf::J) {
@@ -333,7 +358,21 @@ __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds,
 				dd[xb] = bload<2>(src, v_src + xb * XSTEP, src_off);
 			#pragma unroll
 			for (int xb = 0; xb < XB; ++xb)
-				sc_pair_back(dd[xb], lds[lidx + xb * Cf::J], ((which >> (x0 + xb)) & 1ull) != 0ull, v[xb][0], v[xb][1]);
+				sc_pair_back(dd[xb], lds[lidx + xb * Cf::J], ((which.w13 >> (x0 + xb)) & 1ull) != 0ull, v[xb][0], v[xb][1]);
+		} else if constexpr (HALF_IN15) {
+			float dd[XB][4], ff[XB][4];
+			#pragma unroll
+			for (int xb = 0; xb < XB; ++xb)
+				#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					dd[xb][k] = bload<2>(src, v_src + xb * XSTEP, sc_off(15) + k * Cf::SUB_BYTES);
+					ff[xb][k] = bload<2>(src, v_src + xb * XSTEP, sc_off(14) + k * Cf::SUB_BYTES);
+				}
+			#pragma unroll
+			for (int xb = 0; xb < XB; ++xb)
+				#pragma unroll
+				for (int k = 0; k < 4; ++k)
+					sc_pair_back(dd[xb][k], ff[xb][k], ((which.w15[k] >> (x0 + xb)) & 1ull) != 0ull, v[xb][k], v[xb][k + 4]);
 		} else {
 		#pragma unroll
 		for (int xb = 0; xb < XB; ++xb)
@@ -385,9 +424,12 @@ __device__ __forceinline__ void sc_top_pass(rsrc_t soft, rsrc_t llr, float *lds,
 				sc_emit<LB, Cf::LL + D - 1, NH>(soft, lds, v_dst + xb * XSTEP, lidx + xb * Cf::J, t, which, x);
 		}
 	}
-	if constexpr (HALF_OUT) {
-		bstore<2>(soft, v_which, sc_off(Cf::LL + 1) + Cf::SUB_BYTES, __uint_as_float((uint32_t)which));
-		bstore<2>(soft, v_which, sc_off(Cf::LL + 1) + Cf::SUB_BYTES + 4, __uint_as_float((uint32_t)(which >> 32)));
+	if constexpr (HALF_OUT)
+		which_to(sc_off(Cf::LL + 1) + Cf::SUB_BYTES, which.w13);
+	if constexpr (HALF_OUT15) {
+		#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			which_to(sc_off(15) + 4 * Cf::SUB_BYTES + k * 512, which.w15[k]);
 	}
 	if (TOPCHK && top.allow) {
 		// u = h F over the node's NH * 4096 positions (sub-tree, element, lane position); zero wherever a leaf is frozen?
