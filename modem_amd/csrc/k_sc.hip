@@ -28,8 +28,9 @@
 // Round 6: CLEAN nodes - any node, of 64 leaves up to half the code, whose input hard decisions are a codeword of its sub-code - are not
 // walked either (sc_clean, sc_clean_fork, sc_top_pass below: the proof, what min_fork takes from them, and how the halves and quarters
 // are found while the pass that makes them goes by).  A frame with raw bit errors is walked only along the few paths that lead to them:
-// 133 k instructions per codeword in place of 323 k at -20 dB (433 raw errors in a frame), a fifth of that on the configs[3] chain (one
-// or two), and the level-store traffic of the skipped halves and quarters is never made.
+// 145 k instructions per codeword in place of 323 k at -20 dB (433 raw errors in a frame), a fifth of that on the configs[3] chain (one
+// or two), and the level-store traffic of the skipped halves and quarters is never made.  What the store does hold is half arrays where the
+// other half can be had from the f array (sc_emit): 1.64 MB per codeword at -20 dB in place of 2.17.
 #include "dev_common.h"
 #include "kernels.h"
 #include "polar_common.h"
@@ -39,7 +40,8 @@ namespace rx {
 #define SC_WAVE_ORDER() __builtin_amdgcn_wave_barrier()
 #ifndef SC_LOADS
 #define SC_LOADS 64               // level-store loads a lane keeps in flight in the top passes.  -20 dB, 65 536 frames, one codeword per wave at ten
-                                  // decoders per CU: 16 loads 777 k frames/s, 32 807 - 812 k, 64 817 - 821 k (11 registers spilled at 168)
+                                  // decoders per CU: 16 loads 777 k frames/s, 32 807 - 812 k, 64 817 - 821 k (11 registers spilled at 168); with 256
+                                  // VGPRs and eight decoders (round 6): 32 and 64 the same, 128: 36 against 26 ms per 65 536 frames
 #endif
 
 // ---- how a wave is cut: LB = log2 of the lanes that work on one codeword (6: one codeword per wave, 5: two).  The decoder has
