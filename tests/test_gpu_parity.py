@@ -778,6 +778,49 @@ def test_queue_defers_the_list_decoder_across_chunks():
     assert listed[-30.0] == 0, listed             # every call starts with the certificate on
 
 
+def test_last_chunk_in_halves_equals_one_chunk(monkeypatch):
+    """A call of more than one chunk whose outputs are pinned host memory runs its last chunk as two halves when that chunk has 6144 frames
+    or more (api_pipeline.cpp: plan_chunks; nothing runs beside the copies of a call's last chunk).  14 692 frames at the default chunk of
+    8192 - a third each at -30 / -24 / -20 dB, so the syndrome certificate and the list-1 pass (with a run left over between the halves) both
+    take part - with the split and with OFDMRX_NO_TAIL_SPLIT=1: payloads, records and route counters identical, every payload the one sent."""
+    import torch
+    import modem_amd
+    import modem_amd.ofdmrx as M
+    dev = torch.device("cuda:0")
+    n = 8192 + 6500
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        monkeypatch.delenv("OFDMRX_NO_TAIL_SPLIT", raising=False)
+        rx = modem_amd.Receiver(device=0, stream=stream.cuda_stream)
+        spf = rx.tx_frame_samples(6)
+        g = torch.Generator(device=dev)
+        g.manual_seed(78)
+        d_pay = torch.randint(0, 256, (n, 5380), dtype=torch.uint8, device=dev, generator=g)
+        d_in = torch.empty((n, spf, 2), dtype=torch.int16, device=dev)
+        rx.tx_encode(d_pay.data_ptr(), n, d_in.data_ptr())
+        third = n // 3
+        for k, db in enumerate((-30.0, -24.0, -20.0)):
+            lo, hi = k * third, (n if k == 2 else (k + 1) * third)
+            rx.awgn_tile(d_in[lo:hi].data_ptr(), hi - lo, d_in[lo:hi].data_ptr(), hi - lo, spf, db, 6, lo)
+        rx.synchronize()
+        outs = []
+        for whole in (False, True):
+            if whole:
+                monkeypatch.setenv("OFDMRX_NO_TAIL_SPLIT", "1")
+            o = torch.zeros((n, 5380), dtype=torch.uint8, pin_memory=True)
+            rs = torch.zeros((n, M.RESULT_DTYPE.itemsize), dtype=torch.uint8, pin_memory=True)
+            rx.decode_device(d_in.data_ptr(), M.FMT_S16, 2, spf, spf * 4, n, o.data_ptr(), rs.data_ptr())
+            rx.synchronize()
+            outs.append((o.numpy().copy(), rs.numpy().copy().view(M.RESULT_DTYPE).reshape(-1), (rx.list_decoded_frames(), rx.sc_decided_frames())))
+        pays = d_pay.cpu().numpy()
+        rx.close()
+    (oa, ra, ca), (ob, rb, cb) = outs
+    assert (oa == ob).all() and (oa == pays).all()
+    for name in ra.dtype.names:
+        assert (ra[name] == rb[name]).all() or (ra[name].dtype.kind == "f" and np.array_equal(ra[name], rb[name], equal_nan=True)), name
+    assert ca == cb and ca[1] >= third and (ra["status"] == 0).all()
+
+
 def test_two_lanes_equal_one_lane(monkeypatch):
     """With OFDMRX_FLAG_TWO_LANES a device-entry call of four chunks or more is cut in two and its second half runs through the
     handle's second pipeline (include/ofdmrx.h revision 1.6).  Same batch through such a handle and a default one, chunks of 1024 frames,
